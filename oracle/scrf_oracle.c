@@ -1,0 +1,895 @@
+/*
+ * scrf_oracle.c -- CPU restatement of ASR-CRaFT's segmental-CRF hot path (plain C99).
+ *
+ * TEST INFRASTRUCTURE ONLY (see scrf_oracle.h for the parity status of each part).
+ * Every function cites the reference file:line (relative to /root/reference/CRF/src/)
+ * whose arithmetic and loop order it follows.  Canonical arithmetic: fp64,
+ * float->double promotion of features, unfused multiply then add, ascending feature
+ * index, bias last, logAdd = max-shift with the sum in index order.
+ *
+ * Build with -O2 -ffp-contract=off.
+ */
+#include "scrf_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+const double ORC_LOG0 = -1 * DBL_MAX; /* utils/CRF_LogMath.h:26 */
+
+static void set_err(int* err, int code) {
+  if (err && *err == ORC_OK) *err = code;
+}
+
+/* ------------------------------------------------------------------ a1 ---- */
+
+/* utils/CRF_LogMath.cpp:211-224 */
+double orc_expE(double a, int* err) {
+  const double ln_max = log(DBL_MAX); /* CRF_DBL_LN_MAX, CRF_LogMath.h:25 */
+  if (a >= ln_max) {
+    set_err(err, ORC_ERR_EXP_OVERFLOW);
+    return NAN;
+  }
+  double b = exp(a);
+  if (isnan(b) || isinf(b)) {
+    set_err(err, ORC_ERR_EXP_OVERFLOW);
+    return NAN;
+  }
+  return b;
+}
+
+/* utils/CRF_LogMath.cpp:192-205 */
+double orc_logE(double a, int* err) {
+  if (a == 0) {
+    set_err(err, ORC_ERR_LOG_ZERO);
+    return NAN;
+  }
+  double b = log(a);
+  if (isnan(b) || isinf(b)) {
+    set_err(err, ORC_ERR_LOG_NAN);
+    return NAN;
+  }
+  return b;
+}
+
+/* utils/CRF_LogMath.cpp:41-64 */
+double orc_logadd2(double loga, double logb, int* err) {
+  double logx = loga;
+  double logy = logb;
+  if (logy > logx) {
+    logy = loga;
+    logx = logb;
+  }
+  double negDiff = logy - logx;
+  return logx + orc_logE(1.0 + orc_expE(negDiff, err), err);
+}
+
+/* utils/CRF_LogMath.cpp:102-125 */
+double orc_logadd_max_n(const double* R, double max, int n, int* err) {
+  double sum = 0.0;
+  for (int i = 0; i < n; i++) sum += orc_expE(R[i] - max, err);
+  double lsum = orc_logE(sum, err);
+  return max + lsum;
+}
+
+/* utils/CRF_LogMath.cpp:69-96 */
+double orc_logadd_n(const double* R, int n, int* err) {
+  double max = R[0];
+  for (int i = 1; i < n; i++) {
+    if (R[i] > max) max = R[i];
+  }
+  return orc_logadd_max_n(R, max, n, err);
+}
+
+/* ------------------------------------------------------------------ a6 ---- */
+
+/* ftrmaps/CRF_StdFeatureMap.cpp:472-517 (recalc), :280-320, :355-410 with numStates==1 */
+int orc_layout_init(const orc_config* cfg, orc_layout* lay) {
+  const uint32_t L = cfg->num_labs;
+  memset(lay, 0, sizeof(*lay));
+  if (L == 0) return ORC_ERR_CONFIG;
+  uint32_t trans_mult = L * L; /* :481 */
+  uint32_t nff = 0, nsf = 0, ntf = 0;
+  if (cfg->use_state_ftrs) {
+    if (cfg->state_fidx_end < cfg->state_fidx_start) return ORC_ERR_CONFIG;
+    nff += (cfg->state_fidx_end - cfg->state_fidx_start + 1) * L;
+    nsf += (cfg->state_fidx_end - cfg->state_fidx_start + 1);
+  }
+  if (cfg->use_state_bias) {
+    nff += L;
+    nsf += 1;
+  }
+  if (cfg->use_trans_ftrs) {
+    if (cfg->trans_fidx_end < cfg->trans_fidx_start) return ORC_ERR_CONFIG;
+    nff += (cfg->trans_fidx_end - cfg->trans_fidx_start + 1) * trans_mult;
+    ntf += (cfg->trans_fidx_end - cfg->trans_fidx_start + 1);
+  }
+  if (cfg->use_trans_bias) {
+    nff += trans_mult;
+    ntf += 1;
+  }
+  lay->num_state_funcs = nsf;
+  lay->num_trans_funcs = ntf;
+  lay->lambda_len = nff;
+  lay->state_idx = (uint32_t*)malloc(sizeof(uint32_t) * L);
+  lay->trans_idx = (uint32_t*)malloc(sizeof(uint32_t) * L * L);
+  if (!lay->state_idx || !lay->trans_idx) return ORC_ERR_CONFIG;
+  for (uint32_t clab = 0; clab < L; clab++) {
+    /* computeStateFeatureIdx :280-320 */
+    lay->state_idx[clab] = (clab == 0) ? 0 : clab * (nsf + L * ntf);
+    for (uint32_t plab = 0; plab < L; plab++) {
+      /* computeTransFeatureIdx :365 */
+      lay->trans_idx[plab * L + clab] = clab * (nsf + L * ntf) + nsf + plab * ntf;
+    }
+  }
+  return ORC_OK;
+}
+
+void orc_layout_free(orc_layout* lay) {
+  free(lay->state_idx);
+  free(lay->trans_idx);
+  memset(lay, 0, sizeof(*lay));
+}
+
+/* ------------------------------------------------------------- a2 .. a5 ---- */
+
+/* ftrmaps/CRF_StdFeatureMap.cpp:65-81 */
+double orc_state_value(const orc_config* cfg, const orc_layout* lay, const float* x,
+                       const double* lambda, uint32_t clab) {
+  double v = 0.0;
+  uint32_t lc = lay->state_idx[clab];
+  if (cfg->use_state_ftrs) {
+    for (uint32_t f = cfg->state_fidx_start; f <= cfg->state_fidx_end; f++) {
+      v += x[f] * lambda[lc];
+      lc++;
+    }
+  }
+  if (cfg->use_state_bias) {
+    v += lambda[lc] * cfg->state_bias_val;
+    lc++;
+  }
+  return v;
+}
+
+/* ftrmaps/CRF_StdFeatureMap.cpp:94-110 */
+double orc_trans_value(const orc_config* cfg, const orc_layout* lay, const float* x,
+                       const double* lambda, uint32_t plab, uint32_t clab) {
+  double v = 0.0;
+  uint32_t lc = lay->trans_idx[plab * cfg->num_labs + clab];
+  if (cfg->use_trans_ftrs) {
+    for (uint32_t f = cfg->trans_fidx_start; f <= cfg->trans_fidx_end; f++) {
+      v += x[f] * lambda[lc];
+      lc++;
+    }
+  }
+  if (cfg->use_trans_bias) {
+    v += lambda[lc] * cfg->trans_bias_val;
+    lc++;
+  }
+  return v;
+}
+
+/* ftrmaps/CRF_StdFeatureMap.cpp:130-175 (compute_grad == true) */
+double orc_state_expf(const orc_config* cfg, const orc_layout* lay, const float* x,
+                      const double* lambda, double* ExpF, double* grad, double alpha_beta,
+                      uint32_t t_clab, uint32_t clab) {
+  double logLi = 0.0;
+  uint32_t lc = lay->state_idx[clab];
+  if (cfg->use_state_ftrs) {
+    for (uint32_t f = cfg->state_fidx_start; f <= cfg->state_fidx_end; f++) {
+      ExpF[lc] += alpha_beta * x[f];
+      if (t_clab == clab) {
+        grad[lc] += x[f];
+        logLi += lambda[lc] * x[f];
+      }
+      lc++;
+    }
+  }
+  if (cfg->use_state_bias) {
+    ExpF[lc] += alpha_beta * cfg->state_bias_val;
+    if (t_clab == clab) {
+      grad[lc] += cfg->state_bias_val;
+      logLi += lambda[lc] * cfg->state_bias_val;
+    }
+    lc++;
+  }
+  return logLi;
+}
+
+/* ftrmaps/CRF_StdFeatureMap.cpp:197-223 (compute_grad == true) */
+double orc_trans_expf(const orc_config* cfg, const orc_layout* lay, const float* x,
+                      const double* lambda, double* ExpF, double* grad, double alpha_beta,
+                      uint32_t t_plab, uint32_t t_clab, uint32_t plab, uint32_t clab) {
+  double logLi = 0.0;
+  uint32_t lc = lay->trans_idx[plab * cfg->num_labs + clab];
+  if (cfg->use_trans_ftrs) {
+    for (uint32_t f = cfg->trans_fidx_start; f <= cfg->trans_fidx_end; f++) {
+      ExpF[lc] += alpha_beta * x[f];
+      if ((clab == t_clab) && (plab == t_plab)) {
+        grad[lc] += x[f];
+        logLi += lambda[lc] * x[f];
+      }
+      lc++;
+    }
+  }
+  if (cfg->use_trans_bias) {
+    ExpF[lc] += alpha_beta * cfg->trans_bias_val;
+    if ((clab == t_clab) && (plab == t_plab)) {
+      grad[lc] += cfg->trans_bias_val;
+      logLi += lambda[lc] * cfg->trans_bias_val;
+    }
+    lc++;
+  }
+  return logLi;
+}
+
+/* ------------------------------------------------- windows and labels ------- */
+
+/* trainers/gradbuilders/CRF_NewGradBuilder_StdSeg_NoDur_NoTrans.cpp:243-251 */
+uint32_t orc_node_max_dur(uint32_t t, uint32_t D) { return (t + 1 <= D) ? t + 1 : D; }
+
+uint64_t orc_seg_base(uint32_t t, uint32_t D) {
+  if (t < D) return (uint64_t)t * (t + 1) / 2;
+  return (uint64_t)D * (D + 1) / 2 + (uint64_t)(t - D) * D;
+}
+
+uint64_t orc_num_segs(uint32_t T, uint32_t D) { return orc_seg_base(T, D); }
+
+/* io/CRF_InFtrStream_SeqMultiWindow.cpp:50-125 (boundary-delta variant out of scope) */
+uint32_t orc_window_width(uint32_t in_width, uint32_t max_win_len, uint32_t lctx, uint32_t rctx,
+                          int extract_seg_ftr) {
+  if (max_win_len == 1) return (lctx + 1 + rctx) * in_width; /* :53 */
+  if (extract_seg_ftr) return 8 * in_width + max_win_len + (lctx + rctx) * in_width; /* :77-78 */
+  return (lctx + 1 + rctx) * in_width; /* :114 */
+}
+
+/* io/CRF_InFtrStream_SeqMultiWindow.cpp:413-455 and the helpers it calls:
+ * first_frame_left_ctx_ftrs :897-925, sample_ftrs :556-598, avg_ftrs :609-646,
+ * max_ftrs :657-697, min_ftrs :708-748, dur_ftrs :850-884, first_frame_ftrs :1017-1038,
+ * first_frame_right_ctx_ftrs :937-965, last_frame_right_ctx_ftrs :977-1005. */
+void orc_windows(const float* frames, uint32_t T, uint32_t in_width, uint32_t D, uint32_t lctx,
+                 uint32_t rctx, int extract_seg_ftr, float* out, uint32_t out_stride,
+                 uint32_t out_col) {
+  const uint32_t W = in_width;
+  float* acc_sum = (float*)malloc(sizeof(float) * W);
+  float* acc_max = (float*)malloc(sizeof(float) * W);
+  float* acc_min = (float*)malloc(sizeof(float) * W);
+  uint64_t row = 0;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint32_t avail = orc_node_max_dur(t, D);
+    const float* last = frames + (size_t)(lctx + t) * W; /* current (last) frame */
+    for (uint32_t j = 0; j < W; j++) {
+      acc_sum[j] = 0.0f;
+      acc_max[j] = last[j];
+      acc_min[j] = last[j];
+    }
+    for (uint32_t w = 1; w <= avail; w++, row++) {
+      const float* first = last - (size_t)(w - 1) * W; /* first frame of the window */
+      float* o = out + row * out_stride + out_col;
+      /* left context of the window's first frame */
+      const float* lbase = first - (size_t)lctx * W;
+      for (uint32_t c = 0; c < lctx; c++)
+        for (uint32_t j = 0; j < W; j++) *o++ = lbase[(size_t)c * W + j];
+      if (D == 1 || !extract_seg_ftr) {
+        for (uint32_t j = 0; j < W; j++) *o++ = first[j];
+      } else {
+        /* sample frames at 10/30/50/70/90 % (:566-580) */
+        float one_tenth_win_len = (float)(w * 0.1);
+        for (int i = 1; i < 10; i += 2) {
+          float prod = one_tenth_win_len * (float)i;
+          uint32_t frameStep = (uint32_t)ceilf(prod) - 1;
+          const float* s = first + (size_t)frameStep * W;
+          for (uint32_t j = 0; j < W; j++) *o++ = s[j];
+        }
+        /* running sum / max / min from the last frame backwards (:621-631,:669-682,:720-733) */
+        for (uint32_t j = 0; j < W; j++) {
+          acc_sum[j] += first[j];
+          *o++ = acc_sum[j] / (float)w;
+        }
+        for (uint32_t j = 0; j < W; j++) {
+          if (first[j] > acc_max[j]) acc_max[j] = first[j];
+          *o++ = acc_max[j];
+        }
+        for (uint32_t j = 0; j < W; j++) {
+          if (first[j] < acc_min[j]) acc_min[j] = first[j];
+          *o++ = acc_min[j];
+        }
+        for (uint32_t k = 1; k <= D; k++) *o++ = (k == w) ? 1.0f : 0.0f;
+      }
+      /* right context: after the LAST frame for segment features (:449-451),
+       * after the FIRST frame otherwise (:453) */
+      const float* rbase = (extract_seg_ftr) ? last : first;
+      for (uint32_t c = 1; c <= rctx; c++)
+        for (uint32_t j = 0; j < W; j++) *o++ = rbase[(size_t)c * W + j];
+    }
+  }
+  free(acc_sum);
+  free(acc_max);
+  free(acc_min);
+}
+
+/* io/CRF_InLabStream_SeqMultiWindow.cpp:51-110 (groupLabels), :141-180 (run detection),
+ * :284-299 (label emitted at the window's end frame), gradbuilder :216-231 (phone-dur id) */
+void orc_group_labels(const uint32_t* frame_labs, uint32_t T, uint32_t D, uint32_t L,
+                      uint32_t* seg_labels) {
+  for (uint32_t t = 0; t < T; t++) seg_labels[t] = ORC_LAB_BAD;
+  uint32_t start = 0;
+  while (start < T) {
+    uint32_t lab = frame_labs[start];
+    uint32_t next = start + 1;
+    while (next < T && frame_labs[next] == lab) next++;
+    if (lab != ORC_LAB_BAD) {
+      uint32_t dur = next - start;
+      if (dur <= D) {
+        seg_labels[next - 1] = L * (dur - 1) + lab;
+      } else {
+        uint32_t numPieces = (dur % D == 0) ? dur / D : dur / D + 1;
+        uint32_t pieceDur = dur / numPieces;
+        uint32_t remainder = dur % numPieces;
+        uint32_t pieceStart = start;
+        for (uint32_t r = 0; r < numPieces; r++) {
+          uint32_t pd = (r < remainder) ? pieceDur + 1 : pieceDur;
+          uint32_t pieceEnd = pieceStart + pd - 1;
+          seg_labels[pieceEnd] = L * (pd - 1) + lab;
+          pieceStart = pieceEnd + 1;
+        }
+      }
+    }
+    start = next;
+  }
+}
+
+/* ------------------------------------------------------------ a7 .. a12 ---- */
+
+/* nodes/CRF_StdSegStateNode_WithoutDurLab_WithoutSegTransFtr.cpp:39-114 for every node */
+void orc_seg_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                    const float* segftrs, uint32_t T, double* S, double* M) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur, F = cfg->num_feas;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const float* ftrBuf = segftrs + base * F;
+    double* Mt = M + (size_t)t * L * L;
+    for (uint32_t lab = 0; lab < L; lab++)
+      for (uint32_t plab = 0; plab < L; plab++)
+        Mt[plab * L + lab] = orc_trans_value(cfg, lay, ftrBuf, lambda, plab, lab);
+    const uint32_t nd = orc_node_max_dur(t, D);
+    for (uint32_t dur = 1; dur <= nd; dur++) {
+      const float* x = ftrBuf + (size_t)(dur - 1) * F;
+      double* Sd = S + (base + dur - 1) * L;
+      for (uint32_t lab = 0; lab < L; lab++) Sd[lab] = orc_state_value(cfg, lay, x, lambda, lab);
+    }
+  }
+}
+
+static uint32_t num_prev(uint32_t t, uint32_t D) { return (t + 1 <= D) ? t : D; } /* gradbuilder :258-266 */
+
+/* computeFirstAlpha :335-382, computeAlphaPlusTrans :1077-1108, computeAlpha :123-245,
+ * computeAlphaSum nodes/CRF_StdSegStateNode.cpp:447-462 */
+int orc_seg_forward(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                    double* alpha_dur, double* alpha, double* apt, double* Zx) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  uint32_t accn = L > D ? L : D;
+  double* tmp = (double*)malloc(sizeof(double) * accn);
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    if (t == 0) {
+      for (uint32_t lab = 0; lab < L; lab++) {
+        alpha_dur[lab] = S[lab];
+        alpha[lab] = S[lab];
+      }
+      continue;
+    }
+    /* node t-1: alphaPlusTrans with node t's transition matrix (:156) */
+    const double* Mt = M + (size_t)t * L * L;
+    const double* aprev = alpha + (size_t)(t - 1) * L;
+    for (uint32_t next_lab = 0; next_lab < L; next_lab++) {
+      for (uint32_t clab = 0; clab < L; clab++) tmp[clab] = aprev[clab] + Mt[clab * L + next_lab];
+      apt[(size_t)(t - 1) * L + next_lab] = orc_logadd_n(tmp, (int)L, &err);
+    }
+    const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
+    for (uint32_t clab = 0; clab < L; clab++) {
+      uint32_t id = 0;
+      for (uint32_t dur = 1; dur <= np; dur++) {
+        double v = apt[(size_t)(t - dur) * L + clab] + S[(base + dur - 1) * L + clab];
+        tmp[id++] = v;
+        alpha_dur[(base + dur - 1) * L + clab] = v;
+      }
+      for (uint32_t dur = np + 1; dur <= nd; dur++) {
+        double v = S[(base + dur - 1) * L + clab];
+        tmp[id++] = v;
+        alpha_dur[(base + dur - 1) * L + clab] = v;
+      }
+      alpha[(size_t)t * L + clab] = orc_logadd_n(tmp, (int)id, &err);
+    }
+  }
+  *Zx = orc_logadd_n(alpha + (size_t)(T - 1) * L, (int)L, &err);
+  free(tmp);
+  return err;
+}
+
+/* one node of computeBeta :395-466 / setTailBeta nodes/CRF_StdStateNode.cpp:198-204 */
+static void seg_beta_node(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                          uint32_t t, double* beta, double* sd, double* tmp, int* err) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  uint32_t nn = (T - 1 - t <= D) ? T - 1 - t : D; /* gradbuilder :390-398 */
+  double* bt = beta + (size_t)t * L;
+  if (nn == 0) {
+    for (uint32_t l = 0; l < L; l++) bt[l] = 0.0;
+    return;
+  }
+  double* sdt = sd + (size_t)t * L;
+  for (uint32_t nextlab = 0; nextlab < L; nextlab++) {
+    uint32_t id = 0;
+    for (uint32_t dur = 1; dur <= nn; dur++) {
+      const uint64_t nb = orc_seg_base(t + dur, D);
+      tmp[id++] = S[(nb + dur - 1) * L + nextlab] + beta[(size_t)(t + dur) * L + nextlab];
+    }
+    sdt[nextlab] = orc_logadd_n(tmp, (int)id, err);
+  }
+  const double* Mn = M + (size_t)(t + 1) * L * L;
+  for (uint32_t clab = 0; clab < L; clab++) {
+    for (uint32_t nextlab = 0; nextlab < L; nextlab++)
+      tmp[nextlab] = Mn[clab * L + nextlab] + sdt[nextlab];
+    bt[clab] = orc_logadd_n(tmp, (int)L, err);
+  }
+}
+
+int orc_seg_backward(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                     double* beta, double* sd) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  uint32_t accn = L > D ? L : D;
+  double* tmp = (double*)malloc(sizeof(double) * accn);
+  for (uint32_t t = T; t-- > 0;) seg_beta_node(cfg, S, M, T, t, beta, sd, tmp, &err);
+  free(tmp);
+  return err;
+}
+
+/* CRF_NewGradBuilder_StdSeg_NoDur_NoTrans::buildGradient,
+ * trainers/gradbuilders/CRF_NewGradBuilder_StdSeg_NoDur_NoTrans.cpp:65-492, with
+ * computeExpF nodes/...WithoutSegTransFtr.cpp:616-949 inlined in its loop order. */
+int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                           const float* segftrs, const uint32_t* labels, uint32_t T,
+                           double* grad, double* numer, double* Zx_out) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur, F = cfg->num_feas;
+  if (T == 0) return ORC_ERR_EMPTY;
+  const uint64_t nseg = orc_num_segs(T, D);
+  int err = ORC_OK;
+  double* ExpF = (double*)calloc(lay->lambda_len, sizeof(double)); /* :99-101 */
+  double* S = (double*)malloc(sizeof(double) * nseg * L);
+  double* M = (double*)malloc(sizeof(double) * (size_t)T * L * L);
+  double* ad = (double*)malloc(sizeof(double) * nseg * L);
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* apt = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* sd = (double*)malloc(sizeof(double) * (size_t)T * L);
+  uint32_t accn = L > D ? L : D;
+  double* tmp = (double*)malloc(sizeof(double) * accn);
+  double logLi = 0.0, Zx = 0.0;
+
+  orc_seg_scores(cfg, lay, lambda, segftrs, T, S, M);       /* :284 */
+  err = orc_seg_forward(cfg, S, M, T, ad, alpha, apt, &Zx); /* :296,307,343 */
+
+  for (uint32_t t = T; t-- > 0 && err == ORC_OK;) { /* :388-469 */
+    seg_beta_node(cfg, S, M, T, t, beta, sd, tmp, &err);
+    /* label of the next node that carries one (:436-444) */
+    uint32_t next_lab = ORC_LAB_BAD;
+    for (uint32_t u = t + 1; u < T; u++) {
+      next_lab = labels[u];
+      if (next_lab != ORC_LAB_BAD) break;
+    }
+    /* computeExpF :616-949 */
+    uint32_t actualLab = labels[t], labDur = ORC_LAB_BAD;
+    uint32_t actualNextLab = next_lab;
+    if (actualLab != ORC_LAB_BAD) {
+      if (actualLab >= L * D) { err = ORC_ERR_BAD_LABEL; break; }
+      labDur = labels[t] / L + 1;
+      actualLab = labels[t] % L;
+    }
+    if (actualNextLab != ORC_LAB_BAD) {
+      if (actualNextLab >= L * D) { err = ORC_ERR_BAD_LABEL; break; }
+      actualNextLab = next_lab % L;
+    }
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D);
+    const float* ftrBuf = segftrs + base * F;
+    double ab_tot = 0.0, ab_trans_tot = 0.0, nodeLi = 0.0;
+    for (uint32_t lab = 0; lab < L; lab++) {
+      for (uint32_t dur = 1; dur <= nd; dur++) {
+        const float* x = ftrBuf + (size_t)(dur - 1) * F;
+        double ab = orc_expE(ad[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err);
+        ab_tot += ab;
+        int match = (lab == actualLab && dur == labDur);
+        nodeLi += orc_state_expf(cfg, lay, x, lambda, ExpF, grad, ab, match ? actualLab : ORC_LAB_BAD, lab);
+      }
+    }
+    uint32_t nn = (T - 1 - t <= D) ? T - 1 - t : D;
+    if (nn > 0) {
+      const double* Mn = M + (size_t)(t + 1) * L * L;
+      const float* xn = segftrs + orc_seg_base(t + 1, D) * F; /* next node's window 1 (:789) */
+      for (uint32_t nl = 0; nl < L; nl++) {
+        for (uint32_t clab = 0; clab < L; clab++) {
+          double ab = orc_expE(alpha[(size_t)t * L + clab] + Mn[clab * L + nl] + sd[(size_t)t * L + nl] - Zx, &err);
+          ab_trans_tot += ab;
+          int match = (clab == actualLab && nl == actualNextLab);
+          nodeLi += orc_trans_expf(cfg, lay, xn, lambda, ExpF, grad, ab,
+                                   match ? actualLab : ORC_LAB_BAD,
+                                   match ? actualNextLab : ORC_LAB_BAD, clab, nl);
+        }
+      }
+    } else {
+      ab_trans_tot = 1.0;
+    }
+    /* self checks :917-947 */
+    if (ab_tot > 1.000001 || ab_tot < -0.000001 || ab_trans_tot > 1.000001 ||
+        ab_trans_tot < -0.000001 || ab_tot - ab_trans_tot > 0.000001 ||
+        ab_tot - ab_trans_tot < -0.000001) {
+      /* the tail node sets trans_tot=1 while its state mass is 1 too, so the
+       * equality check holds there as well */
+      set_err(&err, ORC_ERR_PROB_SUM);
+    }
+    logLi += nodeLi; /* :453 */
+  }
+  for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i]; /* :471-473 */
+  *Zx_out = Zx;
+  *numer = logLi;
+  free(ExpF); free(S); free(M); free(ad); free(alpha); free(apt); free(beta); free(sd); free(tmp);
+  return err;
+}
+
+int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                       double* gamma, double* xi, double* Zx_out) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  if (T == 0) return ORC_ERR_EMPTY;
+  const uint64_t nseg = orc_num_segs(T, D);
+  double* ad = (double*)malloc(sizeof(double) * nseg * L);
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* apt = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* sd = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double Zx = 0.0;
+  int err = orc_seg_forward(cfg, S, M, T, ad, alpha, apt, &Zx);
+  if (err == ORC_OK) err = orc_seg_backward(cfg, S, M, T, beta, sd);
+  for (uint32_t t = 0; t < T && err == ORC_OK; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D);
+    for (uint32_t dur = 1; dur <= nd; dur++)
+      for (uint32_t lab = 0; lab < L; lab++)
+        gamma[(base + dur - 1) * L + lab] =
+            orc_expE(ad[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err);
+    if (t + 1 < T) {
+      const double* Mn = M + (size_t)(t + 1) * L * L;
+      for (uint32_t c = 0; c < L; c++)
+        for (uint32_t n = 0; n < L; n++)
+          xi[(size_t)t * L * L + c * L + n] =
+              orc_expE(alpha[(size_t)t * L + c] + Mn[c * L + n] + sd[(size_t)t * L + n] - Zx, &err);
+    }
+  }
+  *Zx_out = Zx;
+  free(ad); free(alpha); free(apt); free(beta); free(sd);
+  return err;
+}
+
+/* ------------------------------------------------------------------ a15 ---- */
+
+/* CRF_NewGradBuilder::buildGradient trainers/gradbuilders/CRF_NewGradBuilder.cpp:48-382 with
+ * the CRF_StdStateNode methods nodes/CRF_StdStateNode.cpp:58-299 inlined. ftrs: [T][F]. */
+int orc_frame_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                             const float* ftrs, const uint32_t* labels, uint32_t T,
+                             double* grad, double* numer, double* Zx_out) {
+  const uint32_t L = cfg->num_labs, F = cfg->num_feas;
+  if (T == 0) return ORC_ERR_EMPTY;
+  int err = ORC_OK;
+  double* ExpF = (double*)calloc(lay->lambda_len, sizeof(double));
+  double* S = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* M = (double*)malloc(sizeof(double) * (size_t)T * L * L);
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* acc = (double*)malloc(sizeof(double) * L);
+  double* tempBeta = (double*)malloc(sizeof(double) * L);
+  double logLi = 0.0;
+  for (uint32_t t = 0; t < T; t++) {
+    const float* x = ftrs + (size_t)t * F;
+    /* computeTransMatrix :58-72 */
+    for (uint32_t clab = 0; clab < L; clab++) {
+      S[(size_t)t * L + clab] = orc_state_value(cfg, lay, x, lambda, clab);
+      for (uint32_t plab = 0; plab < L; plab++)
+        M[(size_t)t * L * L + plab * L + clab] = orc_trans_value(cfg, lay, x, lambda, plab, clab);
+    }
+    if (t == 0) { /* computeFirstAlpha :118-128 */
+      for (uint32_t clab = 0; clab < L; clab++) alpha[clab] = S[clab];
+    } else { /* computeAlpha :81-110 */
+      const double* pa = alpha + (size_t)(t - 1) * L;
+      const double* Mt = M + (size_t)t * L * L;
+      for (uint32_t clab = 0; clab < L; clab++) {
+        acc[0] = pa[0] + Mt[0 + clab];
+        double maxv = acc[0];
+        for (uint32_t plab = 1; plab < L; plab++) {
+          acc[plab] = pa[plab] + Mt[plab * L + clab];
+          if (acc[plab] > maxv) maxv = acc[plab];
+        }
+        double a = orc_logadd_max_n(acc, maxv, (int)L, &err);
+        a += S[(size_t)t * L + clab];
+        alpha[(size_t)t * L + clab] = a;
+      }
+    }
+  }
+  double Zx = orc_logadd_n(alpha + (size_t)(T - 1) * L, (int)L, &err); /* :286-299 */
+  for (uint32_t t = T; t-- > 0 && err == ORC_OK;) {
+    double* bt = beta + (size_t)t * L;
+    if (t == T - 1) {
+      for (uint32_t c = 0; c < L; c++) bt[c] = 0.0; /* setTailBeta */
+    } else { /* node t+1 ->computeBeta(beta of node t) :140-173 */
+      const double* bn = beta + (size_t)(t + 1) * L;
+      const double* Sn = S + (size_t)(t + 1) * L;
+      const double* Mn = M + (size_t)(t + 1) * L * L;
+      for (uint32_t c = 0; c < L; c++) tempBeta[c] = bn[c] + Sn[c];
+      for (uint32_t plab = 0; plab < L; plab++) {
+        acc[0] = Mn[plab * L + 0] + tempBeta[0];
+        double maxv = acc[0];
+        for (uint32_t c = 1; c < L; c++) {
+          acc[c] = Mn[plab * L + c] + tempBeta[c];
+          if (acc[c] > maxv) maxv = acc[c];
+        }
+        bt[plab] = orc_logadd_max_n(acc, maxv, (int)L, &err);
+      }
+    }
+    /* computeExpF :221-277 */
+    const float* x = ftrs + (size_t)t * F;
+    const double* pa = (t > 0) ? alpha + (size_t)(t - 1) * L : NULL;
+    uint32_t prev_lab = (t > 0) ? labels[t - 1] : L + 1; /* :299-307 */
+    uint32_t label = labels[t];
+    const double* Mt = M + (size_t)t * L * L;
+    double ab_tot = 0.0, ab_trans_tot = 0.0, nodeLi = 0.0;
+    for (uint32_t clab = 0; clab < L; clab++) {
+      double ab = orc_expE(alpha[(size_t)t * L + clab] + bt[clab] - Zx, &err);
+      ab_tot += ab;
+      nodeLi += orc_state_expf(cfg, lay, x, lambda, ExpF, grad, ab, label, clab);
+      if (prev_lab > L) {
+        ab_trans_tot = 1.0;
+      } else {
+        for (uint32_t plab = 0; plab < L; plab++) {
+          ab = orc_expE(pa[plab] + Mt[plab * L + clab] + S[(size_t)t * L + clab] + bt[clab] - Zx, &err);
+          ab_trans_tot += ab;
+          nodeLi += orc_trans_expf(cfg, lay, x, lambda, ExpF, grad, ab, prev_lab, label, plab, clab);
+        }
+      }
+    }
+    if (ab_tot > 1.1 || ab_tot < 0.9 || ab_trans_tot > 1.1 || ab_trans_tot < 0.9)
+      set_err(&err, ORC_ERR_PROB_SUM);
+    logLi += nodeLi;
+  }
+  for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i];
+  *Zx_out = Zx;
+  *numer = logLi;
+  free(ExpF); free(S); free(M); free(alpha); free(beta); free(acc); free(tempBeta);
+  return err;
+}
+
+/* ------------------------------------------------------------ a13 / a14 ---- */
+
+/* trainers/accumulators/CRF_Minibatch_GradAccumulator.cpp:217-219,296-298,306-308 */
+void orc_minibatch_reduce(const double* sgrad, uint32_t n_streams, const int32_t* active,
+                          uint32_t lambda_len, double* grad) {
+  int n_active = 0;
+  for (uint32_t i = 0; i < lambda_len; i++) grad[i] = 0.0;
+  for (uint32_t s = 0; s < n_streams; s++) {
+    if (!active[s]) continue;
+    ++n_active;
+    const double* g = sgrad + (size_t)s * lambda_len;
+    for (uint32_t i = 0; i < lambda_len; ++i) grad[i] += g[i];
+  }
+  for (uint32_t i = 0; i < lambda_len; ++i) grad[i] /= n_active;
+}
+
+/* trainers/CRF_SGTrainer.cpp:299-325 (useGvar == false) */
+void orc_sgd_step(double* lambda, double* lambda_acc, double* grad_sqr_acc, double* grad,
+                  uint32_t n, double lr_or_eta, int use_adagrad, double eps) {
+  for (uint32_t i = 0; i < n; i++) {
+    if (use_adagrad) {
+      grad_sqr_acc[i] += grad[i] * grad[i];
+      lambda[i] += lr_or_eta / (sqrt(grad_sqr_acc[i]) + eps) * grad[i];
+    } else {
+      lambda[i] += lr_or_eta * grad[i];
+    }
+    lambda_acc[i] += lambda[i];
+    grad[i] = 0.0;
+  }
+}
+
+/* ------------------------------------------------------------ a16 .. a18 ---- */
+
+uint64_t orc_seg_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D) {
+  if (T == 0) return 0;
+  return (uint64_t)(T - 1) * L * L + orc_num_segs(T, D) * L + L;
+}
+uint32_t orc_seg_lattice_num_states(uint32_t T, uint32_t L) {
+  if (T == 0) return 1;
+  return 1 + L + (T - 1) * 2 * L + 1;
+}
+
+/* decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab_WithoutSegTransFtr.h:30-407 */
+uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const double* M,
+                              uint32_t T, int norm, double alpha_sum, orc_arc* arcs,
+                              uint32_t* n_states, int32_t* final_state) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  const int startState = 0;
+  int next_state = 1; /* AddState() for the start state */
+  uint64_t na = 0;
+  int* nss = (int*)malloc(sizeof(int) * ((size_t)T + 2)); /* nodeStartStates */
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
+    if (t == 0) nss[0] = startState + 1; /* :248-250 */
+    uint32_t num_new_states = 0;
+    if (np > 0) { /* boundary states :260-296 */
+      const double* Mt = M + (size_t)t * L * L;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        int cur_state = next_state++;
+        num_new_states++;
+        for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+          float value = -1 * Mt[prev_lab * L + lab];
+          int prev_state = (t == 1) ? nss[t - 1] + (int)prev_lab : nss[t - 1] + (int)L + (int)prev_lab;
+          orc_arc a = {prev_state, 0, 0, value, cur_state};
+          arcs[na++] = a;
+        }
+      }
+    }
+    for (uint32_t lab = 0; lab < L; lab++) { /* end states :300-325 */
+      int cur_state = next_state++;
+      num_new_states++;
+      int cur_lab = (int)lab;
+      for (uint32_t dur = 1; dur <= np; dur++) {
+        float value = -1 * S[(base + dur - 1) * L + lab];
+        int prev_state = nss[t - dur + 1] + (int)lab;
+        orc_arc a = {prev_state, cur_lab + 1, cur_lab + 1, value, cur_state};
+        arcs[na++] = a;
+        cur_lab += (int)L;
+      }
+      for (uint32_t dur = np + 1; dur <= nd; dur++) {
+        float value = -1 * S[(base + dur - 1) * L + lab];
+        orc_arc a = {startState, cur_lab + 1, cur_lab + 1, value, cur_state};
+        arcs[na++] = a;
+        cur_lab += (int)L;
+      }
+    }
+    nss[t + 1] = nss[t] + (int)num_new_states; /* :327-330 */
+  }
+  int fin = -1;
+  if (T > 0) { /* :366-399 */
+    double Zx = 0;
+    if (norm) Zx = -1 * alpha_sum;
+    fin = next_state++;
+    for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+      int prev_state = (T == 1) ? nss[T - 1] + (int)prev_lab : nss[T - 1] + (int)L + (int)prev_lab;
+      float w = -Zx;
+      orc_arc a = {prev_state, 0, 0, w, fin};
+      arcs[na++] = a;
+    }
+  }
+  *n_states = (uint32_t)next_state;
+  *final_state = fin;
+  free(nss);
+  return na;
+}
+
+uint64_t orc_frame_lattice_num_arcs(uint32_t T, uint32_t L) {
+  if (T == 0) return L;
+  return (uint64_t)L + (uint64_t)(T - 1) * L * L + L;
+}
+
+/* decoders/CRF_LatticeBuilder.h:97-204. S: [T][L], M: [T][L*L] */
+uint64_t orc_frame_lattice_arcs(const orc_config* cfg, const double* S, const double* M,
+                                uint32_t T, int norm, double alpha_sum, orc_arc* arcs,
+                                uint32_t* n_states, int32_t* final_state) {
+  const uint32_t L = cfg->num_labs;
+  const int startState = 0;
+  int next_state = 1;
+  uint64_t na = 0;
+  for (uint32_t t = 0; t < T; t++) {
+    if (t == 0) {
+      for (uint32_t cur_lab = 0; cur_lab < L; cur_lab++) {
+        float value = -1 * S[cur_lab];
+        int cur_state = next_state++;
+        orc_arc a = {startState, (int)cur_lab + 1, (int)cur_lab + 1, value, cur_state};
+        arcs[na++] = a;
+      }
+    } else {
+      int cur_time = (int)t + 1;
+      for (uint32_t cur_lab = 0; cur_lab < L; cur_lab++) {
+        int cur_state = next_state++;
+        for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+          /* getFullTransValue nodes/CRF_StdStateNode.cpp:328-334 */
+          float value = -1 * (M[(size_t)t * L * L + prev_lab * L + cur_lab] + S[(size_t)t * L + cur_lab]);
+          int prev_state = (int)L * (cur_time - 2) + ((int)prev_lab + 1);
+          orc_arc a = {prev_state, (int)cur_lab + 1, (int)cur_lab + 1, value, cur_state};
+          arcs[na++] = a;
+        }
+      }
+    }
+  }
+  double Zx = 0;
+  if (norm) Zx = -1 * alpha_sum;
+  int fin = next_state++;
+  for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+    int prev_state = (int)L * ((int)T - 1) + ((int)prev_lab + 1);
+    float w = Zx;
+    orc_arc a = {prev_state, 0, 0, w, fin};
+    arcs[na++] = a;
+  }
+  *n_states = (uint32_t)next_state;
+  *final_state = fin;
+  return na;
+}
+
+/* CRFFstDecode/src/Main.cpp:838-889: ShortestPath(lat,1) -> Project(OUTPUT) -> RmEpsilon ->
+ * TopSort -> olabel-1.  OpenFST is not in /root/reference (un-vendored, unpinned; a stale
+ * comment names OpenFst-1.3.4): its published single-source shortest path over the
+ * tropical semiring is restated here -- relax states in state-id order (the lattices are
+ * built top-sorted, so OpenFST's AutoQueue selects StateOrderQueue), arcs of a state in
+ * insertion order, update only on strict improvement.  PARITY UNPINNED (tie-breaking). */
+int64_t orc_best_path(const orc_arc* arcs, uint64_t n_arcs, uint32_t n_states, int32_t start,
+                      int32_t final_state, uint32_t* out_labels, uint64_t max_out,
+                      float* best_cost) {
+  if (final_state < 0 || (uint32_t)final_state >= n_states) return -1;
+  uint64_t* first = (uint64_t*)calloc((size_t)n_states + 1, sizeof(uint64_t));
+  uint64_t* order = (uint64_t*)malloc(sizeof(uint64_t) * (n_arcs ? n_arcs : 1));
+  float* dist = (float*)malloc(sizeof(float) * n_states);
+  int64_t* parent = (int64_t*)malloc(sizeof(int64_t) * n_states);
+  int64_t ret = -1;
+  for (uint64_t a = 0; a < n_arcs; a++) {
+    if (arcs[a].dst <= arcs[a].src) { ret = -2; goto done; } /* not top-sorted */
+    first[arcs[a].src + 1]++;
+  }
+  for (uint32_t s = 0; s < n_states; s++) first[s + 1] += first[s];
+  {
+    uint64_t* fill = (uint64_t*)malloc(sizeof(uint64_t) * n_states);
+    memcpy(fill, first, sizeof(uint64_t) * n_states);
+    for (uint64_t a = 0; a < n_arcs; a++) order[fill[arcs[a].src]++] = a; /* stable */
+    free(fill);
+  }
+  for (uint32_t s = 0; s < n_states; s++) {
+    dist[s] = INFINITY; /* TropicalWeight::Zero() */
+    parent[s] = -1;
+  }
+  dist[start] = 0.0f; /* One() */
+  for (uint32_t s = 0; s < n_states; s++) {
+    if (dist[s] == INFINITY) continue; /* never enqueued */
+    for (uint64_t k = first[s]; k < first[s + 1]; k++) {
+      const orc_arc* a = &arcs[order[k]];
+      float nd = dist[s] + a->w; /* Times */
+      if (nd < dist[a->dst]) {   /* d != Plus(d, nd) */
+        dist[a->dst] = nd;
+        parent[a->dst] = (int64_t)order[k];
+      }
+    }
+  }
+  if (dist[final_state] == INFINITY) goto done;
+  if (best_cost) *best_cost = dist[final_state] + 0.0f; /* Times(d, Final = One) */
+  {
+    /* backtrace, then emit non-epsilon output labels start -> final */
+    uint64_t n = 0;
+    for (int32_t s = final_state; s != start;) {
+      const orc_arc* a = &arcs[parent[s]];
+      if (a->olabel != 0) n++;
+      s = a->src;
+    }
+    ret = (int64_t)n;
+    uint64_t pos = n;
+    for (int32_t s = final_state; s != start;) {
+      const orc_arc* a = &arcs[parent[s]];
+      if (a->olabel != 0) {
+        pos--;
+        if (pos < max_out) out_labels[pos] = (uint32_t)(a->olabel - 1);
+      }
+      s = a->src;
+    }
+  }
+done:
+  free(first); free(order); free(dist); free(parent);
+  return ret;
+}

@@ -1,0 +1,194 @@
+/*
+ * scrf_oracle.h -- CPU restatement of ASR-CRaFT's segmental-CRF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * only as the checker / reported baseline.  The product (asr-craft_amd/) never
+ * links or calls it.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   a1  (CRF_LogMath)        PINNED: bit-checked against the reference's own
+ *                            CRF_LogMath.cpp compiled from /root/reference into
+ *                            oracle/_ref/ (tests/test_oracle_logmath.py).
+ *   a2..a19 (everything else) PARITY UNPINNED: the reference's remaining sources
+ *                            need QuickNet3 / OpenFST / cblas headers that this image
+ *                            lacks, the reference ships no tests or golden outputs,
+ *                            so these functions are a line-by-line restatement of the
+ *                            cited reference code (same loop order, fp64, unfused
+ *                            multiply-then-add) cross-checked by brute-force
+ *                            enumeration and finite differences, not by the
+ *                            reference binary.
+ *
+ * All paths "file:line" below are relative to /root/reference/CRF/src/.
+ * Build: -O2 -ffp-contract=off (the reference builds -O2 without -march, i.e. no FMA
+ * contraction; configure.ac:12).
+ */
+#ifndef SCRF_ORACLE_H_
+#define SCRF_ORACLE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_LAB_BAD 0xffffffffu /* CRF_LAB_BAD, io/CRF_FeatureStream.h */
+
+/* status codes (the reference throws std::runtime_error; we return codes) */
+enum {
+  ORC_OK = 0,
+  ORC_ERR_LOG_ZERO = 1,     /* utils/CRF_LogMath.cpp:195 */
+  ORC_ERR_LOG_NAN = 2,      /* utils/CRF_LogMath.cpp:200 */
+  ORC_ERR_EXP_OVERFLOW = 3, /* utils/CRF_LogMath.cpp:214,219 */
+  ORC_ERR_PROB_SUM = 4,     /* nodes/...WithoutSegTransFtr.cpp:917-947, nodes/CRF_StdStateNode.cpp:252-275 */
+  ORC_ERR_BAD_LABEL = 5,    /* nodes/...WithoutSegTransFtr.cpp:627-631 */
+  ORC_ERR_CONFIG = 6,
+  ORC_ERR_EMPTY = 7         /* trainers/gradbuilders/...NoDur_NoTrans.cpp:331-335 */
+};
+
+/* modeltype, CRF.h:50 */
+enum {
+  ORC_STDFRAME = 0,
+  ORC_STDSEG = 1,
+  ORC_STDSEG_NO_DUR = 2,
+  ORC_STDSEG_NO_DUR_NO_TRANSFTR = 3,
+  ORC_STDSEG_NO_DUR_NO_SEGTRANSFTR = 4
+};
+
+/* Mirror of CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) + model fields
+ * of CRF_Model (CRF_Model.h). numStates is fixed to 1 (SURVEY #11 out of scope). */
+typedef struct {
+  uint32_t model_type;
+  uint32_t num_labs;      /* numLabs == nActualLabs for the NO_DUR models and STDFRAME */
+  uint32_t lab_max_dur;   /* D; 1 for STDFRAME */
+  uint32_t num_feas;      /* floats per window vector (nFtrsPerSeg) */
+  int32_t use_state_ftrs;
+  uint32_t state_fidx_start, state_fidx_end; /* inclusive */
+  int32_t use_trans_ftrs;
+  uint32_t trans_fidx_start, trans_fidx_end; /* inclusive */
+  int32_t use_state_bias, use_trans_bias;
+  double state_bias_val, trans_bias_val;
+} orc_config;
+
+/* lambda index layout (ftrmaps/CRF_StdFeatureMap.cpp:280-320,355-410,472-517) */
+typedef struct {
+  uint32_t num_state_funcs; /* numStateFuncs */
+  uint32_t num_trans_funcs; /* numTransFuncs */
+  uint32_t lambda_len;      /* numFtrFuncs */
+  uint32_t* state_idx;      /* [L]   stateFeatureIdxCache */
+  uint32_t* trans_idx;      /* [L*L] transFeatureIdxCache[plab*L+clab] */
+} orc_layout;
+
+/* ---- a1: CRF_LogMath ---------------------------------------------------- */
+extern const double ORC_LOG0; /* -DBL_MAX, utils/CRF_LogMath.h:26 */
+double orc_expE(double a, int* err);
+double orc_logE(double a, int* err);
+double orc_logadd2(double a, double b, int* err);
+double orc_logadd_n(const double* R, int n, int* err);
+double orc_logadd_max_n(const double* R, double max, int n, int* err);
+
+/* ---- a6: layout ---------------------------------------------------------- */
+int orc_layout_init(const orc_config* cfg, orc_layout* lay);
+void orc_layout_free(orc_layout* lay);
+
+/* ---- a2..a5: feature map ------------------------------------------------- */
+double orc_state_value(const orc_config* cfg, const orc_layout* lay, const float* x,
+                       const double* lambda, uint32_t clab);
+double orc_trans_value(const orc_config* cfg, const orc_layout* lay, const float* x,
+                       const double* lambda, uint32_t plab, uint32_t clab);
+double orc_state_expf(const orc_config* cfg, const orc_layout* lay, const float* x,
+                      const double* lambda, double* ExpF, double* grad, double alpha_beta,
+                      uint32_t t_clab, uint32_t clab);
+double orc_trans_expf(const orc_config* cfg, const orc_layout* lay, const float* x,
+                      const double* lambda, double* ExpF, double* grad, double alpha_beta,
+                      uint32_t t_plab, uint32_t t_clab, uint32_t plab, uint32_t clab);
+
+/* ---- inputs: segment windows and labels (rows 26/27, adjacent) ------------ */
+/* number of windows ending at frame t, and total over an utterance */
+uint32_t orc_node_max_dur(uint32_t t, uint32_t D);
+uint64_t orc_num_segs(uint32_t T, uint32_t D);
+uint64_t orc_seg_base(uint32_t t, uint32_t D); /* index of window d=1 of frame t */
+
+/* width of one output window, io/CRF_InFtrStream_SeqMultiWindow.cpp:50-125 */
+uint32_t orc_window_width(uint32_t in_width, uint32_t max_win_len, uint32_t lctx, uint32_t rctx,
+                          int extract_seg_ftr);
+/* Windows of all frames of one utterance, in read() order: for t, for d=1..min(t+1,D).
+ * frames: [(T + lctx + rctx)][in_width], i.e. already padded by the caller with lctx
+ * leading and rctx trailing frames (the reference reads those from a padded pfile,
+ * demo/segmental-timit-demo.cfg.in:60).  out: [N_seg][out_stride], writes `width`
+ * floats per window at column out_col. io/CRF_InFtrStream_SeqMultiWindow.cpp:325-470. */
+void orc_windows(const float* frames, uint32_t T, uint32_t in_width, uint32_t D, uint32_t lctx,
+                 uint32_t rctx, int extract_seg_ftr, float* out, uint32_t out_stride,
+                 uint32_t out_col);
+/* frame labels -> per-end-frame segment labels L*(dur-1)+phone or ORC_LAB_BAD;
+ * io/CRF_InLabStream_SeqMultiWindow.cpp:51-110,119-183 + gradbuilder :216-231. */
+void orc_group_labels(const uint32_t* frame_labs, uint32_t T, uint32_t D, uint32_t L,
+                      uint32_t* seg_labels);
+
+/* ---- a7..a12: segmental model #9 ----------------------------------------- */
+/* S: [N_seg][L] (stateArray of node t at rows seg_base(t)..), M: [T][L*L] (transMatrix
+ * of node t, p*L+l). segftrs: [N_seg][num_feas]. */
+void orc_seg_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                    const float* segftrs, uint32_t T, double* S, double* M);
+/* alpha_dur: [N_seg][L] (value for (t,d,l) at (seg_base(t)+d-1)*L+l; the reference
+ * stores it transposed per node as alphaArray_WithDur[l*nodeMaxDur+d-1]),
+ * alpha: [T][L], apt: [T][L] (alphaPlusTrans of node t, computed with M[t+1]; row T-1 unused) */
+int orc_seg_forward(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                    double* alpha_dur, double* alpha, double* apt, double* Zx);
+/* beta: [T][L], sd: [T][L] (tmpBetaArray_nextBetasPlusNextStateValue_sumOverDur; row T-1 unused) */
+int orc_seg_backward(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                     double* beta, double* sd);
+/* Full CRF_NewGradBuilder_StdSeg_NoDur_NoTrans::buildGradient: grad += counts - ExpF,
+ * returns numerator via *numer, Zx via *Zx. labels: [T]. */
+int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                           const float* segftrs, const uint32_t* labels, uint32_t T,
+                           double* grad, double* numer, double* Zx);
+/* posteriors for tests: gamma [N_seg][L], xi [T][L*L] (row T-1 unused) */
+int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                       double* gamma, double* xi, double* Zx);
+
+/* ---- a15: frame-level chain ----------------------------------------------- */
+int orc_frame_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                             const float* ftrs, const uint32_t* labels, uint32_t T,
+                             double* grad, double* numer, double* Zx);
+
+/* ---- a13/a14: minibatch accumulation + optimizer --------------------------- */
+/* grad = (sum_s sgrad[s]) / n_active, trainers/accumulators/CRF_Minibatch_GradAccumulator.cpp:296-308 */
+void orc_minibatch_reduce(const double* sgrad, uint32_t n_streams, const int32_t* active,
+                          uint32_t lambda_len, double* grad);
+/* trainers/CRF_SGTrainer.cpp:299-327 (useGvar off) */
+void orc_sgd_step(double* lambda, double* lambda_acc, double* grad_sqr_acc, double* grad,
+                  uint32_t n, double lr_or_eta, int use_adagrad, double eps);
+
+/* ---- a16..a18: lattice + best path ---------------------------------------- */
+typedef struct {
+  int32_t src, ilabel, olabel;
+  float w;
+  int32_t dst;
+} orc_arc;
+uint64_t orc_seg_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D);
+uint32_t orc_seg_lattice_num_states(uint32_t T, uint32_t L);
+/* arcs in chronological AddArc order; decoders/...WithoutSegTransFtr.h:30-407 */
+/* norm=0: final arcs carry (float)(-0.0); norm!=0: (float)(-(-alpha_sum)) as :371,397 */
+uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const double* M,
+                              uint32_t T, int norm, double alpha_sum, orc_arc* arcs,
+                              uint32_t* n_states, int32_t* final_state);
+uint64_t orc_frame_lattice_num_arcs(uint32_t T, uint32_t L);
+/* decoders/CRF_LatticeBuilder.h:97-204; norm=0: final arcs carry +0.0f, else (float)(-alpha_sum) */
+uint64_t orc_frame_lattice_arcs(const orc_config* cfg, const double* S, const double* M,
+                                uint32_t T, int norm, double alpha_sum, orc_arc* arcs,
+                                uint32_t* n_states, int32_t* final_state);
+/* ShortestPath(n=1) + Project(OUTPUT) + RmEpsilon + TopSort + (olabel-1):
+ * CRFFstDecode/src/Main.cpp:838-889.  Float tropical semiring, relaxation in state
+ * order, arcs of a state in insertion order, strict-improvement update (first relaxed
+ * wins ties).  OpenFST is absent from the image: tie-breaking is parity-unpinned.
+ * Returns number of labels written (<= max_out), or -1 if no path. */
+int64_t orc_best_path(const orc_arc* arcs, uint64_t n_arcs, uint32_t n_states, int32_t start,
+                      int32_t final_state, uint32_t* out_labels, uint64_t max_out,
+                      float* best_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCRF_ORACLE_H_ */

@@ -1,0 +1,275 @@
+"""Oracle self-consistency for rows a2-a18 (PARITY UNPINNED against the reference binary, see
+oracle/scrf_oracle.h): brute-force enumeration of all labelled segmentations, finite
+differences, the reference's own posterior-mass self-checks
+(nodes/CRF_StdSegStateNode_WithoutDurLab_WithoutSegTransFtr.cpp:917-947) and structural
+identities of the lattice (decoders/...WithoutSegTransFtr.h:30-407)."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from scrf_amd import synth
+
+
+def _case(L, D, T, in_w, trans_ftrs=False, seed=0, scale=0.3):
+    rng = np.random.RandomState(seed)
+    frames = rng.random_sample((T, in_w)).astype(np.float32)
+    Fs = orc.window_width(in_w, D, 0, 0, True)
+    if trans_ftrs:
+        # second stream: boundary context (lctx=rctx=1) around each window's first frame
+        pad = np.concatenate([frames[:1], frames, frames[-1:]])
+        Ft = orc.window_width(in_w, D, 1, 1, False)
+        X = np.zeros((orc.num_segs(T, D), Fs + Ft), dtype=np.float32)
+        orc.windows(frames, D, 0, 0, True, out=X, out_col=0)
+        orc.windows(pad, D, 1, 1, False, out=X, out_col=Fs)
+        cfg = orc.config(L=L, D=D, F=Fs + Ft, sfe=Fs - 1, use_trans_ftrs=True, tfs=Fs)
+    else:
+        X = orc.windows(frames, D)
+        cfg = orc.config(L=L, D=D, F=Fs)
+    lay = orc.Layout(cfg)
+    lam = rng.normal(0, scale, lay.lambda_len)
+    labels = synth.group_labels(synth.frame_labels(rng, T, L, D), D, L)
+    return cfg, lay, lam, X, labels
+
+
+@pytest.mark.parametrize("L,D,T,tf", [(2, 2, 4, False), (3, 3, 6, False), (2, 3, 5, True), (3, 2, 5, True),
+                                       (2, 1, 4, True), (3, 3, 1, False), (3, 3, 2, True)])
+def test_forward_backward_vs_enumeration(L, D, T, tf):
+    cfg, lay, lam, X, _ = _case(L, D, T, 2, tf, seed=L * 100 + D * 10 + T)
+    S, M = orc.seg_scores(cfg, lay, lam, X, T)
+    bf = orc.brute_force(S, M, T, L, D)
+    rc, ad, al, apt, zx = orc.seg_forward(cfg, S, M, T)
+    assert rc == 0
+    assert abs(zx - bf["Zx"]) < 1e-12 * max(1, abs(zx))
+    rc, g, xi, zx2 = orc.seg_posteriors(cfg, S, M, T)
+    assert rc == 0 and zx2 == zx
+    np.testing.assert_allclose(g, bf["gamma"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(xi[:T - 1], bf["xi"][:T - 1], rtol=0, atol=1e-12)
+    # reference self checks: per end frame, state mass == outgoing transition mass <= 1
+    for t in range(T):
+        b = orc.seg_base(t, D); nd = min(t + 1, D)
+        sm = g[b:b + nd].sum()
+        assert sm <= 1 + 1e-9
+        if t < T - 1:
+            assert abs(sm - xi[t].sum()) < 1e-9
+        else:
+            assert abs(sm - 1) < 1e-9
+
+
+@pytest.mark.parametrize("L,D,T,tf", [(3, 3, 7, False), (3, 2, 6, True), (4, 4, 9, True)])
+def test_gradient_is_derivative_of_loglik(L, D, T, tf):
+    """grad returned by buildGradient == d(numerator - Zx)/d lambda (central differences)."""
+    cfg, lay, lam, X, labels = _case(L, D, T, 2, tf, seed=5 + T)
+    rc, grad, numer, zx = orc.seg_build_gradient(cfg, lay, lam, X, labels, T)
+    assert rc == 0
+    rng = np.random.RandomState(1)
+    idx = rng.choice(lay.lambda_len, size=min(40, lay.lambda_len), replace=False)
+    eps = 1e-6
+    for i in idx:
+        lp = lam.copy(); lp[i] += eps
+        lm = lam.copy(); lm[i] -= eps
+        _, _, n1, z1 = orc.seg_build_gradient(cfg, lay, lp, X, labels, T)
+        _, _, n0, z0 = orc.seg_build_gradient(cfg, lay, lm, X, labels, T)
+        fd = ((n1 - z1) - (n0 - z0)) / (2 * eps)
+        assert abs(fd - grad[i]) < 2e-6 * max(1.0, abs(grad[i])), (i, fd, grad[i])
+
+
+def test_numerator_is_score_of_reference_path():
+    L, D, T = 3, 3, 9
+    cfg, lay, lam, X, labels = _case(L, D, T, 2, True, seed=11)
+    S, M = orc.seg_scores(cfg, lay, lam, X, T)
+    _, _, numer, zx = orc.seg_build_gradient(cfg, lay, lam, X, labels, T)
+    tot = 0.0
+    prev = None
+    for t in range(T):
+        if labels[t] == orc.LAB_BAD:
+            continue
+        l, d = int(labels[t]) % L, int(labels[t]) // L + 1
+        tot += S[orc.seg_base(t, D) + d - 1, l]
+        if prev is not None:
+            tot += M[t - d + 1, prev * L + l]
+        prev = l
+    assert abs(tot - numer) < 1e-12 * max(1, abs(tot))
+    assert numer <= zx + 1e-9
+
+
+def test_gradient_accumulates_into_caller_buffer():
+    cfg, lay, lam, X, labels = _case(3, 2, 5, 2, False, seed=3)
+    _, g1, _, _ = orc.seg_build_gradient(cfg, lay, lam, X, labels, 5)
+    pre = np.full(lay.lambda_len, 2.5)
+    _, g2, _, _ = orc.seg_build_gradient(cfg, lay, lam, X, labels, 5, grad=pre.copy())
+    np.testing.assert_allclose(g2 - 2.5, g1, atol=1e-12)
+
+
+def test_frame_model_equals_segmental_with_D1():
+    """CRF_StdStateNode (nodes/CRF_StdStateNode.cpp:58-299) is the D=1 case of the segmental node."""
+    L, T, F = 4, 7, 3
+    rng = np.random.RandomState(2)
+    X = rng.random_sample((T, F)).astype(np.float32)
+    labels = rng.randint(0, L, T).astype(np.uint32)
+    cf = orc.config(model_type=orc.STDFRAME, L=L, D=1, F=F, use_trans_ftrs=True)
+    cs = orc.config(L=L, D=1, F=F, use_trans_ftrs=True)
+    lay = orc.Layout(cf)
+    lam = rng.normal(0, 0.5, lay.lambda_len)
+    rc1, g1, n1, z1 = orc.frame_build_gradient(cf, lay, lam, X, labels, T)
+    rc2, g2, n2, z2 = orc.seg_build_gradient(cs, orc.Layout(cs), lam, X, labels, T)
+    assert rc1 == 0 and rc2 == 0
+    assert abs(z1 - z2) < 1e-12 * abs(z1) and abs(n1 - n2) < 1e-12 * max(1, abs(n1))
+    np.testing.assert_allclose(g1, g2, atol=1e-12)
+
+
+def test_bundled_crftrain_fixture_frame_crf():
+    """config 1: the reference's only data fixtures (CRFTrain/test*.ascii): 3 utterances of
+    4,3,4 frames, 3+3 joined features, labels 0..3, 48-label frame CRF.  No expected outputs
+    exist in the reference; we check it runs clean and the invariants hold."""
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    f1 = np.loadtxt(os.path.join(g, "crftrain_test.ascii"))
+    f2 = np.loadtxt(os.path.join(g, "crftrain_test.ftr2.ascii"))
+    lb = np.loadtxt(os.path.join(g, "crftrain_test.lab.ascii"))
+    assert (f1[:, :2] == f2[:, :2]).all() and (f1[:, :2] == lb[:, :2]).all()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6)
+    lay = orc.Layout(cfg)
+    assert lay.lambda_len == 2640
+    lam = synth.make_lambda(lay.lambda_len)
+    grad = np.zeros(lay.lambda_len)
+    lens = []
+    for u in range(3):
+        sel = f1[:, 0] == u
+        X = np.concatenate([f1[sel, 2:], f2[sel, 2:]], axis=1).astype(np.float32)
+        labels = lb[sel, 2].astype(np.uint32)
+        lens.append(int(sel.sum()))
+        rc, grad, numer, zx = orc.frame_build_gradient(cfg, lay, lam, X, labels, X.shape[0], grad=grad)
+        assert rc == 0 and numer < zx
+    assert lens == [4, 3, 4]
+    assert np.isfinite(grad).all() and np.abs(grad).max() > 0
+
+
+def test_windows_recipe():
+    """io/CRF_InFtrStream_SeqMultiWindow.cpp:556-884: [5 samples, avg, max, min, one-hot dur]."""
+    rng = np.random.RandomState(0)
+    T, W, D = 9, 3, 4
+    fr = rng.random_sample((T, W)).astype(np.float32)
+    X = orc.windows(fr, D)
+    assert X.shape == (orc.num_segs(T, D), 8 * W + D)
+    for t in range(T):
+        for d in range(1, min(t + 1, D) + 1):
+            x = X[orc.seg_base(t, D) + d - 1]
+            seg = fr[t - d + 1:t + 1]
+            ot = np.float32(d * 0.1)
+            for k, i in enumerate((1, 3, 5, 7, 9)):
+                step = int(np.ceil(np.float32(ot * np.float32(i)))) - 1
+                assert (x[k * W:(k + 1) * W] == seg[step]).all()
+            acc = np.zeros(W, np.float32)
+            for r in seg[::-1]:
+                acc = (acc + r).astype(np.float32)
+            assert (x[5 * W:6 * W] == (acc / np.float32(d)).astype(np.float32)).all()
+            assert (x[6 * W:7 * W] == seg.max(0)).all() and (x[7 * W:8 * W] == seg.min(0)).all()
+            oh = np.zeros(D, np.float32); oh[d - 1] = 1
+            assert (x[8 * W:] == oh).all()
+    # boundary-context stream: [lctx frames before first | first | rctx frames after first]
+    pad = np.concatenate([fr[:1], fr[:1], fr, fr[-1:]])
+    Xc = orc.windows(pad, D, 2, 1, False)
+    assert Xc.shape[1] == 4 * W
+    for t in range(T):
+        for d in range(1, min(t + 1, D) + 1):
+            first = t - d + 1
+            assert (Xc[orc.seg_base(t, D) + d - 1] == pad[first:first + 4].ravel()).all()
+
+
+def test_group_labels_splits_long_runs():
+    L, D = 5, 3
+    fl = np.array([1, 1, 2, 2, 2, 2, 2, 2, 2, 0, 3, 3, 3, 3], np.uint32)
+    out = orc.group_labels(fl, D, L)
+    assert (out == synth.group_labels(fl, D, L)).all()
+    B = orc.LAB_BAD
+    # run of 7 twos -> 3 pieces 3,2,2 ; run of 4 threes -> 2 pieces 2,2
+    exp = [B, L * 1 + 1, B, B, L * 2 + 2, B, L * 1 + 2, B, L * 1 + 2, 0, B, L * 1 + 3, B, L * 1 + 3]
+    assert list(out) == exp
+
+
+@pytest.mark.parametrize("L,D,T", [(2, 2, 1), (3, 3, 2), (3, 2, 6), (2, 4, 7)])
+def test_segmental_lattice_structure_and_best_path(L, D, T):
+    cfg, lay, lam, X, _ = _case(L, D, T, 2, True, seed=40 + T, scale=1.0)
+    S, M = orc.seg_scores(cfg, lay, lam, X, T)
+    arcs, ns, fin = orc.seg_lattice_arcs(cfg, S, M, T)
+    assert len(arcs) == (T - 1) * L * L + orc.num_segs(T, D) * L + L
+    assert ns == 2 * L * T - L + 2 and fin == ns - 1
+    assert (arcs["dst"] > arcs["src"]).all()  # built top-sorted
+    eps = arcs["ilabel"] == 0
+    assert (arcs["olabel"] == arcs["ilabel"]).all()
+    fin_arcs = arcs[arcs["dst"] == fin]
+    assert len(fin_arcs) == L and (fin_arcs["w"] == 0).all() and np.signbit(fin_arcs["w"]).all()  # -0.0f
+    # every non-epsilon arc weight is float(-S), every boundary arc float(-M)
+    lab = arcs["ilabel"][~eps] - 1
+    assert lab.max() < L * D
+    labels, cost = orc.best_path(arcs, ns, fin)
+    bf = orc.brute_force(S, M, T, L, D)
+    best_sc, best_segs = bf["best"]
+    assert [l + L * (d - 1) for (_, d, l) in best_segs] == list(labels)
+    assert abs(-cost - best_sc) < 1e-4 * max(1, abs(best_sc))
+
+
+def test_frame_lattice_best_path():
+    L, T, F = 3, 5, 2
+    rng = np.random.RandomState(9)
+    X = rng.random_sample((T, F)).astype(np.float32)
+    cfg = orc.config(L=L, D=1, F=F, use_trans_ftrs=True)
+    lay = orc.Layout(cfg)
+    lam = rng.normal(0, 1.0, lay.lambda_len)
+    S, M = orc.seg_scores(cfg, lay, lam, X, T)
+    arcs, ns, fin = orc.frame_lattice_arcs(cfg, S, M, T)
+    assert len(arcs) == L + (T - 1) * L * L + L and ns == L * T + 2
+    fa = arcs[arcs["dst"] == fin]
+    assert (fa["w"] == 0).all() and not np.signbit(fa["w"]).any()  # +0.0f (CRF_LatticeBuilder.h:194-204)
+    labels, cost = orc.best_path(arcs, ns, fin)
+    bf = orc.brute_force(S, M, T, L, 1)
+    assert [l for (_, _, l) in bf["best"][1]] == list(labels)
+
+
+def test_best_path_tie_rule_first_relaxed_wins():
+    """lambda = 0 ties everything: state-order relaxation keeps the lowest source state, i.e.
+    the longest duration (start state first) and the lowest label."""
+    L, D, T = 3, 2, 4
+    cfg = orc.config(L=L, D=D, F=8 * 2 + D)
+    S = np.zeros((orc.num_segs(T, D), L)); M = np.zeros((T, L * L))
+    arcs, ns, fin = orc.seg_lattice_arcs(cfg, S, M, T)
+    labels, cost = orc.best_path(arcs, ns, fin)
+    assert cost == 0
+    assert list(labels) == [0 + L * 1, 0 + L * 1]  # two segments of duration 2, label 0
+
+
+def test_minibatch_reduce_and_sgd_step():
+    rng = np.random.RandomState(4)
+    sg = rng.normal(size=(4, 11))
+    out = orc.minibatch_reduce(sg, [1, 1, 0, 1])
+    exp = ((sg[0] + sg[1]) + sg[3]) / 3
+    assert (out == exp).all()
+    lam = rng.normal(size=11); acc = np.zeros(11); gsa = np.zeros(11); g = out.copy()
+    l0 = lam.copy()
+    orc.sgd_step(lam, acc, gsa, g, 0.1, False)
+    assert (lam == l0 + 0.1 * out).all() and (acc == lam).all() and (g == 0).all()
+    g = out.copy(); l1 = lam.copy()
+    orc.sgd_step(lam, acc, gsa, g, 1.0, True)
+    assert (gsa == out * out).all()
+    assert (lam == l1 + 1.0 / (np.sqrt(out * out) + 1e-12) * out).all()
+
+
+def test_threaded_cpu_path_matches_serial_and_is_thread_count_invariant():
+    L, D, in_w, U, T = 4, 3, 3, 6, 12
+    frames, labels, off = synth.make_batch(U, T, in_w, L, D, seed=77)
+    cfg = orc.config(L=L, D=D, F=8 * in_w + D)
+    lay = orc.Layout(cfg)
+    lam = synth.make_lambda(lay.lambda_len, scale=0.2)
+    rc1, g1, n1, z1, _ = orc.bench_fb(cfg, lam, frames, labels, off, in_w, 1)
+    rc3, g3, n3, z3, _ = orc.bench_fb(cfg, lam, frames, labels, off, in_w, 3)
+    assert rc1 == 0 and rc3 == 0
+    assert (n1 == n3).all() and (z1 == z3).all()
+    # 1 stream: plain sum; 3 streams: sum / 3 (averaged over ACTIVE STREAMS, not utterances)
+    np.testing.assert_allclose(g3 * 3, g1, rtol=1e-12, atol=1e-12)
+    tot = np.zeros(lay.lambda_len)
+    for u in range(U):
+        X = orc.windows(frames[int(off[u]):int(off[u + 1])], D)
+        rc, tot, nu, zu = orc.seg_build_gradient(cfg, lay, lam, X, labels[int(off[u]):int(off[u + 1])], T, grad=tot)
+        assert nu == n1[u] and zu == z1[u]
+    assert (tot == g1).all()

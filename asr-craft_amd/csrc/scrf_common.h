@@ -1,0 +1,65 @@
+// scrf_common.h -- shared host/device definitions of the MI355X segmental-CRF engine.
+// gfx950 only: 64-wide wavefronts are assumed throughout.
+#ifndef SCRF_COMMON_H_
+#define SCRF_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scrf_abi.h"
+
+#define SCRF_WAVE 64
+
+// Lambda layout and feature ranges, closed form of CRF_StdFeatureMap::recalc /
+// computeStateFeatureIdx / computeTransFeatureIdx for numStates == 1
+// (ftrmaps/CRF_StdFeatureMap.cpp:280-320,355-410,472-517): per current label c a block
+// [nsf state weights (features ascending, bias last)][for p: ntf weights of (p->c)].
+struct ScrfLayout {
+  uint32_t L, D, F;
+  int32_t use_sf, use_tf, use_sb, use_tb;
+  uint32_t sfs, sfe, tfs, tfe;
+  double sbv, tbv;
+  uint32_t nsf, ntf;   // numStateFuncs, numTransFuncs (bias included)
+  uint32_t nsfe, ntfe; // feature counts excluding bias
+  uint32_t stride;     // nsf + L*ntf
+  uint32_t lambda_len;
+
+  __host__ __device__ inline uint32_t state_idx(uint32_t c) const { return c * stride; }
+  __host__ __device__ inline uint32_t trans_idx(uint32_t p, uint32_t c) const {
+    return c * stride + nsf + p * ntf;
+  }
+};
+
+// windows ending at frame t: min(t+1, D) (gradbuilder :243-251)
+__host__ __device__ inline uint32_t scrf_node_max_dur(uint32_t t, uint32_t D) {
+  return (t + 1 <= D) ? t + 1 : D;
+}
+// number of previous nodes linked to node t (gradbuilder :258-266)
+__host__ __device__ inline uint32_t scrf_num_prev(uint32_t t, uint32_t D) {
+  return (t + 1 <= D) ? t : D;
+}
+// row of window d=1 of frame t inside its utterance; scrf_seg_base(T) = N_seg
+__host__ __device__ inline uint64_t scrf_seg_base(uint32_t t, uint32_t D) {
+  return (t < D) ? (uint64_t)t * (t + 1) / 2
+                 : (uint64_t)D * (D + 1) / 2 + (uint64_t)(t - D) * D;
+}
+// lattice bookkeeping (decoders/...WithoutSegTransFtr.h:248-330): first state id of node t
+__host__ __device__ inline int32_t scrf_node_start_state(uint32_t t, uint32_t L) {
+  return (t == 0) ? 1 : (int32_t)(1 + L + (t - 1) * 2 * L);
+}
+// index of the first arc emitted while visiting node t
+__host__ __device__ inline uint64_t scrf_arc_base(uint32_t t, uint32_t L, uint32_t D) {
+  return (t == 0) ? 0 : (uint64_t)L + (uint64_t)(t - 1) * L * L + (uint64_t)L * (scrf_seg_base(t, D) - 1);
+}
+
+// Device view of a packed batch (all arrays in HBM).
+struct ScrfBatchView {
+  uint32_t U;
+  const uint32_t* T;          // [U]
+  const uint64_t* frame_off;  // [U+1]
+  const uint64_t* seg_off;    // [U+1]
+  const uint64_t* arc_off;    // [U+1]
+  const uint32_t* labels;     // [sum T] or nullptr
+};
+
+#endif  // SCRF_COMMON_H_

@@ -1,0 +1,1003 @@
+// scrf_engine.cpp -- host side of libscrf_amd.so: the C ABI of include/scrf_abi.h on top of
+// the HIP kernels.  One engine = one GPU, one HIP stream; batches live in HBM; scratch is a
+// single device arena carved per chunk of utterances.  There is NO CPU compute path here:
+// without a HIP device scrf_create fails with SCRF_ERR_NO_DEVICE.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "scrf_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// RCCL, bound lazily (so that loading the library never drags a second RCCL into a process
+// that already has one, e.g. under torch.distributed)
+// ---------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } scrf_nccl_uid;
+typedef void* scrf_nccl_comm;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(scrf_nccl_uid*) = nullptr;
+  int (*CommInitRank)(scrf_nccl_comm*, int, scrf_nccl_uid, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, scrf_nccl_comm, hipStream_t) = nullptr;
+  int (*CommDestroy)(scrf_nccl_comm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static bool rccl_load(std::string* why) {
+  if (g_rccl.lib) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) {
+    *why = std::string("cannot load RCCL: ") + dlerror();
+    return false;
+  }
+  g_rccl.GetUniqueId = (int (*)(scrf_nccl_uid*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(scrf_nccl_comm*, int, scrf_nccl_uid, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, scrf_nccl_comm, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(scrf_nccl_comm))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) {
+    *why = "RCCL symbols missing";
+    return false;
+  }
+  return true;
+}
+enum { SCRF_NCCL_DOUBLE = 8, SCRF_NCCL_SUM = 0 };  // ncclFloat64, ncclSum (rccl.h)
+
+// ---------------------------------------------------------------------------------------------
+struct scrf_engine_s {
+  scrf_config cfg;
+  ScrfLayout lay;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double* d_lambda = nullptr;
+  double* d_lambda_acc = nullptr;
+  double* d_gsa = nullptr;
+  double* d_grad = nullptr;
+  bool own_grad = true;
+  double* d_m0 = nullptr;     // [L*L] time-invariant transition scores (bias-only transitions)
+  bool m0_valid = false;
+  double* d_sums = nullptr;   // {numer, zx, n_utts, active}
+  char* scratch = nullptr;
+  size_t scratch_cap = 0;
+  std::string err;
+  bool timing = false;
+  hipEvent_t ev[SCRF_N_PHASES + 1][2];
+  bool ev_ok = false;
+  float ms[SCRF_N_PHASES];
+  uint32_t nlaunch[SCRF_N_PHASES];
+  scrf_nccl_comm comm = nullptr;
+  int rank = 0, nranks = 1;
+};
+
+struct scrf_batch_s {
+  uint32_t U = 0;
+  int mode = 0;  // 0 = windows resident, 1 = frames + recipe
+  std::vector<uint32_t> T;
+  std::vector<uint64_t> frame_off, seg_off, arc_off;
+  uint32_t* d_T = nullptr;
+  uint64_t* d_frame_off = nullptr;
+  uint64_t* d_seg_off = nullptr;
+  uint64_t* d_arc_off = nullptr;
+  uint32_t* d_labels = nullptr;
+  float* d_windows = nullptr;
+  uint32_t n_streams = 0;
+  scrf_stream_recipe recipe[SCRF_MAX_STREAMS];
+  uint32_t width[SCRF_MAX_STREAMS];
+  float* d_frames[SCRF_MAX_STREAMS] = {nullptr, nullptr, nullptr};
+  uint64_t* d_sframe_off[SCRF_MAX_STREAMS] = {nullptr, nullptr, nullptr};
+  double* d_numer = nullptr;
+  double* d_zx = nullptr;
+  int* d_status = nullptr;
+  ScrfBatchView view() const {
+    ScrfBatchView v;
+    v.U = U; v.T = d_T; v.frame_off = d_frame_off; v.seg_off = d_seg_off; v.arc_off = d_arc_off;
+    v.labels = d_labels;
+    return v;
+  }
+};
+
+static std::string g_create_err;
+
+static int fail(scrf_handle h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(h, SCRF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+static uint32_t window_width(const scrf_stream_recipe& r, uint32_t D) {
+  // io/CRF_InFtrStream_SeqMultiWindow.cpp:50-125
+  if (D == 1) return (r.left_ctx + 1 + r.right_ctx) * r.in_width;
+  if (r.extract_seg_ftr) return 8 * r.in_width + D + (r.left_ctx + r.right_ctx) * r.in_width;
+  return (r.left_ctx + 1 + r.right_ctx) * r.in_width;
+}
+
+static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
+  if (c.abi_version != SCRF_ABI_VERSION) { *why = "abi_version mismatch"; return SCRF_ERR_INVALID; }
+  if (c.num_states != 1) { *why = "only crf_states=1 is built (multi-state nodes are out of scope)"; return SCRF_ERR_INVALID; }
+  if (c.num_labs == 0 || c.lab_max_dur == 0 || c.num_feas == 0) { *why = "num_labs, lab_max_dur, num_feas must be > 0"; return SCRF_ERR_INVALID; }
+  if (c.model_type == SCRF_STDSEG || c.model_type == SCRF_STDSEG_NO_DUR) { *why = "model types stdseg / stdseg_no_dur are not built yet"; return SCRF_ERR_INVALID; }
+  if (c.model_type > SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR) { *why = "unknown model_type"; return SCRF_ERR_INVALID; }
+  if (c.model_type == SCRF_STDFRAME && c.lab_max_dur != 1) { *why = "the maximum duration of labels must be 1 for \"stdframe\" CRF model."; return SCRF_ERR_INVALID; }  // CRFTrain/src/Main.cpp:574-578
+  if (c.map_type > SCRF_STDTRANS) { *why = "only dense stdstate/stdtrans feature maps are built"; return SCRF_ERR_INVALID; }
+  if (c.num_labs > 1024) { *why = "num_labs > 1024 unsupported"; return SCRF_ERR_INVALID; }
+  memset(l, 0, sizeof(*l));
+  l->L = c.num_labs; l->D = c.lab_max_dur; l->F = c.num_feas;
+  l->use_sf = c.use_state_ftrs != 0; l->use_tf = c.use_trans_ftrs != 0;
+  l->use_sb = c.use_state_bias != 0; l->use_tb = c.use_trans_bias != 0;
+  l->sfs = c.state_fidx_start; l->sfe = c.state_fidx_end; l->tfs = c.trans_fidx_start; l->tfe = c.trans_fidx_end;
+  l->sbv = c.state_bias_val; l->tbv = c.trans_bias_val;
+  if (l->use_sf && (l->sfe < l->sfs || l->sfe >= l->F)) { *why = "state feature range outside the window vector"; return SCRF_ERR_INVALID; }
+  if (l->use_tf && (l->tfe < l->tfs || l->tfe >= l->F)) { *why = "transition feature range outside the window vector"; return SCRF_ERR_INVALID; }
+  l->nsfe = l->use_sf ? l->sfe - l->sfs + 1 : 0;
+  l->ntfe = l->use_tf ? l->tfe - l->tfs + 1 : 0;
+  l->nsf = l->nsfe + (l->use_sb ? 1 : 0);
+  l->ntf = l->ntfe + (l->use_tb ? 1 : 0);
+  l->stride = l->nsf + l->L * l->ntf;
+  uint64_t ll = (uint64_t)l->L * l->stride;
+  if (ll == 0 || ll > 0xfffffff0ull) { *why = "lambda_len out of range"; return SCRF_ERR_INVALID; }
+  l->lambda_len = (uint32_t)ll;
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------------
+extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
+  if (!cfg || !out) return fail(nullptr, SCRF_ERR_INVALID, "scrf_create: null argument");
+  *out = nullptr;
+  ScrfLayout lay;
+  std::string why;
+  int rc = build_layout(*cfg, &lay, &why);
+  if (rc != SCRF_OK) return fail(nullptr, rc, "scrf_create: %s", why.c_str());
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, SCRF_ERR_NO_DEVICE, "scrf_create: no HIP device (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev)
+    return fail(nullptr, SCRF_ERR_INVALID, "scrf_create: device_id %d out of range [0,%d)", cfg->device_id, ndev);
+  scrf_handle h = new scrf_engine_s();
+  h->cfg = *cfg;
+  h->lay = lay;
+  h->device = cfg->device_id;
+  if (h->cfg.scratch_bytes == 0) h->cfg.scratch_bytes = 8ull << 30;
+  memset(h->ms, 0, sizeof(h->ms));
+  memset(h->nlaunch, 0, sizeof(h->nlaunch));
+#define CRCHK(call)                                                                          \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      fail(nullptr, SCRF_ERR_HIP, "scrf_create: %s failed: %s", #call, hipGetErrorString(e_)); \
+      delete h;                                                                              \
+      return SCRF_ERR_HIP;                                                                   \
+    }                                                                                        \
+  } while (0)
+  CRCHK(hipSetDevice(h->device));
+  CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->own_stream = true;
+  size_t nb = sizeof(double) * lay.lambda_len;
+  CRCHK(hipMalloc((void**)&h->d_lambda, nb));
+  CRCHK(hipMalloc((void**)&h->d_lambda_acc, nb));
+  CRCHK(hipMalloc((void**)&h->d_gsa, nb));
+  CRCHK(hipMalloc((void**)&h->d_grad, nb));
+  CRCHK(hipMalloc((void**)&h->d_m0, sizeof(double) * lay.L * lay.L));
+  CRCHK(hipMalloc((void**)&h->d_sums, sizeof(double) * 4));
+  CRCHK(hipMemsetAsync(h->d_lambda, 0, nb, h->stream));
+  CRCHK(hipMemsetAsync(h->d_lambda_acc, 0, nb, h->stream));
+  CRCHK(hipMemsetAsync(h->d_gsa, 0, nb, h->stream));
+  CRCHK(hipMemsetAsync(h->d_grad, 0, nb, h->stream));
+  CRCHK(hipMemsetAsync(h->d_sums, 0, sizeof(double) * 4, h->stream));
+  for (int i = 0; i <= SCRF_N_PHASES; i++) {
+    CRCHK(hipEventCreate(&h->ev[i][0]));
+    CRCHK(hipEventCreate(&h->ev[i][1]));
+  }
+  h->ev_ok = true;
+  CRCHK(hipStreamSynchronize(h->stream));
+#undef CRCHK
+  *out = h;
+  return SCRF_OK;
+}
+
+extern "C" int scrf_destroy(scrf_handle h) {
+  if (!h) return SCRF_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  hipFree(h->d_lambda); hipFree(h->d_lambda_acc); hipFree(h->d_gsa);
+  if (h->own_grad) hipFree(h->d_grad);
+  hipFree(h->d_m0); hipFree(h->d_sums); hipFree(h->scratch);
+  if (h->ev_ok)
+    for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return SCRF_OK;
+}
+
+extern "C" const char* scrf_last_error(scrf_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int scrf_set_stream(scrf_handle h, void* s) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->own_stream) { hipStreamDestroy(h->stream); h->own_stream = false; }
+  if (s) {
+    h->stream = (hipStream_t)s;
+  } else {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return SCRF_OK;
+}
+
+extern "C" int scrf_synchronize(scrf_handle h) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout hooks / model state
+// ---------------------------------------------------------------------------------------------
+extern "C" int scrf_lambda_len(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->lay.lambda_len; return SCRF_OK; }
+extern "C" int scrf_num_state_funcs(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->lay.nsf; return SCRF_OK; }
+extern "C" int scrf_num_trans_funcs(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->lay.ntf; return SCRF_OK; }
+extern "C" int scrf_state_idx(scrf_handle h, uint32_t clab, uint32_t fno, uint32_t* idx) {
+  if (!h || !idx) return SCRF_ERR_INVALID;
+  if (clab >= h->lay.L) return fail(h, SCRF_ERR_INVALID, "scrf_state_idx: label %u >= %u", clab, h->lay.L);
+  *idx = h->lay.state_idx(clab) + fno;  // getStateFeatureIdx :421-423
+  return SCRF_OK;
+}
+extern "C" int scrf_trans_idx(scrf_handle h, uint32_t plab, uint32_t clab, uint32_t fno, uint32_t* idx) {
+  if (!h || !idx) return SCRF_ERR_INVALID;
+  if (clab >= h->lay.L || plab >= h->lay.L) return fail(h, SCRF_ERR_INVALID, "scrf_trans_idx: label out of range");
+  *idx = h->lay.trans_idx(plab, clab) + fno;  // getTransFeatureIdx :435-437
+  return SCRF_OK;
+}
+
+static int vec_io(scrf_handle h, double* dev, const double* in, double* out, uint32_t n, const char* what) {
+  if (!h || (!in && !out)) return SCRF_ERR_INVALID;
+  if (n != h->lay.lambda_len) return fail(h, SCRF_ERR_INVALID, "%s: length %u != lambda_len %u", what, n, h->lay.lambda_len);
+  HIPCHK(h, hipSetDevice(h->device));
+  if (in) HIPCHK(h, hipMemcpyAsync(dev, in, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(h, hipMemcpyAsync(out, dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SCRF_OK;
+}
+extern "C" int scrf_set_lambda(scrf_handle h, const double* v, uint32_t n) {
+  int rc = vec_io(h, h ? h->d_lambda : nullptr, v, nullptr, n, "scrf_set_lambda");
+  if (rc == SCRF_OK) h->m0_valid = false;
+  return rc;
+}
+extern "C" int scrf_get_lambda(scrf_handle h, double* v, uint32_t n) { return vec_io(h, h ? h->d_lambda : nullptr, nullptr, v, n, "scrf_get_lambda"); }
+extern "C" int scrf_set_lambda_acc(scrf_handle h, const double* v, uint32_t n) { return vec_io(h, h ? h->d_lambda_acc : nullptr, v, nullptr, n, "scrf_set_lambda_acc"); }
+extern "C" int scrf_get_lambda_acc(scrf_handle h, double* v, uint32_t n) { return vec_io(h, h ? h->d_lambda_acc : nullptr, nullptr, v, n, "scrf_get_lambda_acc"); }
+extern "C" int scrf_set_grad_sqr_acc(scrf_handle h, const double* v, uint32_t n) { return vec_io(h, h ? h->d_gsa : nullptr, v, nullptr, n, "scrf_set_grad_sqr_acc"); }
+extern "C" int scrf_get_grad_sqr_acc(scrf_handle h, double* v, uint32_t n) { return vec_io(h, h ? h->d_gsa : nullptr, nullptr, v, n, "scrf_get_grad_sqr_acc"); }
+extern "C" int scrf_get_grad(scrf_handle h, double* v, uint32_t n) { return vec_io(h, h ? h->d_grad : nullptr, nullptr, v, n, "scrf_get_grad"); }
+
+extern "C" int scrf_zero_grad(scrf_handle h) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemsetAsync(h->d_grad, 0, sizeof(double) * h->lay.lambda_len, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_sums, 0, sizeof(double) * 4, h->stream));
+  return SCRF_OK;
+}
+
+extern "C" int scrf_grad_device_ptr(scrf_handle h, void** p) { if (!h || !p) return SCRF_ERR_INVALID; *p = h->d_grad; return SCRF_OK; }
+
+extern "C" int scrf_set_grad_buffer(scrf_handle h, void* dptr) {
+  // accumulate into caller-owned device memory (e.g. a torch tensor that torch.distributed
+  // all-reduces over RCCL); NULL restores the engine's own buffer
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (dptr) {
+    if (h->own_grad) hipFree(h->d_grad);
+    h->d_grad = (double*)dptr;
+    h->own_grad = false;
+  } else if (!h->own_grad) {
+    HIPCHK(h, hipMalloc((void**)&h->d_grad, sizeof(double) * h->lay.lambda_len));
+    HIPCHK(h, hipMemsetAsync(h->d_grad, 0, sizeof(double) * h->lay.lambda_len, h->stream));
+    h->own_grad = true;
+  }
+  return SCRF_OK;
+}
+
+extern "C" int scrf_get_batch_sums(scrf_handle h, double* sums3) {
+  if (!h || !sums3) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(sums3, h->d_sums, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scratch arena
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+  char* base;
+  size_t cap, off;
+  template <class Tp> Tp* take(size_t n) {
+    size_t bytes = (n * sizeof(Tp) + 255) & ~(size_t)255;
+    Tp* p = (Tp*)(base + off);
+    off += bytes;
+    return p;
+  }
+};
+static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int ensure_scratch(scrf_handle h, size_t bytes) {
+  if (bytes <= h->scratch_cap) return SCRF_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->scratch) hipFree(h->scratch);
+  h->scratch = nullptr;
+  h->scratch_cap = 0;
+  hipError_t e = hipMalloc((void**)&h->scratch, bytes);
+  if (e != hipSuccess) return fail(h, SCRF_ERR_HIP, "scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+  h->scratch_cap = bytes;
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------------------------
+template <class Tp>
+static int upload(scrf_handle h, Tp** d, const Tp* src, size_t n) {
+  *d = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(h, hipMalloc((void**)d, sizeof(Tp) * n));
+  if (src) HIPCHK(h, hipMemcpyAsync(*d, src, sizeof(Tp) * n, hipMemcpyHostToDevice, h->stream));
+  return SCRF_OK;
+}
+
+extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
+  if (!b) return SCRF_OK;
+  if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
+  hipFree(b->d_T); hipFree(b->d_frame_off); hipFree(b->d_seg_off); hipFree(b->d_arc_off);
+  hipFree(b->d_labels); hipFree(b->d_windows);
+  for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
+  hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
+  delete b;
+  return SCRF_OK;
+}
+
+extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n, uint32_t n_streams,
+                                 const scrf_stream_recipe* recipes, scrf_batch* out) {
+  if (!h || !out || (!utts && n)) return SCRF_ERR_INVALID;
+  *out = nullptr;
+  HIPCHK(h, hipSetDevice(h->device));
+  const ScrfLayout& lay = h->lay;
+  if (n == 0) return fail(h, SCRF_ERR_EMPTY, "scrf_batch_create: empty batch");
+  const bool by_windows = utts[0].windows != nullptr;
+  if (!by_windows) {
+    if (n_streams == 0 || n_streams > SCRF_MAX_STREAMS || !recipes)
+      return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: frame input needs 1..%d stream recipes", SCRF_MAX_STREAMS);
+    uint32_t tot = 0;
+    for (uint32_t s = 0; s < n_streams; s++) {
+      if (recipes[s].in_width == 0) return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: stream %u has in_width 0", s);
+      tot += window_width(recipes[s], lay.D);
+    }
+    if (tot != lay.F)
+      return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: joined window width %u != num_feas %u", tot, lay.F);
+  }
+  scrf_batch b = new scrf_batch_s();
+  b->U = n;
+  b->mode = by_windows ? 0 : 1;
+  b->n_streams = by_windows ? 0 : n_streams;
+  b->T.resize(n);
+  b->frame_off.assign(n + 1, 0); b->seg_off.assign(n + 1, 0); b->arc_off.assign(n + 1, 0);
+  bool have_labels = utts[0].labels != nullptr;
+  for (uint32_t u = 0; u < n; u++) {
+    const scrf_utt& q = utts[u];
+    if ((q.windows != nullptr) != by_windows) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: utterance %u mixes window and frame input", u); }
+    if ((q.labels != nullptr) != have_labels) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: labels given for some utterances only"); }
+    if (q.T == 0) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_EMPTY, "scrf_batch_create: utterance %u: No features read from this sentence.", u); }
+    b->T[u] = q.T;
+    b->frame_off[u + 1] = b->frame_off[u] + q.T;
+    b->seg_off[u + 1] = b->seg_off[u] + scrf_seg_base(q.T, lay.D);
+    uint64_t na = (lay.D == 1 && h->cfg.model_type == SCRF_STDFRAME)
+                      ? (uint64_t)lay.L + (uint64_t)(q.T - 1) * lay.L * lay.L + lay.L
+                      : scrf_arc_base(q.T, lay.L, lay.D) + lay.L;
+    b->arc_off[u + 1] = b->arc_off[u] + na;
+  }
+  const uint64_t NF = b->frame_off[n], NS = b->seg_off[n];
+  int rc;
+#define BCHK(x) do { rc = (x); if (rc != SCRF_OK) { scrf_batch_destroy(h, b); return rc; } } while (0)
+  BCHK(upload(h, &b->d_T, b->T.data(), n));
+  BCHK(upload(h, &b->d_frame_off, b->frame_off.data(), n + 1));
+  BCHK(upload(h, &b->d_seg_off, b->seg_off.data(), n + 1));
+  BCHK(upload(h, &b->d_arc_off, b->arc_off.data(), n + 1));
+  if (have_labels) {
+    std::vector<uint32_t> lab(NF);
+    for (uint32_t u = 0; u < n; u++) memcpy(&lab[b->frame_off[u]], utts[u].labels, sizeof(uint32_t) * utts[u].T);
+    BCHK(upload(h, &b->d_labels, lab.data(), NF));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  if (by_windows) {
+    BCHK(upload<float>(h, &b->d_windows, nullptr, NS * lay.F));
+    for (uint32_t u = 0; u < n; u++) {
+      hipError_t e = hipMemcpyAsync(b->d_windows + b->seg_off[u] * lay.F, utts[u].windows,
+                                    sizeof(float) * (b->seg_off[u + 1] - b->seg_off[u]) * lay.F, hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "window upload failed: %s", hipGetErrorString(e)); }
+    }
+  } else {
+    for (uint32_t s = 0; s < n_streams; s++) {
+      b->recipe[s] = recipes[s];
+      b->width[s] = window_width(recipes[s], lay.D);
+      const uint32_t pad = recipes[s].left_ctx + recipes[s].right_ctx;
+      std::vector<uint64_t> so(n + 1, 0);
+      for (uint32_t u = 0; u < n; u++) {
+        if (!utts[u].frames[s]) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: utterance %u has no frames for stream %u", u, s); }
+        so[u + 1] = so[u] + utts[u].T + pad;
+      }
+      BCHK(upload(h, &b->d_sframe_off[s], so.data(), n + 1));
+      BCHK(upload<float>(h, &b->d_frames[s], nullptr, so[n] * recipes[s].in_width));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (uint32_t u = 0; u < n; u++) {
+        hipError_t e = hipMemcpyAsync(b->d_frames[s] + so[u] * recipes[s].in_width, utts[u].frames[s],
+                                      sizeof(float) * (so[u + 1] - so[u]) * recipes[s].in_width, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "frame upload failed: %s", hipGetErrorString(e)); }
+      }
+    }
+  }
+  BCHK(upload<double>(h, &b->d_numer, nullptr, n));
+  BCHK(upload<double>(h, &b->d_zx, nullptr, n));
+  BCHK(upload<int>(h, &b->d_status, nullptr, n));
+#undef BCHK
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *out = b;
+  return SCRF_OK;
+}
+
+extern "C" int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, uint64_t* n_frames, uint64_t* n_segs, uint64_t* n_arcs) {
+  if (!h || !b) return SCRF_ERR_INVALID;
+  if (n_utts) *n_utts = b->U;
+  if (n_frames) *n_frames = b->frame_off[b->U];
+  if (n_segs) *n_segs = b->seg_off[b->U];
+  if (n_arcs) *n_arcs = b->arc_off[b->U];
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunk planning and the per-chunk pipeline
+// ---------------------------------------------------------------------------------------------
+enum { PH_WIN = 0, PH_SCORE = 1, PH_FB = 2, PH_EXPF = 3, PH_REDUCE = 4, PH_VIT = 5, PH_ALL = 6 };
+#define EXPF_ROWS_PER_CHUNK 4096ull
+
+struct ChunkBufs {
+  float* X = nullptr;        // window vectors of the chunk (scratch, or a view into the batch)
+  double* S = nullptr;       // [nseg][L]
+  double* M = nullptr;       // [nfr][L*L] or engine M0
+  int m_per_frame = 0;
+  double* AD = nullptr;      // [nseg][L]
+  double* alpha = nullptr;   // [nfr][L]
+  double* beta = nullptr;    // [nfr][L] (parity hooks only)
+  double* XI = nullptr;      // [nfr][L*L]
+  double* xi_acc = nullptr;  // [nutt][L*L]
+  uint64_t* xrow_cur = nullptr;
+  uint64_t* xrow_next = nullptr;
+  double* slab_s = nullptr;
+  double* slab_t = nullptr;
+  uint16_t* bp_b = nullptr;
+  uint16_t* bp_e = nullptr;
+  uint32_t nch_s = 0, nch_t = 0;
+  uint64_t rpc_t = 0;
+};
+
+struct Need { bool fb, post, beta, vit; };
+
+static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t nfr, uint64_t nseg, const Need& nd) {
+  const ScrfLayout& l = h->lay;
+  const size_t LL = (size_t)l.L * l.L;
+  size_t tot = 0;
+  if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
+  tot += pad256(nseg * l.L * sizeof(double));                       // S
+  if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
+  if (nd.fb) {
+    tot += pad256(nseg * l.L * sizeof(double));                     // AD
+    tot += pad256(nfr * l.L * sizeof(double));                      // alpha
+    if (nd.beta) tot += pad256(nfr * l.L * sizeof(double));
+    if (nd.post) {
+      if (l.use_tf) {
+        tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
+        uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
+        tot += pad256((size_t)nch_t * LL * l.ntf * sizeof(double));
+      } else {
+        tot += pad256(nutt * LL * sizeof(double));
+      }
+      uint64_t nch_s = (nseg + EXPF_ROWS_PER_CHUNK - 1) / EXPF_ROWS_PER_CHUNK;
+      tot += pad256(nch_s * l.L * l.nsf * sizeof(double));
+    }
+  }
+  if (nd.vit) tot += 2 * pad256(nfr * l.L * sizeof(uint16_t));
+  return tot + 4096;
+}
+
+// largest u1 > u0 whose chunk fits the budget (always at least one utterance)
+static uint32_t plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, const Need& nd) {
+  uint32_t u1 = u0 + 1;
+  const uint32_t max_utts = 65535;  // grid.x of the per-frame kernels stays small enough anyway
+  while (u1 < b->U && u1 - u0 < max_utts) {
+    uint64_t nfr = b->frame_off[u1 + 1] - b->frame_off[u0], nseg = b->seg_off[u1 + 1] - b->seg_off[u0];
+    if (chunk_bytes(h, b, u1 + 1 - u0, nfr, nseg, nd) > h->cfg.scratch_bytes) break;
+    if (nfr > 0x7fffffffull) break;
+    u1++;
+  }
+  return u1;
+}
+
+static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Need& nd, ChunkBufs* cb) {
+  const ScrfLayout& l = h->lay;
+  const size_t LL = (size_t)l.L * l.L;
+  const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
+  size_t need = chunk_bytes(h, b, nutt, nfr, nseg, nd);
+  int rc = ensure_scratch(h, need);
+  if (rc != SCRF_OK) return rc;
+  Arena a{h->scratch, h->scratch_cap, 0};
+  if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
+  else cb->X = b->d_windows + b->seg_off[u0] * l.F;
+  cb->S = a.take<double>(nseg * l.L);
+  if (l.use_tf) {
+    cb->M = a.take<double>(nfr * LL);
+    cb->xrow_cur = a.take<uint64_t>(nfr);
+    cb->m_per_frame = 1;
+  } else {
+    cb->M = h->d_m0;
+    cb->m_per_frame = 0;
+  }
+  if (nd.fb) {
+    cb->AD = a.take<double>(nseg * l.L);
+    cb->alpha = a.take<double>(nfr * l.L);
+    if (nd.beta) cb->beta = a.take<double>(nfr * l.L);
+    if (nd.post) {
+      if (l.use_tf) {
+        cb->XI = a.take<double>(nfr * LL);
+        cb->xrow_next = a.take<uint64_t>(nfr);
+        cb->nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
+        if (cb->nch_t == 0) cb->nch_t = 1;
+        cb->rpc_t = (nfr + cb->nch_t - 1) / cb->nch_t;
+        cb->slab_t = a.take<double>((size_t)cb->nch_t * LL * l.ntf);
+      } else {
+        cb->xi_acc = a.take<double>(nutt * LL);
+      }
+      cb->nch_s = (uint32_t)((nseg + EXPF_ROWS_PER_CHUNK - 1) / EXPF_ROWS_PER_CHUNK);
+      cb->slab_s = a.take<double>((size_t)cb->nch_s * l.L * l.nsf);
+    }
+  }
+  if (nd.vit) {
+    cb->bp_b = a.take<uint16_t>(nfr * l.L);
+    cb->bp_e = a.take<uint16_t>(nfr * l.L);
+  }
+  if (a.off > h->scratch_cap) return fail(h, SCRF_ERR_INVALID, "internal: scratch arena overflow");
+  return SCRF_OK;
+}
+
+struct PhaseTimer {
+  scrf_handle h;
+  int ph;
+  PhaseTimer(scrf_handle h_, int p) : h(h_), ph(p) {
+    if (h->timing) hipEventRecord(h->ev[ph][0], h->stream);
+  }
+  void stop(uint32_t launches) {
+    if (!h->timing) return;
+    hipEventRecord(h->ev[ph][1], h->stream);
+    hipEventSynchronize(h->ev[ph][1]);
+    float ms = 0;
+    hipEventElapsedTime(&ms, h->ev[ph][0], h->ev[ph][1]);
+    h->ms[ph] += ms;
+    h->nlaunch[ph] += launches;
+  }
+};
+
+// windows + exact scores of a chunk (both training and decode start here)
+static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb) {
+  const ScrfLayout& l = h->lay;
+  const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
+  ScrfBatchView bv = b->view();
+  if (b->mode == 1) {
+    PhaseTimer tm(h, PH_WIN);
+    uint32_t col = 0;
+    for (uint32_t s = 0; s < b->n_streams; s++) {
+      const scrf_stream_recipe& r = b->recipe[s];
+      launch_windows(h->stream, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
+                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col);
+      col += b->width[s];
+    }
+    tm.stop(b->n_streams);
+  }
+  PhaseTimer tm(h, PH_SCORE);
+  uint32_t nl = 1;
+  launch_scores_exact(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+  if (l.use_tf) {
+    launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
+    launch_scores_exact(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
+    nl += 2;
+  } else if (!h->m0_valid) {
+    // transition scores carry only the bias: one L x L matrix for every frame
+    launch_scores_exact(h->stream, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+    h->m0_valid = true;
+    nl += 1;
+  }
+  tm.stop(nl);
+  HIPCHK(h, hipGetLastError());
+  return SCRF_OK;
+}
+
+static int check_status(scrf_handle h, scrf_batch b) {
+  std::vector<int> st(b->U);
+  HIPCHK(h, hipMemcpyAsync(st.data(), b->d_status, sizeof(int) * b->U, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (uint32_t u = 0; u < b->U; u++) {
+    if (st[u] == SCRF_OK) continue;
+    const char* what = st[u] == SCRF_ERR_BAD_LABEL ? "the label is larger than nActualLabs*labMaxDur"
+                       : st[u] == SCRF_ERR_EMPTY   ? "No features read from this sentence."
+                                                   : "overflow / NaN / log of zero in the log-domain recursion";
+    return fail(h, st[u], "utterance %u: %s", u, what);
+  }
+  return SCRF_OK;
+}
+
+extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double* zx) {
+  if (!h || !b) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const ScrfLayout& l = h->lay;
+  if (!b->d_labels) return fail(h, SCRF_ERR_INVALID, "scrf_fb_batch: the batch carries no labels");
+  if (h->timing) { memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream); }
+  HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+  Need nd{true, true, false, false};
+  ScrfBatchView bv = b->view();
+  for (uint32_t u0 = 0; u0 < b->U;) {
+    const uint32_t u1 = plan_chunk(h, b, u0, nd);
+    ChunkBufs cb;
+    int rc = carve(h, b, u0, u1, nd, &cb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
+    rc = run_scores(h, b, u0, u1, cb);
+    if (rc != SCRF_OK) return rc;
+    {
+      PhaseTimer tm(h, PH_FB);
+      if (cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, h->stream));
+      launch_fb(h->stream, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, nullptr, cb.XI,
+                cb.xi_acc, b->d_numer, b->d_zx, b->d_status, 1);
+      tm.stop(1);
+    }
+    {
+      PhaseTimer tm(h, PH_EXPF);
+      uint32_t nl = 1;
+      launch_expf_gemm(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, EXPF_ROWS_PER_CHUNK, cb.nch_s, cb.slab_s);
+      if (l.use_tf) {
+        launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
+        launch_expf_gemm(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+        nl += 2;
+      }
+      tm.stop(nl);
+    }
+    {
+      PhaseTimer tm(h, PH_REDUCE);
+      launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, 0, h->d_grad);
+      if (l.use_tf) launch_reduce_slabs(h->stream, cb.slab_t, cb.nch_t, l.L * l.L, l, 1, h->d_grad);
+      else launch_reduce_xiacc(h->stream, cb.xi_acc, (uint32_t)nutt, l, h->d_grad);
+      launch_batch_sums(h->stream, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, h->d_sums);
+      tm.stop(3);
+    }
+    HIPCHK(h, hipGetLastError());
+    u0 = u1;
+  }
+  if (h->timing) {
+    hipEventRecord(h->ev[SCRF_N_PHASES][1], h->stream);
+    hipEventSynchronize(h->ev[SCRF_N_PHASES][1]);
+    hipEventElapsedTime(&h->ms[PH_ALL], h->ev[SCRF_N_PHASES][0], h->ev[SCRF_N_PHASES][1]);
+  }
+  if (numer || zx) {
+    int rc = check_status(h, b);
+    if (rc != SCRF_OK) return rc;
+    if (numer) HIPCHK(h, hipMemcpyAsync(numer, b->d_numer, sizeof(double) * b->U, hipMemcpyDeviceToHost, h->stream));
+    if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx, sizeof(double) * b->U, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return SCRF_OK;
+}
+
+extern "C" int scrf_add_grad(scrf_handle h, const double* g, uint32_t n) {
+  if (!h || !g) return SCRF_ERR_INVALID;
+  if (n != h->lay.lambda_len) return fail(h, SCRF_ERR_INVALID, "scrf_add_grad: length mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_scratch(h, sizeof(double) * n);
+  if (rc != SCRF_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->scratch, g, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  launch_add(h->stream, h->d_grad, (const double*)h->scratch, n);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parity hooks (single utterance)
+// ---------------------------------------------------------------------------------------------
+static int check_u(scrf_handle h, scrf_batch b, uint32_t u, const char* fn) {
+  if (!h || !b) return SCRF_ERR_INVALID;
+  if (u >= b->U) return fail(h, SCRF_ERR_INVALID, "%s: utterance %u >= %u", fn, u, b->U);
+  return SCRF_OK;
+}
+
+extern "C" int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* out) {
+  int rc = check_u(h, b, u, "scrf_windows");
+  if (rc != SCRF_OK) return rc;
+  if (!out) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  Need nd{false, false, false, false};
+  ChunkBufs cb;
+  rc = carve(h, b, u, u + 1, nd, &cb);
+  if (rc != SCRF_OK) return rc;
+  rc = run_scores(h, b, u, u + 1, cb);
+  if (rc != SCRF_OK) return rc;
+  uint64_t nseg = b->seg_off[u + 1] - b->seg_off[u];
+  HIPCHK(h, hipMemcpyAsync(out, cb.X, sizeof(float) * nseg * h->lay.F, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SCRF_OK;
+}
+
+static int copy_M(scrf_handle h, const ChunkBufs& cb, uint32_t T, double* M) {
+  const size_t LL = (size_t)h->lay.L * h->lay.L;
+  if (cb.m_per_frame) {
+    HIPCHK(h, hipMemcpyAsync(M, cb.M, sizeof(double) * T * LL, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(M, cb.M, sizeof(double) * LL, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (uint32_t t = 1; t < T; t++) memcpy(M + t * LL, M, sizeof(double) * LL);
+  }
+  return SCRF_OK;
+}
+
+extern "C" int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M) {
+  int rc = check_u(h, b, u, "scrf_scores");
+  if (rc != SCRF_OK) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  Need nd{false, false, false, false};
+  ChunkBufs cb;
+  rc = carve(h, b, u, u + 1, nd, &cb);
+  if (rc != SCRF_OK) return rc;
+  rc = run_scores(h, b, u, u + 1, cb);
+  if (rc != SCRF_OK) return rc;
+  uint64_t nseg = b->seg_off[u + 1] - b->seg_off[u];
+  if (S) HIPCHK(h, hipMemcpyAsync(S, cb.S, sizeof(double) * nseg * h->lay.L, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (M) return copy_M(h, cb, b->T[u], M);
+  return SCRF_OK;
+}
+
+extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, uint32_t prec, double* alpha_dur,
+                                     double* alpha, double* beta, double* zx) {
+  int rc = check_u(h, b, u, "scrf_forward_backward");
+  if (rc != SCRF_OK) return rc;
+  (void)prec;
+  HIPCHK(h, hipSetDevice(h->device));
+  const ScrfLayout& l = h->lay;
+  Need nd{true, false, true, false};
+  ChunkBufs cb;
+  rc = carve(h, b, u, u + 1, nd, &cb);
+  if (rc != SCRF_OK) return rc;
+  rc = run_scores(h, b, u, u + 1, cb);
+  if (rc != SCRF_OK) return rc;
+  HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+  launch_fb(h->stream, l, b->view(), u, 1, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, nullptr, nullptr,
+            b->d_numer, b->d_zx, b->d_status, 0);
+  HIPCHK(h, hipGetLastError());
+  uint64_t nseg = b->seg_off[u + 1] - b->seg_off[u];
+  uint32_t T = b->T[u];
+  if (alpha_dur) HIPCHK(h, hipMemcpyAsync(alpha_dur, cb.AD, sizeof(double) * nseg * l.L, hipMemcpyDeviceToHost, h->stream));
+  if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, cb.alpha, sizeof(double) * T * l.L, hipMemcpyDeviceToHost, h->stream));
+  if (beta) HIPCHK(h, hipMemcpyAsync(beta, cb.beta, sizeof(double) * T * l.L, hipMemcpyDeviceToHost, h->stream));
+  if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int st = 0;
+  HIPCHK(h, hipMemcpy(&st, b->d_status + u, sizeof(int), hipMemcpyDeviceToHost));
+  if (st != SCRF_OK && st != SCRF_ERR_BAD_LABEL) return fail(h, st, "utterance %u: numeric failure in forward-backward", u);
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------
+extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int norm, scrf_arc* arcs, uint64_t* n_arcs,
+                                 uint32_t* n_states, int32_t* final_state) {
+  int rc = check_u(h, b, u, "scrf_lattice_arcs");
+  if (rc != SCRF_OK) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  const ScrfLayout& l = h->lay;
+  const uint32_t T = b->T[u];
+  const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
+  const uint64_t na = b->arc_off[u + 1] - b->arc_off[u];
+  if (n_arcs) *n_arcs = na;
+  if (n_states) *n_states = frame_model ? l.L * T + 2 : (uint32_t)scrf_node_start_state(T, l.L) + 1;
+  if (final_state) *final_state = frame_model ? (int32_t)(l.L * T + 1) : scrf_node_start_state(T, l.L);
+  if (!arcs) return SCRF_OK;
+  Need nd{norm != 0, false, false, false};
+  ChunkBufs cb;
+  rc = carve(h, b, u, u + 1, nd, &cb);
+  if (rc != SCRF_OK) return rc;
+  rc = run_scores(h, b, u, u + 1, cb);
+  if (rc != SCRF_OK) return rc;
+  float final_w = frame_model ? 0.0f : -0.0f;
+  if (norm) {
+    // Zx = -computeAlphaSum(): final arcs carry -Zx (segmental, :371,397) / Zx (frame, CRF_LatticeBuilder.h:191-198)
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    launch_fb(h->stream, l, b->view(), u, 1, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, nullptr, nullptr, nullptr,
+              b->d_numer, b->d_zx, b->d_status, 0);
+    double asum = 0;
+    HIPCHK(h, hipMemcpyAsync(&asum, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double Zx = -1 * asum;
+    final_w = frame_model ? (float)Zx : (float)(-Zx);
+  }
+  scrf_arc* d_arcs = nullptr;
+  HIPCHK(h, hipMalloc((void**)&d_arcs, sizeof(scrf_arc) * na));
+  launch_arcs(h->stream, l, T, frame_model, cb.S, cb.M, cb.m_per_frame, final_w, d_arcs);
+  hipError_t e = hipMemcpyAsync(arcs, d_arcs, sizeof(scrf_arc) * na, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(d_arcs);
+  if (e != hipSuccess) return fail(h, SCRF_ERR_HIP, "scrf_lattice_arcs: %s", hipGetErrorString(e));
+  return SCRF_OK;
+}
+
+extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
+                                  uint64_t* lab_off, float* best_cost) {
+  if (!h || !b || !seg_labels || !lab_off) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const ScrfLayout& l = h->lay;
+  const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
+  if (h->timing) { memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream); }
+  const uint64_t NF = b->frame_off[b->U];
+  uint32_t *d_lab = nullptr, *d_n = nullptr;
+  float* d_cost = nullptr;
+  HIPCHK(h, hipMalloc((void**)&d_lab, sizeof(uint32_t) * NF));
+  HIPCHK(h, hipMalloc((void**)&d_n, sizeof(uint32_t) * b->U));
+  HIPCHK(h, hipMalloc((void**)&d_cost, sizeof(float) * b->U));
+  Need nd{false, false, false, true};
+  int rc = SCRF_OK;
+  for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK;) {
+    const uint32_t u1 = plan_chunk(h, b, u0, nd);
+    ChunkBufs cb;
+    rc = carve(h, b, u0, u1, nd, &cb);
+    if (rc != SCRF_OK) break;
+    rc = run_scores(h, b, u0, u1, cb);
+    if (rc != SCRF_OK) break;
+    PhaseTimer tm(h, PH_VIT);
+    launch_viterbi(h->stream, l, b->view(), u0, u1 - u0, cb.S, cb.M, cb.m_per_frame, frame_model, cb.bp_b, cb.bp_e,
+                   d_lab, d_n, d_cost);
+    tm.stop(1);
+    u0 = u1;
+  }
+  std::vector<uint32_t> lab, cnt(b->U);
+  if (rc == SCRF_OK) {
+    lab.resize(NF);
+    hipError_t e = hipMemcpyAsync(lab.data(), d_lab, sizeof(uint32_t) * NF, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_n, sizeof(uint32_t) * b->U, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && best_cost) e = hipMemcpyAsync(best_cost, d_cost, sizeof(float) * b->U, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(h, SCRF_ERR_HIP, "scrf_viterbi_batch: %s", hipGetErrorString(e));
+  }
+  hipFree(d_lab); hipFree(d_n); hipFree(d_cost);
+  if (rc != SCRF_OK) return rc;
+  if (h->timing) {
+    hipEventRecord(h->ev[SCRF_N_PHASES][1], h->stream);
+    hipEventSynchronize(h->ev[SCRF_N_PHASES][1]);
+    hipEventElapsedTime(&h->ms[PH_ALL], h->ev[SCRF_N_PHASES][0], h->ev[SCRF_N_PHASES][1]);
+  }
+  uint64_t pos = 0;
+  for (uint32_t u = 0; u < b->U; u++) {
+    lab_off[u] = pos;
+    if (pos + cnt[u] > max_labels) return fail(h, SCRF_ERR_INVALID, "scrf_viterbi_batch: seg_labels capacity %llu too small", (unsigned long long)max_labels);
+    memcpy(seg_labels + pos, &lab[b->frame_off[u]], sizeof(uint32_t) * cnt[u]);
+    pos += cnt[u];
+  }
+  lab_off[b->U] = pos;
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// minibatch reduce + optimizer
+// ---------------------------------------------------------------------------------------------
+extern "C" int scrf_comm_unique_id(void* id128) {
+  std::string why;
+  if (!id128) return SCRF_ERR_INVALID;
+  if (!rccl_load(&why)) return fail(nullptr, SCRF_ERR_COMM, "%s", why.c_str());
+  scrf_nccl_uid id;
+  int r = g_rccl.GetUniqueId(&id);
+  if (r != 0) return fail(nullptr, SCRF_ERR_COMM, "ncclGetUniqueId failed: %d", r);
+  memcpy(id128, &id, 128);
+  return SCRF_OK;
+}
+
+extern "C" int scrf_comm_init(scrf_handle h, const void* id128, int rank, int n_ranks) {
+  if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SCRF_ERR_INVALID;
+  std::string why;
+  if (!rccl_load(&why)) return fail(h, SCRF_ERR_COMM, "%s", why.c_str());
+  HIPCHK(h, hipSetDevice(h->device));
+  scrf_nccl_uid id;
+  memcpy(&id, id128, 128);
+  int r = g_rccl.CommInitRank(&h->comm, n_ranks, id, rank);
+  if (r != 0) return fail(h, SCRF_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  h->rank = rank;
+  h->nranks = n_ranks;
+  return SCRF_OK;
+}
+
+__global__ void k_set_active(double* sums4, int active) { sums4[3] = (double)active; }
+__global__ void k_div_by_active(double* __restrict__ g, uint32_t n, const double* __restrict__ sums4) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  double a = sums4[3];
+  if (i < n && a > 0.0) g[i] = __ddiv_rn(g[i], a);  // grad[i] /= nStreams_active (:306-308)
+}
+
+extern "C" int scrf_allreduce_grad(scrf_handle h, int active, double* sums4) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint32_t n = h->lay.lambda_len;
+  hipLaunchKernelGGL(k_set_active, dim3(1), dim3(1), 0, h->stream, h->d_sums, active ? 1 : 0);
+  if (h->comm) {
+    int r = g_rccl.AllReduce(h->d_grad, h->d_grad, n, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
+    if (r == 0) r = g_rccl.AllReduce(h->d_sums, h->d_sums, 4, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
+    if (r != 0) return fail(h, SCRF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  }
+  hipLaunchKernelGGL(k_div_by_active, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_grad, n, h->d_sums);
+  HIPCHK(h, hipGetLastError());
+  if (sums4) {
+    HIPCHK(h, hipMemcpyAsync(sums4, h->d_sums, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return SCRF_OK;
+}
+
+extern "C" int scrf_scale_grad(scrf_handle h, double s) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  launch_scale(h->stream, h->d_grad, h->lay.lambda_len, s, 0);
+  HIPCHK(h, hipGetLastError());
+  return SCRF_OK;
+}
+
+extern "C" int scrf_sgd_step(scrf_handle h, double lr_or_eta, int use_adagrad, double eps) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  launch_sgd_step(h->stream, h->d_lambda, h->d_lambda_acc, h->d_gsa, h->d_grad, h->lay.lambda_len, lr_or_eta,
+                  use_adagrad, eps);
+  HIPCHK(h, hipMemsetAsync(h->d_sums, 0, sizeof(double) * 4, h->stream));
+  h->m0_valid = false;
+  HIPCHK(h, hipGetLastError());
+  return SCRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------
+extern "C" int scrf_enable_timing(scrf_handle h, int on) { if (!h) return SCRF_ERR_INVALID; h->timing = on != 0; return SCRF_OK; }
+extern "C" int scrf_last_timing(scrf_handle h, float* ms, uint32_t* n_launch) {
+  if (!h) return SCRF_ERR_INVALID;
+  if (ms) memcpy(ms, h->ms, sizeof(h->ms));
+  if (n_launch) memcpy(n_launch, h->nlaunch, sizeof(h->nlaunch));
+  return SCRF_OK;
+}

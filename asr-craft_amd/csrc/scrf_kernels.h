@@ -1,0 +1,37 @@
+// scrf_kernels.h -- launch wrappers of the HIP kernels (scrf_kernels.hip, scrf_mfma.hip).
+#ifndef SCRF_KERNELS_H_
+#define SCRF_KERNELS_H_
+
+#include "scrf_common.h"
+
+void launch_windows(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
+                    uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, uint32_t lctx,
+                    uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col);
+void launch_frame_rows(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t u1, uint32_t D,
+                       uint64_t n_frames, uint64_t* xrow, int next);
+void launch_scores_exact(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
+                         const double* lambda, const ScrfLayout& lay, int is_trans, uint32_t n_out, double* out);
+size_t fb_smem_bytes(const ScrfLayout& lay, int NT);
+int fb_block_threads(const ScrfLayout& lay);
+void launch_fb(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+               const double* S, const double* M, int m_per_frame, double* AD, double* alpha_g, double* beta_g,
+               double* XI, double* xi_acc, double* numer, double* zx, int* status, int write_post);
+void launch_expf_gemm(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
+                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
+void launch_reduce_slabs(hipStream_t st, const double* slab, uint32_t n_chunks, uint32_t n_out,
+                         const ScrfLayout& lay, int is_trans, double* grad);
+void launch_reduce_xiacc(hipStream_t st, const double* xi_acc, uint32_t n_utts, const ScrfLayout& lay,
+                         double* grad);
+void launch_batch_sums(hipStream_t st, const double* numer, const double* zx, uint32_t n, double* sums3);
+void launch_viterbi(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                    const double* S, const double* M, int m_per_frame, int frame_model, uint16_t* bp_b,
+                    uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost);
+void launch_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t T, int frame_model, const double* S,
+                 const double* M, int m_per_frame, float final_w, scrf_arc* arcs);
+void launch_sgd_step(hipStream_t st, double* lambda, double* lambda_acc, double* gsa, double* grad, uint32_t n,
+                     double lr, int adagrad, double eps);
+void launch_scale(hipStream_t st, double* v, uint32_t n, double s, int divide);
+void launch_add(hipStream_t st, double* y, const double* x, uint32_t n);
+
+#endif  // SCRF_KERNELS_H_

@@ -1,0 +1,825 @@
+// scrf_kernels.hip -- HIP kernels of the segmental-CRF engine for gfx950 (MI355X, wave64).
+//
+// Kernel inventory (DESIGN.md has the roofline of each):
+//   k_windows        segment-window synthesis from raw frames   (io/CRF_InFtrStream_SeqMultiWindow.cpp:413-455)
+//   k_scores_exact   feature x weight dot products, reference order, unfused fp64
+//                    (ftrmaps/CRF_StdFeatureMap.cpp:65-110 via nodes/...WithoutSegTransFtr.cpp:39-114)
+//   k_fb             per-utterance forward / backward / posteriors (nodes/...WithoutSegTransFtr.cpp:123-949)
+//   k_expf_gemm      expected-minus-observed feature counts        (ftrmaps/CRF_StdFeatureMap.cpp:130-223)
+//   k_reduce_*       deterministic split-K reduction into the gradient
+//   k_viterbi        float tropical best path == ShortestPath on the reference lattice
+//   k_arcs_*         lattice arc emission in AddArc order (decoders/...WithoutSegTransFtr.h:30-407)
+//   k_sgd_step       trainers/CRF_SGTrainer.cpp:299-325
+//
+// This translation unit is compiled with -ffp-contract=off: the EXACT kernels must not fuse
+// multiply and add (the reference is built without FMA contraction).
+#include "scrf_kernels.h"
+
+#include <float.h>
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t find_utt(const uint64_t* off, uint32_t u0, uint32_t u1, uint64_t x) {
+  // largest u in [u0,u1) with off[u] <= x
+  uint32_t lo = u0, hi = u1;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_windows: one block per frame of the chunk, threads over the raw feature index.
+// Arithmetic identical to the reference: float running sum from the LAST frame backwards
+// divided by the length, running max/min, 5 sampled frames at ceil(0.1*k*len)-1.
+// ------------------------------------------------------------------------------------------
+__global__ void k_windows(const float* __restrict__ frames, const uint64_t* __restrict__ sframe_off,
+                          ScrfBatchView bv, uint32_t u0, uint32_t u1, uint32_t W, uint32_t D,
+                          uint32_t lctx, uint32_t rctx, int extract, float* __restrict__ X,
+                          uint32_t F, uint32_t out_col) {
+  const uint64_t gf = bv.frame_off[u0] + blockIdx.x;
+  const uint32_t u = find_utt(bv.frame_off, u0, u1, gf);
+  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  const uint32_t avail = scrf_node_max_dur(t, D);
+  const uint64_t rowbase = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
+  const float* last = frames + (sframe_off[u] + lctx + t) * (uint64_t)W;
+  const bool segftr = (D != 1) && extract;
+  const uint32_t body = segftr ? 8 * W + D : W;
+
+  for (uint32_t j = threadIdx.x; j < W; j += blockDim.x) {
+    float acc_sum = 0.0f, acc_max = last[j], acc_min = last[j];
+    for (uint32_t w = 1; w <= avail; w++) {
+      const float* first = last - (uint64_t)(w - 1) * W;
+      float* o = X + (rowbase + w - 1) * (uint64_t)F + out_col;
+      const float* lb = first - (uint64_t)lctx * W;
+      for (uint32_t c = 0; c < lctx; c++) o[c * W + j] = lb[c * W + j];
+      o += lctx * W;
+      if (!segftr) {
+        o[j] = first[j];
+      } else {
+        float ot = (float)((double)w * 0.1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          float prod = ot * (float)(2 * k + 1);
+          uint32_t step = (uint32_t)ceilf(prod) - 1u;
+          o[k * W + j] = first[(uint64_t)step * W + j];
+        }
+        float v = first[j];
+        acc_sum = __fadd_rn(acc_sum, v);
+        o[5 * W + j] = __fdiv_rn(acc_sum, (float)w);
+        if (v > acc_max) acc_max = v;
+        o[6 * W + j] = acc_max;
+        if (v < acc_min) acc_min = v;
+        o[7 * W + j] = acc_min;
+      }
+      o += body;
+      const float* rb = extract ? last : first;
+      for (uint32_t c = 0; c < rctx; c++) o[c * W + j] = rb[(uint64_t)(c + 1) * W + j];
+    }
+  }
+  if (segftr) {
+    for (uint32_t idx = threadIdx.x; idx < avail * D; idx += blockDim.x) {
+      uint32_t w = idx / D + 1, k = idx % D;
+      X[(rowbase + w - 1) * (uint64_t)F + out_col + lctx * W + 8 * W + k] = (k + 1 == w) ? 1.0f : 0.0f;
+    }
+  }
+}
+
+void launch_windows(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
+                    uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, uint32_t lctx,
+                    uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col) {
+  if (n_frames == 0) return;
+  uint32_t bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
+  hipLaunchKernelGGL(k_windows, dim3((uint32_t)n_frames), dim3(bs), 0, st, frames, sframe_off, bv, u0, u1,
+                     W, D, lctx, rctx, extract, X, F, out_col);
+}
+
+// first window row (d=1) of every frame of the chunk: the transition features of node t
+__global__ void k_frame_rows(ScrfBatchView bv, uint32_t u0, uint32_t u1, uint32_t D, uint64_t n_frames,
+                             uint64_t* __restrict__ xrow, int next) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_frames) return;
+  const uint64_t gf = bv.frame_off[u0] + i;
+  const uint32_t u = find_utt(bv.frame_off, u0, u1, gf);
+  uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  if (next) t = (t + 1 < bv.T[u]) ? t + 1 : t;  // row of node t+1 (ExpF uses the NEXT node's features)
+  xrow[i] = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
+}
+
+void launch_frame_rows(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t u1, uint32_t D,
+                       uint64_t n_frames, uint64_t* xrow, int next) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_frame_rows, dim3((uint32_t)((n_frames + 255) / 256)), dim3(256), 0, st, bv, u0, u1, D,
+                     n_frames, xrow, next);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scores_exact: out[row][o] = sum_f (double)x[row][fs+f] * lambda[woff(o)+f]  (+ bias), the
+// reference's sequential unfused chain.  block = (64 rows) x (4 output groups of NL outputs).
+// ------------------------------------------------------------------------------------------
+#define SC_FC 32
+template <int NL>
+__global__ __launch_bounds__(256) void k_scores_exact(const float* __restrict__ X, uint32_t F,
+                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                      const double* __restrict__ lambda, ScrfLayout lay,
+                                                      int is_trans, uint32_t n_out, double* __restrict__ out) {
+  __shared__ float Xs[64][SC_FC + 1];
+  __shared__ double Ws[4 * NL][SC_FC];
+  const uint32_t tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const uint64_t row0 = (uint64_t)blockIdx.x * 64;
+  const uint32_t o0 = blockIdx.y * 4 * NL;
+  const uint32_t L = lay.L;
+  const uint32_t fs = is_trans ? lay.tfs : lay.sfs;
+  const uint32_t nfe = is_trans ? lay.ntfe : lay.nsfe;
+  const int use_b = is_trans ? lay.use_tb : lay.use_sb;
+  const double bv = is_trans ? lay.tbv : lay.sbv;
+
+  double acc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; k++) acc[k] = 0.0;
+
+  for (uint32_t f0 = 0; f0 < nfe; f0 += SC_FC) {
+    const uint32_t fc = min((uint32_t)SC_FC, nfe - f0);
+    for (uint32_t idx = tid; idx < 64 * SC_FC; idx += 256) {
+      uint32_t r = idx / SC_FC, c = idx % SC_FC;
+      float v = 0.0f;
+      if (row0 + r < n_rows && c < fc) {
+        uint64_t xr = xrow ? xrow[row0 + r] : row0 + r;
+        v = X[xr * F + fs + f0 + c];
+      }
+      Xs[r][c] = v;
+    }
+    for (uint32_t idx = tid; idx < 4 * NL * SC_FC; idx += 256) {
+      uint32_t ol = idx / SC_FC, c = idx % SC_FC;
+      uint32_t o = o0 + ol;
+      double w = 0.0;
+      if (o < n_out && c < fc) {
+        uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
+        w = lambda[woff + f0 + c];
+      }
+      Ws[ol][c] = w;
+    }
+    __syncthreads();
+    for (uint32_t c = 0; c < fc; c++) {
+      const double xv = (double)Xs[tx][c];
+#pragma unroll
+      for (int k = 0; k < NL; k++) acc[k] = __dadd_rn(acc[k], __dmul_rn(xv, Ws[ty * NL + k][c]));
+    }
+    __syncthreads();
+  }
+  if (row0 + tx < n_rows) {
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      uint32_t o = o0 + ty * NL + k;
+      if (o < n_out) {
+        double v = acc[k];
+        if (use_b) {
+          uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
+          v = __dadd_rn(v, __dmul_rn(lambda[woff + nfe], bv));
+        }
+        out[(row0 + tx) * n_out + o] = v;
+      }
+    }
+  }
+}
+
+void launch_scores_exact(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
+                         const double* lambda, const ScrfLayout& lay, int is_trans, uint32_t n_out, double* out) {
+  if (n_rows == 0 || n_out == 0) return;
+  dim3 bs(64, 4);
+  uint32_t gx = (uint32_t)((n_rows + 63) / 64);
+  if (n_out <= 16 || (n_out % 48 != 0 && n_out <= 64)) {
+    const int NL = 4;
+    hipLaunchKernelGGL(k_scores_exact<NL>, dim3(gx, (n_out + 4 * NL - 1) / (4 * NL)), bs, 0, st, X, F, xrow,
+                       n_rows, lambda, lay, is_trans, n_out, out);
+  } else {
+    const int NL = 12;
+    hipLaunchKernelGGL(k_scores_exact<NL>, dim3(gx, (n_out + 4 * NL - 1) / (4 * NL)), bs, 0, st, X, F, xrow,
+                       n_rows, lambda, lay, is_trans, n_out, out);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fb: forward, backward and posteriors of one utterance per workgroup (log domain, fp64).
+//   aPT[t-1][n] = LSE_c(alpha[t-1][c] + M[t][c][n])                         (:1077-1108, :156)
+//   ad[t][d][l] = aPT[t-d][l] + S[t][d][l]  (d <= numPrev) | S[t][d][l]      (:168-200)
+//   alpha[t][l] = LSE_d ad[t][d][l] ;  Zx = LSE_l alpha[T-1][l]              (:204, StdSeg :447-462)
+//   sd[t][n]    = LSE_d(S[t+d][d][n] + beta[t+d][n])                         (:416-429)
+//   beta[t][c]  = LSE_n(M[t+1][c][n] + sd[t][n]) ; beta[T-1] = 0             (:445-455)
+//   gamma = exp(ad + beta - Zx), xi = exp(alpha[t][c] + M[t+1][c][n] + sd[t][n] - Zx) (:685,:773)
+// Outputs R = Y - gamma (over ad, in place) and Y - xi (per frame, or summed per utterance
+// when transitions carry only a bias): the operands of the expected-count contraction.
+// ------------------------------------------------------------------------------------------
+struct FbLse {
+  int L, G, g, j;
+  bool active;
+  double* red_m;
+  double* red_s;
+};
+
+template <class VAL>
+__device__ __forceinline__ double col_lse(const FbLse& c, int n_i, VAL val, int* err) {
+  // returns LSE_i val(i, j) to the threads of group 0 (others get garbage); 3 barriers
+  double m = -INFINITY;
+  if (c.active)
+    for (int i = c.g; i < n_i; i += c.G) m = fmax(m, val(i, c.j, true));
+  if (c.active) c.red_m[c.g * c.L + c.j] = m;
+  __syncthreads();
+  double mm = -INFINITY, s = 0.0;
+  if (c.active) {
+    for (int gg = 0; gg < c.G; gg++) mm = fmax(mm, c.red_m[gg * c.L + c.j]);
+    for (int i = c.g; i < n_i; i += c.G) s += exp(val(i, c.j, false) - mm);
+    c.red_s[c.g * c.L + c.j] = s;
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (c.active && c.g == 0) {
+    double tot = 0.0;
+    for (int gg = 0; gg < c.G; gg++) tot += c.red_s[gg * c.L + c.j];
+    if (!(tot > 0.0) || isinf(tot) || isnan(tot)) *err = SCRF_ERR_NUMERIC;  // logE(0) / NaN / Inf
+    r = mm + log(tot);
+  }
+  return r;
+}
+
+__global__ void k_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
+                     const double* __restrict__ M, int m_per_frame, double* __restrict__ AD,
+                     double* __restrict__ alpha_g, double* __restrict__ beta_g, double* __restrict__ XI,
+                     double* __restrict__ xi_acc, double* __restrict__ numer_out, double* __restrict__ zx_out,
+                     int* __restrict__ status, int write_post) {
+  extern __shared__ double smem[];
+  const int L = lay.L, D = lay.D;
+  const int NT = blockDim.x, tid = threadIdx.x;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* Su = S + s_base * L;
+  double* ADu = AD + s_base * L;
+  double* alu = alpha_g + f_base * L;
+  const uint32_t* labs = bv.labels ? bv.labels + bv.frame_off[u] : nullptr;
+  const size_t LL = (size_t)L * L;
+
+  FbLse c;
+  c.L = L;
+  c.G = NT / L;
+  if (c.G < 1) c.G = 1;
+  c.g = tid / L;
+  c.j = tid - c.g * L;
+  c.active = c.g < c.G && tid < c.G * L;
+  double* apt = smem;                 // [D][L]
+  double* bring = apt + (size_t)D * L;  // [D][L]
+  double* acur = bring + (size_t)D * L; // [L]
+  double* sdv = acur + L;             // [L]
+  c.red_m = sdv + L;                  // [G][L]
+  c.red_s = c.red_m + (size_t)c.G * L; // [G][L]
+  __shared__ double zx_s;
+  int err = 0;
+
+  if (T == 0) {
+    if (tid == 0) { status[u] = SCRF_ERR_EMPTY; numer_out[u] = 0.0; zx_out[u] = 0.0; }
+    return;
+  }
+
+  // ---- forward -------------------------------------------------------------------------
+  for (int l = tid; l < L; l += NT) {
+    double a = Su[l];
+    ADu[l] = a;
+    acur[l] = a;
+    alu[l] = a;
+  }
+  __syncthreads();
+  for (int t = 1; t < T; t++) {
+    const double* Mt = M + (m_per_frame ? (f_base + t) * LL : 0);
+    double r = col_lse(c, L, [&](int ci, int n, bool) { return acur[ci] + Mt[(size_t)ci * L + n]; }, &err);
+    if (c.active && c.g == 0) apt[((t - 1) % D) * L + c.j] = r;
+    __syncthreads();
+    const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+    const uint64_t base = scrf_seg_base(t, D);
+    r = col_lse(c, nd,
+                [&](int di, int l, bool first) {
+                  const int d = di + 1;
+                  double s = Su[(base + di) * L + l];
+                  double v = (d <= np) ? apt[((t - d) % D) * L + l] + s : s;
+                  if (first) ADu[(base + di) * L + l] = v;
+                  return v;
+                },
+                &err);
+    if (c.active && c.g == 0) {
+      acur[c.j] = r;
+      alu[(size_t)t * L + c.j] = r;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {  // computeAlphaSum: logAdd(alphaArray, L) in index order
+    double mx = acur[0];
+    for (int l = 1; l < L; l++) if (acur[l] > mx) mx = acur[l];
+    double sum = 0.0;
+    for (int l = 0; l < L; l++) sum += exp(acur[l] - mx);
+    zx_s = mx + log(sum);
+  }
+  __syncthreads();
+  const double Zx = zx_s;
+  if (isnan(Zx) || isinf(Zx)) err = SCRF_ERR_NUMERIC;
+
+  // ---- backward + posteriors -------------------------------------------------------------
+  const double LN_MAX = 709.782712893384;  // log(DBL_MAX): expE overflow guard (CRF_LogMath.cpp:213)
+  double numer = 0.0;
+  uint32_t cur_next = SCRF_LAB_BAD;
+  for (int t = T - 1; t >= 0; t--) {
+    const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+    const double* Mn = M + (m_per_frame ? (f_base + t + 1) * LL : 0);
+    double* bt = bring + (size_t)(t % D) * L;
+    if (nn == 0) {
+      for (int l = tid; l < L; l += NT) bt[l] = 0.0;
+      __syncthreads();
+    } else {
+      double r = col_lse(c, nn,
+                         [&](int di, int n, bool) {
+                           const int d = di + 1;
+                           return Su[(scrf_seg_base(t + d, D) + di) * L + n] + bring[((t + d) % D) * L + n];
+                         },
+                         &err);
+      if (c.active && c.g == 0) sdv[c.j] = r;
+      __syncthreads();
+      r = col_lse(c, L, [&](int n, int ci, bool) { return Mn[(size_t)ci * L + n] + sdv[n]; }, &err);
+      if (c.active && c.g == 0) bt[c.j] = r;
+      __syncthreads();
+    }
+    if (beta_g)
+      for (int l = tid; l < L; l += NT) beta_g[(f_base + t) * L + l] = bt[l];
+
+    // true labels of this node (computeExpF :620-644)
+    uint32_t lab = labs ? labs[t] : SCRF_LAB_BAD;
+    uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD, anl = SCRF_LAB_BAD;
+    if (lab != SCRF_LAB_BAD) {
+      if (lab >= (uint32_t)L * D) err = SCRF_ERR_BAD_LABEL;
+      al = lab % L;
+      ld = lab / L + 1;
+    }
+    if (cur_next != SCRF_LAB_BAD) {
+      if (cur_next >= (uint32_t)L * D) err = SCRF_ERR_BAD_LABEL;
+      anl = cur_next % L;
+    }
+    const int nd = (int)scrf_node_max_dur(t, D);
+    const uint64_t base = scrf_seg_base(t, D);
+    if (write_post) {
+      for (int idx = tid; idx < nd * L; idx += NT) {
+        const int di = idx / L, l = idx - di * L;
+        double a = ADu[(base + di) * L + l] + bt[l] - Zx;
+        if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+        double g = exp(a);
+        double y = ((uint32_t)l == al && (uint32_t)(di + 1) == ld) ? 1.0 : 0.0;
+        ADu[(base + di) * L + l] = y - g;
+      }
+      if (nn > 0) {
+        for (int idx = tid; idx < L * L; idx += NT) {
+          const int ci = idx / L, n = idx - ci * L;
+          double a = alu[(size_t)t * L + ci] + Mn[idx] + sdv[n] - Zx;
+          if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+          double x = exp(a);
+          double y = ((uint32_t)ci == al && (uint32_t)n == anl) ? 1.0 : 0.0;
+          if (XI) XI[(f_base + t) * LL + idx] = y - x;
+          else xi_acc[(size_t)blockIdx.x * LL + idx] += y - x;
+        }
+      } else if (XI) {
+        for (int idx = tid; idx < L * L; idx += NT) XI[(f_base + t) * LL + idx] = 0.0;
+      }
+    }
+    if (tid == 0 && lab != SCRF_LAB_BAD) {
+      double nodeLi = 0.0;
+      if (ld <= (uint32_t)nd) nodeLi += Su[(base + ld - 1) * L + al];
+      if (nn > 0 && anl != SCRF_LAB_BAD) nodeLi += Mn[(size_t)al * L + anl];
+      numer += nodeLi;
+    }
+    if (lab != SCRF_LAB_BAD) cur_next = lab;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    numer_out[u] = numer;
+    zx_out[u] = Zx;
+  }
+  if (err) atomicMax(&status[u], err);
+}
+
+size_t fb_smem_bytes(const ScrfLayout& lay, int NT) {
+  int G = NT / (int)lay.L;
+  if (G < 1) G = 1;
+  return sizeof(double) * ((size_t)2 * lay.D * lay.L + 2 * lay.L + (size_t)2 * G * lay.L);
+}
+
+int fb_block_threads(const ScrfLayout& lay) { return lay.L <= 256 ? 256 : 1024; }
+
+void launch_fb(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+               const double* S, const double* M, int m_per_frame, double* AD, double* alpha_g, double* beta_g,
+               double* XI, double* xi_acc, double* numer, double* zx, int* status, int write_post) {
+  if (n_utts == 0) return;
+  int NT = fb_block_threads(lay);
+  size_t sm = fb_smem_bytes(lay, NT);
+  hipFuncSetAttribute((const void*)k_fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(k_fb, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, S, M, m_per_frame, AD, alpha_g, beta_g,
+                     XI, xi_acc, numer, zx, status, write_post);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_expf_gemm: slab[z][o][f] = sum_{rows of K-chunk z} A[row][o] * xs[row][f], xs = window
+// features of the state/transition range with the bias value as the last column.  A = Y - gamma
+// (state) or Y - xi (transition), so the result is directly (observed - expected) counts.
+// ------------------------------------------------------------------------------------------
+#define EG_KT 32
+template <int NL>
+__global__ __launch_bounds__(256) void k_expf_gemm(const double* __restrict__ A, uint32_t n_out,
+                                                   const float* __restrict__ X, uint32_t F,
+                                                   const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                   ScrfLayout lay, int is_trans, uint64_t rows_per_chunk,
+                                                   double* __restrict__ slab) {
+  __shared__ double As[EG_KT][4 * NL];
+  const uint32_t tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const uint32_t fs = is_trans ? lay.tfs : lay.sfs;
+  const uint32_t nfe = is_trans ? lay.ntfe : lay.nsfe;
+  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+  const double bias = is_trans ? lay.tbv : lay.sbv;
+  const uint32_t col = blockIdx.x * 64 + tx;
+  const uint32_t o0 = blockIdx.y * 4 * NL;
+  const uint64_t r_begin = (uint64_t)blockIdx.z * rows_per_chunk;
+  const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
+  double acc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; k++) acc[k] = 0.0;
+
+  for (uint64_t r0 = r_begin; r0 < r_end; r0 += EG_KT) {
+    const uint32_t kt = (uint32_t)min((uint64_t)EG_KT, r_end - r0);
+    for (uint32_t idx = tid; idx < EG_KT * 4 * NL; idx += 256) {
+      uint32_t r = idx / (4 * NL), ol = idx % (4 * NL);
+      double v = 0.0;
+      if (r < kt && o0 + ol < n_out) v = A[(r0 + r) * n_out + o0 + ol];
+      As[r][ol] = v;
+    }
+    __syncthreads();
+    for (uint32_t r = 0; r < kt; r++) {
+      double xv = 0.0;
+      if (col < nfe) {
+        uint64_t xr = xrow ? xrow[r0 + r] : r0 + r;
+        xv = (double)X[xr * F + fs + col];
+      } else if (col == nfe) {
+        xv = bias;
+      }
+#pragma unroll
+      for (int k = 0; k < NL; k++) acc[k] = fma(As[r][ty * NL + k], xv, acc[k]);
+    }
+    __syncthreads();
+  }
+  if (col < nfun) {
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      uint32_t o = o0 + ty * NL + k;
+      if (o < n_out) slab[((uint64_t)blockIdx.z * n_out + o) * nfun + col] = acc[k];
+    }
+  }
+}
+
+void launch_expf_gemm(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
+                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+  if (n_rows == 0 || n_chunks == 0) return;
+  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+  dim3 bs(64, 4);
+  if (n_out <= 16) {
+    const int NL = 4;
+    hipLaunchKernelGGL(k_expf_gemm<NL>, dim3((nfun + 63) / 64, (n_out + 4 * NL - 1) / (4 * NL), n_chunks), bs, 0,
+                       st, A, n_out, X, F, xrow, n_rows, lay, is_trans, rows_per_chunk, slab);
+  } else {
+    const int NL = 12;
+    hipLaunchKernelGGL(k_expf_gemm<NL>, dim3((nfun + 63) / 64, (n_out + 4 * NL - 1) / (4 * NL), n_chunks), bs, 0,
+                       st, A, n_out, X, F, xrow, n_rows, lay, is_trans, rows_per_chunk, slab);
+  }
+}
+
+// grad[woff(o)+f] += sum_z slab[z][o][f], fixed z order (bit-reproducible)
+__global__ void k_reduce_slabs(const double* __restrict__ slab, uint32_t n_chunks, uint32_t n_out,
+                               ScrfLayout lay, int is_trans, double* __restrict__ grad) {
+  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)n_out * nfun) return;
+  uint32_t o = (uint32_t)(i / nfun), f = (uint32_t)(i % nfun);
+  double s = 0.0;
+  for (uint32_t z = 0; z < n_chunks; z++) s += slab[(uint64_t)z * n_out * nfun + i];
+  uint32_t woff = is_trans ? lay.trans_idx(o / lay.L, o % lay.L) : lay.state_idx(o);
+  grad[woff + f] += s;
+}
+
+void launch_reduce_slabs(hipStream_t st, const double* slab, uint32_t n_chunks, uint32_t n_out,
+                         const ScrfLayout& lay, int is_trans, double* grad) {
+  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+  uint64_t n = (uint64_t)n_out * nfun;
+  if (n == 0 || n_chunks == 0) return;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, slab, n_chunks, n_out,
+                     lay, is_trans, grad);
+}
+
+// bias-only transitions: grad[trans_idx(c,n)] += tbv * sum_u xi_acc[u][c*L+n]
+__global__ void k_reduce_xiacc(const double* __restrict__ xi_acc, uint32_t n_utts, ScrfLayout lay,
+                               double* __restrict__ grad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t LL = lay.L * lay.L;
+  if (i >= LL) return;
+  double s = 0.0;
+  for (uint32_t u = 0; u < n_utts; u++) s += xi_acc[(uint64_t)u * LL + i];
+  grad[lay.trans_idx(i / lay.L, i % lay.L)] += s * lay.tbv;
+}
+
+void launch_reduce_xiacc(hipStream_t st, const double* xi_acc, uint32_t n_utts, const ScrfLayout& lay,
+                         double* grad) {
+  if (n_utts == 0 || !lay.use_tb) return;
+  uint32_t LL = lay.L * lay.L;
+  hipLaunchKernelGGL(k_reduce_xiacc, dim3((LL + 255) / 256), dim3(256), 0, st, xi_acc, n_utts, lay, grad);
+}
+
+// sums of numer/zx over a range, accumulated into sums3 = {numer, zx, n_utts}
+__global__ void k_batch_sums(const double* __restrict__ numer, const double* __restrict__ zx, uint32_t n,
+                             double* __restrict__ sums3) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (uint32_t i = 0; i < n; i++) { a += numer[i]; b += zx[i]; }
+    sums3[0] += a;
+    sums3[1] += b;
+    sums3[2] += (double)n;
+  }
+}
+void launch_batch_sums(hipStream_t st, const double* numer, const double* zx, uint32_t n, double* sums3) {
+  hipLaunchKernelGGL(k_batch_sums, dim3(1), dim3(64), 0, st, numer, zx, n, sums3);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_viterbi: best path over the reference lattice without materialising it.  Float tropical
+// semiring, path cost = left-to-right float sum of float(-score) arc weights, relaxation in
+// state order with strict improvement (first relaxed wins):
+//   boundary(t,l) <- end(t-1,p), p ascending ; end(t,l) <- start (d=t+1) then boundary(t',l),
+//   t' ascending (d descending) ; final <- end(T-1,l), l ascending, weight -0.0f.
+// Frame model (CRF_LatticeBuilder.h:97-204): state(t,c) <- state(t-1,p), w = float(-(M+S)).
+// ------------------------------------------------------------------------------------------
+__global__ void k_viterbi(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
+                          const double* __restrict__ M, int m_per_frame, int frame_model,
+                          uint16_t* __restrict__ bp_b, uint16_t* __restrict__ bp_e,
+                          uint32_t* __restrict__ out_labels, uint32_t* __restrict__ out_n,
+                          float* __restrict__ out_cost) {
+  extern __shared__ float vsm[];
+  const int L = lay.L, D = lay.D;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* Su = S + s_base * L;
+  const size_t LL = (size_t)L * L;
+  float* de_prev = vsm;               // [L]
+  float* de_cur = de_prev + L;        // [L]
+  float* db = de_cur + L;             // [D][L]
+  uint16_t* bpb = bp_b + f_base * L;
+  uint16_t* bpe = bp_e + f_base * L;
+  uint32_t* outl = out_labels + bv.frame_off[u];
+  if (T == 0) {
+    if (tid == 0) { out_n[u] = 0; out_cost[u] = INFINITY; }
+    return;
+  }
+  for (int t = 0; t < T; t++) {
+    const double* Mt = M + (m_per_frame ? (f_base + t) * LL : 0);
+    const uint64_t base = scrf_seg_base(t, D);
+    if (frame_model) {
+      for (int l = tid; l < L; l += NT) {
+        float best = INFINITY;
+        int arg = 0;
+        if (t == 0) {
+          best = 0.0f + (float)(-1.0 * Su[l]);
+        } else {
+          for (int p = 0; p < L; p++) {
+            float w = (float)(-1.0 * (Mt[(size_t)p * L + l] + Su[(size_t)t * L + l]));
+            float cst = de_prev[p] + w;
+            if (cst < best) { best = cst; arg = p; }
+          }
+        }
+        de_cur[l] = best;
+        bpb[(size_t)t * L + l] = (uint16_t)arg;
+      }
+      __syncthreads();
+    } else {
+      if (t >= 1) {
+        for (int l = tid; l < L; l += NT) {
+          float best = INFINITY;
+          int arg = 0;
+          for (int p = 0; p < L; p++) {
+            float cst = de_prev[p] + (float)(-1.0 * Mt[(size_t)p * L + l]);
+            if (cst < best) { best = cst; arg = p; }
+          }
+          db[(t % D) * L + l] = best;
+          bpb[(size_t)t * L + l] = (uint16_t)arg;
+        }
+      }
+      __syncthreads();
+      for (int l = tid; l < L; l += NT) {
+        float best = INFINITY;
+        int arg = 0;
+        if (t < D) {  // from the start state: duration t+1
+          float cst = 0.0f + (float)(-1.0 * Su[(base + t) * L + l]);
+          if (cst < best) { best = cst; arg = t + 1; }
+        }
+        const int tp0 = (t - D + 1 > 1) ? t - D + 1 : 1;
+        for (int tp = tp0; tp <= t; tp++) {
+          const int d = t - tp + 1;
+          float cst = db[(tp % D) * L + l] + (float)(-1.0 * Su[(base + d - 1) * L + l]);
+          if (cst < best) { best = cst; arg = d; }
+        }
+        de_cur[l] = best;
+        bpe[(size_t)t * L + l] = (uint16_t)arg;
+      }
+      __syncthreads();
+    }
+    for (int l = tid; l < L; l += NT) de_prev[l] = de_cur[l];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float best = INFINITY;
+    int bl = -1;
+    const float wf = frame_model ? 0.0f : -0.0f;
+    for (int l = 0; l < L; l++) {
+      float cst = de_prev[l] + wf;
+      if (cst < best) { best = cst; bl = l; }
+    }
+    uint32_t n = 0;
+    if (bl >= 0) {
+      int t = T - 1, l = bl;
+      if (frame_model) {
+        while (true) {
+          outl[n++] = (uint32_t)l;
+          if (t == 0) break;
+          l = bpb[(size_t)t * L + l];
+          t--;
+        }
+      } else {
+        while (true) {
+          int d = bpe[(size_t)t * L + l];
+          outl[n++] = (uint32_t)(l + L * (d - 1));
+          int ts = t - d + 1;  // first frame of the segment
+          if (ts == 0) break;
+          l = bpb[(size_t)ts * L + l];
+          t = ts - 1;
+        }
+      }
+      for (uint32_t i = 0; i < n / 2; i++) {
+        uint32_t tmp = outl[i];
+        outl[i] = outl[n - 1 - i];
+        outl[n - 1 - i] = tmp;
+      }
+      best = best + 0.0f;  // Times(distance, Final = One)
+    }
+    out_n[u] = n;
+    out_cost[u] = best;
+  }
+}
+
+void launch_viterbi(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                    const double* S, const double* M, int m_per_frame, int frame_model, uint16_t* bp_b,
+                    uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost) {
+  if (n_utts == 0) return;
+  int NT = ((int)lay.L + 63) / 64 * 64;
+  if (NT > 1024) NT = 1024;
+  size_t sm = sizeof(float) * ((size_t)2 * lay.L + (size_t)lay.D * lay.L);
+  hipFuncSetAttribute((const void*)k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(k_viterbi, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, S, M, m_per_frame, frame_model,
+                     bp_b, bp_e, out_labels, out_n, out_cost);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_arcs_seg / k_arcs_frame: one block per node (+1 for the final arcs), arcs written at the
+// index the reference's AddArc call order gives them.
+// ------------------------------------------------------------------------------------------
+__global__ void k_arcs_seg(ScrfLayout lay, uint32_t T, const double* __restrict__ S,
+                           const double* __restrict__ M, int m_per_frame, float final_w,
+                           scrf_arc* __restrict__ arcs) {
+  const uint32_t L = lay.L, D = lay.D;
+  const uint32_t t = blockIdx.x;
+  const size_t LL = (size_t)L * L;
+  if (t == T) {  // final arcs (:366-399)
+    const uint64_t ab = scrf_arc_base(T, L, D);
+    const int32_t fin = scrf_node_start_state(T, L);
+    for (uint32_t p = threadIdx.x; p < L; p += blockDim.x) {
+      int32_t src = (T == 1) ? scrf_node_start_state(0, L) + (int32_t)p
+                             : scrf_node_start_state(T - 1, L) + (int32_t)L + (int32_t)p;
+      scrf_arc a = {src, 0, 0, final_w, fin};
+      arcs[ab + p] = a;
+    }
+    return;
+  }
+  const uint64_t ab = scrf_arc_base(t, L, D);
+  const uint32_t np = scrf_num_prev(t, D), nd = scrf_node_max_dur(t, D);
+  const uint64_t base = scrf_seg_base(t, D);
+  const int32_t nss = scrf_node_start_state(t, L);
+  uint64_t eb = ab;
+  if (np > 0) {  // boundary arcs (:260-296): for lab, for prev_lab
+    const double* Mt = M + (m_per_frame ? (size_t)t * LL : 0);
+    const int32_t pbase = (t == 1) ? scrf_node_start_state(0, L) : scrf_node_start_state(t - 1, L) + (int32_t)L;
+    for (uint32_t idx = threadIdx.x; idx < L * L; idx += blockDim.x) {
+      uint32_t lab = idx / L, pl = idx % L;
+      scrf_arc a = {pbase + (int32_t)pl, 0, 0, (float)(-1.0 * Mt[(size_t)pl * L + lab]), nss + (int32_t)lab};
+      arcs[ab + idx] = a;
+    }
+    eb += LL;
+  }
+  const int32_t ebase = (t == 0) ? nss : nss + (int32_t)L;  // end states of node t
+  for (uint32_t idx = threadIdx.x; idx < L * nd; idx += blockDim.x) {  // (:300-325): for lab, for dur
+    uint32_t lab = idx / nd, d = idx % nd + 1;
+    int32_t src = (d <= np) ? scrf_node_start_state(t - d + 1, L) + (int32_t)lab : 0;
+    int32_t lb = (int32_t)(lab + L * (d - 1) + 1);
+    scrf_arc a = {src, lb, lb, (float)(-1.0 * S[(base + d - 1) * L + lab]), ebase + (int32_t)lab};
+    arcs[eb + idx] = a;
+  }
+}
+
+__global__ void k_arcs_frame(ScrfLayout lay, uint32_t T, const double* __restrict__ S,
+                             const double* __restrict__ M, int m_per_frame, float final_w,
+                             scrf_arc* __restrict__ arcs) {
+  const uint32_t L = lay.L;
+  const uint32_t t = blockIdx.x;
+  const size_t LL = (size_t)L * L;
+  if (t == T) {
+    const uint64_t ab = (uint64_t)L + (uint64_t)(T - 1) * LL;
+    const int32_t fin = (int32_t)(L * T + 1);
+    for (uint32_t p = threadIdx.x; p < L; p += blockDim.x) {
+      scrf_arc a = {(int32_t)(L * (T - 1) + p + 1), 0, 0, final_w, fin};
+      arcs[ab + p] = a;
+    }
+    return;
+  }
+  if (t == 0) {
+    for (uint32_t c = threadIdx.x; c < L; c += blockDim.x) {
+      scrf_arc a = {0, (int32_t)c + 1, (int32_t)c + 1, (float)(-1.0 * S[c]), (int32_t)c + 1};
+      arcs[c] = a;
+    }
+    return;
+  }
+  const uint64_t ab = (uint64_t)L + (uint64_t)(t - 1) * LL;
+  const double* Mt = M + (m_per_frame ? (size_t)t * LL : 0);
+  for (uint32_t idx = threadIdx.x; idx < L * L; idx += blockDim.x) {
+    uint32_t c = idx / L, p = idx % L;
+    float w = (float)(-1.0 * (Mt[(size_t)p * L + c] + S[(size_t)t * L + c]));
+    scrf_arc a = {(int32_t)(L * (t - 1) + p + 1), (int32_t)c + 1, (int32_t)c + 1, w, (int32_t)(L * t + c + 1)};
+    arcs[ab + idx] = a;
+  }
+}
+
+void launch_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t T, int frame_model, const double* S,
+                 const double* M, int m_per_frame, float final_w, scrf_arc* arcs) {
+  if (T == 0) return;
+  if (frame_model)
+    hipLaunchKernelGGL(k_arcs_frame, dim3(T + 1), dim3(256), 0, st, lay, T, S, M, m_per_frame, final_w, arcs);
+  else
+    hipLaunchKernelGGL(k_arcs_seg, dim3(T + 1), dim3(256), 0, st, lay, T, S, M, m_per_frame, final_w, arcs);
+}
+
+// ------------------------------------------------------------------------------------------
+// optimizer and vector utilities
+// ------------------------------------------------------------------------------------------
+__global__ void k_sgd_step(double* __restrict__ lambda, double* __restrict__ lambda_acc,
+                           double* __restrict__ gsa, double* __restrict__ grad, uint32_t n, double lr,
+                           int adagrad, double eps) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double g = grad[i], lam = lambda[i];
+  if (adagrad) {  // :314-315
+    double a = __dadd_rn(gsa[i], __dmul_rn(g, g));
+    gsa[i] = a;
+    lam = __dadd_rn(lam, __dmul_rn(__ddiv_rn(lr, __dadd_rn(__dsqrt_rn(a), eps)), g));
+  } else {  // :317
+    lam = __dadd_rn(lam, __dmul_rn(lr, g));
+  }
+  lambda[i] = lam;
+  lambda_acc[i] = __dadd_rn(lambda_acc[i], lam);  // :319
+  grad[i] = 0.0;                                  // :321
+}
+void launch_sgd_step(hipStream_t st, double* lambda, double* lambda_acc, double* gsa, double* grad, uint32_t n,
+                     double lr, int adagrad, double eps) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_sgd_step, dim3((n + 255) / 256), dim3(256), 0, st, lambda, lambda_acc, gsa, grad, n, lr,
+                     adagrad, eps);
+}
+
+__global__ void k_scale(double* __restrict__ v, uint32_t n, double s, int divide) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = divide ? __ddiv_rn(v[i], s) : __dmul_rn(v[i], s);
+}
+void launch_scale(hipStream_t st, double* v, uint32_t n, double s, int divide) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_scale, dim3((n + 255) / 256), dim3(256), 0, st, v, n, s, divide);
+}
+
+__global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+void launch_add(hipStream_t st, double* y, const double* x, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_axpy, dim3((n + 255) / 256), dim3(256), 0, st, y, x, n);
+}

@@ -1,0 +1,307 @@
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # asr-craft_amd/
+
+LAB_BAD = 0xFFFFFFFF
+STDFRAME, STDSEG, STDSEG_NO_DUR, STDSEG_NO_DUR_NO_TRANSFTR, STDSEG_NO_DUR_NO_SEGTRANSFTR = range(5)
+STDSTATE, STDTRANS = 0, 1
+PREC_EXACT, PREC_FAST = 0, 1
+ABI_VERSION = 1
+MAX_STREAMS = 3
+N_PHASES = 7
+PHASES = ("windows", "scores", "fwd_bwd", "expf", "reduce", "viterbi", "total")
+
+ARC_DTYPE = np.dtype([("src", "<i4"), ("ilabel", "<i4"), ("olabel", "<i4"), ("w", "<f4"), ("dst", "<i4")])
+
+
+class ScrfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("scrf error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("model_type", C.c_uint32), ("map_type", C.c_uint32),
+        ("num_labs", C.c_uint32), ("num_feas", C.c_uint32), ("num_states", C.c_uint32),
+        ("lab_max_dur", C.c_uint32), ("use_state_ftrs", C.c_int32),
+        ("state_fidx_start", C.c_uint32), ("state_fidx_end", C.c_uint32),
+        ("use_trans_ftrs", C.c_int32), ("trans_fidx_start", C.c_uint32), ("trans_fidx_end", C.c_uint32),
+        ("use_state_bias", C.c_int32), ("use_trans_bias", C.c_int32),
+        ("state_bias_val", C.c_double), ("trans_bias_val", C.c_double),
+        ("device_id", C.c_int32), ("train_precision", C.c_uint32), ("scratch_bytes", C.c_uint64),
+    ]
+
+
+class StreamRecipe(C.Structure):
+    _fields_ = [("in_width", C.c_uint32), ("left_ctx", C.c_uint32), ("right_ctx", C.c_uint32),
+                ("extract_seg_ftr", C.c_int32)]
+
+
+class Utt(C.Structure):
+    _fields_ = [("T", C.c_uint32), ("windows", C.c_void_p), ("frames", C.c_void_p * MAX_STREAMS),
+                ("labels", C.c_void_p)]
+
+
+def lib_path():
+    return os.path.join(PKG_ROOT, "lib", "libscrf_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libscrf_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ScrfError(-1, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+        _lib = C.CDLL(p)
+        _lib.scrf_last_error.restype = C.c_char_p
+        _lib.scrf_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def window_width(in_width, D, lctx=0, rctx=0, extract_seg=True):
+    """io/CRF_InFtrStream_SeqMultiWindow.cpp:50-125"""
+    if D == 1:
+        return (lctx + 1 + rctx) * in_width
+    if extract_seg:
+        return 8 * in_width + D + (lctx + rctx) * in_width
+    return (lctx + 1 + rctx) * in_width
+
+
+def make_config(model_type=STDSEG_NO_DUR_NO_SEGTRANSFTR, L=48, D=25, F=337, sfs=0, sfe=-1, use_trans_ftrs=False,
+                tfs=0, tfe=-1, use_state_ftrs=True, use_state_bias=True, use_trans_bias=True,
+                state_bias_val=1.0, trans_bias_val=1.0, device_id=0, precision=PREC_EXACT, scratch_bytes=0):
+    """Same meaning as CRFTrain's set_fmap_config (CRFTrain/src/Main.cpp:372-430)."""
+    if sfe is None or sfe < 0:
+        sfe = F - 1
+    if tfe is None or tfe < 0:
+        tfe = F - 1
+    return Config(ABI_VERSION, model_type, STDTRANS if use_trans_ftrs else STDSTATE, L, F, 1, D,
+                  int(use_state_ftrs), sfs, sfe, int(use_trans_ftrs), tfs, tfe, int(use_state_bias),
+                  int(use_trans_bias), state_bias_val, trans_bias_val, device_id, precision, scratch_bytes)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Batch:
+    def __init__(self, eng, handle, n, keep):
+        self.eng, self.handle, self.n = eng, handle, n
+        self._keep = keep
+        nu = C.c_uint32(); nf = C.c_uint64(); ns = C.c_uint64(); na = C.c_uint64()
+        eng._chk(eng.lib.scrf_batch_info(eng.h, handle, C.byref(nu), C.byref(nf), C.byref(ns), C.byref(na)))
+        self.n_frames, self.n_segs, self.n_arcs = nf.value, ns.value, na.value
+
+    def close(self):
+        if self.handle:
+            self.eng.lib.scrf_batch_destroy(self.eng.h, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, cfg):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.lib.scrf_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise ScrfError(rc, self.lib.scrf_last_error(None).decode())
+        n = C.c_uint32()
+        self._chk(self.lib.scrf_lambda_len(self.h, C.byref(n)))
+        self.lambda_len = n.value
+        self.L, self.D, self.F = cfg.num_labs, cfg.lab_max_dur, cfg.num_feas
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ScrfError(rc, self.lib.scrf_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.scrf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- layout / model state
+    def state_idx(self, clab, fno=0):
+        v = C.c_uint32(); self._chk(self.lib.scrf_state_idx(self.h, clab, fno, C.byref(v))); return v.value
+
+    def trans_idx(self, plab, clab, fno=0):
+        v = C.c_uint32(); self._chk(self.lib.scrf_trans_idx(self.h, plab, clab, fno, C.byref(v))); return v.value
+
+    def num_state_funcs(self):
+        v = C.c_uint32(); self._chk(self.lib.scrf_num_state_funcs(self.h, C.byref(v))); return v.value
+
+    def num_trans_funcs(self):
+        v = C.c_uint32(); self._chk(self.lib.scrf_num_trans_funcs(self.h, C.byref(v))); return v.value
+
+    def set_lambda(self, lam):
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        self._chk(self.lib.scrf_set_lambda(self.h, _p(lam), C.c_uint32(lam.shape[0])))
+
+    def _get(self, fn):
+        out = np.empty(self.lambda_len, dtype=np.float64)
+        self._chk(fn(self.h, _p(out), C.c_uint32(self.lambda_len)))
+        return out
+
+    def get_lambda(self): return self._get(self.lib.scrf_get_lambda)
+    def get_lambda_acc(self): return self._get(self.lib.scrf_get_lambda_acc)
+    def get_grad_sqr_acc(self): return self._get(self.lib.scrf_get_grad_sqr_acc)
+    def get_grad(self): return self._get(self.lib.scrf_get_grad)
+
+    def zero_grad(self): self._chk(self.lib.scrf_zero_grad(self.h))
+    def synchronize(self): self._chk(self.lib.scrf_synchronize(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.scrf_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_grad_buffer(self, dptr):
+        self._chk(self.lib.scrf_set_grad_buffer(self.h, C.c_void_p(dptr)))
+
+    def grad_device_ptr(self):
+        p = C.c_void_p(); self._chk(self.lib.scrf_grad_device_ptr(self.h, C.byref(p))); return p.value
+
+    def add_grad(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        self._chk(self.lib.scrf_add_grad(self.h, _p(g), C.c_uint32(g.shape[0])))
+
+    def batch_sums(self):
+        s = np.zeros(3); self._chk(self.lib.scrf_get_batch_sums(self.h, _p(s))); return s
+
+    # ---- batches
+    def batch_from_frames(self, frames_list, labels_list=None, recipes=None, streams2=None):
+        """frames_list: list of [T(+ctx), in_width] arrays (stream 0); streams2: optional list of
+        lists for the further streams; recipes: list of StreamRecipe (default: one segment-feature stream)."""
+        n = len(frames_list)
+        all_streams = [frames_list] + (streams2 or [])
+        if recipes is None:
+            recipes = [StreamRecipe(frames_list[0].shape[1], 0, 0, 1)]
+        assert len(recipes) == len(all_streams)
+        keep = []
+        utts = (Utt * n)()
+        for u in range(n):
+            r0 = recipes[0]
+            utts[u].T = all_streams[0][u].shape[0] - r0.left_ctx - r0.right_ctx
+            utts[u].windows = None
+            for s, st in enumerate(all_streams):
+                a = np.ascontiguousarray(st[u], dtype=np.float32)
+                keep.append(a)
+                utts[u].frames[s] = a.ctypes.data
+            if labels_list is not None:
+                lb = np.ascontiguousarray(labels_list[u], dtype=np.uint32)
+                keep.append(lb)
+                utts[u].labels = lb.ctypes.data
+        rec = (StreamRecipe * len(recipes))(*recipes)
+        hb = C.c_void_p()
+        self._chk(self.lib.scrf_batch_create(self.h, utts, C.c_uint32(n), C.c_uint32(len(recipes)), rec, C.byref(hb)))
+        return Batch(self, hb, n, None)
+
+    def batch_from_windows(self, windows_list, T_list, labels_list=None):
+        n = len(windows_list)
+        keep = []
+        utts = (Utt * n)()
+        for u in range(n):
+            a = np.ascontiguousarray(windows_list[u], dtype=np.float32)
+            keep.append(a)
+            utts[u].T = int(T_list[u])
+            utts[u].windows = a.ctypes.data
+            if labels_list is not None:
+                lb = np.ascontiguousarray(labels_list[u], dtype=np.uint32)
+                keep.append(lb)
+                utts[u].labels = lb.ctypes.data
+        hb = C.c_void_p()
+        self._chk(self.lib.scrf_batch_create(self.h, utts, C.c_uint32(n), C.c_uint32(0), None, C.byref(hb)))
+        return Batch(self, hb, n, None)
+
+    # ---- hot path
+    def fb_batch(self, batch, want_scalars=True):
+        if want_scalars:
+            numer = np.zeros(batch.n); zx = np.zeros(batch.n)
+            self._chk(self.lib.scrf_fb_batch(self.h, batch.handle, _p(numer), _p(zx)))
+            return numer, zx
+        self._chk(self.lib.scrf_fb_batch(self.h, batch.handle, None, None))
+        return None, None
+
+    def num_segs(self, T):
+        D = self.D
+        return T * (T + 1) // 2 if T < D else D * (D + 1) // 2 + (T - D) * D
+
+    def scores(self, batch, u, T):
+        S = np.zeros((self.num_segs(T), self.L)); M = np.zeros((T, self.L * self.L))
+        self._chk(self.lib.scrf_scores(self.h, batch.handle, C.c_uint32(u), _p(S), _p(M)))
+        return S, M
+
+    def windows(self, batch, u, T):
+        X = np.zeros((self.num_segs(T), self.F), dtype=np.float32)
+        self._chk(self.lib.scrf_windows(self.h, batch.handle, C.c_uint32(u), _p(X)))
+        return X
+
+    def forward_backward(self, batch, u, T, prec=PREC_EXACT):
+        ad = np.zeros((self.num_segs(T), self.L)); al = np.zeros((T, self.L)); be = np.zeros((T, self.L))
+        zx = C.c_double()
+        self._chk(self.lib.scrf_forward_backward(self.h, batch.handle, C.c_uint32(u), C.c_uint32(prec), _p(ad), _p(al),
+                                                 _p(be), C.byref(zx)))
+        return ad, al, be, zx.value
+
+    # ---- decode
+    def lattice_arcs(self, batch, u, norm=False):
+        na = C.c_uint64(); ns = C.c_uint32(); fin = C.c_int32()
+        self._chk(self.lib.scrf_lattice_arcs(self.h, batch.handle, C.c_uint32(u), C.c_int(int(norm)), None,
+                                             C.byref(na), C.byref(ns), C.byref(fin)))
+        arcs = np.zeros(na.value, dtype=ARC_DTYPE)
+        self._chk(self.lib.scrf_lattice_arcs(self.h, batch.handle, C.c_uint32(u), C.c_int(int(norm)), _p(arcs),
+                                             C.byref(na), C.byref(ns), C.byref(fin)))
+        return arcs, ns.value, fin.value
+
+    def viterbi_batch(self, batch):
+        cap = batch.n_frames
+        labs = np.zeros(cap, dtype=np.uint32); off = np.zeros(batch.n + 1, dtype=np.uint64)
+        cost = np.zeros(batch.n, dtype=np.float32)
+        self._chk(self.lib.scrf_viterbi_batch(self.h, batch.handle, _p(labs), C.c_uint64(cap), _p(off), _p(cost)))
+        return [labs[int(off[u]):int(off[u + 1])].copy() for u in range(batch.n)], cost
+
+    # ---- reduce + optimizer
+    def allreduce_grad(self, active=True):
+        s = np.zeros(4)
+        self._chk(self.lib.scrf_allreduce_grad(self.h, C.c_int(int(active)), _p(s)))
+        return s
+
+    def comm_init_single(self):
+        """RCCL communicator of one rank (exercises the native path on a single GPU)."""
+        uid = (C.c_char * 128)()
+        rc = self.lib.scrf_comm_unique_id(uid)
+        if rc != 0:
+            raise ScrfError(rc, self.lib.scrf_last_error(None).decode())
+        self._chk(self.lib.scrf_comm_init(self.h, uid, 0, 1))
+
+    def scale_grad(self, s): self._chk(self.lib.scrf_scale_grad(self.h, C.c_double(s)))
+
+    def sgd_step(self, lr_or_eta, use_adagrad=False, eps=1e-12):
+        self._chk(self.lib.scrf_sgd_step(self.h, C.c_double(lr_or_eta), C.c_int(int(use_adagrad)), C.c_double(eps)))
+
+    # ---- measurement
+    def enable_timing(self, on=True): self._chk(self.lib.scrf_enable_timing(self.h, C.c_int(int(on))))
+
+    def last_timing(self):
+        ms = (C.c_float * N_PHASES)(); nl = (C.c_uint32 * N_PHASES)()
+        self._chk(self.lib.scrf_last_timing(self.h, ms, nl))
+        return {PHASES[i]: (ms[i], nl[i]) for i in range(N_PHASES)}

@@ -1,0 +1,227 @@
+/*
+ * scrf_abi.h -- C ABI of the MI355X-native segmental-CRF DP engine (libscrf_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of OSU-slatelab/ASR-CRaFT: per-utterance
+ * segment/transition scores, forward-backward with expected-feature-count gradient,
+ * Viterbi / lattice-arc emission, the minibatch gradient reduce and the SGD/AdaGrad step.
+ * The reference has no FFI: the path sits behind in-process C++ virtual interfaces.  Each
+ * entry point below names the reference interface it replaces (file:line relative to
+ * /root/reference/CRF/src/).  C++ adaptor classes with the reference's own names
+ * (CRF_Model, CRF_StdFeatureMap, CRF_StateNode accessors, CRF_GradBuilder,
+ * CRF_Minibatch_GradAccumulator, CRF_LatticeBuilder_*) sit on top of this ABI in
+ * asr-craft_amd/host/; INTEGRATION.md shows how a maintainer wires them in.
+ *
+ * Conventions
+ *  - plain pointers and sizes, no C++/torch types; every call returns SCRF_OK (0) or an
+ *    error code, scrf_last_error(h) gives the message the adaptor re-throws as
+ *    std::runtime_error (the reference throws everywhere; SURVEY 8b "Errors").
+ *  - one handle per process and GPU, calls serialized per handle (reference: one builder
+ *    per pthread, model shared read-only; SURVEY 8b "Threading").
+ *  - the engine fails loudly (SCRF_ERR_NO_DEVICE) when no gfx950 device is present: there
+ *    is NO CPU fallback in this library.
+ *  - labels: per frame t either SCRF_LAB_BAD or nActualLabs*(dur-1)+phone of the true
+ *    segment ENDING at t (trainers/gradbuilders/CRF_NewGradBuilder_StdSeg_NoDur_NoTrans.cpp:216-231).
+ *  - window order: for frame t the windows d=1..min(t+1,D) ending at t, each num_feas
+ *    floats (what CRF_FeatureStream::read(bunch_size=min(t+1,D)) returns, :166).
+ */
+#ifndef SCRF_ABI_H_
+#define SCRF_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCRF_ABI_VERSION 1
+#define SCRF_LAB_BAD 0xffffffffu /* CRF_LAB_BAD */
+
+enum scrf_status {
+  SCRF_OK = 0,
+  SCRF_ERR_INVALID = 1,    /* bad argument / unsupported configuration */
+  SCRF_ERR_NO_DEVICE = 2,  /* no HIP device: the product path never falls back to CPU */
+  SCRF_ERR_HIP = 3,        /* a HIP runtime call or kernel failed */
+  SCRF_ERR_NUMERIC = 4,    /* overflow/NaN/log(0) as thrown by utils/CRF_LogMath.cpp:192-224,
+                              or posterior-mass check of nodes/...WithoutSegTransFtr.cpp:917-947 */
+  SCRF_ERR_BAD_LABEL = 5,  /* label >= nActualLabs*labMaxDur (:627-631) */
+  SCRF_ERR_EMPTY = 6,      /* "No features read from this sentence" (gradbuilder :331-335) */
+  SCRF_ERR_COMM = 7        /* RCCL failure */
+};
+
+/* modeltype, CRF.h:50 */
+enum scrf_model_type {
+  SCRF_STDFRAME = 0,
+  SCRF_STDSEG = 1,                       /* not built */
+  SCRF_STDSEG_NO_DUR = 2,                /* not built */
+  SCRF_STDSEG_NO_DUR_NO_TRANSFTR = 3,    /* served by the same engine (bias-only transitions) */
+  SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR = 4  /* the TIMIT-demo model */
+};
+
+/* ftrmaptype, CRF.h:40 (dense maps only) */
+enum scrf_map_type { SCRF_STDSTATE = 0, SCRF_STDTRANS = 1 };
+
+/* Arithmetic policy of the score / expected-count contractions.
+ *  EXACT : fp64, ascending feature order, unfused multiply-then-add == the reference's
+ *          CRF_StdFeatureMap::computeStateArrayValue bit for bit (needed for bit-identical
+ *          lattice arcs / Viterbi).  Always used by the decode entry points.
+ *  FAST  : fp64 MFMA (v_mfma_f64_16x16x4_f64); sums reordered, results within 1e-4 rel. */
+enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1 };
+
+/* Mirrors CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) plus the model fields
+ * CRFTrain sets on CRF_Model (CRFTrain/src/Main.cpp:539-597). */
+typedef struct scrf_config {
+  uint32_t abi_version;     /* SCRF_ABI_VERSION */
+  uint32_t model_type;      /* scrf_model_type */
+  uint32_t map_type;        /* scrf_map_type */
+  uint32_t num_labs;        /* numLabs == nActualLabs (crf_label_size) */
+  uint32_t num_feas;        /* numFeas: floats per window (joined streams) */
+  uint32_t num_states;      /* must be 1 (crf_states) */
+  uint32_t lab_max_dur;     /* label_maximum_duration; 1 for STDFRAME */
+  int32_t use_state_ftrs;
+  uint32_t state_fidx_start, state_fidx_end; /* inclusive */
+  int32_t use_trans_ftrs;
+  uint32_t trans_fidx_start, trans_fidx_end; /* inclusive */
+  int32_t use_state_bias, use_trans_bias;
+  double state_bias_val, trans_bias_val;
+  int32_t device_id;        /* HIP device ordinal */
+  uint32_t train_precision; /* scrf_precision for scrf_fb_* (decode is always EXACT) */
+  uint64_t scratch_bytes;   /* per-chunk device scratch budget, 0 = default (8 GiB) */
+} scrf_config;
+
+/* One input stream of CRFTrain (ftr1/ftr2/ftr3 flags, CRFTrain/src/Main.cpp:146-256):
+ * raw frames plus the window recipe of io/CRF_InFtrStream_SeqMultiWindow.cpp.  The frame
+ * array of an utterance has (T + left_ctx + right_ctx) rows: the caller supplies the
+ * context padding (the demo reads it from a padded pfile). */
+typedef struct scrf_stream_recipe {
+  uint32_t in_width;        /* floats per raw frame */
+  uint32_t left_ctx, right_ctx;
+  int32_t extract_seg_ftr;  /* 1: [5 samples,avg,max,min,one-hot dur]; 0: boundary context */
+} scrf_stream_recipe;
+
+#define SCRF_MAX_STREAMS 3
+
+/* One utterance.  Either `windows` (materialised window vectors, any feature pipeline) or
+ * `frames[s]` for every stream of the batch recipe.  Host pointers. */
+typedef struct scrf_utt {
+  uint32_t T;                             /* frames */
+  const float* windows;                   /* [N_seg(T)][num_feas] or NULL */
+  const float* frames[SCRF_MAX_STREAMS];  /* [(T+lctx+rctx)][in_width] per stream, or NULL */
+  const uint32_t* labels;                 /* [T] or NULL (decode only) */
+} scrf_utt;
+
+/* StdArc as OpenFST lays it out: int32 ilabel, olabel; float weight; int32 nextstate, plus
+ * the source state the reference passes to AddArc. */
+typedef struct scrf_arc {
+  int32_t src, ilabel, olabel;
+  float w;
+  int32_t dst;
+} scrf_arc;
+
+typedef struct scrf_engine_s* scrf_handle;
+typedef struct scrf_batch_s* scrf_batch;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* replaces: new CRF_Model + CRF_FeatureMap::createFeatureMap (CRF_Model.cpp:75,
+ * ftrmaps/CRF_FeatureMap.cpp, CRFTrain/src/Main.cpp:539-597) */
+int scrf_create(const scrf_config* cfg, scrf_handle* out);
+int scrf_destroy(scrf_handle h);
+const char* scrf_last_error(scrf_handle h); /* h may be NULL: error of the last failed create */
+/* run everything on this hipStream_t (e.g. torch's current stream); NULL = engine's own */
+int scrf_set_stream(scrf_handle h, void* hip_stream);
+int scrf_synchronize(scrf_handle h);
+
+/* ---- lambda layout (parity hooks for CRF_StdFeatureMap::recalc/get*Idx, :421-517) ------ */
+int scrf_lambda_len(scrf_handle h, uint32_t* n);
+int scrf_num_state_funcs(scrf_handle h, uint32_t* n);
+int scrf_num_trans_funcs(scrf_handle h, uint32_t* n);
+int scrf_state_idx(scrf_handle h, uint32_t clab, uint32_t fno, uint32_t* idx);
+int scrf_trans_idx(scrf_handle h, uint32_t plab, uint32_t clab, uint32_t fno, uint32_t* idx);
+
+/* ---- model state (CRF_Model::setLambda/getLambda/getLambdaAcc/getGradSqrAcc) ----------- */
+int scrf_set_lambda(scrf_handle h, const double* lambda, uint32_t n);
+int scrf_get_lambda(scrf_handle h, double* lambda, uint32_t n);
+int scrf_set_lambda_acc(scrf_handle h, const double* v, uint32_t n);
+int scrf_get_lambda_acc(scrf_handle h, double* v, uint32_t n);
+int scrf_set_grad_sqr_acc(scrf_handle h, const double* v, uint32_t n);
+int scrf_get_grad_sqr_acc(scrf_handle h, double* v, uint32_t n);
+
+/* ---- batches: utterances resident in HBM ------------------------------------------------ */
+/* replaces: CRF_FeatureStream views + CRF_InFtrStream_SeqMultiWindow / CRF_InLabStream_
+ * SeqMultiWindow (io/, rows 25-27): packs and uploads n utterances once; all compute entry
+ * points then run from HBM.  n_streams/recipes describe the frame inputs (ignored for
+ * utterances given as windows). */
+int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n, uint32_t n_streams,
+                      const scrf_stream_recipe* recipes, scrf_batch* out);
+int scrf_batch_destroy(scrf_handle h, scrf_batch b);
+int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, uint64_t* n_frames,
+                    uint64_t* n_segs, uint64_t* n_arcs);
+
+/* ---- hot path: forward-backward + gradient ------------------------------------------------ */
+/* replaces: CRF_NewGradBuilder_StdSeg_NoDur_NoTrans::buildGradient (trainers/gradbuilders/
+ * ...NoDur_NoTrans.cpp:65-492; frame model: CRF_NewGradBuilder.cpp:48-382) for every
+ * utterance of the batch.  The engine's device gradient accumulates (+=) the sum over
+ * utterances of (observed - expected) counts; numer[u]/zx[u] (host, may be NULL) receive the
+ * per-utterance numerator and log-partition (caller forms logLi = numer - zx,
+ * trainers/CRF_SGTrainer.cpp:274).  Asynchronous on the engine stream unless numer/zx given. */
+int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double* zx);
+int scrf_zero_grad(scrf_handle h);
+int scrf_get_grad(scrf_handle h, double* grad, uint32_t n);      /* device -> host copy */
+int scrf_add_grad(scrf_handle h, const double* grad, uint32_t n); /* grad += host vector */
+int scrf_grad_device_ptr(scrf_handle h, void** dptr);            /* for an external all-reduce */
+/* accumulate into caller-owned device memory of lambda_len doubles (e.g. a tensor that
+ * torch.distributed all-reduces over RCCL); NULL restores the engine's own buffer */
+int scrf_set_grad_buffer(scrf_handle h, void* dptr);
+/* sums over the batch kept on device: {sum numer, sum zx, n_utts} */
+int scrf_get_batch_sums(scrf_handle h, double* sums3);
+
+/* ---- parity hooks: the node accessors of nodes/CRF_StateNode.h:67-115 ---------------------- */
+/* getStateValue(lab,dur) / getTransValue(p,c): S[N_seg][L], M[T][L*L] of utterance u (EXACT) */
+int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M);
+/* window synthesis of utterance u: [N_seg][num_feas] (io/CRF_InFtrStream_SeqMultiWindow.cpp) */
+int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* windows);
+/* getAlpha / alphaArray_WithDur / getBeta / computeAlphaSum, with precision `prec`:
+ * alpha_dur [N_seg][L], alpha [T][L], beta [T][L] (any may be NULL) */
+int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, uint32_t prec,
+                          double* alpha_dur, double* alpha, double* beta, double* zx);
+
+/* ---- decode -------------------------------------------------------------------------------- */
+/* replaces: buildLattice<StdArc> (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab_
+ * WithoutSegTransFtr.h:30-407; frame model decoders/CRF_LatticeBuilder.h:97-204): arcs in
+ * the reference's AddArc order, weights float(-double).  Call with arcs==NULL to get counts. */
+int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int norm, scrf_arc* arcs,
+                      uint64_t* n_arcs, uint32_t* n_states, int32_t* final_state);
+/* replaces: buildLattice + ShortestPath/Project/RmEpsilon/TopSort + (olabel-1)
+ * (CRFFstDecode/src/Main.cpp:804-889) for every utterance: seg_labels receives the labels
+ * back to back, lab_off[u]..lab_off[u+1] (lab_off has n_utts+1 entries), best_cost[u] the
+ * float path weight.  max_labels = capacity of seg_labels (sum of T is always enough). */
+int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
+                       uint64_t* lab_off, float* best_cost);
+
+/* ---- minibatch reduce + optimizer ------------------------------------------------------------ */
+/* replaces the join/sum/average of CRF_Minibatch_GradAccumulator::accumulateGradient
+ * (trainers/accumulators/CRF_Minibatch_GradAccumulator.cpp:277-312): all-reduce (sum) of the
+ * device gradient and of {numer, zx, n_utts, active} over the communicator's ranks, then
+ * grad /= number of active ranks.  Without a communicator (single GPU) it only divides by
+ * `active` (1).  sums4 (host, may be NULL) = reduced {numer, zx, n_utts, n_active}. */
+int scrf_comm_unique_id(void* id128);                       /* ncclGetUniqueId, 128 bytes */
+int scrf_comm_init(scrf_handle h, const void* id128, int rank, int n_ranks);
+int scrf_allreduce_grad(scrf_handle h, int active, double* sums4);
+/* grad *= s  (used with an external all-reduce: s = 1/n_active) */
+int scrf_scale_grad(scrf_handle h, double s);
+/* replaces CRF_SGTrainer::sgtrainMinibatch's update (trainers/CRF_SGTrainer.cpp:299-325):
+ * lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0. */
+int scrf_sgd_step(scrf_handle h, double lr_or_eta, int use_adagrad, double eps);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* HIP-event time (ms) of the phases of the last scrf_fb_batch / scrf_viterbi_batch on the
+ * engine stream: [0] windows, [1] scores, [2] forward-backward+posteriors, [3] expected
+ * counts (ExpF GEMM), [4] reduce, [5] viterbi, [6] whole call; n_launch[i] = kernel launches. */
+#define SCRF_N_PHASES 7
+int scrf_last_timing(scrf_handle h, float* ms, uint32_t* n_launch);
+int scrf_enable_timing(scrf_handle h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCRF_ABI_H_ */

@@ -1,0 +1,270 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bars: bit-exact for window vectors, scores (EXACT mode), lattice arcs and Viterbi label
+sequences; forward log-likelihood and gradients within 1e-4 relative (BASELINE.json) -- the
+tests assert much tighter bounds than the contract wherever the fp64 path allows it."""
+import numpy as np
+import pytest
+
+import orc
+import scrf_amd
+from cases import Case
+
+pytestmark = pytest.mark.gpu
+
+REL_CONTRACT = 1e-4  # BASELINE.json north_star: log-likelihood and gradients within 1e-4 relative
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+CASES = [
+    dict(L=3, D=3, in_w=2, Ts=[1, 2, 3, 4, 7]),                       # T around D, incl. T=1
+    dict(L=2, D=4, in_w=3, Ts=[3, 4, 5, 12], trans_ctx=1),            # transition features
+    dict(L=5, D=1, in_w=4, Ts=[1, 6, 9], trans_ctx=2),                # D=1 segmental
+    dict(L=7, D=10, in_w=5, Ts=[9, 10, 11, 30]),                      # T = D-1, D, D+1, 3D
+    dict(L=48, D=25, in_w=39, Ts=[60, 33]),                           # config-2 shape, short
+    dict(L=48, D=10, in_w=8, Ts=[40, 25], trans_ctx=1, lam_scale=0.05),  # TIMIT-like: stdtrans
+]
+
+
+@pytest.fixture(scope="module", params=range(len(CASES)), ids=lambda i: "case%d" % i)
+def case(request):
+    c = Case(seed=100 + request.param, **CASES[request.param])
+    eng = c.engine()
+    b = c.batch(eng)
+    yield c, eng, b
+    b.close(); eng.close()
+
+
+def test_layout_hooks(case):
+    c, eng, _ = case
+    assert eng.lambda_len == c.olay.lambda_len
+    assert eng.num_state_funcs() == c.olay.num_state_funcs and eng.num_trans_funcs() == c.olay.num_trans_funcs
+    for l in range(c.L):
+        assert eng.state_idx(l) == c.olay.state_idx[l]
+        for p in range(c.L):
+            assert eng.trans_idx(p, l) == c.olay.trans_idx[p * c.L + l]
+
+
+def test_windows_bit_exact(case):
+    c, eng, b = case
+    for u, T in enumerate(c.Ts):
+        assert np.array_equal(bits(eng.windows(b, u, T)), bits(c.windows(u)))
+
+
+def test_scores_bit_exact(case):
+    c, eng, b = case
+    for u, T in enumerate(c.Ts):
+        S, M = eng.scores(b, u, T)
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        assert np.array_equal(bits(S), bits(So))
+        assert np.array_equal(bits(M), bits(Mo))
+
+
+def test_forward_backward(case):
+    c, eng, b = case
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        rc, ad, al, apt, zx = orc.seg_forward(c.ocfg, So, Mo, T)
+        rc2, be, sd = orc.seg_backward(c.ocfg, So, Mo, T)
+        assert rc == 0 and rc2 == 0
+        gad, gal, gbe, gzx = eng.forward_backward(b, u, T)
+        tol = 1e-11
+        assert abs(gzx - zx) <= tol * max(1, abs(zx))
+        np.testing.assert_allclose(gad, ad, rtol=tol, atol=tol)
+        np.testing.assert_allclose(gal, al, rtol=tol, atol=tol)
+        np.testing.assert_allclose(gbe, be, rtol=tol, atol=tol)
+
+
+def test_fb_batch_gradient(case):
+    c, eng, b = case
+    eng.zero_grad()
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-12 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-11 * np.abs(ozx).max()
+    scale = np.abs(og).max()
+    err = np.abs(g - og).max() / scale
+    assert err <= REL_CONTRACT
+    assert err <= 1e-9, err  # what the fp64 path actually delivers
+    s = eng.batch_sums()
+    assert abs(s[0] - onumer.sum()) < 1e-9 * max(1, abs(onumer.sum())) and s[2] == len(c.Ts)
+    # gradient accumulates (+=) like the reference's per-thread buffer
+    eng.fb_batch(b)
+    np.testing.assert_allclose(eng.get_grad(), 2 * g, rtol=1e-12, atol=1e-12 * scale)
+
+
+def test_lattice_arcs_bit_exact(case):
+    c, eng, b = case
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+        ga, gns, gfin = eng.lattice_arcs(b, u)
+        assert (gns, gfin) == (ons, ofin)
+        assert ga.tobytes() == oa.tobytes()
+
+
+def test_viterbi_matches_shortest_path_on_reference_lattice(case):
+    c, eng, b = case
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol)
+        assert np.float32(cost[u]).tobytes() == np.float32(oc).tobytes()
+
+
+def test_viterbi_tie_rule_on_zero_weights():
+    c = Case(L=3, D=2, in_w=2, Ts=[4, 5], seed=1)
+    c.lam[:] = 0.0
+    eng = c.engine(); b = c.batch(eng)
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        S = np.zeros((orc.num_segs(T, c.D), c.L)); M = np.zeros((T, c.L * c.L))
+        oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, S, M, T)
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol) and cost[u] == oc
+    b.close(); eng.close()
+
+
+def test_frame_model_config1_shape():
+    """frame-level CRF (a15, a17): gradient, lattice arcs and best path."""
+    c = Case(L=6, D=1, in_w=3, Ts=[4, 3, 4, 9], trans_ctx=0, seed=5, frame_model=True)
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    og, on, oz = c.oracle_gradient()
+    assert np.abs(numer - on).max() < 1e-12 * max(1, np.abs(on).max()) and np.abs(zx - oz).max() < 1e-11 * np.abs(oz).max()
+    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() < 1e-9
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.frame_lattice_arcs(c.ocfg, So, Mo, T)
+        ga, gns, gfin = eng.lattice_arcs(b, u)
+        assert (gns, gfin) == (ons, ofin) and ga.tobytes() == oa.tobytes()
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol) and np.float32(cost[u]).tobytes() == np.float32(oc).tobytes()
+    b.close(); eng.close()
+
+
+def test_materialised_windows_input_equals_frame_input():
+    c = Case(L=4, D=3, in_w=3, Ts=[5, 8], trans_ctx=1, seed=9)
+    eng = c.engine()
+    b1 = c.batch(eng)
+    b2 = eng.batch_from_windows([c.windows(u) for u in range(2)], c.Ts, c.labels)
+    eng.zero_grad(); n1, z1 = eng.fb_batch(b1); g1 = eng.get_grad()
+    eng.zero_grad(); n2, z2 = eng.fb_batch(b2); g2 = eng.get_grad()
+    assert np.array_equal(n1, n2) and np.array_equal(z1, z2) and np.array_equal(g1, g2)
+    b1.close(); b2.close(); eng.close()
+
+
+def test_chunking_is_invisible():
+    """a tiny scratch budget forces one chunk per utterance; results must not change."""
+    kw = dict(L=5, D=4, in_w=3, Ts=[6, 9, 4, 12, 7], trans_ctx=1, seed=21)
+    c1 = Case(**kw); c2 = Case(scratch_bytes=1 << 16, **kw)
+    e1, e2 = c1.engine(), c2.engine()
+    b1, b2 = c1.batch(e1), c2.batch(e2)
+    n1, z1 = e1.fb_batch(b1); n2, z2 = e2.fb_batch(b2)
+    assert np.array_equal(n1, n2) and np.array_equal(z1, z2)
+    np.testing.assert_allclose(e1.get_grad(), e2.get_grad(), rtol=1e-12, atol=1e-13)
+    l1, c1c = e1.viterbi_batch(b1); l2, c2c = e2.viterbi_batch(b2)
+    assert all(list(a) == list(bb) for a, bb in zip(l1, l2)) and np.array_equal(c1c, c2c)
+    for x in (b1, b2): x.close()
+    e1.close(); e2.close()
+
+
+def test_minibatch_reduce_and_optimizer_step():
+    c = Case(L=4, D=3, in_w=2, Ts=[6, 5, 8], seed=33)
+    eng = c.engine(); b = c.batch(eng)
+    eng.fb_batch(b)
+    g = eng.get_grad()
+    s = eng.allreduce_grad(active=True)          # single rank: grad /= 1
+    assert s[3] == 1 and np.array_equal(eng.get_grad(), g)
+    lam = c.lam.copy(); acc = np.zeros_like(lam); gsa = np.zeros_like(lam); gg = g.copy()
+    orc.sgd_step(lam, acc, gsa, gg, 0.1, False)
+    eng.sgd_step(0.1, False)
+    assert np.array_equal(eng.get_lambda(), lam) and np.array_equal(eng.get_lambda_acc(), acc)
+    assert not eng.get_grad().any()
+    eng.fb_batch(b)
+    g2 = eng.get_grad(); gg = g2.copy()
+    orc.sgd_step(lam, acc, gsa, gg, 1.0, True, 1e-12)
+    eng.sgd_step(1.0, True, 1e-12)
+    assert np.array_equal(eng.get_lambda(), lam) and np.array_equal(eng.get_grad_sqr_acc(), gsa)
+    assert np.array_equal(eng.get_lambda_acc(), acc)
+    b.close(); eng.close()
+
+
+def test_native_rccl_single_rank():
+    c = Case(L=3, D=2, in_w=2, Ts=[5], seed=2)
+    eng = c.engine(); b = c.batch(eng)
+    eng.comm_init_single()
+    eng.fb_batch(b); g = eng.get_grad()
+    s = eng.allreduce_grad(active=True)
+    assert s[3] == 1 and s[2] == 1 and np.array_equal(eng.get_grad(), g)
+    b.close(); eng.close()
+
+
+def test_error_behaviour():
+    c = Case(L=3, D=2, in_w=2, Ts=[5], seed=2)
+    eng = c.engine()
+    bad = [np.array([scrf_amd.LAB_BAD, 3 * 2 + 1, scrf_amd.LAB_BAD, 0, 1], dtype=np.uint32)]  # label >= L*D
+    b = eng.batch_from_frames(c.frames, bad, c.recipes)
+    with pytest.raises(scrf_amd.ScrfError) as ei:
+        eng.fb_batch(b)
+    assert ei.value.code == 5
+    b.close()
+    with pytest.raises(scrf_amd.ScrfError) as ei:
+        eng.batch_from_frames([np.zeros((0, 2), np.float32)], [np.zeros(0, np.uint32)], c.recipes)
+    assert ei.value.code == 6  # "No features read from this sentence."
+    with pytest.raises(scrf_amd.ScrfError):
+        scrf_amd.Engine(scrf_amd.make_config(model_type=scrf_amd.STDFRAME, L=4, D=3, F=5))  # stdframe needs D=1
+    eng.close()
+
+
+def test_full_size_config2_utterances():
+    """BASELINE config 2 at full size (L=48, D=25, 39-dim x 300 frames): oracle on 2 utterances,
+    size-independent properties on all."""
+    from scrf_amd import synth
+    L, D, in_w, T, U = 48, 25, 39, 300, 6
+    frames, labels, off = synth.make_batch(U, T, in_w, L, D)
+    F = 8 * in_w + D
+    lam = synth.make_lambda(L * (F + 1 + L))
+    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F)); eng.set_lambda(lam)
+    fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
+    ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
+    b = eng.batch_from_frames(fl, ll)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    assert np.isfinite(g).all() and (numer < zx).all()
+    ocfg = orc.config(L=L, D=D, F=F); olay = orc.Layout(ocfg)
+    og = np.zeros(olay.lambda_len)
+    for u in range(2):
+        X = orc.windows(fl[u], D)
+        rc, og, on, oz = orc.seg_build_gradient(ocfg, olay, lam, X, ll[u], T, grad=og)
+        assert rc == 0
+        assert abs(on - numer[u]) <= 1e-12 * abs(on) and abs(oz - zx[u]) <= 1e-11 * abs(oz)
+    eng.zero_grad()
+    b2 = eng.batch_from_frames(fl[:2], ll[:2])
+    eng.fb_batch(b2)
+    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() < 1e-9
+    # property: sum over labels of the state-bias gradient = (#true segments) - E[#segments]; and the
+    # expected number of segment ends per utterance equals 1 at the last frame => bias grads are finite
+    # and transition-bias gradient mass = state mass minus one segment per utterance
+    nsf = F + 1
+    sb = np.array([g[l * (nsf + L) + F] for l in range(L)]).sum()
+    tb = sum(g[l * (nsf + L) + nsf:(l + 1) * (nsf + L)].sum() for l in range(L))
+    assert abs((sb - tb)) < 1e-6 * U * T  # every segment but the last of an utterance has one outgoing transition
+    labs, cost = eng.viterbi_batch(b)
+    for u in range(U):
+        durs = [int(x) // L + 1 for x in labs[u]]
+        assert sum(durs) == T and max(durs) <= D
+    So, Mo = orc.seg_scores(ocfg, olay, lam, orc.windows(fl[0], D), T)
+    oa, ons, ofin = orc.seg_lattice_arcs(ocfg, So, Mo, T)
+    ol, oc = orc.best_path(oa, ons, ofin)
+    assert list(labs[0]) == list(ol) and np.float32(cost[0]).tobytes() == np.float32(oc).tobytes()
+    ga, gns, gfin = eng.lattice_arcs(b, 0)
+    assert ga.tobytes() == oa.tobytes()
+    b.close(); b2.close(); eng.close()

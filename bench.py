@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/sec of segmental-CRF forward-backward (+ gradient reduce + SGD step)
+on synthetic TIMIT-shape feature streams, BASELINE.json config 2:
+  48 labels, max segment length 25, 39-dim x 300-frame utterances, `stdstate` feature map.
+
+One "step" = one SGD minibatch on every rank: forward-backward + expected-count gradient over
+the rank's utterances (already resident in HBM), all-reduce (sum) of the weight gradient over
+RCCL, divide by the active ranks, SGD update.  Weak scaling: every rank processes --utts
+utterances per step.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "asr-craft_amd", "python"))
+
+import numpy as np  # noqa: E402
+
+L, D, IN_W, T_FRAMES = 48, 25, 39, 300
+F = 8 * IN_W + D  # 337 segment features (io/CRF_InFtrStream_SeqMultiWindow.cpp:77-78)
+PEAK = {"mfma_f64_tflops": 78.6, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md (HBM); fp64 MFMA: SURVEY 8d vendor peak
+
+
+def n_segs(T, Dm):
+    return T * (T + 1) // 2 if T < Dm else Dm * (Dm + 1) // 2 + (T - Dm) * Dm
+
+
+def cpu_baseline(frames, labels, off, lam):
+    """The oracle (CPU restatement of the reference path, `port`) timed on this box's host cores
+    over a bounded sample of the same workload.  Reported beside the GPU number, never shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    n = min(len(off) - 1, cores * 24)
+    cfg = orc.config(L=L, D=D, F=F)
+    o = np.asarray(off[:n + 1])
+    rc, g, numer, zx, sec = orc.bench_fb(cfg, lam, frames[:int(o[-1])], labels[:int(o[-1])], o, IN_W, cores)
+    assert rc == 0
+    rc1, _, _, _, sec1 = orc.bench_fb(cfg, lam, frames[:int(o[2])], labels[:int(o[2])], o[:3], IN_W, 1)
+    return {"value": round(n / sec, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d utterances of the same batch, %d threads, %.1f s; single thread %.2f utt/s"
+                      % (n, cores, sec, 2 / sec1)}, (g, numer, zx, n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import scrf_amd
+    from scrf_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    U = args.utts
+    # synthetic data of the config-2 shape; every rank owns a different contiguous utterance range
+    frames, labels, off = synth.make_batch(U, T_FRAMES, IN_W, L, D, seed=1234 + 100003 * rank)
+    cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank)
+    eng = scrf_amd.Engine(cfg)
+    lam = synth.make_lambda(eng.lambda_len)
+    eng.set_lambda(lam)
+    stream = torch.cuda.Stream()  # a real (non-null) HIP stream shared by the engine and torch/RCCL
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
+    grad = torch.zeros(eng.lambda_len, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(4, dtype=torch.float64, device="cuda")
+    eng.set_grad_buffer(grad.data_ptr())
+    fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
+    ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
+    batch = eng.batch_from_frames(fl, ll)  # inputs resident in HBM from here on
+    lr = 0.1 / U
+
+    def step():
+        eng.zero_grad()
+        eng.fb_batch(batch, want_scalars=False)  # async on torch's current stream
+        if dist is not None:
+            dist.all_reduce(grad)                # RCCL over xGMI: sum of the weight gradient
+            eng.scale_grad(1.0 / world)          # / active ranks (Minibatch_GradAccumulator.cpp:306-308)
+        eng.sgd_step(lr, False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: one extra instrumented step (HIP events on the
+        # engine's stream around every phase), outside the timed region
+        eng.set_lambda(lam)
+        eng.enable_timing(True)
+        eng.zero_grad()
+        eng.fb_batch(batch, want_scalars=False)
+        eng.synchronize()
+        tm = eng.last_timing()
+        eng.enable_timing(False)
+        nseg = n_segs(T_FRAMES, D)
+        flops_gemm = 2.0 * nseg * L * F * U          # per phase: scores or expected counts
+        bytes_dp = (8.0 * (5 * nseg * L + 4 * T_FRAMES * L)) * U
+        phases = {
+            "scores": ("mfma", flops_gemm / 1e12, "TFLOP/s", PEAK["mfma_f64_tflops"]),
+            "expf": ("mfma", flops_gemm / 1e12, "TFLOP/s", PEAK["mfma_f64_tflops"]),
+            "fwd_bwd": ("hbm", bytes_dp / 1e9, "GB/s", PEAK["hbm_gbs"]),
+        }
+        dom = max(phases, key=lambda k: tm[k][0])
+        bound, work, unit, peak = phases[dom]
+        ms, nl = tm[dom]
+        achieved = work / (ms / 1e3)
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 5), "traffic": None,
+                    "launches": int(nl), "avg_launch_ms": round(ms / max(1, nl), 4),
+                    "phase_ms": {k: round(v[0], 3) for k, v in tm.items()}}
+        out = {
+            "metric": "utterances/sec SCRF forward-backward (TIMIT-shape)",
+            "value": round(U * world * args.steps / dt, 2),
+            "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: segmental CRF forward-backward, 48 labels, max-seg-len 25, "
+                                   "39-dim x 300-frame utterances, stdstate map (lambda_len 18528)",
+                       "utts_per_rank_per_step": U, "global_minibatch": U * world,
+                       "parallelism": "dp%d" % world},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            cb, _ = cpu_baseline(frames, labels, off, lam)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / cb["value"], 1)
+    batch.close()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

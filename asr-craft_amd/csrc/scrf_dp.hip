@@ -1,0 +1,473 @@
+// scrf_dp.hip -- wavefront-per-utterance forward/backward for L <= 64 labels (gfx950, wave64).
+//
+// Design (DESIGN.md "DP kernels"):
+//  * one 64-lane wavefront owns one utterance, lane = label; no workgroup barriers in the
+//    time loop, all cross-label traffic is v_readlane broadcasts and wave reductions;
+//  * the L x L transition step runs in the linear domain:
+//        aPT[n] = amax + shift + log( sum_c exp(alpha[c]-amax) * E[c][n] ),  E = exp(M - shift)
+//    i.e. L exps + L*L FMAs per frame instead of L*L exps (mathematically the reference's
+//    logAdd over c; differs in rounding only, ~1e-16 relative);
+//  * the duration step stays in the log domain: alpha[l] = LSE_d(aPT[t-d][l] + S[t][d][l]);
+//  * forward and backward are independent given the scores, so one launch runs them as two
+//    halves of the grid (blockIdx parity), doubling the wavefronts in flight;
+//  * posteriors (gamma, xi) need no recursion: they are separate fully parallel kernels.
+// Reference arithmetic being reproduced: nodes/CRF_StdSegStateNode_WithoutDurLab_WithoutSegTransFtr.cpp
+//   computeAlpha :123-245, computeAlphaPlusTrans :1077-1108, computeBeta :395-466, computeExpF :616-949.
+#include "scrf_kernels.h"
+
+#include <float.h>
+#include <math.h>
+
+#define DP_WPB 6  // wavefronts (utterances) per workgroup
+
+__device__ __forceinline__ double rdlane(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// E = exp(M - max(M)), its transpose, and the shift; one workgroup per L x L matrix
+__global__ void k_exp_m(const double* __restrict__ M, uint32_t L, double* __restrict__ E,
+                        double* __restrict__ ET, double* __restrict__ mshift) {
+  __shared__ double red[256];
+  const uint32_t LL = L * L;
+  const double* Mb = M + (size_t)blockIdx.x * LL;
+  double mx = -INFINITY;
+  for (uint32_t i = threadIdx.x; i < LL; i += blockDim.x) mx = fmax(mx, Mb[i]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  for (uint32_t i = threadIdx.x; i < LL; i += blockDim.x) {
+    double e = exp(Mb[i] - mx);
+    E[(size_t)blockIdx.x * LL + i] = e;
+    ET[(size_t)blockIdx.x * LL + (size_t)(i % L) * L + i / L] = e;
+  }
+  if (threadIdx.x == 0) mshift[blockIdx.x] = mx;
+}
+
+void launch_exp_m(hipStream_t st, const double* M, uint32_t L, uint64_t n_mat, double* E, double* ET,
+                  double* mshift) {
+  if (n_mat == 0) return;
+  hipLaunchKernelGGL(k_exp_m, dim3((uint32_t)n_mat), dim3(256), 0, st, M, L, E, ET, mshift);
+}
+
+// sum_c bcast(a, c) * Em[c*L + lc]; four partial sums break the FMA dependency chain.
+// AS = address space of Em is known at compile time (LDS or global), never a flat pointer.
+template <class PTR>
+__device__ __forceinline__ double matvec_bcast(const double a, PTR Em, const int L, const int lc) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int c = 0;
+  for (; c + 4 <= L; c += 4) {
+    const double e0 = Em[(c + 0) * L + lc], e1 = Em[(c + 1) * L + lc];
+    const double e2 = Em[(c + 2) * L + lc], e3 = Em[(c + 3) * L + lc];
+    s0 = fma(rdlane(a, c + 0), e0, s0);
+    s1 = fma(rdlane(a, c + 1), e1, s1);
+    s2 = fma(rdlane(a, c + 2), e2, s2);
+    s3 = fma(rdlane(a, c + 3), e3, s3);
+  }
+  for (; c < L; c++) s0 = fma(rdlane(a, c), Em[c * L + lc], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
+template <int DMAX, int MPF>
+__global__ __launch_bounds__(DP_WPB * 64) void k_dp_wave(
+    ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ S,
+    const double* __restrict__ E, const double* __restrict__ ET, const double* __restrict__ mshift,
+    double* __restrict__ AD, double* __restrict__ alpha_g, double* __restrict__ beta_g,
+    double* __restrict__ sd_g, double* __restrict__ zx_out, int* __restrict__ status) {
+  extern __shared__ double dsm[];
+  const int L = lay.L, D = lay.D;
+  const int LL = L * L;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
+  const uint32_t ul = (blockIdx.x >> 1) * DP_WPB + wave;
+  double* Es = dsm;                                         // [L*L] (time-invariant transitions only)
+  double* ring = dsm + (MPF ? 0 : LL) + (size_t)wave * D * L;  // [D][L], private to this wavefront
+  if (!MPF) {
+    const double* src = dir ? ET : E;
+    for (int i = threadIdx.x; i < LL; i += blockDim.x) Es[i] = src[i];
+    __syncthreads();
+  }
+  if (ul >= n_utts) return;
+  const uint32_t u = u0 + ul;
+  const int T = (int)bv.T[u];
+  if (T == 0) return;
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* Su = S + s_base * L;
+  const bool act = lane < L;
+  const int lc = act ? lane : L - 1;  // clamped label: idle lanes shadow the last label
+  const double sh0 = MPF ? 0.0 : mshift[0];
+  int err = 0;
+
+  if (dir == 0) {
+    // ---------------------------------------------------------------- forward
+    double* ADu = AD + s_base * L;
+    double* alu = alpha_g + f_base * L;
+    double alpha = Su[lc];
+    if (act) { ADu[lane] = alpha; alu[lane] = alpha; }
+    int rpos = D - 1;
+    for (int t = 1; t < T; t++) {
+      rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      const uint64_t base = scrf_seg_base(t, D);
+      // scores of the nd windows ending at t: independent of the recursion, issued first
+      double sv[DMAX];
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) sv[d0] = Su[(base + (d0 < nd ? d0 : 0)) * L + lc];
+      const double amax = (double)wave_max_f32((float)alpha);
+      const double a = exp(alpha - amax);
+      double usum;
+      double sh = sh0;
+      if (MPF) {
+        usum = matvec_bcast(a, E + (f_base + t) * (size_t)LL, L, lc);
+        sh = mshift[f_base + t];
+      } else {
+        usum = matvec_bcast(a, Es, L, lc);
+      }
+      if (!(usum > 0.0 && usum < INFINITY)) err = 1;
+      const double apt = amax + sh + log(usum);
+      ring[rpos * L + lc] = apt;  // idle lanes rewrite lane L-1's value with the same number
+      double v[DMAX];
+      double m = -INFINITY;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        int slot = rpos - d0;
+        if (slot < 0) slot += D;
+        const double r = (d0 == 0) ? apt : ring[(d0 < np ? slot : rpos) * L + lc];
+        double x = (d0 < np) ? r + sv[d0] : sv[d0];
+        x = (d0 < nd) ? x : -INFINITY;
+        v[d0] = x;
+        m = fmax(m, x);
+      }
+      double ssum = 0.0;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) ssum += exp(v[d0] - m);
+      alpha = m + log(ssum);
+      if (act) {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++)
+          if (d0 < nd) ADu[(base + d0) * L + lane] = v[d0];
+        alu[(size_t)t * L + lane] = alpha;
+      }
+    }
+    // Zx = LSE_l alpha[T-1][l]  (computeAlphaSum)
+    const double mx = (double)wave_max_f32((float)alpha);
+    const double tot = wave_sum_f64(act ? exp(alpha - mx) : 0.0);
+    const double Zx = mx + log(tot);
+    if (!(Zx == Zx) || isinf(Zx)) err = 1;
+    if (lane == 0) zx_out[u] = Zx;
+  } else {
+    // ---------------------------------------------------------------- backward
+    double* beu = beta_g + f_base * L;
+    double* sdu = sd_g + f_base * L;
+    int tpos = (T - 1) % D;
+    ring[tpos * L + lc] = 0.0;  // setTailBeta
+    if (act) { beu[(size_t)(T - 1) * L + lane] = 0.0; sdu[(size_t)(T - 1) * L + lane] = 0.0; }
+    for (int t = T - 2; t >= 0; t--) {
+      const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+      tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
+      double v[DMAX];
+      double m = -INFINITY;
+      uint64_t sb = scrf_seg_base(t + 1, D);
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        const bool ok = d0 < nn;
+        int slot = tpos + d0 + 1;  // node t + d0 + 1
+        if (slot >= D) slot -= D;
+        const double sc = Su[(ok ? sb + d0 : 0) * L + lc];
+        const double bt = ring[(ok ? slot : tpos) * L + lc];
+        const double x = ok ? sc + bt : -INFINITY;
+        v[d0] = x;
+        m = fmax(m, x);
+        sb += scrf_node_max_dur(t + 1 + d0, D);
+      }
+      double ssum = 0.0;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) ssum += exp(v[d0] - m);
+      const double sd = m + log(ssum);
+      const double smax = (double)wave_max_f32((float)sd);
+      const double b = exp(sd - smax);
+      double w;
+      double sh = sh0;
+      if (MPF) {
+        w = matvec_bcast(b, ET + (f_base + t + 1) * (size_t)LL, L, lc);
+        sh = mshift[f_base + t + 1];
+      } else {
+        w = matvec_bcast(b, Es, L, lc);
+      }
+      if (!(w > 0.0 && w < INFINITY)) err = 1;
+      const double beta = smax + sh + log(w);
+      ring[tpos * L + lc] = beta;
+      if (act) { sdu[(size_t)t * L + lane] = sd; beu[(size_t)t * L + lane] = beta; }
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicMax(&status[u], SCRF_ERR_NUMERIC);
+}
+
+int dp_wave_supported(const ScrfLayout& lay) { return lay.L <= 64 && lay.D <= 32; }
+
+void launch_dp_wave(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                    const double* S, const double* E, const double* ET, const double* mshift, int m_per_frame,
+                    double* AD, double* alpha_g, double* beta_g, double* sd_g, double* zx, int* status) {
+  if (n_utts == 0) return;
+  const uint32_t nblk = 2 * ((n_utts + DP_WPB - 1) / DP_WPB);
+  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * lay.D * lay.L);
+#define DP_LAUNCH2(DM, MPF)                                                                                   \
+  do {                                                                                                          \
+    hipFuncSetAttribute((const void*)k_dp_wave<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \
+    hipLaunchKernelGGL((k_dp_wave<DM, MPF>), dim3(nblk), dim3(DP_WPB * 64), sm, st, lay, bv, u0, n_utts, S, E, ET, \
+                       mshift, AD, alpha_g, beta_g, sd_g, zx, status);                                          \
+  } while (0)
+#define DP_LAUNCH(DM)                     \
+  do {                                    \
+    if (m_per_frame) DP_LAUNCH2(DM, 1);   \
+    else DP_LAUNCH2(DM, 0);               \
+  } while (0)
+  if (lay.D <= 1) DP_LAUNCH(1);
+  else if (lay.D <= 4) DP_LAUNCH(4);
+  else if (lay.D <= 10) DP_LAUNCH(10);
+  else if (lay.D <= 16) DP_LAUNCH(16);
+  else if (lay.D <= 25) DP_LAUNCH(25);
+  else DP_LAUNCH(32);
+#undef DP_LAUNCH
+#undef DP_LAUNCH2
+}
+
+// ------------------------------------------------------------------------------------------
+// k_post_state: R = Y - gamma over ad (in place), gamma = exp(ad + beta - Zx)    (:673-702)
+// plus the per-frame numerator term (true state score + true transition score).
+// One workgroup per frame of the chunk.
+// ------------------------------------------------------------------------------------------
+__global__ void k_post_state(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                             const uint32_t* __restrict__ next_lab, const double* __restrict__ S,
+                             const double* __restrict__ M, int m_per_frame, double* __restrict__ AD,
+                             const double* __restrict__ beta_g, const double* __restrict__ zx,
+                             double* __restrict__ numer_f, int* __restrict__ status) {
+  const uint32_t L = lay.L, D = lay.D;
+  const uint64_t fi = blockIdx.x;  // frame index inside the chunk
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  uint32_t lo = u0, hi = u1;
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (bv.frame_off[mid] <= gf) lo = mid; else hi = mid; }
+  const uint32_t u = lo;
+  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  const uint32_t T = bv.T[u];
+  const uint64_t row0 = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
+  const uint32_t nd = scrf_node_max_dur(t, D);
+  const double Zx = zx[u];
+  const uint32_t lab = bv.labels ? bv.labels[gf] : SCRF_LAB_BAD;
+  uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD;
+  int err = 0;
+  if (lab != SCRF_LAB_BAD) {
+    if (lab >= L * D) err = SCRF_ERR_BAD_LABEL;
+    al = lab % L;
+    ld = lab / L + 1;
+  }
+  const double LN_MAX = 709.782712893384;
+  const double* bt = beta_g + fi * L;
+  for (uint32_t idx = threadIdx.x; idx < nd * L; idx += blockDim.x) {
+    const uint32_t d0 = idx / L, l = idx - d0 * L;
+    double a = AD[(row0 + d0) * L + l] + bt[l] - Zx;
+    if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+    double y = (l == al && d0 + 1 == ld) ? 1.0 : 0.0;
+    AD[(row0 + d0) * L + l] = y - exp(a);
+  }
+  if (threadIdx.x == 0) {
+    double nodeLi = 0.0;
+    if (lab != SCRF_LAB_BAD && err == 0) {
+      if (ld <= nd) nodeLi += S[(row0 + ld - 1) * L + al];
+      const uint32_t nl = next_lab[gf];
+      if (t + 1 < T && nl != SCRF_LAB_BAD) {
+        if (nl >= L * D) err = SCRF_ERR_BAD_LABEL;
+        else {
+          const double* Mn = M + (m_per_frame ? (fi + 1) * (size_t)L * L : 0);
+          nodeLi += Mn[(size_t)al * L + nl % L];
+        }
+      }
+    }
+    numer_f[fi] = nodeLi;
+  }
+  if (err) atomicMax(&status[u], err);
+}
+
+void launch_post_state(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                       uint64_t n_frames, const uint32_t* next_lab, const double* S, const double* M,
+                       int m_per_frame, double* AD, const double* beta_g, const double* zx, double* numer_f,
+                       int* status) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_post_state, dim3((uint32_t)n_frames), dim3(256), 0, st, lay, bv, u0, u1, next_lab, S, M,
+                     m_per_frame, AD, beta_g, zx, numer_f, status);
+}
+
+// numer[u] = sum of the per-frame terms in the reference's order (t = T-1 .. 0, :388-469)
+__global__ void k_numer_reduce(ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ numer_f,
+                               double* __restrict__ numer) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_utts) return;
+  const uint32_t u = u0 + i;
+  const uint64_t fb = bv.frame_off[u] - bv.frame_off[u0];
+  double s = 0.0;
+  for (uint32_t t = bv.T[u]; t-- > 0;) s += numer_f[fb + t];
+  numer[u] = s;
+}
+void launch_numer_reduce(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* numer_f,
+                         double* numer) {
+  if (n_utts == 0) return;
+  hipLaunchKernelGGL(k_numer_reduce, dim3((n_utts + 63) / 64), dim3(64), 0, st, bv, u0, n_utts, numer_f, numer);
+}
+
+// ------------------------------------------------------------------------------------------
+// transition posteriors xi[t][c][n] = exp(alpha[t][c] + M[t+1][c][n] + sd[t][n] - Zx) (:773-776)
+// factorised as A[t][c] * exp(M[t+1][c][n]) * B[t][n],  A = exp(alpha - m_t), B = exp(sd + m_t - Zx).
+// k_xi_factors: one wavefront per frame.
+// ------------------------------------------------------------------------------------------
+__global__ void k_xi_factors(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t u1, uint64_t n_frames,
+                             const double* __restrict__ alpha_g, const double* __restrict__ sd_g,
+                             const double* __restrict__ zx, double* __restrict__ A, double* __restrict__ B) {
+  const uint32_t L = lay.L;
+  const uint64_t fi = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (fi >= n_frames) return;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  uint32_t lo = u0, hi = u1;
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (bv.frame_off[mid] <= gf) lo = mid; else hi = mid; }
+  const uint32_t u = lo;
+  const bool last = (gf + 1 == bv.frame_off[u + 1]);
+  float mx = -INFINITY;
+  for (uint32_t l = lane; l < L; l += 64) mx = fmaxf(mx, (float)alpha_g[fi * L + l]);
+  const double m = (double)wave_max_f32(mx);
+  const double Zx = zx[u];
+  for (uint32_t l = lane; l < L; l += 64) {
+    A[fi * L + l] = exp(alpha_g[fi * L + l] - m);
+    B[fi * L + l] = last ? 0.0 : exp(sd_g[fi * L + l] + m - Zx);
+  }
+}
+void launch_xi_factors(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                       uint64_t n_frames, const double* alpha_g, const double* sd_g, const double* zx, double* A,
+                       double* B) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_xi_factors, dim3((uint32_t)((n_frames + 3) / 4)), dim3(256), 0, st, lay, bv, u0, u1,
+                     n_frames, alpha_g, sd_g, zx, A, B);
+}
+
+// bias-only transitions: C[z][c][n] = sum_{frames of K-chunk z} A[f][c] * B[f][n]
+#define ATB_KT 32
+__global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const double* __restrict__ B, uint32_t L,
+                                             uint64_t n_frames, uint64_t rows_per_chunk, double* __restrict__ slab) {
+  extern __shared__ double absm[];
+  double* As = absm;                       // [ATB_KT][L]
+  double* Bs = absm + (size_t)ATB_KT * L;  // [ATB_KT][L]
+  const uint32_t LL = L * L;
+  const uint64_t r_begin = (uint64_t)blockIdx.x * rows_per_chunk;
+  const uint64_t r_end = min(n_frames, r_begin + rows_per_chunk);
+  const uint32_t per = (LL + 255) / 256;  // outputs per thread, idx = tid + k*256
+  double acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc[k] = 0.0;
+  for (uint64_t r0 = r_begin; r0 < r_end; r0 += ATB_KT) {
+    const uint32_t kt = (uint32_t)min((uint64_t)ATB_KT, r_end - r0);
+    for (uint32_t i = threadIdx.x; i < kt * L; i += 256) {
+      As[i] = A[r0 * L + i];
+      Bs[i] = B[r0 * L + i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t idx = threadIdx.x + k * 256;
+      if ((uint32_t)k < per && idx < LL) {
+        const uint32_t c = idx / L, n = idx - c * L;
+        double s = acc[k];
+        for (uint32_t r = 0; r < kt; r++) s = fma(As[r * L + c], Bs[r * L + n], s);
+        acc[k] = s;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t idx = threadIdx.x + k * 256;
+    if ((uint32_t)k < per && idx < LL) slab[(size_t)blockIdx.x * LL + idx] = acc[k];
+  }
+}
+// grad[trans_idx(c,n)] -= tbv * exp(M0[c][n]) * sum_z C[z][c][n]   (expected transition-bias counts)
+__global__ void k_reduce_atb(const double* __restrict__ slab, uint32_t n_chunks, const double* __restrict__ M0,
+                             ScrfLayout lay, double* __restrict__ grad) {
+  const uint32_t LL = lay.L * lay.L;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= LL) return;
+  double s = 0.0;
+  for (uint32_t z = 0; z < n_chunks; z++) s += slab[(size_t)z * LL + i];
+  grad[lay.trans_idx(i / lay.L, i % lay.L) + lay.ntfe] -= lay.tbv * exp(M0[i]) * s;
+}
+int atb_supported(const ScrfLayout& lay) { return lay.L * lay.L <= 16 * 256; }
+void launch_atb(hipStream_t st, const ScrfLayout& lay, const double* A, const double* B, uint64_t n_frames,
+                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad) {
+  if (n_frames == 0 || n_chunks == 0 || !lay.use_tb) return;
+  const size_t sm = sizeof(double) * 2 * ATB_KT * lay.L;
+  hipLaunchKernelGGL(k_atb, dim3(n_chunks), dim3(256), sm, st, A, B, lay.L, n_frames, rows_per_chunk, slab);
+  const uint32_t LL = lay.L * lay.L;
+  hipLaunchKernelGGL(k_reduce_atb, dim3((LL + 255) / 256), dim3(256), 0, st, slab, n_chunks, M0, lay, grad);
+}
+// observed transition-bias counts of the whole batch (integers, precomputed at batch creation)
+__global__ void k_add_trans_counts(const uint32_t* __restrict__ counts, ScrfLayout lay, double* __restrict__ grad) {
+  const uint32_t LL = lay.L * lay.L;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= LL) return;
+  grad[lay.trans_idx(i / lay.L, i % lay.L) + lay.ntfe] += lay.tbv * (double)counts[i];
+}
+void launch_add_trans_counts(hipStream_t st, const uint32_t* counts, const ScrfLayout& lay, double* grad) {
+  if (!lay.use_tb) return;
+  const uint32_t LL = lay.L * lay.L;
+  hipLaunchKernelGGL(k_add_trans_counts, dim3((LL + 255) / 256), dim3(256), 0, st, counts, lay, grad);
+}
+
+// transition features: XI[f][c][n] = y - A[f][c] * E[f+1][c][n] * exp(shift[f+1]) * B[f][n]
+__global__ void k_xi_full(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                          const uint32_t* __restrict__ next_lab, const double* __restrict__ A,
+                          const double* __restrict__ B, const double* __restrict__ E,
+                          const double* __restrict__ mshift, double* __restrict__ XI) {
+  const uint32_t L = lay.L, D = lay.D, LL = L * L;
+  const uint64_t fi = blockIdx.x;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  uint32_t lo = u0, hi = u1;
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (bv.frame_off[mid] <= gf) lo = mid; else hi = mid; }
+  const uint32_t u = lo;
+  const bool last = (gf + 1 == bv.frame_off[u + 1]);
+  double* out = XI + fi * (size_t)LL;
+  if (last) {
+    for (uint32_t i = threadIdx.x; i < LL; i += blockDim.x) out[i] = 0.0;
+    return;
+  }
+  const uint32_t lab = bv.labels ? bv.labels[gf] : SCRF_LAB_BAD;
+  const uint32_t nl = next_lab[gf];
+  const uint32_t al = (lab != SCRF_LAB_BAD && lab < L * D) ? lab % L : SCRF_LAB_BAD;
+  const uint32_t anl = (nl != SCRF_LAB_BAD && nl < L * D) ? nl % L : SCRF_LAB_BAD;
+  const double es = exp(mshift[fi + 1]);
+  const double* En = E + (fi + 1) * (size_t)LL;
+  for (uint32_t i = threadIdx.x; i < LL; i += blockDim.x) {
+    const uint32_t c = i / L, n = i - c * L;
+    const double y = (c == al && n == anl) ? 1.0 : 0.0;
+    out[i] = y - A[fi * L + c] * En[i] * es * B[fi * L + n];
+  }
+}
+void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                    uint64_t n_frames, const uint32_t* next_lab, const double* A, const double* B, const double* E,
+                    const double* mshift, double* XI) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_xi_full, dim3((uint32_t)n_frames), dim3(256), 0, st, lay, bv, u0, u1, next_lab, A, B, E,
+                     mshift, XI);
+}

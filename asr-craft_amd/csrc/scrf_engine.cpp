@@ -65,6 +65,9 @@ struct scrf_engine_s {
   double* d_grad = nullptr;
   bool own_grad = true;
   double* d_m0 = nullptr;     // [L*L] time-invariant transition scores (bias-only transitions)
+  double* d_e0 = nullptr;     // exp(M0 - shift), its transpose and the shift (linear-domain DP)
+  double* d_et0 = nullptr;
+  double* d_msh0 = nullptr;
   bool m0_valid = false;
   double* d_sums = nullptr;   // {numer, zx, n_utts, active}
   char* scratch = nullptr;
@@ -89,6 +92,8 @@ struct scrf_batch_s {
   uint64_t* d_seg_off = nullptr;
   uint64_t* d_arc_off = nullptr;
   uint32_t* d_labels = nullptr;
+  uint32_t* d_next_lab = nullptr;      // [sum T] label of the next labelled frame (gradbuilder :436-444)
+  uint32_t* d_trans_counts = nullptr;  // [L*L] observed (c -> n) transitions of the whole batch
   float* d_windows = nullptr;
   uint32_t n_streams = 0;
   scrf_stream_recipe recipe[SCRF_MAX_STREAMS];
@@ -203,6 +208,9 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_gsa, nb));
   CRCHK(hipMalloc((void**)&h->d_grad, nb));
   CRCHK(hipMalloc((void**)&h->d_m0, sizeof(double) * lay.L * lay.L));
+  CRCHK(hipMalloc((void**)&h->d_e0, sizeof(double) * lay.L * lay.L));
+  CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
+  CRCHK(hipMalloc((void**)&h->d_msh0, sizeof(double)));
   CRCHK(hipMalloc((void**)&h->d_sums, sizeof(double) * 4));
   CRCHK(hipMemsetAsync(h->d_lambda, 0, nb, h->stream));
   CRCHK(hipMemsetAsync(h->d_lambda_acc, 0, nb, h->stream));
@@ -227,7 +235,7 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   hipFree(h->d_lambda); hipFree(h->d_lambda_acc); hipFree(h->d_gsa);
   if (h->own_grad) hipFree(h->d_grad);
-  hipFree(h->d_m0); hipFree(h->d_sums); hipFree(h->scratch);
+  hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -377,7 +385,7 @@ extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   if (!b) return SCRF_OK;
   if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
   hipFree(b->d_T); hipFree(b->d_frame_off); hipFree(b->d_seg_off); hipFree(b->d_arc_off);
-  hipFree(b->d_labels); hipFree(b->d_windows);
+  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows);
   for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
   hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
   delete b;
@@ -434,10 +442,26 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     std::vector<uint32_t> lab(NF);
     for (uint32_t u = 0; u < n; u++) memcpy(&lab[b->frame_off[u]], utts[u].labels, sizeof(uint32_t) * utts[u].T);
     BCHK(upload(h, &b->d_labels, lab.data(), NF));
+    std::vector<uint32_t> nxt(NF), cnt((size_t)lay.L * lay.L, 0);
+    for (uint32_t u = 0; u < n; u++) {
+      uint32_t cur = SCRF_LAB_BAD;
+      for (uint32_t t = b->T[u]; t-- > 0;) {
+        const uint64_t f = b->frame_off[u] + t;
+        nxt[f] = cur;
+        const uint32_t lb = lab[f];
+        if (lb != SCRF_LAB_BAD) {
+          if (t + 1 < b->T[u] && cur != SCRF_LAB_BAD && lb < lay.L * lay.D && cur < lay.L * lay.D)
+            cnt[(size_t)(lb % lay.L) * lay.L + cur % lay.L]++;
+          cur = lb;
+        }
+      }
+    }
+    BCHK(upload(h, &b->d_next_lab, nxt.data(), NF));
+    BCHK(upload(h, &b->d_trans_counts, cnt.data(), cnt.size()));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   if (by_windows) {
-    BCHK(upload<float>(h, &b->d_windows, nullptr, NS * lay.F));
+    BCHK(upload<float>(h, &b->d_windows, nullptr, NS * lay.F + 64));  // tail pad: wide loads may over-read 12 B
     for (uint32_t u = 0; u < n; u++) {
       hipError_t e = hipMemcpyAsync(b->d_windows + b->seg_off[u] * lay.F, utts[u].windows,
                                     sizeof(float) * (b->seg_off[u + 1] - b->seg_off[u]) * lay.F, hipMemcpyHostToDevice, h->stream);
@@ -486,6 +510,13 @@ extern "C" int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, ui
 // ---------------------------------------------------------------------------------------------
 enum { PH_WIN = 0, PH_SCORE = 1, PH_FB = 2, PH_EXPF = 3, PH_REDUCE = 4, PH_VIT = 5, PH_ALL = 6 };
 #define EXPF_ROWS_PER_CHUNK 4096ull
+// split-K plan of the state expected-count contraction: about 1024 K-chunks (2 per CU-slot
+// of the 512-thread MFMA kernel), at least 4096 rows each
+static uint64_t expf_rows_per_chunk(uint64_t nseg) {
+  uint64_t rpc = (nseg + 1023) / 1024;
+  rpc = (rpc + 31) & ~31ull;
+  return rpc < EXPF_ROWS_PER_CHUNK ? EXPF_ROWS_PER_CHUNK : rpc;
+}
 
 struct ChunkBufs {
   float* X = nullptr;        // window vectors of the chunk (scratch, or a view into the batch)
@@ -504,7 +535,19 @@ struct ChunkBufs {
   uint16_t* bp_b = nullptr;
   uint16_t* bp_e = nullptr;
   uint32_t nch_s = 0, nch_t = 0;
-  uint64_t rpc_t = 0;
+  uint64_t rpc_s = 0, rpc_t = 0;
+  // wavefront-per-utterance DP
+  bool wave = false;
+  double* E = nullptr;       // exp(M - shift) per frame, or the engine's E0
+  double* ET = nullptr;
+  double* msh = nullptr;
+  double* sd = nullptr;      // [nfr][L]
+  double* fA = nullptr;      // [nfr][L] xi factors
+  double* fB = nullptr;
+  double* numer_f = nullptr; // [nfr]
+  double* slab_atb = nullptr;
+  uint32_t nch_atb = 0;
+  uint64_t rpc_atb = 0;
 };
 
 struct Need { bool fb, post, beta, vit; };
@@ -519,16 +562,25 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   if (nd.fb) {
     tot += pad256(nseg * l.L * sizeof(double));                     // AD
     tot += pad256(nfr * l.L * sizeof(double));                      // alpha
-    if (nd.beta) tot += pad256(nfr * l.L * sizeof(double));
+    if (nd.beta || dp_wave_supported(l)) tot += pad256(nfr * l.L * sizeof(double));
+    if (dp_wave_supported(l)) {
+      tot += pad256(nfr * l.L * sizeof(double));                    // sd
+      if (l.use_tf) tot += 2 * pad256(nfr * LL * sizeof(double)) + pad256(nfr * sizeof(double));  // E, ET, shift
+      if (nd.post) {
+        tot += 2 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * sizeof(double));  // A, B, numer_f
+        if (!l.use_tf) tot += pad256(((nfr + 2047) / 2048) * LL * sizeof(double));
+      }
+    }
     if (nd.post) {
       if (l.use_tf) {
         tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
         uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
         tot += pad256((size_t)nch_t * LL * l.ntf * sizeof(double));
-      } else {
+      } else if (!dp_wave_supported(l)) {
         tot += pad256(nutt * LL * sizeof(double));
       }
-      uint64_t nch_s = (nseg + EXPF_ROWS_PER_CHUNK - 1) / EXPF_ROWS_PER_CHUNK;
+      const uint64_t rpc_s = expf_rows_per_chunk(nseg);
+      uint64_t nch_s = (nseg + rpc_s - 1) / rpc_s;
       tot += pad256(nch_s * l.L * l.nsf * sizeof(double));
     }
   }
@@ -571,7 +623,28 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   if (nd.fb) {
     cb->AD = a.take<double>(nseg * l.L);
     cb->alpha = a.take<double>(nfr * l.L);
-    if (nd.beta) cb->beta = a.take<double>(nfr * l.L);
+    cb->wave = dp_wave_supported(l);
+    if (nd.beta || cb->wave) cb->beta = a.take<double>(nfr * l.L);
+    if (cb->wave) {
+      cb->sd = a.take<double>(nfr * l.L);
+      if (l.use_tf) {
+        cb->E = a.take<double>(nfr * LL);
+        cb->ET = a.take<double>(nfr * LL);
+        cb->msh = a.take<double>(nfr);
+      } else {
+        cb->E = h->d_e0; cb->ET = h->d_et0; cb->msh = h->d_msh0;
+      }
+      if (nd.post) {
+        cb->fA = a.take<double>(nfr * l.L);
+        cb->fB = a.take<double>(nfr * l.L);
+        cb->numer_f = a.take<double>(nfr);
+        if (!l.use_tf) {
+          cb->rpc_atb = 2048;
+          cb->nch_atb = (uint32_t)((nfr + cb->rpc_atb - 1) / cb->rpc_atb);
+          cb->slab_atb = a.take<double>((size_t)cb->nch_atb * LL);
+        }
+      }
+    }
     if (nd.post) {
       if (l.use_tf) {
         cb->XI = a.take<double>(nfr * LL);
@@ -580,10 +653,11 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
         if (cb->nch_t == 0) cb->nch_t = 1;
         cb->rpc_t = (nfr + cb->nch_t - 1) / cb->nch_t;
         cb->slab_t = a.take<double>((size_t)cb->nch_t * LL * l.ntf);
-      } else {
+      } else if (!cb->wave) {
         cb->xi_acc = a.take<double>(nutt * LL);
       }
-      cb->nch_s = (uint32_t)((nseg + EXPF_ROWS_PER_CHUNK - 1) / EXPF_ROWS_PER_CHUNK);
+      cb->rpc_s = expf_rows_per_chunk(nseg);
+      cb->nch_s = (uint32_t)((nseg + cb->rpc_s - 1) / cb->rpc_s);
       cb->slab_s = a.take<double>((size_t)cb->nch_s * l.L * l.nsf);
     }
   }
@@ -613,7 +687,7 @@ struct PhaseTimer {
 };
 
 // windows + exact scores of a chunk (both training and decode start here)
-static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb) {
+static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool fast = false) {
   const ScrfLayout& l = h->lay;
   const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
   ScrfBatchView bv = b->view();
@@ -630,18 +704,56 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   }
   PhaseTimer tm(h, PH_SCORE);
   uint32_t nl = 1;
-  launch_scores_exact(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+  if (fast) launch_scores_mfma(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+  else launch_scores_exact(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
   if (l.use_tf) {
     launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
-    launch_scores_exact(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
+    if (fast) launch_scores_mfma(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
+    else launch_scores_exact(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
     nl += 2;
   } else if (!h->m0_valid) {
     // transition scores carry only the bias: one L x L matrix for every frame
     launch_scores_exact(h->stream, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+    launch_exp_m(h->stream, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
     h->m0_valid = true;
-    nl += 1;
+    nl += 2;
   }
   tm.stop(nl);
+  HIPCHK(h, hipGetLastError());
+  return SCRF_OK;
+}
+
+// forward + backward (+ posteriors when `post`): wavefront-per-utterance kernels for L <= 64,
+// the workgroup-per-utterance kernel otherwise.  Leaves R = Y - gamma in cb.AD (post) or
+// alpha-with-duration (no post), alpha in cb.alpha, beta in cb.beta (wave path or nd.beta).
+static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool post, uint32_t* nl_out) {
+  const ScrfLayout& l = h->lay;
+  const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0];
+  ScrfBatchView bv = b->view();
+  uint32_t nl = 0;
+  if (!cb.wave) {
+    if (post && cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, h->stream));
+    launch_fb(h->stream, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, post ? cb.XI : nullptr,
+              post ? cb.xi_acc : nullptr, b->d_numer, b->d_zx, b->d_status, post ? 1 : 0);
+    nl = 1;
+  } else {
+    if (cb.m_per_frame) { launch_exp_m(h->stream, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh); nl++; }
+    launch_dp_wave(h->stream, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
+                   cb.beta, cb.sd, b->d_zx, b->d_status);
+    nl++;
+    if (post) {
+      launch_post_state(h->stream, l, bv, u0, u1, nfr, b->d_next_lab, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.beta,
+                        b->d_zx, cb.numer_f, b->d_status);
+      launch_numer_reduce(h->stream, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
+      launch_xi_factors(h->stream, l, bv, u0, u1, nfr, cb.alpha, cb.sd, b->d_zx, cb.fA, cb.fB);
+      nl += 3;
+      if (l.use_tf) {
+        launch_xi_full(h->stream, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
+        nl++;
+      }
+    }
+  }
+  if (nl_out) *nl_out = nl;
   HIPCHK(h, hipGetLastError());
   return SCRF_OK;
 }
@@ -669,28 +781,31 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
   HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
   Need nd{true, true, false, false};
   ScrfBatchView bv = b->view();
+  const bool fast = h->cfg.train_precision == SCRF_PREC_FAST;
   for (uint32_t u0 = 0; u0 < b->U;) {
     const uint32_t u1 = plan_chunk(h, b, u0, nd);
     ChunkBufs cb;
     int rc = carve(h, b, u0, u1, nd, &cb);
     if (rc != SCRF_OK) return rc;
     const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
-    rc = run_scores(h, b, u0, u1, cb);
+    rc = run_scores(h, b, u0, u1, cb, fast);
     if (rc != SCRF_OK) return rc;
     {
       PhaseTimer tm(h, PH_FB);
-      if (cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, h->stream));
-      launch_fb(h->stream, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, nullptr, cb.XI,
-                cb.xi_acc, b->d_numer, b->d_zx, b->d_status, 1);
-      tm.stop(1);
+      uint32_t nl = 0;
+      rc = run_dp(h, b, u0, u1, cb, true, &nl);
+      if (rc != SCRF_OK) return rc;
+      tm.stop(nl);
     }
     {
       PhaseTimer tm(h, PH_EXPF);
       uint32_t nl = 1;
-      launch_expf_gemm(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, EXPF_ROWS_PER_CHUNK, cb.nch_s, cb.slab_s);
+      if (fast) launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+      else launch_expf_gemm(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
       if (l.use_tf) {
         launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
-        launch_expf_gemm(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+        if (fast) launch_expf_mfma(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+        else launch_expf_gemm(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
         nl += 2;
       }
       tm.stop(nl);
@@ -699,6 +814,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
       PhaseTimer tm(h, PH_REDUCE);
       launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, 0, h->d_grad);
       if (l.use_tf) launch_reduce_slabs(h->stream, cb.slab_t, cb.nch_t, l.L * l.L, l, 1, h->d_grad);
+      else if (cb.wave) launch_atb(h->stream, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, h->d_grad);
       else launch_reduce_xiacc(h->stream, cb.xi_acc, (uint32_t)nutt, l, h->d_grad);
       launch_batch_sums(h->stream, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, h->d_sums);
       tm.stop(3);
@@ -706,6 +822,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     HIPCHK(h, hipGetLastError());
     u0 = u1;
   }
+  if (!l.use_tf && dp_wave_supported(l)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_grad);
   if (h->timing) {
     hipEventRecord(h->ev[SCRF_N_PHASES][1], h->stream);
     hipEventSynchronize(h->ev[SCRF_N_PHASES][1]);
@@ -803,9 +920,8 @@ extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, ui
   rc = run_scores(h, b, u, u + 1, cb);
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
-  launch_fb(h->stream, l, b->view(), u, 1, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, nullptr, nullptr,
-            b->d_numer, b->d_zx, b->d_status, 0);
-  HIPCHK(h, hipGetLastError());
+  rc = run_dp(h, b, u, u + 1, cb, false, nullptr);
+  if (rc != SCRF_OK) return rc;
   uint64_t nseg = b->seg_off[u + 1] - b->seg_off[u];
   uint32_t T = b->T[u];
   if (alpha_dur) HIPCHK(h, hipMemcpyAsync(alpha_dur, cb.AD, sizeof(double) * nseg * l.L, hipMemcpyDeviceToHost, h->stream));
@@ -845,8 +961,8 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
   if (norm) {
     // Zx = -computeAlphaSum(): final arcs carry -Zx (segmental, :371,397) / Zx (frame, CRF_LatticeBuilder.h:191-198)
     HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
-    launch_fb(h->stream, l, b->view(), u, 1, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, nullptr, nullptr, nullptr,
-              b->d_numer, b->d_zx, b->d_status, 0);
+    rc = run_dp(h, b, u, u + 1, cb, false, nullptr);
+    if (rc != SCRF_OK) return rc;
     double asum = 0;
     HIPCHK(h, hipMemcpyAsync(&asum, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

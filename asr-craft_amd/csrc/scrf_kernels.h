@@ -34,4 +34,35 @@ void launch_sgd_step(hipStream_t st, double* lambda, double* lambda_acc, double*
 void launch_scale(hipStream_t st, double* v, uint32_t n, double s, int divide);
 void launch_add(hipStream_t st, double* y, const double* x, uint32_t n);
 
+// scrf_mfma.hip: fp64 MFMA contractions (FAST training precision)
+void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
+                        const double* lambda, const ScrfLayout& lay, int is_trans, uint32_t n_out, double* out);
+void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
+                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
+
+// scrf_dp.hip: wavefront-per-utterance DP and the parallel posterior kernels
+int dp_wave_supported(const ScrfLayout& lay);
+int atb_supported(const ScrfLayout& lay);
+void launch_exp_m(hipStream_t st, const double* M, uint32_t L, uint64_t n_mat, double* E, double* ET,
+                  double* mshift);
+void launch_dp_wave(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                    const double* S, const double* E, const double* ET, const double* mshift, int m_per_frame,
+                    double* AD, double* alpha_g, double* beta_g, double* sd_g, double* zx, int* status);
+void launch_post_state(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                       uint64_t n_frames, const uint32_t* next_lab, const double* S, const double* M,
+                       int m_per_frame, double* AD, const double* beta_g, const double* zx, double* numer_f,
+                       int* status);
+void launch_numer_reduce(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* numer_f,
+                         double* numer);
+void launch_xi_factors(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                       uint64_t n_frames, const double* alpha_g, const double* sd_g, const double* zx, double* A,
+                       double* B);
+void launch_atb(hipStream_t st, const ScrfLayout& lay, const double* A, const double* B, uint64_t n_frames,
+                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad);
+void launch_add_trans_counts(hipStream_t st, const uint32_t* counts, const ScrfLayout& lay, double* grad);
+void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                    uint64_t n_frames, const uint32_t* next_lab, const double* A, const double* B, const double* E,
+                    const double* mshift, double* XI);
+
 #endif  // SCRF_KERNELS_H_

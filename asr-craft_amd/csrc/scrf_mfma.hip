@@ -1,2 +1,274 @@
 // scrf_mfma.hip -- MFMA (v_mfma_f64_16x16x4_f64) contractions of the FAST training path.
+//
+//   k_scores_mfma : out[row][o]   = sum_f x[row][f] * lambda[woff(o)+f] + bias   (M = rows, N = outputs, K = features)
+//   k_expf_mfma   : slab[z][o][f] = sum_rows A[row][o] * xs[row][f]              (M = outputs, N = features, K = rows)
+//
+// Same mathematics as the EXACT kernels; the MFMA fuses and reorders the fp64 sums, so results
+// differ from the reference chain in the last bits (training contract: 1e-4 relative).
+//
+// v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md section 3): lane l holds
+//   A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D reg r: row = (l>>4) + 4r, col = l&15.
+// LDS images are laid out so that every fragment read is conflict-free:
+//   - k-major [k][n] doubles with an even row stride of 96 words: the two 32-lane halves of a
+//     ds_read_b64 (k, k+1) fall on disjoint bank halves;
+//   - row-major floats with stride == 2 (mod 32) words for the A operand of the score kernel.
 #include "scrf_kernels.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// 16-byte loads from 4-byte aligned addresses: hipcc emits global_load_dwordx4 for these
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(8))) d2u { double x, y; };
+
+#define SM_ROWS 256  // rows per workgroup (4 waves x 4 M-tiles)
+#define SM_KC 32     // features per staged chunk (8 MFMA k-steps)
+#define SM_XS 34     // float row stride of the X image (== 2 mod 32: conflict-free A fragments)
+#define SM_NO 48     // outputs per workgroup (3 N-tiles)
+
+// Software pipeline: while the MFMAs of chunk i run from LDS, the global loads of chunk i+1
+// are in flight into registers (8 x 16 B of X and 6 x 8 B of lambda per thread).
+__global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
+                                                     const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                     const double* __restrict__ lambda, ScrfLayout lay,
+                                                     int is_trans, uint32_t n_out, double* __restrict__ out) {
+  __shared__ float Xs[SM_ROWS * SM_XS];
+  __shared__ double Ws[SM_KC * SM_NO];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint64_t row0 = (uint64_t)blockIdx.x * SM_ROWS;
+  const uint32_t o0 = blockIdx.y * SM_NO;
+  const uint32_t L = lay.L;
+  const uint32_t fs = is_trans ? lay.tfs : lay.sfs;
+  const uint32_t nfe = is_trans ? lay.ntfe : lay.nsfe;
+  const int use_b = is_trans ? lay.use_tb : lay.use_sb;
+  const double bv = is_trans ? lay.tbv : lay.sbv;
+
+  v4f64 acc[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  // staging coordinates: 8 threads cover one row's 32-float chunk, 32 rows per pass, 8 passes
+  const uint32_t sq = tid & 7, sr = tid >> 3;
+  const float* xbase[8];
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const uint64_t r = row0 + sr + it * 32;
+    const uint64_t rr = r < n_rows ? r : (n_rows - 1);
+    const uint64_t xr = xrow ? xrow[rr] : rr;
+    xbase[it] = X + xr * F + fs + sq * 4;
+  }
+  // lambda chunk: thread loads W[o][c] for idx = tid + k*256 -> o = idx / 32, c = idx % 32
+  const double* wbase[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const uint32_t idx = tid + k * 256;
+    uint32_t o = o0 + idx / SM_KC;
+    if (o >= n_out) o = n_out - 1;
+    const uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
+    wbase[k] = lambda + woff + (idx % SM_KC);
+  }
+  f4u xr_[8];
+  double wr_[6];
+  auto load_chunk = [&](uint32_t f0) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      // a quad that starts inside the feature range may read <= 12 B past it (masked in
+      // store_chunk; buffers carry 256 B of tail padding); quads fully outside are not loaded
+      if (f0 + sq * 4 < nfe) xr_[it] = *(const f4u*)(xbase[it] + f0);
+      else xr_[it] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const uint32_t c = (tid + k * 256) % SM_KC;
+      wr_[k] = (f0 + c < nfe) ? wbase[k][f0] : 0.0;
+    }
+  };
+  auto store_chunk = [&](uint32_t f0) {
+    const uint32_t c0 = f0 + sq * 4;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      f4u v = xr_[it];
+      if (c0 + 0 >= nfe) v.x = 0.0f;
+      if (c0 + 1 >= nfe) v.y = 0.0f;
+      if (c0 + 2 >= nfe) v.z = 0.0f;
+      if (c0 + 3 >= nfe) v.w = 0.0f;
+      float* d = &Xs[(sr + it * 32) * SM_XS + sq * 4];
+      *(float2*)(d) = make_float2(v.x, v.y);
+      *(float2*)(d + 2) = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const uint32_t idx = tid + k * 256;
+      Ws[(idx % SM_KC) * SM_NO + idx / SM_KC] = wr_[k];
+    }
+  };
+
+  if (nfe > 0) load_chunk(0);
+  for (uint32_t f0 = 0; f0 < nfe; f0 += SM_KC) {
+    store_chunk(f0);
+    __syncthreads();
+    if (f0 + SM_KC < nfe) load_chunk(f0 + SM_KC);
+#pragma unroll
+    for (int ks = 0; ks < SM_KC / 4; ks++) {
+      double b[3];
+#pragma unroll
+      for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SM_NO + n * 16 + li];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const double a = (double)Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
+#pragma unroll
+        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    const uint32_t o = o0 + n * 16 + li;
+    if (o >= n_out) continue;
+    double bias = 0.0;
+    if (use_b) {
+      const uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
+      bias = lambda[woff + nfe] * bv;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint64_t row = row0 + wave * 64 + m * 16 + lk + 4 * r;
+        if (row < n_rows) out[row * n_out + o] = acc[m][n][r] + bias;
+      }
+  }
+}
+
+void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
+                        const double* lambda, const ScrfLayout& lay, int is_trans, uint32_t n_out, double* out) {
+  if (n_rows == 0 || n_out == 0) return;
+  dim3 grid((uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS), (n_out + SM_NO - 1) / SM_NO);
+  hipLaunchKernelGGL(k_scores_mfma, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, is_trans, n_out, out);
+}
+
+// ------------------------------------------------------------------------------------------
+#define EM_KC 32    // rows per staged chunk (8 MFMA k-steps)
+#define EM_NO 48    // outputs per workgroup (3 M-tiles)
+#define EM_NF 384   // feature columns per workgroup (8 waves x 3 N-tiles)
+#define EM_XS 400   // float row stride of the X image (== 16 mod 32)
+
+__global__ __launch_bounds__(512) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
+                                                   const float* __restrict__ X, uint32_t F,
+                                                   const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                   ScrfLayout lay, int is_trans, uint64_t rows_per_chunk,
+                                                   double* __restrict__ slab) {
+  __shared__ double Rs[EM_KC * EM_NO];
+  __shared__ __attribute__((aligned(16))) float Xs[EM_KC * EM_XS];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t fs = is_trans ? lay.tfs : lay.sfs;
+  const uint32_t nfe = is_trans ? lay.ntfe : lay.nsfe;
+  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+  const float bias = (float)(is_trans ? lay.tbv : lay.sbv);
+  const bool bias_exact = (double)bias == (is_trans ? lay.tbv : lay.sbv);
+  const uint32_t fb = blockIdx.x * EM_NF;
+  const uint32_t o0 = blockIdx.y * EM_NO;
+  const uint64_t r_begin = (uint64_t)blockIdx.z * rows_per_chunk;
+  const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
+
+  v4f64 acc[3][3];
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  // X staging: idx = tid + k*512 -> row idx/96, column quad idx%96 (6 x 16 B per thread);
+  // A staging: idx = tid + k*512 -> row idx/48, output idx%48 (3 x 8 B per thread)
+  f4u xr_[6];
+  double ar_[3];
+  auto load_chunk = [&](uint64_t r0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const uint32_t idx = tid + k * 512;
+      const uint32_t r = idx / 96, q = idx % 96;
+      uint64_t row = r0 + r;
+      if (row >= r_end) row = r_end - 1;
+      const uint64_t xr = xrow ? xrow[row] : row;
+      const uint32_t col = fb + q * 4;
+      if (col < nfe) xr_[k] = *(const f4u*)(X + xr * F + fs + col);  // may read <= 12 B past the range
+      else xr_[k] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const uint32_t idx = tid + k * 512;
+      const uint32_t r = idx / EM_NO, ol = idx % EM_NO;
+      uint64_t row = r0 + r;
+      double v = 0.0;
+      if (row < r_end && o0 + ol < n_out) v = A[row * n_out + o0 + ol];
+      ar_[k] = v;
+    }
+  };
+  auto store_chunk = [&](uint64_t r0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const uint32_t idx = tid + k * 512;
+      const uint32_t r = idx / 96, q = idx % 96;
+      const uint32_t col = fb + q * 4;
+      const bool rok = r0 + r < r_end;
+      const f4u v = xr_[k];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint32_t cc = col + c;
+        o[c] = !rok ? 0.0f : (cc < nfe ? e[c] : (cc == nfe ? bias : 0.0f));
+      }
+      *(float4*)(&Xs[r * EM_XS + q * 4]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) Rs[tid + k * 512] = ar_[k];
+  };
+
+  if (r_begin < r_end) load_chunk(r_begin);
+  for (uint64_t r0 = r_begin; r0 < r_end; r0 += EM_KC) {
+    store_chunk(r0);
+    __syncthreads();
+    if (r0 + EM_KC < r_end) load_chunk(r0 + EM_KC);
+#pragma unroll
+    for (int ks = 0; ks < EM_KC / 4; ks++) {
+      double a[3], b[3];
+#pragma unroll
+      for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
+#pragma unroll
+      for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * EM_XS + wave * 48 + n * 16 + li];
+#pragma unroll
+      for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // the bias column was staged as float: rescale if the bias value is not exactly representable
+  const double bfix = bias_exact ? 1.0 : (is_trans ? lay.tbv : lay.sbv) / (double)bias;
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    const uint32_t col = fb + wave * 48 + n * 16 + li;
+    if (col >= nfun) continue;
+    const double sc = (col == nfe) ? bfix : 1.0;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t o = o0 + m * 16 + lk + 4 * r;
+        if (o < n_out) slab[((uint64_t)blockIdx.z * n_out + o) * nfun + col] = acc[m][n][r] * sc;
+      }
+  }
+}
+
+void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
+                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+  if (n_rows == 0 || n_chunks == 0) return;
+  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+  dim3 grid((nfun + EM_NF - 1) / EM_NF, (n_out + EM_NO - 1) / EM_NO, n_chunks);
+  hipLaunchKernelGGL(k_expf_mfma, grid, dim3(512), 0, st, A, n_out, X, F, xrow, n_rows, lay, is_trans,
+                     rows_per_chunk, slab);
+}

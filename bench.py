@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", action="store_true", help="reference-order unfused fp64 contractions instead of MFMA")
+    ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +85,8 @@ def main():
     U = args.utts
     # synthetic data of the config-2 shape; every rank owns a different contiguous utterance range
     frames, labels, off = synth.make_batch(U, T_FRAMES, IN_W, L, D, seed=1234 + 100003 * rank)
-    cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank)
+    cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank, scratch_bytes=args.scratch_gib << 30,
+                               precision=0 if args.exact else 1)
     eng = scrf_amd.Engine(cfg)
     lam = synth.make_lambda(eng.lambda_len)
     eng.set_lambda(lam)

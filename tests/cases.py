@@ -13,7 +13,7 @@ class Case:
     TIMIT demo's ftr2 stream (demo/segmental-timit-demo.cfg.in:21-24)."""
 
     def __init__(self, L, D, in_w, Ts, trans_ctx=None, seed=0, lam_scale=0.3, frame_model=False,
-                 scratch_bytes=0):
+                 scratch_bytes=0, precision=0):
         self.L, self.D, self.in_w, self.Ts = L, D, in_w, list(Ts)
         self.trans_ctx = trans_ctx
         rng = np.random.RandomState(seed)
@@ -39,7 +39,7 @@ class Case:
         self.Fs = Fs
         self.ocfg = orc.config(**kw)
         self.olay = orc.Layout(self.ocfg)
-        self.gcfg = scrf_amd.make_config(scratch_bytes=scratch_bytes, **kw)
+        self.gcfg = scrf_amd.make_config(scratch_bytes=scratch_bytes, precision=precision, **kw)
         self.lam = rng.normal(0, lam_scale, self.olay.lambda_len)
 
     def windows(self, u):

@@ -97,6 +97,25 @@ def test_fb_batch_gradient(case):
     np.testing.assert_allclose(eng.get_grad(), 2 * g, rtol=1e-12, atol=1e-12 * scale)
 
 
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_fb_batch_gradient_fast_precision(ci):
+    """FAST training precision: scores and expected counts on fp64 MFMA (sums reordered)."""
+    c = Case(seed=100 + ci, precision=1, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-11 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-11 * np.abs(ozx).max()
+    err = np.abs(g - og).max() / np.abs(og).max()
+    assert err <= REL_CONTRACT and err <= 1e-9, err
+    # decode entry points stay EXACT whatever the training precision
+    So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(0), c.Ts[0])
+    S, M = eng.scores(b, 0, c.Ts[0])
+    assert np.array_equal(bits(S), bits(So)) and np.array_equal(bits(M), bits(Mo))
+    b.close(); eng.close()
+
+
 def test_lattice_arcs_bit_exact(case):
     c, eng, b = case
     for u, T in enumerate(c.Ts):
@@ -232,7 +251,7 @@ def test_full_size_config2_utterances():
     frames, labels, off = synth.make_batch(U, T, in_w, L, D)
     F = 8 * in_w + D
     lam = synth.make_lambda(L * (F + 1 + L))
-    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F)); eng.set_lambda(lam)
+    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F, precision=1)); eng.set_lambda(lam)
     fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
     ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
     b = eng.batch_from_frames(fl, ll)

@@ -1,0 +1,52 @@
+// CRFFstDecode -- lattice decode front-end (CRFFstDecode/src/Main.cpp): per utterance build the
+// lattice, take the best path (ShortestPath/Project/RmEpsilon/TopSort), write `sent pos label`
+// lines (the ILAB content as ascii); crf_lat_outdir additionally dumps the arc list as text.
+// LM / dictionary composition needs OpenFST and stays host-side future work.
+#include "cli_common.h"
+
+int main(int argc, char** argv) {
+  Args a(argc, argv);
+  CliModel m;
+  auto data = load_streams(a, &m);
+  if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
+  CRF_Model crf(m.L);
+  crf.setLabMaxDur(m.D);
+  crf.setNActualLabs(m.fmap.nActualLabs);
+  crf.setModelType(m.mtype);
+  try {
+    crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));
+  } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+  if (!crf.readFromFile(a.str("weight_file").c_str())) { std::cerr << "ERROR! File " << a.str("weight_file") << " unable to be opened for reading" << std::endl; return -1; }
+  CRF_MemoryFeatureStream strm(m.recipes, m.D, m.fmap.nActualLabs);
+  const size_t U = data[0].size();
+  for (size_t u = 0; u < U; u++) {
+    std::vector<std::vector<float> > fr(data.size());
+    for (size_t s = 0; s < data.size(); s++)
+      for (const auto& row : data[s][u]) fr[s].insert(fr[s].end(), row.begin(), row.end());
+    strm.addUtterance(fr, std::vector<uint32_t>());
+  }
+  std::ofstream out;
+  if (a.has("crf_output_labelfile")) out.open(a.str("crf_output_labelfile").c_str());
+  std::ostream& os = out.is_open() ? (std::ostream&)out : std::cout;
+  strm.rewind();
+  size_t u = 0;
+  while (strm.nextseg() != QN_SEGID_BAD) {
+    try {  // the reference prints the exception and continues with the next utterance (:1052-1054)
+      if (a.has("crf_lat_outdir")) {
+        crf_amd::ArcListFst fst;
+        CRF_LatticeBuilder lb(&strm, &crf);
+        lb.buildLattice(&fst, false, (crf_amd::ArcListFst*)nullptr, false);
+        std::ofstream lf((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".txt").c_str());
+        for (const scrf_arc& c : fst.arcs) lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << c.w << "\n";
+        lf << fst.final_state << "\n";
+      }
+      float cost = 0;
+      std::vector<uint32_t> labs = crf_amd_best_path(&strm, &crf, &cost);
+      for (size_t i = 0; i < labs.size(); i++) os << u << " " << i << " " << labs[i] << "\n";
+    } catch (std::exception& e) {
+      std::cerr << "Exception: " << e.what() << std::endl;
+    }
+    u++;
+  }
+  return 0;
+}

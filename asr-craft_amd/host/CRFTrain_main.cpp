@@ -1,0 +1,61 @@
+// CRFTrain -- training front-end with the reference's `name=value` surface (CRFTrain/src/Main.cpp)
+// on the MI355X engine: SGD / AdaGrad over minibatches, `threads` data-parallel streams with
+// contiguous utterance views, per-iteration checkpoints and .done.train markers.
+#include "cli_common.h"
+
+int main(int argc, char** argv) {
+  Args a(argc, argv);
+  try {
+    CliModel m;
+    auto data = load_streams(a, &m);
+    if (!a.has("hardtarget_file")) { std::cerr << "hardtarget_file is required" << std::endl; return 1; }
+    if (!a.has("out_weight_file")) { std::cerr << "out_weight_file is required" << std::endl; return 1; }
+    auto labs = read_ascii_labs(a.str("hardtarget_file"));
+    if (a.str("crf_train_method", "sg") != "sg") { std::cerr << "only crf_train_method=sg is built" << std::endl; return 1; }
+    if (a.str("crf_train_order", "seq") != "seq") std::cout << "NOTE: crf_train_order=" << a.str("crf_train_order") << " ignored: sequential presentation (QuickNet's RNG is not reproducible here)" << std::endl;
+
+    CRF_Model crf(m.L);
+    crf.setLabMaxDur(m.D);
+    crf.setNActualLabs(m.fmap.nActualLabs);
+    crf.setModelType(m.mtype);
+    std::cout << "LABELS: " << crf.getNLabs() << std::endl;
+    std::cout << "LABEL_MAXIMUM_DURATION: " << crf.getLabMaxDur() << std::endl;
+    crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));
+    std::cout << "FEATURES: " << crf.getLambdaLen() << std::endl;
+    if (a.has("init_weight_file") && !crf.readFromFile(a.str("init_weight_file").c_str())) { std::cerr << "ERROR! File " << a.str("init_weight_file") << " unable to be opened for reading" << std::endl; return -1; }
+    if (a.has("avg_weight_file")) crf.readAverageFromFile(a.str("avg_weight_file").c_str(), (int)a.num("avg_weight_present", 0));
+    if (a.has("grad_sqr_acc_file")) crf.readGradSqrAccFromFile(a.str("grad_sqr_acc_file").c_str());
+    crf.setInitIter((QNUInt32)a.num("init_iter", 0));
+
+    CRF_MemoryFeatureStream all(m.recipes, m.D, m.fmap.nActualLabs);
+    const size_t U = data[0].size();
+    for (size_t u = 0; u < U; u++) {
+      std::vector<std::vector<float> > fr(data.size());
+      for (size_t s = 0; s < data.size(); s++)
+        for (const auto& row : data[s][u]) fr[s].insert(fr[s].end(), row.begin(), row.end());
+      all.addUtterance(fr, u < labs.size() ? labs[u] : std::vector<uint32_t>());
+    }
+    // `threads` child streams over contiguous ranges (io/CRF_FeatureStreamManager.cpp:425-464)
+    const size_t N = (size_t)std::max(1L, a.num("threads", 1));
+    std::vector<std::unique_ptr<CRF_MemoryFeatureStream> > views;
+    std::vector<CRF_FeatureStream*> streams;
+    for (size_t s = 0; s < N; s++) {
+      const size_t per = U / N, lo = s * per, cnt = s == N - 1 ? U - lo : per;
+      views.emplace_back(all.view(lo, cnt));
+      streams.push_back(views.back().get());
+    }
+    CRF_SGTrainer tr(&crf, streams, a.str("out_weight_file").c_str());
+    tr.setMaxIters((int)a.num("crf_epochs", 10));
+    tr.setLR((float)a.real("crf_lr", 0.008));
+    tr.setLRDecayRate((float)a.real("crf_lr_decay_rate", 1.0));
+    tr.setMinibatch((QNUInt32)a.num("crf_bunch_size", 1));
+    tr.setUseAdagrad(a.num("crf_use_adagrad", 0) != 0);
+    tr.setEta(a.real("crf_adagrad_eta", 1.0));
+    tr.setUttRpt((QNUInt32)a.num("crf_utt_rpt", 100));
+    tr.train();
+  } catch (std::exception& e) {
+    std::cerr << "Exception: " << e.what() << std::endl;
+    return -1;
+  }
+  return 0;
+}

@@ -1,0 +1,137 @@
+// cli_common.h -- `name=value` argument table and ascii feature/label readers shared by the
+// CRFTrain / CRFFstDecode front-ends (the reference parses the same flag names with QuickNet's
+// QN_initargs, CRFTrain/src/Main.cpp:146-256, CRFFstDecode/src/Main.cpp).  Only the flags that
+// reach the hot path are honoured; the others are accepted and ignored with a notice.
+// Feature files: QuickNet "ascii" pfile layout, one line per frame `sent frame v0 v1 ...`
+// (the layout of the reference's bundled CRFTrain/test*.ascii fixtures); label files
+// `sent frame label`.  Binary pfile/ILAB readers are SURVEY row f1 ("next").
+#ifndef CLI_COMMON_H_
+#define CLI_COMMON_H_
+
+#include <stdlib.h>
+
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "crf_amd.h"
+
+struct Args {
+  std::map<std::string, std::string> kv;
+  Args(int argc, char** argv) {
+    for (int i = 1; i < argc; i++) {
+      std::string a(argv[i]);
+      size_t k = a.find('=');
+      if (k == std::string::npos) { std::cerr << "argument '" << a << "' is not name=value" << std::endl; exit(1); }
+      kv[a.substr(0, k)] = a.substr(k + 1);
+    }
+  }
+  bool has(const std::string& k) const { return kv.count(k) && !kv.at(k).empty(); }
+  std::string str(const std::string& k, const std::string& d = "") const { return has(k) ? kv.at(k) : d; }
+  long num(const std::string& k, long d) const { return has(k) ? atol(kv.at(k).c_str()) : d; }
+  double real(const std::string& k, double d) const { return has(k) ? atof(kv.at(k).c_str()) : d; }
+};
+
+// utterances of one ascii stream: [utt][frame][value]
+inline std::vector<std::vector<std::vector<float> > > read_ascii_ftrs(const std::string& path, size_t* width) {
+  std::ifstream f(path.c_str());
+  if (!f.is_open()) { std::cerr << "cannot open feature file " << path << std::endl; exit(1); }
+  std::vector<std::vector<std::vector<float> > > utts;
+  std::string line;
+  *width = 0;
+  while (getline(f, line)) {
+    std::istringstream is(line);
+    long s, t;
+    if (!(is >> s >> t)) continue;
+    std::vector<float> v;
+    float x;
+    while (is >> x) v.push_back(x);
+    if (*width == 0) *width = v.size();
+    if (v.size() != *width) { std::cerr << path << ": ragged feature line" << std::endl; exit(1); }
+    if ((size_t)s >= utts.size()) utts.resize(s + 1);
+    utts[s].push_back(v);
+  }
+  return utts;
+}
+
+inline std::vector<std::vector<uint32_t> > read_ascii_labs(const std::string& path) {
+  std::ifstream f(path.c_str());
+  if (!f.is_open()) { std::cerr << "cannot open label file " << path << std::endl; exit(1); }
+  std::vector<std::vector<uint32_t> > utts;
+  long s, t, l;
+  while (f >> s >> t >> l) {
+    if ((size_t)s >= utts.size()) utts.resize(s + 1);
+    utts[s].push_back((uint32_t)l);
+  }
+  return utts;
+}
+
+struct CliModel {
+  CRF_FeatureMap_config fmap;
+  std::vector<scrf_stream_recipe> recipes;
+  uint32_t D = 1, L = 0, F = 0;
+  modeltype mtype = STDFRAME;
+};
+
+inline modeltype parse_model_type(const std::string& s) {
+  if (s == "stdseg") return STDSEG;
+  if (s == "stdseg_no_dur") return STDSEG_NO_DUR;
+  if (s == "stdseg_no_dur_no_transftr") return STDSEG_NO_DUR_NO_TRANSFTR;
+  if (s == "stdseg_no_dur_no_segtransftr") return STDSEG_NO_DUR_NO_SEGTRANSFTR;
+  return STDFRAME;
+}
+
+// streams (ftr1/ftr2/ftr3) + set_fmap_config of CRFTrain/src/Main.cpp:372-430
+inline std::vector<std::vector<std::vector<std::vector<float> > > > load_streams(const Args& a, CliModel* m) {
+  std::vector<std::vector<std::vector<std::vector<float> > > > data;
+  m->D = (uint32_t)a.num("label_maximum_duration", 1);
+  m->L = (uint32_t)a.num("crf_label_size", 0);
+  m->mtype = parse_model_type(a.str("crf_model_type", "stdframe"));
+  if (m->L == 0) { std::cerr << "crf_label_size is required" << std::endl; exit(1); }
+  m->F = 0;
+  for (int k = 1; k <= 3; k++) {
+    std::string p = "ftr" + std::to_string(k) + "_";
+    if (!a.has(p + "file")) break;
+    if (a.str(p + "format", "ascii") != "ascii") { std::cerr << p << "format: only ascii is built (pfile: next round)" << std::endl; exit(1); }
+    size_t w = 0;
+    data.push_back(read_ascii_ftrs(a.str(p + "file"), &w));
+    scrf_stream_recipe r;
+    r.in_width = (uint32_t)w;
+    r.left_ctx = (uint32_t)a.num(p + "left_context_len", 0);
+    r.right_ctx = (uint32_t)a.num(p + "right_context_len", 0);
+    r.extract_seg_ftr = (int32_t)a.num(p + "extract_seg_ftr", 0);
+    m->recipes.push_back(r);
+    m->F += (m->D == 1) ? (r.left_ctx + 1 + r.right_ctx) * r.in_width
+            : r.extract_seg_ftr ? 8 * r.in_width + m->D + (r.left_ctx + r.right_ctx) * r.in_width
+                                : (r.left_ctx + 1 + r.right_ctx) * r.in_width;
+  }
+  if (data.empty()) { std::cerr << "ftr1_file is required" << std::endl; exit(1); }
+  CRF_FeatureMap_config& c = m->fmap;
+  const std::string fm = a.str("crf_featuremap", "stdstate");
+  c.map_type = fm == "stdtrans" ? STDTRANS : STDSTATE;
+  if (fm != "stdstate" && fm != "stdtrans") { std::cerr << "crf_featuremap=" << fm << " is not built" << std::endl; exit(1); }
+  c.numLabs = m->L;
+  c.numFeas = m->F;
+  c.numStates = (QNUInt32)a.num("crf_states", 1);
+  c.useStateFtrs = true;
+  c.stateFidxStart = (QNUInt32)a.num("crf_stateftr_start", 0);
+  long e = a.num("crf_stateftr_end", -1);
+  c.stateFidxEnd = e >= 0 ? (QNUInt32)e : m->F - 1;
+  c.useTransFtrs = c.map_type == STDTRANS;
+  c.transFidxStart = (QNUInt32)a.num("crf_transftr_start", 0);
+  e = a.num("crf_transftr_end", -1);
+  c.transFidxEnd = e >= 0 ? (QNUInt32)e : m->F - 1;
+  c.useStateBias = a.num("crf_use_state_bias", 1) != 0;
+  c.useTransBias = a.num("crf_use_trans_bias", 1) != 0;
+  c.stateBiasVal = a.real("crf_state_bias_value", 1.0);
+  c.transBiasVal = a.real("crf_trans_bias_value", 1.0);
+  c.maxDur = m->D;
+  c.durFtrStart = (QNUInt32)a.num("dur_ftr_start", 0);
+  c.nActualLabs = (QNUInt32)a.num("num_actual_labs", m->L);
+  return data;
+}
+
+#endif  // CLI_COMMON_H_

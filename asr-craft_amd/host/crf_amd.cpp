@@ -1,0 +1,564 @@
+// crf_amd.cpp -- implementation of the reference-named host classes on the MI355X engine.
+#include "crf_amd.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+using std::runtime_error;
+using std::string;
+
+// ------------------------------------------------------------------------------------------
+// CRF_FeatureMap: lambda layout of the dense maps, numStates == 1
+// (same closed form as ScrfLayout; ftrmaps/CRF_StdFeatureMap.cpp:280-320,355-410,472-517)
+// ------------------------------------------------------------------------------------------
+CRF_FeatureMap::CRF_FeatureMap(CRF_FeatureMap_config* cnf) : config(cnf) { recalc(); }
+
+CRF_FeatureMap* CRF_FeatureMap::createFeatureMap(CRF_FeatureMap_config* cnf) {
+  if (cnf->map_type != STDSTATE && cnf->map_type != STDTRANS)
+    throw runtime_error("createFeatureMap: only the dense stdstate/stdtrans maps are built");
+  return new CRF_FeatureMap(cnf);
+}
+
+QNUInt32 CRF_FeatureMap::recalc() {
+  if (config->numStates != 1)
+    throw runtime_error("CRF_StdFeatureMap created exception: only single-state models are built");
+  const QNUInt32 L = config->numLabs;
+  numStateFuncs = numTransFuncs = 0;
+  if (config->useStateFtrs) numStateFuncs += config->stateFidxEnd - config->stateFidxStart + 1;
+  if (config->useStateBias) numStateFuncs += 1;
+  if (config->useTransFtrs) numTransFuncs += config->transFidxEnd - config->transFidxStart + 1;
+  if (config->useTransBias) numTransFuncs += 1;
+  numFtrFuncs = L * (numStateFuncs + L * numTransFuncs);
+  return numFtrFuncs;
+}
+
+QNUInt32 CRF_FeatureMap::getStateFeatureIdx(QNUInt32 clab, QNUInt32 fno) {
+  return clab * (numStateFuncs + config->numLabs * numTransFuncs) + fno;
+}
+
+QNUInt32 CRF_FeatureMap::getTransFeatureIdx(QNUInt32 clab, QNUInt32 plab, QNUInt32 fno) {
+  return clab * (numStateFuncs + config->numLabs * numTransFuncs) + numStateFuncs + plab * numTransFuncs + fno;
+}
+
+// ------------------------------------------------------------------------------------------
+// crf_amd::Engine
+// ------------------------------------------------------------------------------------------
+namespace crf_amd {
+
+Engine::Engine(const scrf_config& cfg) {
+  int rc = scrf_create(&cfg, &h);
+  if (rc != SCRF_OK) throw runtime_error(string("scrf_create: ") + scrf_last_error(nullptr));
+  scrf_lambda_len(h, &lambda_len);
+}
+Engine::~Engine() { scrf_destroy(h); }
+void Engine::check(int rc, const char* what) {
+  if (rc != SCRF_OK) throw runtime_error(string(what) + " caught exception: " + scrf_last_error(h));
+}
+
+scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision) {
+  CRF_FeatureMap* fm = crf->getFeatureMap();
+  if (!fm) throw runtime_error("CRF_Model has no feature map");
+  const CRF_FeatureMap_config* c = fm->getConfig();
+  scrf_config g;
+  memset(&g, 0, sizeof(g));
+  g.abi_version = SCRF_ABI_VERSION;
+  g.model_type = (uint32_t)crf->getModelType();
+  g.map_type = c->map_type == STDTRANS ? SCRF_STDTRANS : SCRF_STDSTATE;
+  g.num_labs = c->numLabs;
+  g.num_feas = c->numFeas;
+  g.num_states = c->numStates;
+  g.lab_max_dur = crf->getLabMaxDur();
+  g.use_state_ftrs = c->useStateFtrs;
+  g.state_fidx_start = c->stateFidxStart;
+  g.state_fidx_end = c->stateFidxEnd;
+  g.use_trans_ftrs = c->useTransFtrs;
+  g.trans_fidx_start = c->transFidxStart;
+  g.trans_fidx_end = c->transFidxEnd;
+  g.use_state_bias = c->useStateBias;
+  g.use_trans_bias = c->useTransBias;
+  g.state_bias_val = c->stateBiasVal;
+  g.trans_bias_val = c->transBiasVal;
+  g.device_id = device;
+  g.train_precision = precision;
+  return g;
+}
+
+}  // namespace crf_amd
+
+// ------------------------------------------------------------------------------------------
+// CRF_Model
+// ------------------------------------------------------------------------------------------
+CRF_Model::CRF_Model(QNUInt32 num_labs) : nlabs(num_labs), nActualLabs(num_labs) {}
+CRF_Model::~CRF_Model() { delete featureMap; }
+
+void CRF_Model::setFeatureMap(CRF_FeatureMap* map) {
+  delete featureMap;
+  featureMap = map;
+  const QNUInt32 n = map->getNumFtrFuncs();
+  lambda.assign(n, 0.0);
+  lambdaAcc.assign(n, 0.0);
+  gradSqrAcc.assign(n, 0.0);
+  eng.reset();
+}
+
+void CRF_Model::setLambda(double* v, QNUInt32 n) {
+  if (n != lambda.size()) throw runtime_error("CRF_Model::setLambda: length mismatch");
+  std::copy(v, v + n, lambda.begin());
+}
+void CRF_Model::resetLambda() { std::fill(lambda.begin(), lambda.end(), 0.0); }
+
+static bool write_vec(const char* fname, const double* v, size_t n) {
+  std::ofstream o(fname);
+  if (!o.is_open()) throw runtime_error(string("CRF_Model::writeToFile() caught exception: cannot open the file:\n") + fname);
+  for (size_t i = 0; i < n; i++) o << v[i] << std::endl;  // default precision: 6 significant digits
+  if (o.bad() || o.fail()) throw runtime_error(string("CRF_Model::writeToFile() caught exception: errors when writing the weights to the file:\n") + fname);
+  return true;
+}
+static bool read_vec(const char* fname, double* v, size_t n, double scale) {
+  std::ifstream f(fname);
+  if (!f.is_open()) return false;
+  for (size_t i = 0; i < n; i++) {
+    string s;
+    getline(f, s);
+    std::istringstream iss(s);
+    iss >> std::dec >> v[i];
+    if (scale != 1.0) v[i] *= scale;
+  }
+  return true;
+}
+bool CRF_Model::writeToFile(const char* fname) { return write_vec(fname, lambda.data(), lambda.size()); }
+bool CRF_Model::writeToFile(const char* fname, double* lam, QNUInt32 ll) { return write_vec(fname, lam, ll); }
+bool CRF_Model::readFromFile(const char* fname) { return read_vec(fname, lambda.data(), lambda.size(), 1.0); }
+bool CRF_Model::readAverageFromFile(const char* fname, int present) {
+  init_present = present;
+  return read_vec(fname, lambdaAcc.data(), lambdaAcc.size(), present > 0 ? (double)present : 1.0);
+}
+bool CRF_Model::readGradSqrAccFromFile(const char* fname) { return read_vec(fname, gradSqrAcc.data(), gradSqrAcc.size(), 1.0); }
+
+crf_amd::Engine* CRF_Model::engine(int device, uint32_t precision) {
+  if (!eng) eng.reset(new crf_amd::Engine(crf_amd::makeConfig(this, device, precision)));
+  return eng.get();
+}
+void CRF_Model::pushLambda() {
+  crf_amd::Engine* e = engine();
+  const QNUInt32 n = (QNUInt32)lambda.size();
+  e->check(scrf_set_lambda(e->h, lambda.data(), n), "CRF_Model::pushLambda");
+  e->check(scrf_set_lambda_acc(e->h, lambdaAcc.data(), n), "CRF_Model::pushLambda");
+  e->check(scrf_set_grad_sqr_acc(e->h, gradSqrAcc.data(), n), "CRF_Model::pushLambda");
+}
+void CRF_Model::pullLambda() {
+  crf_amd::Engine* e = engine();
+  const QNUInt32 n = (QNUInt32)lambda.size();
+  e->check(scrf_get_lambda(e->h, lambda.data(), n), "CRF_Model::pullLambda");
+  e->check(scrf_get_lambda_acc(e->h, lambdaAcc.data(), n), "CRF_Model::pullLambda");
+  e->check(scrf_get_grad_sqr_acc(e->h, gradSqrAcc.data(), n), "CRF_Model::pullLambda");
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_MemoryFeatureStream
+// ------------------------------------------------------------------------------------------
+static uint32_t recipe_width(const scrf_stream_recipe& r, uint32_t D) {
+  if (D == 1) return (r.left_ctx + 1 + r.right_ctx) * r.in_width;
+  if (r.extract_seg_ftr) return 8 * r.in_width + D + (r.left_ctx + r.right_ctx) * r.in_width;
+  return (r.left_ctx + 1 + r.right_ctx) * r.in_width;
+}
+
+CRF_MemoryFeatureStream::CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe> recipes, QNUInt32 max_dur,
+                                                 QNUInt32 n_actual_labs)
+    : store_(new Store()) {
+  store_->recipes = recipes;
+  store_->D = max_dur;
+  store_->L = n_actual_labs;
+  for (const auto& r : recipes) width_ += recipe_width(r, max_dur);
+}
+
+void CRF_MemoryFeatureStream::addUtterance(const std::vector<std::vector<float> >& frames,
+                                           const std::vector<uint32_t>& fl) {
+  Store& s = *store_;
+  if (frames.size() != s.recipes.size()) throw runtime_error("addUtterance: one frame matrix per stream expected");
+  const scrf_stream_recipe& r0 = s.recipes[0];
+  const uint32_t T = (uint32_t)(frames[0].size() / r0.in_width) - r0.left_ctx - r0.right_ctx;
+  for (size_t k = 0; k < frames.size(); k++) {
+    const scrf_stream_recipe& r = s.recipes[k];
+    if (frames[k].size() != (size_t)(T + r.left_ctx + r.right_ctx) * r.in_width)
+      throw runtime_error("addUtterance: stream lengths disagree");
+  }
+  s.T.push_back(T);
+  s.frames.push_back(frames);
+  // frame labels -> (label, start) at segment end frames; runs longer than D are split evenly
+  std::vector<uint32_t> lab(T, CRF_LAB_BAD), st(T, CRF_LAB_BAD);
+  if (!fl.empty()) {
+    if (fl.size() != T) throw runtime_error("addUtterance: one label per frame expected");
+    const uint32_t D = s.D, L = s.L;
+    for (uint32_t a = 0; a < T;) {
+      uint32_t b = a + 1;
+      while (b < T && fl[b] == fl[a]) b++;
+      if (fl[a] != CRF_LAB_BAD) {
+        const uint32_t dur = b - a;
+        const uint32_t pieces = dur <= D ? 1 : (dur % D == 0 ? dur / D : dur / D + 1);
+        const uint32_t pd = dur / pieces, rem = dur % pieces;
+        uint32_t ps = a;
+        for (uint32_t p = 0; p < pieces; p++) {
+          const uint32_t d = p < rem ? pd + 1 : pd;
+          lab[ps + d - 1] = L * (d - 1) + fl[a];
+          st[ps + d - 1] = ps;
+          ps += d;
+        }
+      }
+      a = b;
+    }
+  }
+  s.seg_labels.push_back(lab);
+  s.seg_start.push_back(st);
+  end_ = s.T.size();
+}
+
+CRF_MemoryFeatureStream* CRF_MemoryFeatureStream::view(size_t start, size_t count) {
+  CRF_MemoryFeatureStream* v = new CRF_MemoryFeatureStream(*this);
+  v->begin_ = begin_ + start;
+  v->end_ = std::min(end_, v->begin_ + count);
+  v->cur_ = -1;
+  return v;
+}
+
+QN_SegID CRF_MemoryFeatureStream::nextseg() {
+  long nxt = cur_ < 0 ? (long)begin_ : cur_ + 1;
+  if (nxt >= (long)end_) { cur_ = (long)end_; return QN_SEGID_BAD; }
+  cur_ = nxt;
+  frame_ = 0;
+  return (QN_SegID)(cur_ - (long)begin_);
+}
+int CRF_MemoryFeatureStream::rewind() { cur_ = -1; frame_ = 0; return 0; }
+
+bool CRF_MemoryFeatureStream::currentUtterance(Utterance* u) {
+  if (cur_ < (long)begin_ || cur_ >= (long)end_) return false;
+  const Store& s = *store_;
+  u->T = s.T[cur_];
+  u->frames.clear();
+  for (const auto& f : s.frames[cur_]) u->frames.push_back(f.data());
+  u->windows = nullptr;
+  u->labels = s.seg_labels[cur_].data();
+  return true;
+}
+
+// windows ending at the current frame, d = 1..bunch, joined over the streams
+// (what io/CRF_InFtrStream_SeqMultiWindow produces; host-side compatibility path only --
+// the engine synthesises windows on the GPU from currentUtterance())
+size_t CRF_MemoryFeatureStream::read(size_t bunch, float* out, QNUInt32* lab_buf) {
+  if (cur_ < (long)begin_ || cur_ >= (long)end_) return 0;
+  const Store& s = *store_;
+  const uint32_t T = s.T[cur_], D = s.D, t = frame_;
+  if (t >= T) return 0;
+  const uint32_t avail = t + 1 <= D ? t + 1 : D;
+  if (bunch != avail) throw runtime_error("CRF_MemoryFeatureStream::read: the number of windows has to be min(t+1, max_dur) at the current frame");
+  size_t col = 0;
+  for (size_t k = 0; k < s.recipes.size(); k++) {
+    const scrf_stream_recipe& r = s.recipes[k];
+    const uint32_t W = r.in_width;
+    const float* fr = s.frames[cur_][k].data();
+    const float* last = fr + (size_t)(r.left_ctx + t) * W;
+    const bool seg = D != 1 && r.extract_seg_ftr;
+    std::vector<float> sum(W, 0.0f), mx(last, last + W), mn(last, last + W);
+    for (uint32_t w = 1; w <= avail; w++) {
+      const float* first = last - (size_t)(w - 1) * W;
+      float* o = out + (size_t)(w - 1) * width_ + col;
+      for (uint32_t c = 0; c < r.left_ctx; c++)
+        for (uint32_t j = 0; j < W; j++) *o++ = first[((long)c - (long)r.left_ctx) * (long)W + j];
+      if (!seg) {
+        for (uint32_t j = 0; j < W; j++) *o++ = first[j];
+      } else {
+        const float ot = (float)(w * 0.1);
+        for (int i = 1; i < 10; i += 2) {
+          const uint32_t step = (uint32_t)ceilf(ot * (float)i) - 1;
+          for (uint32_t j = 0; j < W; j++) *o++ = first[(size_t)step * W + j];
+        }
+        for (uint32_t j = 0; j < W; j++) { sum[j] += first[j]; *o++ = sum[j] / (float)w; }
+        for (uint32_t j = 0; j < W; j++) { if (first[j] > mx[j]) mx[j] = first[j]; *o++ = mx[j]; }
+        for (uint32_t j = 0; j < W; j++) { if (first[j] < mn[j]) mn[j] = first[j]; *o++ = mn[j]; }
+        for (uint32_t kk = 1; kk <= D; kk++) *o++ = kk == w ? 1.0f : 0.0f;
+      }
+      const float* rb = r.extract_seg_ftr ? last : first;
+      for (uint32_t c = 1; c <= r.right_ctx; c++)
+        for (uint32_t j = 0; j < W; j++) *o++ = rb[(size_t)c * W + j];
+    }
+    col += recipe_width(r, D);
+  }
+  if (lab_buf) {
+    const uint32_t lb = s.seg_labels[cur_][t];
+    if (lb == CRF_LAB_BAD) {
+      lab_buf[0] = lab_buf[1] = lab_buf[2] = lab_buf[3] = CRF_LAB_BAD;
+    } else {
+      lab_buf[0] = lb % s.L;
+      lab_buf[1] = s.seg_start[cur_][t];
+      lab_buf[2] = t;
+      lab_buf[3] = 0;
+    }
+  }
+  frame_++;
+  return avail;
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers: one engine batch from a list of utterances
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct HeldUtt {
+  CRF_FeatureStream::Utterance u;
+  std::vector<float> windows;     // when the stream only offers read()
+  std::vector<uint32_t> labels;
+};
+
+// pull the stream's current utterance, through the fast path or the read() protocol
+void grab(CRF_FeatureStream* strm, CRF_Model* crf, HeldUtt* h) {
+  if (strm->currentUtterance(&h->u)) return;
+  const uint32_t D = crf->getLabMaxDur(), L = crf->getNActualLabs();
+  const size_t F = strm->num_ftrs(), LW = strm->num_labs();
+  std::vector<float> buf(F * D);
+  std::vector<QNUInt32> lab(LW ? LW : 1);
+  size_t bunch = 1;
+  uint32_t t = 0;
+  while (true) {
+    size_t n = strm->read(bunch, buf.data(), LW ? lab.data() : nullptr);
+    if (n == 0) break;
+    h->windows.insert(h->windows.end(), buf.begin(), buf.begin() + n * F);
+    uint32_t lb = CRF_LAB_BAD;
+    if (LW && lab[0] != CRF_LAB_BAD) lb = L * (lab[2] - lab[1]) + lab[0];  // nActualLabs*(dur-1)+phone
+    h->labels.push_back(lb);
+    t++;
+    if (bunch < D) bunch++;
+  }
+  if (t == 0) throw runtime_error("CRF_NewGradBuilder_StdSeg::buildGradient() caught exception: No features read from this sentence.");
+  h->u.T = t;
+  h->u.windows = h->windows.data();
+  h->u.labels = h->labels.data();
+  h->u.frames.clear();
+}
+
+struct BatchGuard {
+  crf_amd::Engine* e;
+  scrf_batch b = nullptr;
+  ~BatchGuard() { if (b) scrf_batch_destroy(e->h, b); }
+};
+
+void make_batch(crf_amd::Engine* e, CRF_FeatureStream* strm, const std::vector<HeldUtt>& utts, BatchGuard* g) {
+  std::vector<scrf_utt> su(utts.size());
+  const auto& rec = strm->recipes();
+  for (size_t i = 0; i < utts.size(); i++) {
+    memset(&su[i], 0, sizeof(scrf_utt));
+    su[i].T = utts[i].u.T;
+    su[i].windows = utts[i].u.windows;
+    for (size_t s = 0; s < utts[i].u.frames.size() && s < SCRF_MAX_STREAMS; s++) su[i].frames[s] = utts[i].u.frames[s];
+    su[i].labels = utts[i].u.labels;
+  }
+  e->check(scrf_batch_create(e->h, su.data(), (uint32_t)su.size(), (uint32_t)rec.size(), rec.empty() ? nullptr : rec.data(), &g->b),
+           "scrf_batch_create");
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// CRF_GradBuilder
+// ------------------------------------------------------------------------------------------
+CRF_GradBuilder* CRF_GradBuilder::create(CRF_Model* crf, objfunctype ofunc) {
+  if (ofunc != EXPF) throw runtime_error("CRF_GradBuilder::create: only the EXPF objective is built (the reference disables the others)");
+  return new CRF_GradBuilder(crf);
+}
+
+double CRF_GradBuilder::buildGradient(CRF_FeatureStream* ftr_strm, double* grad, double* Zx_out) {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  e->check(scrf_zero_grad(e->h), "buildGradient");
+  double numer = 0, zx = 0;
+  e->check(scrf_fb_batch(e->h, g.b, &numer, &zx), "CRF_NewGradBuilder_StdSeg_NoDur_NoTrans::buildGradient()");
+  std::vector<double> gd(e->lambda_len);
+  e->check(scrf_get_grad(e->h, gd.data(), e->lambda_len), "buildGradient");
+  for (uint32_t i = 0; i < e->lambda_len; i++) grad[i] += gd[i];
+  *Zx_out = zx;
+  return numer;
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_Minibatch_GradAccumulator
+// ------------------------------------------------------------------------------------------
+CRF_Minibatch_GradAccumulator::CRF_Minibatch_GradAccumulator(CRF_Model* c, std::vector<CRF_FeatureStream*> s)
+    : crf(c), ftrStrms(s), segids(s.size(), QN_SEGID_BAD) {}
+
+void CRF_Minibatch_GradAccumulator::setMinibatch(QNUInt32 mb) {
+  if (mb != 0 && mb < ftrStrms.size())
+    throw runtime_error("CRF_Minibatch_GradAccumulator::setMinibatch() Error: minibatch size is less than the number of threads.");
+  minibatch = mb == 0 ? CRF_UINT32_MAX : mb;
+}
+
+void CRF_Minibatch_GradAccumulator::rewindAllAndNextSegs() {
+  for (size_t s = 0; s < ftrStrms.size(); s++) {
+    ftrStrms[s]->rewind();
+    segids[s] = ftrStrms[s]->nextseg();
+  }
+}
+
+double CRF_Minibatch_GradAccumulator::accumulateGradient(double* grad, double* Zx_out, QNUInt32* uttCount,
+                                                         bool* isEndOfIter) {
+  crf_amd::Engine* e = crf->engine();
+  const QNUInt32 n = e->lambda_len, N = (QNUInt32)ftrStrms.size();
+  *uttCount = 0;
+  *Zx_out = 0.0;
+  for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
+  const QNUInt32 per = minibatch == CRF_UINT32_MAX ? CRF_UINT32_MAX : minibatch / N;
+  const QNUInt32 rem = minibatch == CRF_UINT32_MAX ? 0 : minibatch % N;
+  int nEnd = 0, nActive = 0;
+  for (QNUInt32 s = 0; s < N; s++) if (segids[s] == QN_SEGID_BAD) ++nEnd;
+  if (nEnd == (int)N) throw runtime_error("All feature streams are at the end! You don't have any utterances or you forget to rewind all the streams.");
+  double totNumer = 0.0;
+  std::vector<double> sgrad(n);
+  for (QNUInt32 s = 0; s < N; s++) {  // stream order == the reference's join/sum order
+    if (segids[s] == QN_SEGID_BAD) continue;
+    const QNUInt32 share = per == CRF_UINT32_MAX ? CRF_UINT32_MAX : per + (s < rem ? 1 : 0);
+    std::vector<HeldUtt> utts;
+    do {  // thread run loop: at least one utterance, then until the share is reached or the view ends
+      utts.emplace_back();
+      grab(ftrStrms[s], crf, &utts.back());
+      segids[s] = ftrStrms[s]->nextseg();
+    } while (utts.size() < share && segids[s] != QN_SEGID_BAD);
+    BatchGuard g{e};
+    make_batch(e, ftrStrms[s], utts, &g);
+    std::vector<double> numer(utts.size()), zx(utts.size());
+    e->check(scrf_zero_grad(e->h), "accumulateGradient");
+    e->check(scrf_fb_batch(e->h, g.b, numer.data(), zx.data()), "CRF_Minibatch_GradAccumulator::accumulateGradient()");
+    e->check(scrf_get_grad(e->h, sgrad.data(), n), "accumulateGradient");
+    ++nActive;
+    for (size_t i = 0; i < utts.size(); i++) { totNumer += numer[i]; *Zx_out += zx[i]; }
+    *uttCount += (QNUInt32)utts.size();
+    if (segids[s] == QN_SEGID_BAD) ++nEnd;
+    for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
+  }
+  for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;  // averaged over ACTIVE STREAMS (reference quirk)
+  *isEndOfIter = nEnd == (int)N;
+  return totNumer;
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_SGTrainer
+// ------------------------------------------------------------------------------------------
+CRF_SGTrainer::CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> s, const char* wf)
+    : crf_ptr(crf), streams(s), weight_fname(wf) {}
+
+static string dir_of(const string& p) {
+  size_t k = p.find_last_of('/');
+  return k == string::npos ? string(".") : p.substr(0, k);
+}
+static void touch(const string& f) { std::ofstream o(f.c_str()); if (!o.is_open()) std::cerr << "ERROR: cannot touch the done file " << f << std::endl; }
+
+void CRF_SGTrainer::train() {
+  crf_amd::Engine* e = crf_ptr->engine();
+  crf_ptr->pushLambda();
+  const QNUInt32 n = crf_ptr->getLambdaLen();
+  CRF_Minibatch_GradAccumulator gaccum(crf_ptr, streams);
+  gaccum.setMinibatch(minibatch);
+  gaccum.setUttReport(uttRpt);
+  std::vector<double> grad(n, 0.0), lambdaAvg(n, 0.0);
+  int iCounter = (int)crf_ptr->getInitIter();
+  QNUInt32 uCounter = 0;
+  int accCnt = (int)crf_ptr->getPresentations();
+  double totLogLi = 0.0;
+  gaccum.rewindAllAndNextSegs();
+  bool start = true;
+  while (iCounter < maxIters) {
+    if (start) {
+      if (useAdagrad) std::cout << "Iteration: " << iCounter << " starting AdaGrad scaling factor (eta): " << eta << std::endl;
+      else std::cout << "Iteration: " << iCounter << " starting LR: " << lr << std::endl;
+      start = false;
+    }
+    QNUInt32 inc = 0;
+    bool endOfIter = false;
+    double Zx = 0.0;
+    const double numer = gaccum.accumulateGradient(grad.data(), &Zx, &inc, &endOfIter);
+    const double logLi = numer - Zx;
+    totLogLi += logLi;
+    uCounter += inc;
+    if (uttRpt > 0 && uCounter % uttRpt == 0)
+      std::cout << " Finished Utt: " << uCounter - 1 << " Batch-Avg Numerator: " << numer / inc << " Batch-Avg Zx: " << Zx / inc
+                << " Batch-Avg LogLi: " << logLi / inc << " Iter-Avg LogLi: " << totLogLi / uCounter << std::endl;
+    // update on the device: lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0
+    e->check(scrf_zero_grad(e->h), "sgtrainMinibatch");
+    e->check(scrf_add_grad(e->h, grad.data(), n), "sgtrainMinibatch");
+    e->check(scrf_sgd_step(e->h, useAdagrad ? eta : (double)lr, useAdagrad, eps), "sgtrainMinibatch");
+    accCnt += (int)inc;
+    if (endOfIter) {
+      crf_ptr->pullLambda();
+      std::stringstream ss;
+      ss << weight_fname << ".i" << iCounter << ".out";
+      std::cout << "Writing Iteration " << iCounter << " weights to file " << ss.str() << std::endl;
+      crf_ptr->writeToFile(ss.str().c_str());
+      const double* acc = crf_ptr->getLambdaAcc();
+      for (QNUInt32 i = 0; i < n; i++) lambdaAvg[i] = acc[i] / (float)accCnt;
+      std::stringstream sa;
+      sa << weight_fname << ".i" << iCounter << ".avg.out";
+      crf_ptr->writeToFile(sa.str().c_str(), lambdaAvg.data(), n);
+      if (useAdagrad) {
+        std::stringstream sg;
+        sg << weight_fname << ".i" << iCounter << ".gradSqrAcc.out";
+        crf_ptr->writeToFile(sg.str().c_str(), crf_ptr->getGradSqrAcc(), n);
+      }
+      gaccum.rewindAllAndNextSegs();
+      std::stringstream sd;
+      sd << dir_of(weight_fname) << "/.done.train.i" << iCounter;
+      touch(sd.str());
+      iCounter++;
+      uCounter = 0;
+      totLogLi = 0.0;
+      start = true;
+      if (!useAdagrad) {
+        lr *= lr_decay_rate;
+        std::cout << "Learning rate is decayed by " << lr_decay_rate << " to " << lr << std::endl;
+      }
+    }
+  }
+  crf_ptr->pullLambda();
+  std::cout << "Writing Final Iteration weights to file " << weight_fname << std::endl;
+  crf_ptr->writeToFile(weight_fname.c_str());
+  crf_ptr->writeToFile((weight_fname + ".avg.out").c_str(), lambdaAvg.data(), n);
+  touch(dir_of(weight_fname) + "/.done.train");
+}
+
+// ------------------------------------------------------------------------------------------
+// lattice / best path
+// ------------------------------------------------------------------------------------------
+int CRF_LatticeBuilder::latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint32_t* n_states, int32_t* fin) {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  uint64_t na = 0;
+  e->check(scrf_lattice_arcs(e->h, g.b, 0, norm, nullptr, &na, n_states, fin), "buildLattice");
+  arcs->resize(na);
+  e->check(scrf_lattice_arcs(e->h, g.b, 0, norm, arcs->data(), &na, n_states, fin), "buildLattice");
+  return (int)utts[0].u.T;
+}
+
+std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* crf, float* cost) {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  std::vector<uint32_t> labs(utts[0].u.T);
+  uint64_t off[2] = {0, 0};
+  float c = 0;
+  e->check(scrf_viterbi_batch(e->h, g.b, labs.data(), labs.size(), off, &c), "ShortestPath");
+  labs.resize(off[1]);
+  if (cost) *cost = c;
+  return labs;
+}

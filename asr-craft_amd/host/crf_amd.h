@@ -1,0 +1,290 @@
+// crf_amd.h -- C++ host side above the C ABI (include/scrf_abi.h): the reference's plugin /
+// operator interface for the hot path, with the reference's own names, argument meaning and
+// error behaviour (std::runtime_error), implemented on the MI355X engine.  Written from the
+// interface descriptions in SURVEY.md section 8b; nothing here is reference code.
+//
+//   CRF_FeatureMap_config / CRF_FeatureMap / CRF_StdFeatureMap   ftrmaps/CRF_FeatureMap.h:24-96
+//   CRF_Model                                                    CRF_Model.h
+//   CRF_FeatureStream (abstract) + CRF_MemoryFeatureStream       io/CRF_FeatureStream.h:54-66
+//   CRF_GradBuilder::buildGradient                               trainers/gradbuilders/CRF_GradBuilder.h:40
+//   CRF_Minibatch_GradAccumulator::accumulateGradient            trainers/accumulators/...h:66-67
+//   CRF_SGTrainer                                                trainers/CRF_SGTrainer.h:45-48
+//   CRF_LatticeBuilder_* ::buildLattice<Fst>                     decoders/...WithoutSegTransFtr.h:26
+//
+// QuickNet3 and OpenFST are not dependencies: feature streams are an abstract interface the
+// caller implements (a QuickNet-backed one is a 30-line subclass), and
+// buildLattice is a template over any FST type with AddState/SetStart/AddArc/SetFinal
+// (fst::VectorFst<fst::StdArc> fits; crf_amd::ArcListFst is provided for OpenFST-less builds).
+#ifndef CRF_AMD_H_
+#define CRF_AMD_H_
+
+#include <stdint.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "scrf_abi.h"
+
+typedef uint32_t QNUInt32;
+typedef int32_t QNInt32;
+typedef long QN_SegID;
+#define QN_SEGID_BAD (-1L)
+#define CRF_LAB_BAD SCRF_LAB_BAD
+#define CRF_UINT32_MAX (0xffffffffu)
+
+enum ftrmaptype { STDSTATE, STDTRANS, STDSPARSE, STDSPARSETRANS, INFILE };                       // CRF.h:40
+enum modeltype { STDFRAME, STDSEG, STDSEG_NO_DUR, STDSEG_NO_DUR_NO_TRANSFTR, STDSEG_NO_DUR_NO_SEGTRANSFTR };  // CRF.h:50
+enum objfunctype { EXPF, EXPFSOFT, FERR };                                                       // CRF.h:44
+
+struct CRF_FeatureMap_config {
+  ftrmaptype map_type = STDSTATE;
+  QNUInt32 numLabs = 0, numFeas = 0, numStates = 1;
+  bool useStateFtrs = true;
+  QNUInt32 stateFidxStart = 0, stateFidxEnd = 0;
+  bool useTransFtrs = false;
+  QNUInt32 transFidxStart = 0, transFidxEnd = 0;
+  bool useStateBias = true, useTransBias = true;
+  double stateBiasVal = 1.0, transBiasVal = 1.0;
+  QNUInt32 maxDur = 1, durFtrStart = 0, nActualLabs = 0;
+};
+
+// lambda index layout of the dense maps (host-only arithmetic, same closed form the kernels use)
+class CRF_FeatureMap {
+ public:
+  explicit CRF_FeatureMap(CRF_FeatureMap_config* cnf);
+  virtual ~CRF_FeatureMap() {}
+  static CRF_FeatureMap* createFeatureMap(CRF_FeatureMap_config* cnf);
+  virtual QNUInt32 getNumFtrFuncs() { return numFtrFuncs; }
+  virtual QNUInt32 getNumStates() { return config->numStates; }
+  virtual QNUInt32 getNumStateFuncs(QNUInt32) { return numStateFuncs; }
+  virtual QNUInt32 getNumTransFuncs(QNUInt32, QNUInt32) { return numTransFuncs; }
+  virtual QNUInt32 getStateFeatureIdx(QNUInt32 clab, QNUInt32 fno = 0);
+  virtual QNUInt32 getTransFeatureIdx(QNUInt32 clab, QNUInt32 plab, QNUInt32 fno = 0);
+  virtual QNUInt32 getStateBiasIdx(QNUInt32 clab) { return getStateFeatureIdx(clab, numStateFuncs - 1); }
+  virtual QNUInt32 getTransBiasIdx(QNUInt32 clab, QNUInt32 plab) { return getTransFeatureIdx(clab, plab, numTransFuncs - 1); }
+  virtual QNUInt32 recalc();
+  CRF_FeatureMap_config* getConfig() { return config; }
+
+ protected:
+  CRF_FeatureMap_config* config;
+  QNUInt32 numFtrFuncs = 0, numStateFuncs = 0, numTransFuncs = 0;
+};
+typedef CRF_FeatureMap CRF_StdFeatureMap;
+
+namespace crf_amd { class Engine; }
+
+// lambda / lambdaAcc / gradSqrAcc container + the text weight-file format (one value per line,
+// default ostream precision = 6 significant digits, CRF_Model.cpp:205-233,290)
+class CRF_Model {
+ public:
+  explicit CRF_Model(QNUInt32 num_labs);
+  virtual ~CRF_Model();
+  QNUInt32 getNLabs() { return nlabs; }
+  virtual void setFeatureMap(CRF_FeatureMap* map);  // takes ownership; sizes lambda
+  virtual CRF_FeatureMap* getFeatureMap() { return featureMap; }
+  virtual double* getLambda() { return lambda.data(); }
+  virtual QNUInt32 getLambdaLen() { return (QNUInt32)lambda.size(); }
+  virtual double* getLambdaAcc() { return lambdaAcc.data(); }
+  virtual double* getGradSqrAcc() { return gradSqrAcc.data(); }
+  virtual QNUInt32 getPresentations() { return init_present; }
+  virtual void setLambda(double* v, QNUInt32 n);
+  virtual void resetLambda();
+  virtual bool writeToFile(const char* fname);
+  virtual bool writeToFile(const char* fname, double* lam, QNUInt32 ll);
+  virtual bool readFromFile(const char* fname);
+  virtual bool readAverageFromFile(const char* fname, int present);
+  virtual bool readGradSqrAccFromFile(const char* fname);
+  virtual void setLabMaxDur(QNUInt32 d) { lab_max_dur = d; }
+  virtual QNUInt32 getLabMaxDur() { return lab_max_dur; }
+  virtual void setNActualLabs(QNUInt32 n) { nActualLabs = n; }
+  virtual QNUInt32 getNActualLabs() { return nActualLabs; }
+  virtual void setModelType(modeltype m) { model_type = m; }
+  virtual modeltype getModelType() { return model_type; }
+  virtual void setInitIter(QNUInt32 i) { init_iter = i; }
+  virtual QNUInt32 getInitIter() { return init_iter; }
+  // the engine bound to this model (created lazily on `device`); lambda is pushed before use
+  crf_amd::Engine* engine(int device = 0, uint32_t precision = SCRF_PREC_EXACT);
+  void pushLambda();   // host lambda/lambdaAcc/gradSqrAcc -> device
+  void pullLambda();   // device -> host
+
+ protected:
+  QNUInt32 nlabs;
+  std::vector<double> lambda, lambdaAcc, gradSqrAcc;
+  CRF_FeatureMap* featureMap = nullptr;
+  QNUInt32 init_present = 0, lab_max_dur = 1, nActualLabs = 0, init_iter = 0;
+  modeltype model_type = STDFRAME;
+  std::unique_ptr<crf_amd::Engine> eng;
+};
+
+// The stream interface the hot path consumes (io/CRF_FeatureStream.h:54-66).  read() returns
+// `bunch` windows ending at the current frame, each num_ftrs() floats, and the 4 label words
+// {label, start, end, broken} of the segment ending there (CRF_LAB_BAD x4 if none).
+class CRF_FeatureStream {
+ public:
+  virtual ~CRF_FeatureStream() {}
+  virtual QN_SegID nextseg() = 0;
+  virtual size_t read(size_t bunch, float* ftr_buf, QNUInt32* lab_buf) = 0;
+  virtual int rewind() = 0;
+  virtual size_t num_ftrs() = 0;
+  virtual size_t num_labs() = 0;
+  // Engine fast path: whole utterance at once.  frames[s] = raw frames of stream s incl. context
+  // padding (empty when only windows are available), labels = per-end-frame segment labels.
+  struct Utterance {
+    uint32_t T = 0;
+    std::vector<const float*> frames;
+    const float* windows = nullptr;
+    const uint32_t* labels = nullptr;
+  };
+  virtual bool currentUtterance(Utterance* u) { (void)u; return false; }
+  virtual const std::vector<scrf_stream_recipe>& recipes() { static std::vector<scrf_stream_recipe> e; return e; }
+};
+
+// In-memory stream over raw frames (what CRF_FeatureStreamManager builds from pfiles):
+// per utterance one frame matrix per input stream + frame-level phone labels.
+class CRF_MemoryFeatureStream : public CRF_FeatureStream {
+ public:
+  CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe> recipes, QNUInt32 max_dur, QNUInt32 n_actual_labs);
+  // frames[s]: (T + lctx_s + rctx_s) x in_width_s, frame_labels: T phone ids (or empty)
+  void addUtterance(const std::vector<std::vector<float> >& frames, const std::vector<uint32_t>& frame_labels);
+  CRF_MemoryFeatureStream* view(size_t start, size_t count);  // child stream over a contiguous range
+  size_t numUtterances() const { return end_ - begin_; }
+  QN_SegID nextseg() override;
+  size_t read(size_t bunch, float* ftr_buf, QNUInt32* lab_buf) override;
+  int rewind() override;
+  size_t num_ftrs() override { return width_; }
+  size_t num_labs() override { return 4; }
+  bool currentUtterance(Utterance* u) override;
+  const std::vector<scrf_stream_recipe>& recipes() override { return store_->recipes; }
+
+ private:
+  struct Store {
+    std::vector<scrf_stream_recipe> recipes;
+    QNUInt32 D, L;
+    std::vector<uint32_t> T;
+    std::vector<std::vector<std::vector<float> > > frames;  // [utt][stream]
+    std::vector<std::vector<uint32_t> > seg_labels;         // [utt][T]
+    std::vector<std::vector<uint32_t> > seg_start;          // [utt][T] start frame of the segment ending at t
+  };
+  std::shared_ptr<Store> store_;
+  size_t begin_ = 0, end_ = 0, width_ = 0;
+  long cur_ = -1;
+  uint32_t frame_ = 0;
+};
+
+namespace crf_amd {
+
+// RAII over scrf_handle; every failure becomes std::runtime_error(scrf_last_error)
+class Engine {
+ public:
+  Engine(const scrf_config& cfg);
+  ~Engine();
+  scrf_handle h = nullptr;
+  uint32_t lambda_len = 0;
+  void check(int rc, const char* what);
+};
+
+scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision);
+
+// minimal FST recorder with the four calls buildLattice needs
+struct ArcListFst {
+  struct Arc { int ilabel, olabel; float weight; int nextstate; Arc(int i, int o, float w, int n) : ilabel(i), olabel(o), weight(w), nextstate(n) {} };
+  int AddState() { return n_states++; }
+  void SetStart(int s) { start = s; }
+  void AddArc(int s, const Arc& a) { arcs.push_back(scrf_arc{s, a.ilabel, a.olabel, a.weight, a.nextstate}); }
+  void SetFinal(int s, float w) { final_state = s; final_weight = w; }
+  int n_states = 0, start = -1, final_state = -1;
+  float final_weight = 0;
+  std::vector<scrf_arc> arcs;
+};
+
+}  // namespace crf_amd
+
+// per-utterance gradient (CRF_GradBuilder::buildGradient, factory create())
+class CRF_GradBuilder {
+ public:
+  static CRF_GradBuilder* create(CRF_Model* crf, objfunctype ofunc);
+  explicit CRF_GradBuilder(CRF_Model* crf_in) : crf(crf_in) {}
+  virtual ~CRF_GradBuilder() {}
+  // grad += observed - expected counts of the stream's CURRENT utterance; *Zx_out = log partition;
+  // returns the numerator (caller forms logLi = numerator - Zx)
+  virtual double buildGradient(CRF_FeatureStream* ftr_strm, double* grad, double* Zx_out);
+
+ protected:
+  CRF_Model* crf;
+};
+
+// data-parallel layer: N streams (ranks), minibatch split, sum / n_active
+class CRF_Minibatch_GradAccumulator {
+ public:
+  CRF_Minibatch_GradAccumulator(CRF_Model* crf, std::vector<CRF_FeatureStream*> streams);
+  virtual ~CRF_Minibatch_GradAccumulator() {}
+  void setMinibatch(QNUInt32 mb);
+  void setUttReport(QNUInt32 r) { uttReport = r; }
+  void rewindAllAndNextSegs();
+  double accumulateGradient(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
+
+ protected:
+  CRF_Model* crf;
+  std::vector<CRF_FeatureStream*> ftrStrms;
+  std::vector<QN_SegID> segids;
+  QNUInt32 minibatch = CRF_UINT32_MAX, uttReport = 0;
+};
+
+class CRF_SGTrainer {
+ public:
+  CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> streams, const char* weight_fname);
+  void setMaxIters(int n) { maxIters = n; }
+  void setLR(float v) { lr = v; }
+  void setLRDecayRate(float v) { lr_decay_rate = v; }
+  void setMinibatch(QNUInt32 mb) { minibatch = mb; }
+  void setUseAdagrad(bool b) { useAdagrad = b; }
+  void setEta(double e) { eta = e; }
+  void setUttRpt(QNUInt32 r) { uttRpt = r; }
+  void train();
+
+ protected:
+  CRF_Model* crf_ptr;
+  std::vector<CRF_FeatureStream*> streams;
+  std::string weight_fname;
+  int maxIters = 10;
+  float lr = 0.008f, lr_decay_rate = 1.0f;
+  QNUInt32 minibatch = 1, uttRpt = 100;
+  bool useAdagrad = false;
+  double eta = 1.0, eps = 1e-12;
+};
+
+// lattice builders: same call as the reference's templates; the arcs come from the engine in
+// AddArc order and are replayed into the caller's FST object
+class CRF_LatticeBuilder {
+ public:
+  CRF_LatticeBuilder(CRF_FeatureStream* ftr_strm_in, CRF_Model* crf_in) : ftr_strm(ftr_strm_in), crf(crf_in) {}
+  virtual ~CRF_LatticeBuilder() {}
+  template <class Fst>
+  int buildLattice(Fst* fst, bool align = false, Fst* alignFst = nullptr, bool norm = true) {
+    (void)alignFst;
+    if (align) throw std::runtime_error("buildLattice: alignment lattices are outside the built hot path");
+    std::vector<scrf_arc> arcs;
+    uint32_t n_states = 0;
+    int32_t fin = -1;
+    int seq_len = latticeArcs(norm, &arcs, &n_states, &fin);
+    for (uint32_t s = 0; s < n_states; s++) fst->AddState();
+    fst->SetStart(0);
+    typedef typename Fst::Arc Arc;
+    for (const scrf_arc& a : arcs) fst->AddArc(a.src, Arc(a.ilabel, a.olabel, a.w, a.dst));
+    if (fin >= 0) fst->SetFinal(fin, 0);
+    return seq_len;
+  }
+
+ protected:
+  int latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint32_t* n_states, int32_t* final_state);
+  CRF_FeatureStream* ftr_strm;
+  CRF_Model* crf;
+};
+typedef CRF_LatticeBuilder CRF_LatticeBuilder_StdSeg_WithoutDurLab_WithoutSegTransFtr;
+
+// best path of CRFFstDecode (ShortestPath -> Project(OUTPUT) -> RmEpsilon -> TopSort -> olabel-1)
+std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* crf, float* cost);
+
+#endif  // CRF_AMD_H_

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the collective path)")
     ap.add_argument("--exact", action="store_true", help="reference-order unfused fp64 contractions instead of MFMA")
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     args = ap.parse_args()
@@ -77,9 +78,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     U = args.utts
@@ -101,12 +103,15 @@ def main():
     batch = eng.batch_from_frames(fl, ll)  # inputs resident in HBM from here on
     lr = 0.1 / U
 
+    from scrf_amd.dist import reduce_minibatch
+
     def step():
         eng.zero_grad()
-        eng.fb_batch(batch, want_scalars=False)  # async on torch's current stream
+        eng.fb_batch(batch, want_scalars=False)  # async on the shared stream
         if dist is not None:
-            dist.all_reduce(grad)                # RCCL over xGMI: sum of the weight gradient
-            eng.scale_grad(1.0 / world)          # / active ranks (Minibatch_GradAccumulator.cpp:306-308)
+            # RCCL all-reduce (sum) of the weight gradient over xGMI, then / active ranks
+            # (Minibatch_GradAccumulator.cpp:296-308); every rank is active in this bench
+            reduce_minibatch(grad, sums[:3], True)
         eng.sgd_step(lr, False)
 
     def barrier():

@@ -1,0 +1,120 @@
+"""-m gpu: the reference-named C++ host classes and the CRFTrain / CRFFstDecode front-ends,
+driven exactly like the reference binaries (`name=value` flags) on the reference's own bundled
+fixtures (BASELINE config 1: frame-level CRF, 48 labels, test.ascii + test.ftr2.ascii +
+test.lab.ascii), checked against an oracle-driven restatement of the SGD loop
+(trainers/CRF_SGTrainer.cpp:207-424)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+BIN = os.path.join(ROOT, "asr-craft_amd", "bin")
+
+
+def _fixture():
+    f1 = np.loadtxt(os.path.join(G, "crftrain_test.ascii"))
+    f2 = np.loadtxt(os.path.join(G, "crftrain_test.ftr2.ascii"))
+    lb = np.loadtxt(os.path.join(G, "crftrain_test.lab.ascii"))
+    utts = []
+    for u in range(3):
+        sel = f1[:, 0] == u
+        utts.append((np.concatenate([f1[sel, 2:], f2[sel, 2:]], axis=1).astype(np.float32), lb[sel, 2].astype(np.uint32)))
+    return utts
+
+
+def _common_flags():
+    return ["ftr1_file=" + os.path.join(G, "crftrain_test.ascii"), "ftr1_format=ascii",
+            "ftr2_file=" + os.path.join(G, "crftrain_test.ftr2.ascii"), "ftr2_format=ascii",
+            "crf_label_size=48", "crf_model_type=stdframe", "label_maximum_duration=1", "crf_featuremap=stdstate"]
+
+
+@pytest.mark.parametrize("threads,bunch,adagrad", [(1, 1, 0), (2, 2, 0), (1, 3, 1)])
+def test_crftrain_then_fstdecode_on_bundled_fixture(tmp_path, threads, bunch, adagrad):
+    out = str(tmp_path / "weights.out")
+    lr, eta, epochs = 0.1, 0.5, 2
+    cmd = [os.path.join(BIN, "CRFTrain")] + _common_flags() + [
+        "hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + out,
+        "crf_epochs=%d" % epochs, "crf_lr=%g" % lr, "crf_bunch_size=%d" % bunch, "threads=%d" % threads,
+        "crf_use_adagrad=%d" % adagrad, "crf_adagrad_eta=%g" % eta, "crf_utt_rpt=1", "crf_train_order=seq"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FEATURES: 2640" in r.stdout
+    for k in range(epochs):
+        assert os.path.exists(out + ".i%d.out" % k) and os.path.exists(out + ".i%d.avg.out" % k)
+        assert os.path.exists(str(tmp_path / (".done.train.i%d" % k)))
+    assert os.path.exists(str(tmp_path / ".done.train")) and os.path.exists(out + ".avg.out")
+    w = np.loadtxt(out)
+
+    # oracle restatement of the same run
+    utts = _fixture()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    lam = np.zeros(lay.lambda_len); acc = np.zeros_like(lam); gsa = np.zeros_like(lam)
+    U = len(utts); per = U // threads
+    views = [(s * per, U if s == threads - 1 else (s + 1) * per) for s in range(threads)]
+    for _ in range(epochs):
+        pos = [v[0] for v in views]
+        while any(pos[s] < views[s][1] for s in range(threads)):
+            sg = np.zeros((threads, lay.lambda_len)); act = []
+            for s in range(threads):
+                act.append(1 if pos[s] < views[s][1] else 0)
+                share = bunch // threads + (1 if s < bunch % threads else 0)
+                n = 0
+                while act[s] and pos[s] < views[s][1] and (n < share or n == 0):
+                    X, lab = utts[pos[s]]
+                    rc, _, _, _ = orc.frame_build_gradient(cfg, lay, lam, X, lab, X.shape[0], grad=sg[s])
+                    assert rc == 0
+                    pos[s] += 1; n += 1
+            g = orc.minibatch_reduce(sg, act)
+            orc.sgd_step(lam, acc, gsa, g, eta if adagrad else np.float32(lr), bool(adagrad), 1e-12)
+    ref = np.array([float("%g" % v) for v in lam])  # the weight file keeps 6 significant digits
+    np.testing.assert_allclose(w, ref, rtol=2e-5, atol=1e-12)
+
+    # decode with the weights as the binary reads them back
+    dec = str(tmp_path / "labels.txt")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + _common_flags() + ["weight_file=" + out, "crf_output_labelfile=" + dec],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.loadtxt(dec).astype(int)
+    for u, (X, _) in enumerate(utts):
+        S, M = orc.seg_scores(cfg, lay, w, X, X.shape[0])
+        arcs, ns, fin = orc.frame_lattice_arcs(cfg, S, M, X.shape[0])
+        ol, _ = orc.best_path(arcs, ns, fin)
+        assert list(got[got[:, 0] == u][:, 2]) == list(ol)
+
+
+def test_segmental_gradbuilder_via_read_protocol(tmp_path):
+    """segmental model through CRFTrain with on-GPU window synthesis: one epoch, bunch=all."""
+    rng = np.random.RandomState(0)
+    L, D, W = 5, 3, 2
+    f = str(tmp_path / "f.ascii"); l = str(tmp_path / "l.ascii")
+    utts = []
+    with open(f, "w") as ff, open(l, "w") as lf:
+        for u, T in enumerate([7, 9]):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T].astype(np.uint32)
+            utts.append((X, lab))
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    out = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain"), "ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1",
+                        "hardtarget_file=" + l, "out_weight_file=" + out, "crf_label_size=%d" % L,
+                        "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D,
+                        "crf_epochs=1", "crf_lr=0.05", "crf_bunch_size=2", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F); lay = orc.Layout(cfg)
+    g = np.zeros(lay.lambda_len)
+    for X, lab in utts:
+        Xw = orc.windows(np.loadtxt(f)[:0].reshape(0, 0) if False else X, D)
+        rc, g, _, _ = orc.seg_build_gradient(cfg, lay, np.zeros(lay.lambda_len), Xw, orc.group_labels(lab, D, L), X.shape[0], grad=g)
+        assert rc == 0
+    ref = np.float32(0.05) * g
+    np.testing.assert_allclose(np.loadtxt(out), np.array([float("%g" % v) for v in ref]), rtol=2e-5, atol=1e-9)

@@ -30,6 +30,28 @@ struct ScrfLayout {
   }
 };
 
+// Which slice of the window vector / weight block a contraction covers.
+//   kind 0: outputs = labels,            woff(o) = state_idx(o) + wadd
+//   kind 1: outputs = (p,c) pairs,       woff(o) = trans_idx(o / L, o % L) + wadd
+//   kind 2: outputs = (group k, label),  woff(o) = state_idx(o % L) + (o / L) * rw + wadd   (per-frame projections)
+struct ScrfGemmSpec {
+  uint32_t kind;
+  uint32_t fs;        // first X column used
+  uint32_t nfe;       // number of X columns
+  uint32_t use_bias;  // append a bias column of value `bias`
+  double bias;
+  uint32_t wadd;
+  uint32_t rw;
+  __host__ __device__ inline uint32_t nfun() const { return nfe + (use_bias ? 1 : 0); }
+  __host__ __device__ inline uint32_t woff(const ScrfLayout& l, uint32_t o) const {
+    if (kind == 0) return l.state_idx(o) + wadd;
+    if (kind == 1) return l.trans_idx(o / l.L, o % l.L) + wadd;
+    return l.state_idx(o % l.L) + (o / l.L) * rw + wadd;
+  }
+};
+inline ScrfGemmSpec scrf_spec_state(const ScrfLayout& l) { return ScrfGemmSpec{0, l.sfs, l.nsfe, (uint32_t)l.use_sb, l.sbv, 0, 0}; }
+inline ScrfGemmSpec scrf_spec_trans(const ScrfLayout& l) { return ScrfGemmSpec{1, l.tfs, l.ntfe, (uint32_t)l.use_tb, l.tbv, 0, 0}; }
+
 // windows ending at frame t: min(t+1, D) (gradbuilder :243-251)
 __host__ __device__ inline uint32_t scrf_node_max_dur(uint32_t t, uint32_t D) {
   return (t + 1 <= D) ? t + 1 : D;

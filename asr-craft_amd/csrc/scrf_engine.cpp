@@ -548,15 +548,46 @@ struct ChunkBufs {
   double* slab_atb = nullptr;
   uint32_t nch_atb = 0;
   uint64_t rpc_atb = 0;
+  // recipe-factorised path
+  bool factored = false;
+  uint32_t XF = 0;           // row width of X (num_feas, or 2W+D for the factored image)
+  double* P = nullptr;       // [nfr][6L]
+  double* Z = nullptr;       // [nfr+nutt][6L]
+  uint64_t* slot_row = nullptr;
+  double* slab_l = nullptr;
+  uint32_t nch_l = 0;
+  uint64_t rpc_l = 0;
 };
 
-struct Need { bool fb, post, beta, vit; };
+struct Need { bool fb, post, beta, vit; bool factored = false; };
+
+// recipe-factorised path: one segment-recipe stream without context whose window is exactly the
+// state feature range, no transition features
+static bool factored_ok(scrf_handle h, scrf_batch b) {
+  const ScrfLayout& l = h->lay;
+  if (b->mode != 1 || b->n_streams != 1 || l.use_tf || !l.use_sf || l.D <= 1) return false;
+  const scrf_stream_recipe& r = b->recipe[0];
+  if (!r.extract_seg_ftr || r.left_ctx || r.right_ctx) return false;
+  return l.sfs == 0 && l.nsfe == 8 * r.in_width + l.D && l.nsfe == l.F;
+}
+static ScrfGemmSpec spec_mm(const ScrfLayout& l, uint32_t W) {
+  return ScrfGemmSpec{0, 0, 2 * W + l.D, (uint32_t)l.use_sb, l.sbv, 6 * W, 0};
+}
+static ScrfGemmSpec spec_lin(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0.0, 0, W}; }
 
 static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t nfr, uint64_t nseg, const Need& nd) {
   const ScrfLayout& l = h->lay;
   const size_t LL = (size_t)l.L * l.L;
   size_t tot = 0;
-  if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
+  const uint32_t W0 = b->mode == 1 ? b->recipe[0].in_width : 0;
+  if (nd.factored) {
+    tot += pad256(nseg * (2 * W0 + l.D) * sizeof(float));          // X_mm
+    tot += pad256(nfr * 6 * l.L * sizeof(double));                // P
+    if (nd.post) {
+      tot += pad256((nfr + nutt) * 6 * l.L * sizeof(double)) + pad256((nfr + nutt) * 8);  // Z, slot rows
+      tot += pad256((size_t)256 * 6 * l.L * W0 * sizeof(double));  // slab of the final contraction
+    }
+  } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
   tot += pad256(nseg * l.L * sizeof(double));                       // S
   if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
   if (nd.fb) {
@@ -609,7 +640,22 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   int rc = ensure_scratch(h, need);
   if (rc != SCRF_OK) return rc;
   Arena a{h->scratch, h->scratch_cap, 0};
-  if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
+  cb->XF = l.F;
+  cb->factored = nd.factored;
+  if (nd.factored) {
+    const uint32_t W0 = b->recipe[0].in_width;
+    cb->XF = 2 * W0 + l.D;
+    cb->X = a.take<float>(nseg * cb->XF);
+    cb->P = a.take<double>(nfr * 6 * l.L);
+    if (nd.post) {
+      const uint64_t nslots = nfr + nutt;
+      cb->Z = a.take<double>(nslots * 6 * l.L);
+      cb->slot_row = a.take<uint64_t>(nslots);
+      cb->rpc_l = ((nslots + 255) / 256 + 31) & ~31ull;
+      cb->nch_l = (uint32_t)((nslots + cb->rpc_l - 1) / cb->rpc_l);
+      cb->slab_l = a.take<double>((size_t)256 * 6 * l.L * W0);
+    }
+  } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
   cb->S = a.take<double>(nseg * l.L);
   if (l.use_tf) {
@@ -691,6 +737,32 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   const ScrfLayout& l = h->lay;
   const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
   ScrfBatchView bv = b->view();
+  if (cb.factored) {
+    const scrf_stream_recipe& r = b->recipe[0];
+    const uint32_t W0 = r.in_width;
+    {
+      PhaseTimer tm(h, PH_WIN);
+      launch_windows_mm(h->stream, b->d_frames[0], b->d_sframe_off[0], bv, u0, u1, nfr, W0, l.D, cb.X, cb.XF);
+      tm.stop(1);
+    }
+    PhaseTimer tm(h, PH_SCORE);
+    uint32_t nl = 3;
+    // dense part: [max | min | one-hot dur] + bias
+    launch_scores_mfma(h->stream, cb.X, cb.XF, nullptr, nseg, h->d_lambda, l, spec_mm(l, W0), l.L, cb.S);
+    // linear part: per-frame projections of the 5 sample blocks and the average block, then gathers
+    launch_scores_mfma(h->stream, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
+                       spec_lin(W0), 6 * l.L, cb.P);
+    launch_lin_scores(h->stream, l, bv, u0, u1, nfr, cb.P, cb.S);
+    if (!h->m0_valid) {
+      launch_scores_exact(h->stream, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+      launch_exp_m(h->stream, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
+      h->m0_valid = true;
+      nl += 2;
+    }
+    tm.stop(nl);
+    HIPCHK(h, hipGetLastError());
+    return SCRF_OK;
+  }
   if (b->mode == 1) {
     PhaseTimer tm(h, PH_WIN);
     uint32_t col = 0;
@@ -704,11 +776,11 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   }
   PhaseTimer tm(h, PH_SCORE);
   uint32_t nl = 1;
-  if (fast) launch_scores_mfma(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+  if (fast) launch_scores_mfma(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S);
   else launch_scores_exact(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
   if (l.use_tf) {
     launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
-    if (fast) launch_scores_mfma(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
+    if (fast) launch_scores_mfma(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M);
     else launch_scores_exact(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
     nl += 2;
   } else if (!h->m0_valid) {
@@ -781,7 +853,8 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
   HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
   Need nd{true, true, false, false};
   ScrfBatchView bv = b->view();
-  const bool fast = h->cfg.train_precision == SCRF_PREC_FAST;
+  const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
+  nd.factored = h->cfg.train_precision == SCRF_PREC_FACTORED && factored_ok(h, b);
   for (uint32_t u0 = 0; u0 < b->U;) {
     const uint32_t u1 = plan_chunk(h, b, u0, nd);
     ChunkBufs cb;
@@ -800,11 +873,20 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     {
       PhaseTimer tm(h, PH_EXPF);
       uint32_t nl = 1;
-      if (fast) launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+      if (cb.factored) {
+        const uint32_t W0 = b->recipe[0].in_width;
+        const uint64_t nslots = nfr + nutt;
+        launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, cb.XF, nullptr, nseg, l, spec_mm(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s);
+        launch_lin_expf_z(h->stream, l, bv, u0, u1, nslots, cb.AD, cb.Z);
+        launch_suffix_avg(h->stream, l, bv, u0, (uint32_t)nutt, cb.Z, cb.slot_row);
+        launch_expf_mfma(h->stream, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
+                         spec_lin(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
+        nl += 3;
+      } else if (fast) launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s);
       else launch_expf_gemm(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
       if (l.use_tf) {
         launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
-        if (fast) launch_expf_mfma(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+        if (fast) launch_expf_mfma(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t);
         else launch_expf_gemm(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
         nl += 2;
       }
@@ -812,8 +894,12 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     }
     {
       PhaseTimer tm(h, PH_REDUCE);
-      launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, 0, h->d_grad);
-      if (l.use_tf) launch_reduce_slabs(h->stream, cb.slab_t, cb.nch_t, l.L * l.L, l, 1, h->d_grad);
+      if (cb.factored) {
+        const uint32_t W0 = b->recipe[0].in_width;
+        launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, spec_mm(l, W0), h->d_grad);
+        launch_reduce_slabs(h->stream, cb.slab_l, cb.nch_l, 6 * l.L, l, spec_lin(W0), h->d_grad);
+      } else launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), h->d_grad);
+      if (l.use_tf) launch_reduce_slabs(h->stream, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), h->d_grad);
       else if (cb.wave) launch_atb(h->stream, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, h->d_grad);
       else launch_reduce_xiacc(h->stream, cb.xi_acc, (uint32_t)nutt, l, h->d_grad);
       launch_batch_sums(h->stream, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, h->d_sums);

@@ -20,7 +20,7 @@ void launch_expf_gemm(hipStream_t st, const double* A, uint32_t n_out, const flo
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
 void launch_reduce_slabs(hipStream_t st, const double* slab, uint32_t n_chunks, uint32_t n_out,
-                         const ScrfLayout& lay, int is_trans, double* grad);
+                         const ScrfLayout& lay, const ScrfGemmSpec& sp, double* grad);
 void launch_reduce_xiacc(hipStream_t st, const double* xi_acc, uint32_t n_utts, const ScrfLayout& lay,
                          double* grad);
 void launch_batch_sums(hipStream_t st, const double* numer, const double* zx, uint32_t n, double* sums3);
@@ -36,9 +36,10 @@ void launch_add(hipStream_t st, double* y, const double* x, uint32_t n);
 
 // scrf_mfma.hip: fp64 MFMA contractions (FAST training precision)
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
-                        const double* lambda, const ScrfLayout& lay, int is_trans, uint32_t n_out, double* out);
+                        const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
+                        double* out);
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
-                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
+                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
 
 // scrf_dp.hip: wavefront-per-utterance DP and the parallel posterior kernels
@@ -64,5 +65,15 @@ void launch_add_trans_counts(hipStream_t st, const uint32_t* counts, const ScrfL
 void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
                     uint64_t n_frames, const uint32_t* next_lab, const double* A, const double* B, const double* E,
                     const double* mshift, double* XI);
+
+// scrf_factored.hip: recipe-factorised contractions
+void launch_windows_mm(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
+                       uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, float* X, uint32_t F);
+void launch_lin_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                       uint64_t n_frames, const double* P, double* S);
+void launch_lin_expf_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                       uint64_t n_slots, const double* R, double* Z);
+void launch_suffix_avg(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                       double* Z, uint64_t* slot_row);
 
 #endif  // SCRF_KERNELS_H_

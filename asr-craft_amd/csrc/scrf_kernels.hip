@@ -500,24 +500,22 @@ void launch_expf_gemm(hipStream_t st, const double* A, uint32_t n_out, const flo
 
 // grad[woff(o)+f] += sum_z slab[z][o][f], fixed z order (bit-reproducible)
 __global__ void k_reduce_slabs(const double* __restrict__ slab, uint32_t n_chunks, uint32_t n_out,
-                               ScrfLayout lay, int is_trans, double* __restrict__ grad) {
-  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
+                               ScrfLayout lay, ScrfGemmSpec sp, double* __restrict__ grad) {
+  const uint32_t nfun = sp.nfun();
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (uint64_t)n_out * nfun) return;
   uint32_t o = (uint32_t)(i / nfun), f = (uint32_t)(i % nfun);
   double s = 0.0;
   for (uint32_t z = 0; z < n_chunks; z++) s += slab[(uint64_t)z * n_out * nfun + i];
-  uint32_t woff = is_trans ? lay.trans_idx(o / lay.L, o % lay.L) : lay.state_idx(o);
-  grad[woff + f] += s;
+  grad[sp.woff(lay, o) + f] += s;
 }
 
 void launch_reduce_slabs(hipStream_t st, const double* slab, uint32_t n_chunks, uint32_t n_out,
-                         const ScrfLayout& lay, int is_trans, double* grad) {
-  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
-  uint64_t n = (uint64_t)n_out * nfun;
+                         const ScrfLayout& lay, const ScrfGemmSpec& sp, double* grad) {
+  uint64_t n = (uint64_t)n_out * sp.nfun();
   if (n == 0 || n_chunks == 0) return;
   hipLaunchKernelGGL(k_reduce_slabs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, slab, n_chunks, n_out,
-                     lay, is_trans, grad);
+                     lay, sp, grad);
 }
 
 // bias-only transitions: grad[trans_idx(c,n)] += tbv * sum_u xi_acc[u][c*L+n]

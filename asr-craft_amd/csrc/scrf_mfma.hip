@@ -23,24 +23,24 @@ struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 #define SM_KC 32     // features per staged chunk (8 MFMA k-steps)
 #define SM_XS 34     // float row stride of the X image (== 2 mod 32: conflict-free A fragments)
 #define SM_NO 48     // outputs per workgroup (3 N-tiles)
+#define SM_WS 49     // double row stride of the lambda image [k][SM_WS]: transposed stores stay <= 2-way
 
 // Software pipeline: while the MFMAs of chunk i run from LDS, the global loads of chunk i+1
 // are in flight into registers (8 x 16 B of X and 6 x 8 B of lambda per thread).
 __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      const double* __restrict__ lambda, ScrfLayout lay,
-                                                     int is_trans, uint32_t n_out, double* __restrict__ out) {
+                                                     ScrfGemmSpec sp, uint32_t n_out, double* __restrict__ out) {
   __shared__ float Xs[SM_ROWS * SM_XS];
-  __shared__ double Ws[SM_KC * SM_NO];
+  __shared__ double Ws[SM_KC * SM_WS];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint64_t row0 = (uint64_t)blockIdx.x * SM_ROWS;
   const uint32_t o0 = blockIdx.y * SM_NO;
-  const uint32_t L = lay.L;
-  const uint32_t fs = is_trans ? lay.tfs : lay.sfs;
-  const uint32_t nfe = is_trans ? lay.ntfe : lay.nsfe;
-  const int use_b = is_trans ? lay.use_tb : lay.use_sb;
-  const double bv = is_trans ? lay.tbv : lay.sbv;
+  const uint32_t fs = sp.fs;
+  const uint32_t nfe = sp.nfe;
+  const int use_b = sp.use_bias;
+  const double bv = sp.bias;
 
   v4f64 acc[4][3];
 #pragma unroll
@@ -65,23 +65,24 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
     const uint32_t idx = tid + k * 256;
     uint32_t o = o0 + idx / SM_KC;
     if (o >= n_out) o = n_out - 1;
-    const uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
-    wbase[k] = lambda + woff + (idx % SM_KC);
+    wbase[k] = lambda + sp.woff(lay, o) + (idx % SM_KC);
   }
   f4u xr_[8];
   double wr_[6];
+  // offset that keeps (sq*4 + offset) inside the feature range for the masked tail quads
+  const uint32_t fclamp = (nfe > sq * 4 + 4) ? ((nfe - sq * 4 - 1) & ~31u) : 0;
   auto load_chunk = [&](uint32_t f0) {
+    // branch-free: a quad that starts inside the feature range may read <= 12 B past it, quads
+    // fully outside re-read the last valid quad; both are masked in store_chunk (buffers carry
+    // 256 B of tail padding)
+    const uint32_t fo = (f0 + sq * 4 < nfe) ? f0 : fclamp;
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-      // a quad that starts inside the feature range may read <= 12 B past it (masked in
-      // store_chunk; buffers carry 256 B of tail padding); quads fully outside are not loaded
-      if (f0 + sq * 4 < nfe) xr_[it] = *(const f4u*)(xbase[it] + f0);
-      else xr_[it] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
-    }
+    for (int it = 0; it < 8; it++) xr_[it] = *(const f4u*)(xbase[it] + fo);
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const uint32_t c = (tid + k * 256) % SM_KC;
-      wr_[k] = (f0 + c < nfe) ? wbase[k][f0] : 0.0;
+      const double w = wbase[k][(f0 + c < nfe) ? f0 : 0];
+      wr_[k] = (f0 + c < nfe) ? w : 0.0;
     }
   };
   auto store_chunk = [&](uint32_t f0) {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const uint32_t idx = tid + k * 256;
-      Ws[(idx % SM_KC) * SM_NO + idx / SM_KC] = wr_[k];
+      Ws[(idx % SM_KC) * SM_WS + idx / SM_KC] = wr_[k];
     }
   };
 
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
     for (int ks = 0; ks < SM_KC / 4; ks++) {
       double b[3];
 #pragma unroll
-      for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SM_NO + n * 16 + li];
+      for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SM_WS + n * 16 + li];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const double a = (double)Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
@@ -128,10 +129,7 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
     const uint32_t o = o0 + n * 16 + li;
     if (o >= n_out) continue;
     double bias = 0.0;
-    if (use_b) {
-      const uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
-      bias = lambda[woff + nfe] * bv;
-    }
+    if (use_b) bias = lambda[sp.woff(lay, o) + nfe] * bv;
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -143,33 +141,42 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
 }
 
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
-                        const double* lambda, const ScrfLayout& lay, int is_trans, uint32_t n_out, double* out) {
+                        const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
+                        double* out) {
   if (n_rows == 0 || n_out == 0) return;
   dim3 grid((uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS), (n_out + SM_NO - 1) / SM_NO);
-  hipLaunchKernelGGL(k_scores_mfma, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, is_trans, n_out, out);
+  hipLaunchKernelGGL(k_scores_mfma, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
 }
 
 // ------------------------------------------------------------------------------------------
 #define EM_KC 32    // rows per staged chunk (8 MFMA k-steps)
 #define EM_NO 48    // outputs per workgroup (3 M-tiles)
-#define EM_NF 384   // feature columns per workgroup (8 waves x 3 N-tiles)
-#define EM_XS 400   // float row stride of the X image (== 16 mod 32)
 
-__global__ __launch_bounds__(512) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
-                                                   const float* __restrict__ X, uint32_t F,
-                                                   const uint64_t* __restrict__ xrow, uint64_t n_rows,
-                                                   ScrfLayout lay, int is_trans, uint64_t rows_per_chunk,
-                                                   double* __restrict__ slab) {
+// NW wavefronts per workgroup, each owning 48 feature columns (3 N-tiles): NW = 8 covers 384
+// columns (the full 338-wide state block of config 2 in one workgroup, so R is read once);
+// narrow contractions (factorised max/min/dur block, per-frame projections) use fewer waves.
+template <int HAS_XROW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
+                                                      const float* __restrict__ X, uint32_t F,
+                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                      ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
+                                                      double* __restrict__ slab) {
+  constexpr int NT = 64 * NW;            // threads
+  constexpr int NF = 48 * NW;            // feature columns per workgroup
+  constexpr int XS = NF + 16;            // float row stride of the X image (== 16 mod 32)
+  constexpr int QR = NF / 4;             // 16-byte quads per row
+  constexpr int XIT = EM_KC * QR / NT;   // X quads per thread per chunk (= 6)
+  constexpr int AIT = (EM_KC * EM_NO + NT - 1) / NT;
   __shared__ double Rs[EM_KC * EM_NO];
-  __shared__ __attribute__((aligned(16))) float Xs[EM_KC * EM_XS];
+  __shared__ __attribute__((aligned(16))) float Xs[EM_KC * XS];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
-  const uint32_t fs = is_trans ? lay.tfs : lay.sfs;
-  const uint32_t nfe = is_trans ? lay.ntfe : lay.nsfe;
-  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
-  const float bias = (float)(is_trans ? lay.tbv : lay.sbv);
-  const bool bias_exact = (double)bias == (is_trans ? lay.tbv : lay.sbv);
-  const uint32_t fb = blockIdx.x * EM_NF;
+  const uint32_t fs = sp.fs;
+  const uint32_t nfe = sp.nfe;
+  const uint32_t nfun = sp.nfun();
+  const float bias = sp.use_bias ? (float)sp.bias : 0.0f;
+  const bool bias_exact = (double)bias == sp.bias;
+  const uint32_t fb = blockIdx.x * NF;
   const uint32_t o0 = blockIdx.y * EM_NO;
   const uint64_t r_begin = (uint64_t)blockIdx.z * rows_per_chunk;
   const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
@@ -180,51 +187,72 @@ __global__ __launch_bounds__(512) void k_expf_mfma(const double* __restrict__ A,
 #pragma unroll
     for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-  // X staging: idx = tid + k*512 -> row idx/96, column quad idx%96 (6 x 16 B per thread);
-  // A staging: idx = tid + k*512 -> row idx/48, output idx%48 (3 x 8 B per thread)
-  f4u xr_[6];
-  double ar_[3];
-  auto load_chunk = [&](uint64_t r0) {
+  // Staging coordinates and tail masks are fixed per thread: computed once, outside the loop.
+  f4u xr_[XIT];
+  double ar_[AIT];
+  uint32_t xrw[XIT], xcl[XIT], xlds[XIT], arw[AIT], acol[AIT];
+  bool aok[AIT];
+  float xfill[XIT][4];   // value for masked components: bias column or zero
+  bool xkeep[XIT][4];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const uint32_t idx = tid + k * 512;
-      const uint32_t r = idx / 96, q = idx % 96;
-      uint64_t row = r0 + r;
-      if (row >= r_end) row = r_end - 1;
-      const uint64_t xr = xrow ? xrow[row] : row;
-      const uint32_t col = fb + q * 4;
-      if (col < nfe) xr_[k] = *(const f4u*)(X + xr * F + fs + col);  // may read <= 12 B past the range
-      else xr_[k] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k = 0; k < XIT; k++) {
+    const uint32_t idx = tid + k * NT;
+    xrw[k] = idx / QR;
+    const uint32_t q = idx % QR;
+    const uint32_t col = fb + q * 4;
+    xlds[k] = xrw[k] * XS + q * 4;
+    // quads outside the feature range re-read a valid quad (masked at the LDS store)
+    xcl[k] = col < nfe ? col : (nfe >= 4 ? nfe - 4 : 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t cc = col + c;
+      xkeep[k][c] = cc < nfe;
+      xfill[k][c] = (cc == nfe && sp.use_bias) ? bias : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < AIT; k++) {
+    const uint32_t idx = tid + k * NT;
+    arw[k] = idx / EM_NO;
+    const uint32_t o = o0 + idx % EM_NO;
+    aok[k] = idx < EM_KC * EM_NO && o < n_out;
+    acol[k] = o < n_out ? o : n_out - 1;
+  }
+  // branch-free loads: rows past the chunk end re-read its last row (may read <= 12 B past the
+  // feature range; buffers carry tail padding)
+  auto load_chunk = [&](uint64_t r0) {
+    uint64_t xr[XIT];
+#pragma unroll
+    for (int k = 0; k < XIT; k++) {
+      uint64_t row = r0 + xrw[k];
+      row = row < r_end ? row : r_end - 1;
+      xr[k] = HAS_XROW ? xrow[row] : row;
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const uint32_t idx = tid + k * 512;
-      const uint32_t r = idx / EM_NO, ol = idx % EM_NO;
-      uint64_t row = r0 + r;
-      double v = 0.0;
-      if (row < r_end && o0 + ol < n_out) v = A[row * n_out + o0 + ol];
-      ar_[k] = v;
+    for (int k = 0; k < XIT; k++) xr_[k] = *(const f4u*)(X + xr[k] * F + fs + xcl[k]);
+#pragma unroll
+    for (int k = 0; k < AIT; k++) {
+      uint64_t row = r0 + arw[k];
+      const bool ok = row < r_end && aok[k];
+      row = row < r_end ? row : r_end - 1;
+      const double v = A[row * n_out + acol[k]];
+      ar_[k] = ok ? v : 0.0;
     }
   };
   auto store_chunk = [&](uint64_t r0) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const uint32_t idx = tid + k * 512;
-      const uint32_t r = idx / 96, q = idx % 96;
-      const uint32_t col = fb + q * 4;
-      const bool rok = r0 + r < r_end;
+    for (int k = 0; k < XIT; k++) {
+      const bool rok = r0 + xrw[k] < r_end;
       const f4u v = xr_[k];
       const float e[4] = {v.x, v.y, v.z, v.w};
       float o[4];
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const uint32_t cc = col + c;
-        o[c] = !rok ? 0.0f : (cc < nfe ? e[c] : (cc == nfe ? bias : 0.0f));
-      }
-      *(float4*)(&Xs[r * EM_XS + q * 4]) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int c = 0; c < 4; c++) o[c] = !rok ? 0.0f : (xkeep[k][c] ? e[c] : xfill[k][c]);
+      *(float4*)(&Xs[xlds[k]]) = make_float4(o[0], o[1], o[2], o[3]);
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) Rs[tid + k * 512] = ar_[k];
+    for (int k = 0; k < AIT; k++)
+      if (tid + k * NT < EM_KC * EM_NO) Rs[tid + k * NT] = ar_[k];
   };
 
   if (r_begin < r_end) load_chunk(r_begin);
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(512) void k_expf_mfma(const double* __restrict__ A,
 #pragma unroll
       for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
 #pragma unroll
-      for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * EM_XS + wave * 48 + n * 16 + li];
+      for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wave * 48 + n * 16 + li];
 #pragma unroll
       for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -247,7 +275,7 @@ __global__ __launch_bounds__(512) void k_expf_mfma(const double* __restrict__ A,
     __syncthreads();
   }
   // the bias column was staged as float: rescale if the bias value is not exactly representable
-  const double bfix = bias_exact ? 1.0 : (is_trans ? lay.tbv : lay.sbv) / (double)bias;
+  const double bfix = (bias_exact || !sp.use_bias) ? 1.0 : sp.bias / (double)bias;
 #pragma unroll
   for (int n = 0; n < 3; n++) {
     const uint32_t col = fb + wave * 48 + n * 16 + li;
@@ -263,12 +291,29 @@ __global__ __launch_bounds__(512) void k_expf_mfma(const double* __restrict__ A,
   }
 }
 
+template <int NW>
+static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                                const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
+                                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+  const uint32_t nfun = sp.nfun();
+  dim3 grid((nfun + 48 * NW - 1) / (48 * NW), (n_out + EM_NO - 1) / EM_NO, n_chunks);
+  if (xrow)
+    hipLaunchKernelGGL((k_expf_mfma<1, NW>), grid, dim3(64 * NW), 0, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab);
+  else
+    hipLaunchKernelGGL((k_expf_mfma<0, NW>), grid, dim3(64 * NW), 0, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab);
+}
+
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
-                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
+                      const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   if (n_rows == 0 || n_chunks == 0) return;
-  const uint32_t nfun = is_trans ? lay.ntf : lay.nsf;
-  dim3 grid((nfun + EM_NF - 1) / EM_NF, (n_out + EM_NO - 1) / EM_NO, n_chunks);
-  hipLaunchKernelGGL(k_expf_mfma, grid, dim3(512), 0, st, A, n_out, X, F, xrow, n_rows, lay, is_trans,
-                     rows_per_chunk, slab);
+  const uint32_t nfun = sp.nfun();
+  const uint32_t tiles = (nfun + 47) / 48;  // 48-column wave tiles needed
+  if (tiles <= 1) launch_expf_mfma_nw<1>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else if (tiles <= 2) launch_expf_mfma_nw<2>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else if (tiles <= 3) launch_expf_mfma_nw<3>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else if (tiles <= 4) launch_expf_mfma_nw<4>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else launch_expf_mfma_nw<8>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
 }

@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the collective path)")
-    ap.add_argument("--exact", action="store_true", help="reference-order unfused fp64 contractions instead of MFMA")
+    ap.add_argument("--precision", choices=["exact", "fast", "factored"], default="factored",
+                    help="exact: reference-order unfused fp64; fast: fp64 MFMA; factored: fp64 MFMA + recipe-factorised contraction")
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     args = ap.parse_args()
 
@@ -88,7 +89,7 @@ def main():
     # synthetic data of the config-2 shape; every rank owns a different contiguous utterance range
     frames, labels, off = synth.make_batch(U, T_FRAMES, IN_W, L, D, seed=1234 + 100003 * rank)
     cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank, scratch_bytes=args.scratch_gib << 30,
-                               precision=0 if args.exact else 1)
+                               precision={"exact": 0, "fast": 1, "factored": 2}[args.precision])
     eng = scrf_amd.Engine(cfg)
     lam = synth.make_lambda(eng.lambda_len)
     eng.set_lambda(lam)

@@ -65,8 +65,14 @@ enum scrf_map_type { SCRF_STDSTATE = 0, SCRF_STDTRANS = 1 };
  *  EXACT : fp64, ascending feature order, unfused multiply-then-add == the reference's
  *          CRF_StdFeatureMap::computeStateArrayValue bit for bit (needed for bit-identical
  *          lattice arcs / Viterbi).  Always used by the decode entry points.
- *  FAST  : fp64 MFMA (v_mfma_f64_16x16x4_f64); sums reordered, results within 1e-4 rel. */
-enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1 };
+ *  FAST  : fp64 MFMA (v_mfma_f64_16x16x4_f64); sums reordered, results within 1e-4 rel.
+ *  FACTORED : FAST plus the recipe-factorised contraction: the window columns that are linear in
+ *          the raw frames (5 sampled frames + average of the standard segment recipe) go through
+ *          per-frame projections instead of the dense product; only max/min/one-hot-duration
+ *          columns use the dense MFMA kernels.  Applies to single-stream segment-recipe batches
+ *          without transition features, otherwise the engine silently uses FAST.  The window
+ *          average is formed in fp64 instead of the reference's float running sum (~1e-7 rel). */
+enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FACTORED = 2 };
 
 /* Mirrors CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) plus the model fields
  * CRFTrain sets on CRF_Model (CRFTrain/src/Main.cpp:539-597). */

@@ -116,6 +116,23 @@ def test_fb_batch_gradient_fast_precision(ci):
     b.close(); eng.close()
 
 
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_fb_batch_gradient_factored_precision(ci):
+    """FACTORED training precision: sample/avg columns through per-frame projections, max/min/dur
+    columns through the dense MFMA kernels.  The window average is formed in fp64 instead of the
+    reference's float running sum, hence the looser (still 100x inside the contract) bound."""
+    c = Case(seed=100 + ci, precision=2, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-6 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-7 * np.abs(ozx).max()
+    err = np.abs(g - og).max() / np.abs(og).max()
+    assert err <= REL_CONTRACT and err <= 1e-6, err
+    b.close(); eng.close()
+
+
 def test_lattice_arcs_bit_exact(case):
     c, eng, b = case
     for u, T in enumerate(c.Ts):
@@ -251,7 +268,7 @@ def test_full_size_config2_utterances():
     frames, labels, off = synth.make_batch(U, T, in_w, L, D)
     F = 8 * in_w + D
     lam = synth.make_lambda(L * (F + 1 + L))
-    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F, precision=1)); eng.set_lambda(lam)
+    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F, precision=2)); eng.set_lambda(lam)
     fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
     ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
     b = eng.batch_from_frames(fl, ll)
@@ -264,11 +281,11 @@ def test_full_size_config2_utterances():
         X = orc.windows(fl[u], D)
         rc, og, on, oz = orc.seg_build_gradient(ocfg, olay, lam, X, ll[u], T, grad=og)
         assert rc == 0
-        assert abs(on - numer[u]) <= 1e-12 * abs(on) and abs(oz - zx[u]) <= 1e-11 * abs(oz)
+        assert abs(on - numer[u]) <= 1e-6 * abs(on) and abs(oz - zx[u]) <= 1e-7 * abs(oz)
     eng.zero_grad()
     b2 = eng.batch_from_frames(fl[:2], ll[:2])
     eng.fb_batch(b2)
-    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() < 1e-9
+    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() < 1e-6
     # property: sum over labels of the state-bias gradient = (#true segments) - E[#segments]; and the
     # expected number of segment ends per utterance equals 1 at the last frame => bias grads are finite
     # and transition-bias gradient mass = state mass minus one segment per utterance

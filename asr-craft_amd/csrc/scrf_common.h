@@ -84,4 +84,15 @@ struct ScrfBatchView {
   const uint32_t* labels;     // [sum T] or nullptr
 };
 
+// Fused linear epilogue of the factorised score kernel: out += sum_k P[first+step_k(d)][k][o]
+// + (CA[first+d] - CA[first]) / d.  P: [frames][6L]; CA: [frames+1][L] running prefix of the
+// average-block projections over the chunk's frames; steps: [D][5] sample offsets.
+struct ScrfLinEpilogue {
+  const double* P;
+  const double* CA;
+  const uint8_t* steps;
+  ScrfBatchView bv;
+  uint32_t u0, u1;
+};
+
 #endif  // SCRF_COMMON_H_

@@ -36,6 +36,32 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// exp(x) for x <= 0 (including -inf -> 0): the log-sum-exp terms are always max-shifted, so the
+// overflow/NaN handling of the library exp is dead weight in the recursion's inner loop.
+// Cody-Waite reduction by ln2 (hi/lo) + degree-13 Taylor/Horner on |r| <= ln2/2 (truncation
+// 4e-18), scaled with v_ldexp_f64 (which flushes to 0 below the subnormal range): ~1 ulp.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -1000.0);  // also maps -inf; exp(-1000) underflows to 0 through ldexp
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = fma(p, r, 2.0876756987868100e-09);             // 1/12!
+  p = fma(p, r, 2.5052108385441720e-08);             // 1/11!
+  p = fma(p, r, 2.7557319223985888e-07);             // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);             // 1/9!
+  p = fma(p, r, 2.4801587301587302e-05);             // 1/8!
+  p = fma(p, r, 1.9841269841269841e-04);             // 1/7!
+  p = fma(p, r, 1.3888888888888889e-03);             // 1/6!
+  p = fma(p, r, 8.3333333333333332e-03);             // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);             // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);             // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+
 // E = exp(M - max(M)), its transpose, and the shift; one workgroup per L x L matrix
 __global__ void k_exp_m(const double* __restrict__ M, uint32_t L, double* __restrict__ E,
                         double* __restrict__ ET, double* __restrict__ mshift) {
@@ -84,7 +110,7 @@ __device__ __forceinline__ double matvec_bcast(const double a, PTR Em, const int
 }
 
 template <int DMAX, int MPF>
-__global__ __launch_bounds__(DP_WPB * 64) void k_dp_wave(
+__global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_wave(
     ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ S,
     const double* __restrict__ E, const double* __restrict__ ET, const double* __restrict__ mshift,
     double* __restrict__ AD, double* __restrict__ alpha_g, double* __restrict__ beta_g,
@@ -125,12 +151,18 @@ __global__ __launch_bounds__(DP_WPB * 64) void k_dp_wave(
       rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
       const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
       const uint64_t base = scrf_seg_base(t, D);
+      const bool full = (nd == DMAX) && (np == DMAX);  // steady state: every duration has a predecessor
       // scores of the nd windows ending at t: independent of the recursion, issued first
       double sv[DMAX];
+      if (full) {
 #pragma unroll
-      for (int d0 = 0; d0 < DMAX; d0++) sv[d0] = Su[(base + (d0 < nd ? d0 : 0)) * L + lc];
+        for (int d0 = 0; d0 < DMAX; d0++) sv[d0] = Su[(base + d0) * L + lc];
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) sv[d0] = Su[(base + (d0 < nd ? d0 : 0)) * L + lc];
+      }
       const double amax = (double)wave_max_f32((float)alpha);
-      const double a = exp(alpha - amax);
+      const double a = exp_nonpos(alpha - amax);
       double usum;
       double sh = sh0;
       if (MPF) {
@@ -144,30 +176,46 @@ __global__ __launch_bounds__(DP_WPB * 64) void k_dp_wave(
       ring[rpos * L + lc] = apt;  // idle lanes rewrite lane L-1's value with the same number
       double v[DMAX];
       double m = -INFINITY;
+      if (full) {
 #pragma unroll
-      for (int d0 = 0; d0 < DMAX; d0++) {
-        int slot = rpos - d0;
-        if (slot < 0) slot += D;
-        const double r = (d0 == 0) ? apt : ring[(d0 < np ? slot : rpos) * L + lc];
-        double x = (d0 < np) ? r + sv[d0] : sv[d0];
-        x = (d0 < nd) ? x : -INFINITY;
-        v[d0] = x;
-        m = fmax(m, x);
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = rpos - d0;
+          slot += (slot < 0) ? D : 0;
+          const double x = ((d0 == 0) ? apt : ring[slot * L + lc]) + sv[d0];
+          v[d0] = x;
+          m = fmax(m, x);
+        }
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = rpos - d0;
+          if (slot < 0) slot += D;
+          const double r = (d0 == 0) ? apt : ring[(d0 < np ? slot : rpos) * L + lc];
+          double x = (d0 < np) ? r + sv[d0] : sv[d0];
+          x = (d0 < nd) ? x : -INFINITY;
+          v[d0] = x;
+          m = fmax(m, x);
+        }
       }
       double ssum = 0.0;
 #pragma unroll
-      for (int d0 = 0; d0 < DMAX; d0++) ssum += exp(v[d0] - m);
+      for (int d0 = 0; d0 < DMAX; d0++) ssum += exp_nonpos(v[d0] - m);
       alpha = m + log(ssum);
       if (act) {
+        if (full) {
 #pragma unroll
-        for (int d0 = 0; d0 < DMAX; d0++)
-          if (d0 < nd) ADu[(base + d0) * L + lane] = v[d0];
+          for (int d0 = 0; d0 < DMAX; d0++) ADu[(base + d0) * L + lane] = v[d0];
+        } else {
+#pragma unroll
+          for (int d0 = 0; d0 < DMAX; d0++)
+            if (d0 < nd) ADu[(base + d0) * L + lane] = v[d0];
+        }
         alu[(size_t)t * L + lane] = alpha;
       }
     }
     // Zx = LSE_l alpha[T-1][l]  (computeAlphaSum)
     const double mx = (double)wave_max_f32((float)alpha);
-    const double tot = wave_sum_f64(act ? exp(alpha - mx) : 0.0);
+    const double tot = wave_sum_f64(act ? exp_nonpos(alpha - mx) : 0.0);
     const double Zx = mx + log(tot);
     if (!(Zx == Zx) || isinf(Zx)) err = 1;
     if (lane == 0) zx_out[u] = Zx;
@@ -184,24 +232,37 @@ __global__ __launch_bounds__(DP_WPB * 64) void k_dp_wave(
       double v[DMAX];
       double m = -INFINITY;
       uint64_t sb = scrf_seg_base(t + 1, D);
+      if (nn == DMAX && t + 1 >= D) {
+        // steady state: all D successors exist and every node t+1.. carries D windows, so the
+        // window (t+d0+1, d0+1) sits at row seg_base(t+1) + d0*(D+1)
 #pragma unroll
-      for (int d0 = 0; d0 < DMAX; d0++) {
-        const bool ok = d0 < nn;
-        int slot = tpos + d0 + 1;  // node t + d0 + 1
-        if (slot >= D) slot -= D;
-        const double sc = Su[(ok ? sb + d0 : 0) * L + lc];
-        const double bt = ring[(ok ? slot : tpos) * L + lc];
-        const double x = ok ? sc + bt : -INFINITY;
-        v[d0] = x;
-        m = fmax(m, x);
-        sb += scrf_node_max_dur(t + 1 + d0, D);
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = tpos + d0 + 1;
+          slot -= (slot >= D) ? D : 0;
+          const double x = Su[(sb + (uint64_t)d0 * (DMAX + 1)) * L + lc] + ring[slot * L + lc];
+          v[d0] = x;
+          m = fmax(m, x);
+        }
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          const bool ok = d0 < nn;
+          int slot = tpos + d0 + 1;  // node t + d0 + 1
+          if (slot >= D) slot -= D;
+          const double sc = Su[(ok ? sb + d0 : 0) * L + lc];
+          const double bt = ring[(ok ? slot : tpos) * L + lc];
+          const double x = ok ? sc + bt : -INFINITY;
+          v[d0] = x;
+          m = fmax(m, x);
+          sb += scrf_node_max_dur(t + 1 + d0, D);
+        }
       }
       double ssum = 0.0;
 #pragma unroll
-      for (int d0 = 0; d0 < DMAX; d0++) ssum += exp(v[d0] - m);
+      for (int d0 = 0; d0 < DMAX; d0++) ssum += exp_nonpos(v[d0] - m);
       const double sd = m + log(ssum);
       const double smax = (double)wave_max_f32((float)sd);
-      const double b = exp(sd - smax);
+      const double b = exp_nonpos(sd - smax);
       double w;
       double sh = sh0;
       if (MPF) {

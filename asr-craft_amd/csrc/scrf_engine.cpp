@@ -552,6 +552,9 @@ struct ChunkBufs {
   bool factored = false;
   uint32_t XF = 0;           // row width of X (num_feas, or 2W+D for the factored image)
   double* P = nullptr;       // [nfr][6L]
+  double* CA = nullptr;      // [nfr+1][L] running prefix of the average-block projections
+  double* blocksum = nullptr;
+  uint8_t* steps = nullptr;  // [D][5] sample offsets
   double* Z = nullptr;       // [nfr+nutt][6L]
   uint64_t* slot_row = nullptr;
   double* slab_l = nullptr;
@@ -565,7 +568,7 @@ struct Need { bool fb, post, beta, vit; bool factored = false; };
 // state feature range, no transition features
 static bool factored_ok(scrf_handle h, scrf_batch b) {
   const ScrfLayout& l = h->lay;
-  if (b->mode != 1 || b->n_streams != 1 || l.use_tf || !l.use_sf || l.D <= 1) return false;
+  if (b->mode != 1 || b->n_streams != 1 || l.use_tf || !l.use_sf || l.D <= 1 || l.D > 64) return false;
   const scrf_stream_recipe& r = b->recipe[0];
   if (!r.extract_seg_ftr || r.left_ctx || r.right_ctx) return false;
   return l.sfs == 0 && l.nsfe == 8 * r.in_width + l.D && l.nsfe == l.F;
@@ -583,6 +586,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   if (nd.factored) {
     tot += pad256(nseg * (2 * W0 + l.D) * sizeof(float));          // X_mm
     tot += pad256(nfr * 6 * l.L * sizeof(double));                // P
+    tot += pad256((nfr + 1) * l.L * sizeof(double)) + pad256(((nfr + 255) / 256 + 1) * l.L * sizeof(double)) + 4096;  // CA, block sums, steps
     if (nd.post) {
       tot += pad256((nfr + nutt) * 6 * l.L * sizeof(double)) + pad256((nfr + nutt) * 8);  // Z, slot rows
       tot += pad256((size_t)256 * 6 * l.L * W0 * sizeof(double));  // slab of the final contraction
@@ -599,7 +603,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
       if (l.use_tf) tot += 2 * pad256(nfr * LL * sizeof(double)) + pad256(nfr * sizeof(double));  // E, ET, shift
       if (nd.post) {
         tot += 2 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * sizeof(double));  // A, B, numer_f
-        if (!l.use_tf) tot += pad256(((nfr + 2047) / 2048) * LL * sizeof(double));
+        if (!l.use_tf) tot += pad256(((nfr + 511) / 512) * LL * sizeof(double));
       }
     }
     if (nd.post) {
@@ -647,6 +651,9 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     cb->XF = 2 * W0 + l.D;
     cb->X = a.take<float>(nseg * cb->XF);
     cb->P = a.take<double>(nfr * 6 * l.L);
+    cb->CA = a.take<double>((nfr + 1) * l.L);
+    cb->blocksum = a.take<double>(((nfr + 255) / 256 + 1) * l.L);
+    cb->steps = a.take<uint8_t>(5 * 64 > l.D * 5 ? 5 * 64 : l.D * 5);
     if (nd.post) {
       const uint64_t nslots = nfr + nutt;
       cb->Z = a.take<double>(nslots * 6 * l.L);
@@ -685,7 +692,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
         cb->fB = a.take<double>(nfr * l.L);
         cb->numer_f = a.take<double>(nfr);
         if (!l.use_tf) {
-          cb->rpc_atb = 2048;
+          cb->rpc_atb = 512;
           cb->nch_atb = (uint32_t)((nfr + cb->rpc_atb - 1) / cb->rpc_atb);
           cb->slab_atb = a.take<double>((size_t)cb->nch_atb * LL);
         }
@@ -746,13 +753,14 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
       tm.stop(1);
     }
     PhaseTimer tm(h, PH_SCORE);
-    uint32_t nl = 3;
-    // dense part: [max | min | one-hot dur] + bias
-    launch_scores_mfma(h->stream, cb.X, cb.XF, nullptr, nseg, h->d_lambda, l, spec_mm(l, W0), l.L, cb.S);
-    // linear part: per-frame projections of the 5 sample blocks and the average block, then gathers
+    uint32_t nl = 5;
+    // linear part: per-frame projections of the 5 sample blocks and the average block + its prefix
     launch_scores_mfma(h->stream, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
                        spec_lin(W0), 6 * l.L, cb.P);
-    launch_lin_scores(h->stream, l, bv, u0, u1, nfr, cb.P, cb.S);
+    launch_lin_prefix(h->stream, l, nfr, cb.P, cb.CA, cb.blocksum, cb.steps);
+    // dense part [max | min | one-hot dur] + bias, the linear part gathered in its epilogue
+    ScrfLinEpilogue le{cb.P, cb.CA, cb.steps, bv, u0, u1};
+    launch_scores_mfma(h->stream, cb.X, cb.XF, nullptr, nseg, h->d_lambda, l, spec_mm(l, W0), l.L, cb.S, &le);
     if (!h->m0_valid) {
       launch_scores_exact(h->stream, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
       launch_exp_m(h->stream, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
@@ -877,7 +885,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
         const uint32_t W0 = b->recipe[0].in_width;
         const uint64_t nslots = nfr + nutt;
         launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, cb.XF, nullptr, nseg, l, spec_mm(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s);
-        launch_lin_expf_z(h->stream, l, bv, u0, u1, nslots, cb.AD, cb.Z);
+        launch_lin_expf_z(h->stream, l, bv, u0, u1, nslots, cb.AD, cb.Z, cb.steps);
         launch_suffix_avg(h->stream, l, bv, u0, (uint32_t)nutt, cb.Z, cb.slot_row);
         launch_expf_mfma(h->stream, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
                          spec_lin(W0), cb.rpc_l, cb.nch_l, cb.slab_l);

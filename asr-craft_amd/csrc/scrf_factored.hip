@@ -83,50 +83,66 @@ void launch_windows_mm(hipStream_t st, const float* frames, const uint64_t* sfra
                      X, F);
 }
 
-// S[row][l] += sum_k P[pos_k][k][l] + (1/d) * running sum of P[.][5][l]; 4 frames per workgroup, lane = label
-__global__ __launch_bounds__(256) void k_lin_scores(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
-                                                    uint64_t n_frames, const double* __restrict__ P,
-                                                    double* __restrict__ S) {
-  const uint32_t L = lay.L, D = lay.D;
-  const uint64_t n_groups = (n_frames + 3) / 4;
-  const uint64_t grp = xcd_remap(blockIdx.x, n_groups);
-  if (grp >= n_groups) return;
-  const uint64_t fi = grp * 4 + (threadIdx.x >> 6);
-  if (fi >= n_frames) return;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t gf = bv.frame_off[u0] + fi;
-  const uint32_t u = find_utt_f(bv.frame_off, u0, u1, gf);
-  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
-  const uint64_t fb = bv.frame_off[u] - bv.frame_off[u0];  // first frame row of the utterance in the chunk
-  const uint64_t row0 = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
-  const uint32_t nd = scrf_node_max_dur(t, D);
+// CA[f][l] = sum_{f' < f} P[f'][5][l] over the chunk's frames (running prefix; a window sum is the
+// difference of two entries inside one utterance), three small passes: per-block sums, scan of
+// the block sums, per-block prefix.  Also fills the [D][5] table of sample offsets.
+#define LP_FB 256  // frames per block
+__global__ __launch_bounds__(256) void k_lin_prefix_a(ScrfLayout lay, uint64_t n_frames, const double* __restrict__ P,
+                                                      double* __restrict__ blocksum) {
+  const uint32_t L = lay.L;
   const size_t PL = (size_t)6 * L;
-  for (uint32_t l = lane; l < L; l += 64) {
-    double run = 0.0;
-    for (uint32_t d = 1; d <= nd; d++) {
-      const uint32_t first = t - d + 1;
-      run += P[(fb + first) * PL + 5 * L + l];
-      double lin = 0.0;
-#pragma unroll
-      for (int k = 0; k < 5; k++) lin += P[(fb + first + sample_step(d, k)) * PL + (size_t)k * L + l];
-      S[(row0 + d - 1) * L + l] += lin + run / (double)d;
-    }
+  const uint64_t f0 = (uint64_t)blockIdx.x * LP_FB;
+  for (uint32_t l = threadIdx.x; l < L; l += blockDim.x) {
+    double s = 0.0;
+    for (uint32_t i = 0; i < LP_FB && f0 + i < n_frames; i++) s += P[(f0 + i) * PL + 5 * L + l];
+    blocksum[(size_t)blockIdx.x * L + l] = s;
   }
 }
-void launch_lin_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
-                       uint64_t n_frames, const double* P, double* S) {
+__global__ __launch_bounds__(256) void k_lin_prefix_b(ScrfLayout lay, uint32_t n_blocks, double* __restrict__ blocksum,
+                                                      uint8_t* __restrict__ steps) {
+  const uint32_t L = lay.L;
+  for (uint32_t l = threadIdx.x; l < L; l += blockDim.x) {
+    double run = 0.0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+      const double v = blocksum[(size_t)b * L + l];
+      blocksum[(size_t)b * L + l] = run;
+      run += v;
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < lay.D * 5; i += blockDim.x) steps[i] = (uint8_t)sample_step(i / 5 + 1, i % 5);
+}
+__global__ __launch_bounds__(256) void k_lin_prefix_c(ScrfLayout lay, uint64_t n_frames, const double* __restrict__ P,
+                                                      const double* __restrict__ blocksum, double* __restrict__ CA) {
+  const uint32_t L = lay.L;
+  const size_t PL = (size_t)6 * L;
+  const uint64_t f0 = (uint64_t)blockIdx.x * LP_FB;
+  for (uint32_t l = threadIdx.x; l < L; l += blockDim.x) {
+    double run = blocksum[(size_t)blockIdx.x * L + l];
+    for (uint32_t i = 0; i < LP_FB && f0 + i < n_frames; i++) {
+      CA[(f0 + i) * L + l] = run;
+      run += P[(f0 + i) * PL + 5 * L + l];
+    }
+    if (f0 + LP_FB >= n_frames) CA[n_frames * L + l] = run;
+  }
+}
+void launch_lin_prefix(hipStream_t st, const ScrfLayout& lay, uint64_t n_frames, const double* P, double* CA,
+                       double* blocksum, uint8_t* steps) {
   if (n_frames == 0) return;
-  const uint64_t n_groups = (n_frames + 3) / 4;
-  hipLaunchKernelGGL(k_lin_scores, dim3((uint32_t)(((n_groups + 7) / 8) * 8)), dim3(256), 0, st, lay, bv, u0, u1,
-                     n_frames, P, S);
+  const uint32_t nb = (uint32_t)((n_frames + LP_FB - 1) / LP_FB);
+  hipLaunchKernelGGL(k_lin_prefix_a, dim3(nb), dim3(64), 0, st, lay, n_frames, P, blocksum);
+  hipLaunchKernelGGL(k_lin_prefix_b, dim3(1), dim3(256), 0, st, lay, nb, blocksum, steps);
+  hipLaunchKernelGGL(k_lin_prefix_c, dim3(nb), dim3(64), 0, st, lay, n_frames, P, blocksum, CA);
 }
 
 // Z[slot][k][l] (k<5) = sum of R over the windows whose k-th sample is this frame;
 // Z'[slot][5][l] = sum_d R[slot-1][d]/d (windows ending just before) - sum_d R[slot+d-1][d]/d (windows starting here)
 __global__ __launch_bounds__(256) void k_lin_expf_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
                                                     uint64_t n_slots, const double* __restrict__ R,
-                                                    double* __restrict__ Z) {
+                                                    double* __restrict__ Z, const uint8_t* __restrict__ steps) {
+  __shared__ uint8_t stp_s[5 * 64];
   const uint32_t L = lay.L, D = lay.D;
+  for (uint32_t i = threadIdx.x; i < D * 5 && i < 5 * 64; i += blockDim.x) stp_s[i] = steps[i];
+  __syncthreads();
   const uint64_t n_groups = (n_slots + 3) / 4;
   const uint64_t grp = xcd_remap(blockIdx.x, n_groups);
   if (grp >= n_groups) return;
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256) void k_lin_expf_z(ScrfLayout lay, ScrfBatchVie
       for (uint32_t d = 1; d <= D; d++) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-          const uint32_t stp = sample_step(d, k);
+          const uint32_t stp = stp_s[(d - 1) * 5 + k];
           if (s >= stp) {
             const uint32_t t = s - stp + d - 1;
             if (t < T) z[k] += Ru[(scrf_seg_base(t, D) + d - 1) * L + l];
@@ -167,11 +183,11 @@ __global__ __launch_bounds__(256) void k_lin_expf_z(ScrfLayout lay, ScrfBatchVie
   }
 }
 void launch_lin_expf_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
-                       uint64_t n_slots, const double* R, double* Z) {
+                       uint64_t n_slots, const double* R, double* Z, const uint8_t* steps) {
   if (n_slots == 0) return;
   const uint64_t n_groups = (n_slots + 3) / 4;
   hipLaunchKernelGGL(k_lin_expf_z, dim3((uint32_t)(((n_groups + 7) / 8) * 8)), dim3(256), 0, st, lay, bv, u0, u1,
-                     n_slots, R, Z);
+                     n_slots, R, Z, steps);
 }
 
 // avg block: Z[s][5][l] <- sum_{f > s} Z'[f][5][l]   (coefficient of frame s in sum_f CF[f] Z'[f]);

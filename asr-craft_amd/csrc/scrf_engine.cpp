@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -72,6 +73,15 @@ struct scrf_engine_s {
   double* d_sums = nullptr;   // {numer, zx, n_utts, active}
   char* scratch = nullptr;
   size_t scratch_cap = 0;
+  // second lane: alternate chunks of a batch run on a second stream so that the VALU-bound DP
+  // kernels of one chunk overlap the MFMA-bound contractions of the other
+  hipStream_t stream2 = nullptr;
+  char* scratch2 = nullptr;
+  size_t scratch2_cap = 0;
+  double* d_grad2 = nullptr;
+  double* d_sums2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int n_lanes = 2;
   std::string err;
   bool timing = false;
   hipEvent_t ev[SCRF_N_PHASES + 1][2];
@@ -188,6 +198,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   h->lay = lay;
   h->device = cfg->device_id;
   if (h->cfg.scratch_bytes == 0) h->cfg.scratch_bytes = 8ull << 30;
+  if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knob
   memset(h->ms, 0, sizeof(h->ms));
   memset(h->nlaunch, 0, sizeof(h->nlaunch));
 #define CRCHK(call)                                                                          \
@@ -212,6 +223,11 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_msh0, sizeof(double)));
   CRCHK(hipMalloc((void**)&h->d_sums, sizeof(double) * 4));
+  CRCHK(hipMalloc((void**)&h->d_grad2, nb));
+  CRCHK(hipMalloc((void**)&h->d_sums2, sizeof(double) * 4));
+  CRCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  CRCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  CRCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   CRCHK(hipMemsetAsync(h->d_lambda, 0, nb, h->stream));
   CRCHK(hipMemsetAsync(h->d_lambda_acc, 0, nb, h->stream));
   CRCHK(hipMemsetAsync(h->d_gsa, 0, nb, h->stream));
@@ -235,6 +251,10 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   hipFree(h->d_lambda); hipFree(h->d_lambda_acc); hipFree(h->d_gsa);
   if (h->own_grad) hipFree(h->d_grad);
+  hipFree(h->d_grad2); hipFree(h->d_sums2); hipFree(h->scratch2);
+  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
   hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
@@ -263,6 +283,7 @@ extern "C" int scrf_synchronize(scrf_handle h) {
   if (!h) return SCRF_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream2));
   return SCRF_OK;
 }
 
@@ -357,15 +378,18 @@ struct Arena {
 };
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-static int ensure_scratch(scrf_handle h, size_t bytes) {
-  if (bytes <= h->scratch_cap) return SCRF_OK;
+static int ensure_scratch(scrf_handle h, size_t bytes, int lane = 0) {
+  char*& buf = lane ? h->scratch2 : h->scratch;
+  size_t& cap = lane ? h->scratch2_cap : h->scratch_cap;
+  if (bytes <= cap) return SCRF_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->scratch) hipFree(h->scratch);
-  h->scratch = nullptr;
-  h->scratch_cap = 0;
-  hipError_t e = hipMalloc((void**)&h->scratch, bytes);
+  HIPCHK(h, hipStreamSynchronize(h->stream2));
+  if (buf) hipFree(buf);
+  buf = nullptr;
+  cap = 0;
+  hipError_t e = hipMalloc((void**)&buf, bytes);
   if (e != hipSuccess) return fail(h, SCRF_ERR_HIP, "scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
-  h->scratch_cap = bytes;
+  cap = bytes;
   return SCRF_OK;
 }
 
@@ -519,6 +543,9 @@ static uint64_t expf_rows_per_chunk(uint64_t nseg) {
 }
 
 struct ChunkBufs {
+  hipStream_t st = nullptr;  // stream of the lane this chunk runs on
+  double* grad = nullptr;    // gradient / batch sums this lane accumulates into
+  double* sums = nullptr;
   float* X = nullptr;        // window vectors of the chunk (scratch, or a view into the batch)
   double* S = nullptr;       // [nseg][L]
   double* M = nullptr;       // [nfr][L*L] or engine M0
@@ -636,14 +663,17 @@ static uint32_t plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, const Need&
   return u1;
 }
 
-static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Need& nd, ChunkBufs* cb) {
+static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Need& nd, ChunkBufs* cb, int lane = 0) {
   const ScrfLayout& l = h->lay;
   const size_t LL = (size_t)l.L * l.L;
   const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
   size_t need = chunk_bytes(h, b, nutt, nfr, nseg, nd);
-  int rc = ensure_scratch(h, need);
+  int rc = ensure_scratch(h, need, lane);
   if (rc != SCRF_OK) return rc;
-  Arena a{h->scratch, h->scratch_cap, 0};
+  Arena a{lane ? h->scratch2 : h->scratch, lane ? h->scratch2_cap : h->scratch_cap, 0};
+  cb->st = lane ? h->stream2 : h->stream;
+  cb->grad = lane ? h->d_grad2 : h->d_grad;
+  cb->sums = lane ? h->d_sums2 : h->d_sums;
   cb->XF = l.F;
   cb->factored = nd.factored;
   if (nd.factored) {
@@ -718,19 +748,20 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     cb->bp_b = a.take<uint16_t>(nfr * l.L);
     cb->bp_e = a.take<uint16_t>(nfr * l.L);
   }
-  if (a.off > h->scratch_cap) return fail(h, SCRF_ERR_INVALID, "internal: scratch arena overflow");
+  if (a.off > a.cap) return fail(h, SCRF_ERR_INVALID, "internal: scratch arena overflow");
   return SCRF_OK;
 }
 
 struct PhaseTimer {
   scrf_handle h;
   int ph;
-  PhaseTimer(scrf_handle h_, int p) : h(h_), ph(p) {
-    if (h->timing) hipEventRecord(h->ev[ph][0], h->stream);
+  hipStream_t st;
+  PhaseTimer(scrf_handle h_, int p, hipStream_t s_ = nullptr) : h(h_), ph(p), st(s_ ? s_ : h_->stream) {
+    if (h->timing) hipEventRecord(h->ev[ph][0], st);
   }
   void stop(uint32_t launches) {
     if (!h->timing) return;
-    hipEventRecord(h->ev[ph][1], h->stream);
+    hipEventRecord(h->ev[ph][1], st);
     hipEventSynchronize(h->ev[ph][1]);
     float ms = 0;
     hipEventElapsedTime(&ms, h->ev[ph][0], h->ev[ph][1]);
@@ -748,22 +779,22 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     const scrf_stream_recipe& r = b->recipe[0];
     const uint32_t W0 = r.in_width;
     {
-      PhaseTimer tm(h, PH_WIN);
-      launch_windows_mm(h->stream, b->d_frames[0], b->d_sframe_off[0], bv, u0, u1, nfr, W0, l.D, cb.X, cb.XF);
+      PhaseTimer tm(h, PH_WIN, cb.st);
+      launch_windows_mm(cb.st, b->d_frames[0], b->d_sframe_off[0], bv, u0, u1, nfr, W0, l.D, cb.X, cb.XF);
       tm.stop(1);
     }
-    PhaseTimer tm(h, PH_SCORE);
+    PhaseTimer tm(h, PH_SCORE, cb.st);
     uint32_t nl = 5;
     // linear part: per-frame projections of the 5 sample blocks and the average block + its prefix
-    launch_scores_mfma(h->stream, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
+    launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
                        spec_lin(W0), 6 * l.L, cb.P);
-    launch_lin_prefix(h->stream, l, nfr, cb.P, cb.CA, cb.blocksum, cb.steps);
+    launch_lin_prefix(cb.st, l, nfr, cb.P, cb.CA, cb.blocksum, cb.steps);
     // dense part [max | min | one-hot dur] + bias, the linear part gathered in its epilogue
     ScrfLinEpilogue le{cb.P, cb.CA, cb.steps, bv, u0, u1};
-    launch_scores_mfma(h->stream, cb.X, cb.XF, nullptr, nseg, h->d_lambda, l, spec_mm(l, W0), l.L, cb.S, &le);
+    launch_scores_mfma(cb.st, cb.X, cb.XF, nullptr, nseg, h->d_lambda, l, spec_mm(l, W0), l.L, cb.S, &le);
     if (!h->m0_valid) {
-      launch_scores_exact(h->stream, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
-      launch_exp_m(h->stream, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
+      launch_scores_exact(cb.st, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+      launch_exp_m(cb.st, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
       h->m0_valid = true;
       nl += 2;
     }
@@ -772,29 +803,29 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     return SCRF_OK;
   }
   if (b->mode == 1) {
-    PhaseTimer tm(h, PH_WIN);
+    PhaseTimer tm(h, PH_WIN, cb.st);
     uint32_t col = 0;
     for (uint32_t s = 0; s < b->n_streams; s++) {
       const scrf_stream_recipe& r = b->recipe[s];
-      launch_windows(h->stream, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
+      launch_windows(cb.st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
                      r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col);
       col += b->width[s];
     }
     tm.stop(b->n_streams);
   }
-  PhaseTimer tm(h, PH_SCORE);
+  PhaseTimer tm(h, PH_SCORE, cb.st);
   uint32_t nl = 1;
-  if (fast) launch_scores_mfma(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S);
-  else launch_scores_exact(h->stream, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+  if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S);
+  else launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
   if (l.use_tf) {
-    launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
-    if (fast) launch_scores_mfma(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M);
-    else launch_scores_exact(h->stream, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
+    launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
+    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M);
+    else launch_scores_exact(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
     nl += 2;
   } else if (!h->m0_valid) {
     // transition scores carry only the bias: one L x L matrix for every frame
-    launch_scores_exact(h->stream, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
-    launch_exp_m(h->stream, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
+    launch_scores_exact(cb.st, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+    launch_exp_m(cb.st, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
     h->m0_valid = true;
     nl += 2;
   }
@@ -812,23 +843,23 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
   ScrfBatchView bv = b->view();
   uint32_t nl = 0;
   if (!cb.wave) {
-    if (post && cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, h->stream));
-    launch_fb(h->stream, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, post ? cb.XI : nullptr,
+    if (post && cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, cb.st));
+    launch_fb(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, post ? cb.XI : nullptr,
               post ? cb.xi_acc : nullptr, b->d_numer, b->d_zx, b->d_status, post ? 1 : 0);
     nl = 1;
   } else {
-    if (cb.m_per_frame) { launch_exp_m(h->stream, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh); nl++; }
-    launch_dp_wave(h->stream, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
+    if (cb.m_per_frame) { launch_exp_m(cb.st, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh); nl++; }
+    launch_dp_wave(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
                    cb.beta, cb.sd, b->d_zx, b->d_status);
     nl++;
     if (post) {
-      launch_post_state(h->stream, l, bv, u0, u1, nfr, b->d_next_lab, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.beta,
+      launch_post_state(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.beta,
                         b->d_zx, cb.numer_f, b->d_status);
-      launch_numer_reduce(h->stream, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
-      launch_xi_factors(h->stream, l, bv, u0, u1, nfr, cb.alpha, cb.sd, b->d_zx, cb.fA, cb.fB);
+      launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
+      launch_xi_factors(cb.st, l, bv, u0, u1, nfr, cb.alpha, cb.sd, b->d_zx, cb.fA, cb.fB);
       nl += 3;
       if (l.use_tf) {
-        launch_xi_full(h->stream, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
+        launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
         nl++;
       }
     }
@@ -863,58 +894,94 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
   ScrfBatchView bv = b->view();
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
   nd.factored = h->cfg.train_precision == SCRF_PREC_FACTORED && factored_ok(h, b);
-  for (uint32_t u0 = 0; u0 < b->U;) {
-    const uint32_t u1 = plan_chunk(h, b, u0, nd);
+
+  // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
+  // at least four chunks so that both streams always have work
+  std::vector<uint32_t> cuts(1, 0);
+  const bool two_lanes = h->n_lanes > 1 && !h->timing && b->U >= 64;
+  {
+    const uint32_t cap = two_lanes ? (b->U + 3) / 4 : b->U;
+    for (uint32_t u0 = 0; u0 < b->U;) {
+      uint32_t u1 = plan_chunk(h, b, u0, nd);
+      if (u1 - u0 > cap) u1 = u0 + cap;
+      cuts.push_back(u1);
+      u0 = u1;
+    }
+  }
+  const size_t n_chunks = cuts.size() - 1;
+  const bool use2 = two_lanes && n_chunks >= 2;
+  if (!h->m0_valid && !l.use_tf) {
+    // transition scores carry only the bias: one L x L matrix (and its exp) for every frame;
+    // computed before the lanes fork
+    launch_scores_exact(h->stream, nullptr, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+    launch_exp_m(h->stream, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
+    h->m0_valid = true;
+  }
+  if (use2) {
+    HIPCHK(h, hipMemsetAsync(h->d_grad2, 0, sizeof(double) * l.lambda_len, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_sums2, 0, sizeof(double) * 4, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  }
+  for (size_t ci = 0; ci < n_chunks; ci++) {
+    const uint32_t u0 = cuts[ci], u1 = cuts[ci + 1];
+    const int lane = use2 ? (int)(ci & 1) : 0;
     ChunkBufs cb;
-    int rc = carve(h, b, u0, u1, nd, &cb);
+    int rc = carve(h, b, u0, u1, nd, &cb, lane);
     if (rc != SCRF_OK) return rc;
     const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
     rc = run_scores(h, b, u0, u1, cb, fast);
     if (rc != SCRF_OK) return rc;
     {
-      PhaseTimer tm(h, PH_FB);
+      PhaseTimer tm(h, PH_FB, cb.st);
       uint32_t nl = 0;
       rc = run_dp(h, b, u0, u1, cb, true, &nl);
       if (rc != SCRF_OK) return rc;
       tm.stop(nl);
     }
     {
-      PhaseTimer tm(h, PH_EXPF);
+      PhaseTimer tm(h, PH_EXPF, cb.st);
       uint32_t nl = 1;
       if (cb.factored) {
         const uint32_t W0 = b->recipe[0].in_width;
         const uint64_t nslots = nfr + nutt;
-        launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, cb.XF, nullptr, nseg, l, spec_mm(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s);
-        launch_lin_expf_z(h->stream, l, bv, u0, u1, nslots, cb.AD, cb.Z, cb.steps);
-        launch_suffix_avg(h->stream, l, bv, u0, (uint32_t)nutt, cb.Z, cb.slot_row);
-        launch_expf_mfma(h->stream, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
+        launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, cb.XF, nullptr, nseg, l, spec_mm(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s);
+        launch_lin_expf_z(cb.st, l, bv, u0, u1, nslots, cb.AD, cb.Z, cb.steps);
+        launch_suffix_avg(cb.st, l, bv, u0, (uint32_t)nutt, cb.Z, cb.slot_row);
+        launch_expf_mfma(cb.st, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
                          spec_lin(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 3;
-      } else if (fast) launch_expf_mfma(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s);
-      else launch_expf_gemm(h->stream, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+      } else if (fast) launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s);
+      else launch_expf_gemm(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
       if (l.use_tf) {
-        launch_frame_rows(h->stream, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
-        if (fast) launch_expf_mfma(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t);
-        else launch_expf_gemm(h->stream, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+        launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
+        if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t);
+        else launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
         nl += 2;
       }
       tm.stop(nl);
     }
     {
-      PhaseTimer tm(h, PH_REDUCE);
+      PhaseTimer tm(h, PH_REDUCE, cb.st);
       if (cb.factored) {
         const uint32_t W0 = b->recipe[0].in_width;
-        launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, spec_mm(l, W0), h->d_grad);
-        launch_reduce_slabs(h->stream, cb.slab_l, cb.nch_l, 6 * l.L, l, spec_lin(W0), h->d_grad);
-      } else launch_reduce_slabs(h->stream, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), h->d_grad);
-      if (l.use_tf) launch_reduce_slabs(h->stream, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), h->d_grad);
-      else if (cb.wave) launch_atb(h->stream, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, h->d_grad);
-      else launch_reduce_xiacc(h->stream, cb.xi_acc, (uint32_t)nutt, l, h->d_grad);
-      launch_batch_sums(h->stream, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, h->d_sums);
+        launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_mm(l, W0), cb.grad);
+        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 6 * l.L, l, spec_lin(W0), cb.grad);
+      } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
+      if (l.use_tf) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
+      else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad);
+      else launch_reduce_xiacc(cb.st, cb.xi_acc, (uint32_t)nutt, l, cb.grad);
+      launch_batch_sums(cb.st, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, cb.sums);
       tm.stop(3);
     }
     HIPCHK(h, hipGetLastError());
-    u0 = u1;
+  }
+  if (use2) {
+    // join: lane 1's partial gradient and sums are added once, in a fixed order
+    HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    launch_add(h->stream, h->d_grad, h->d_grad2, l.lambda_len);
+    launch_add(h->stream, h->d_sums, h->d_sums2, 3);
   }
   if (!l.use_tf && dp_wave_supported(l)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_grad);
   if (h->timing) {

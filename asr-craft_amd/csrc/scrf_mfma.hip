@@ -199,13 +199,14 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 }
 
 // ------------------------------------------------------------------------------------------
-#define EM_KC 32    // rows per staged chunk (8 MFMA k-steps)
 #define EM_NO 48    // outputs per workgroup (3 M-tiles)
 
 // NW wavefronts per workgroup, each owning 48 feature columns (3 N-tiles): NW = 8 covers 384
 // columns (the full 338-wide state block of config 2 in one workgroup, so R is read once);
 // narrow contractions (factorised max/min/dur block, per-frame projections) use fewer waves.
-template <int HAS_XROW, int NW>
+// KC = rows per staged chunk (KC/4 MFMA k-steps): 32 for the wide tile, 64 for narrow tiles so
+// that the staging/barrier cost per MFMA stays low when few wavefronts share one R tile.
+template <int HAS_XROW, int NW, int EM_KC>
 __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
@@ -217,8 +218,9 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   constexpr int QR = NF / 4;             // 16-byte quads per row
   constexpr int XIT = EM_KC * QR / NT;   // X quads per thread per chunk (= 6)
   constexpr int AIT = (EM_KC * EM_NO + NT - 1) / NT;
-  __shared__ double Rs[EM_KC * EM_NO];
-  __shared__ __attribute__((aligned(16))) float Xs[EM_KC * XS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
+  double* Rs = (double*)em_smem;                                  // [EM_KC][EM_NO]
+  float* Xs = (float*)(em_smem + sizeof(double) * EM_KC * EM_NO);  // [EM_KC][XS]
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t fs = sp.fs;
@@ -341,18 +343,22 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   }
 }
 
-template <int NW>
+template <int NW, int KC>
 static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                 const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   const uint32_t nfun = sp.nfun();
   dim3 grid((nfun + 48 * NW - 1) / (48 * NW), (n_out + EM_NO - 1) / EM_NO, n_chunks);
-  if (xrow)
-    hipLaunchKernelGGL((k_expf_mfma<1, NW>), grid, dim3(64 * NW), 0, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+  const size_t sm = sizeof(double) * KC * EM_NO + sizeof(float) * KC * (48 * NW + 16);
+  if (xrow) {
+    hipFuncSetAttribute((const void*)k_expf_mfma<1, NW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab);
-  else
-    hipLaunchKernelGGL((k_expf_mfma<0, NW>), grid, dim3(64 * NW), 0, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+  } else {
+    hipFuncSetAttribute((const void*)k_expf_mfma<0, NW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab);
+  }
 }
 
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
@@ -361,9 +367,9 @@ void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const flo
   if (n_rows == 0 || n_chunks == 0) return;
   const uint32_t nfun = sp.nfun();
   const uint32_t tiles = (nfun + 47) / 48;  // 48-column wave tiles needed
-  if (tiles <= 1) launch_expf_mfma_nw<1>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else if (tiles <= 2) launch_expf_mfma_nw<2>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else if (tiles <= 3) launch_expf_mfma_nw<3>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else if (tiles <= 4) launch_expf_mfma_nw<4>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else launch_expf_mfma_nw<8>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  if (tiles <= 1) launch_expf_mfma_nw<1, 32>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else if (tiles <= 2) launch_expf_mfma_nw<2, 64>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else if (tiles <= 3) launch_expf_mfma_nw<3, 64>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else if (tiles <= 4) launch_expf_mfma_nw<4, 64>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else launch_expf_mfma_nw<8, 32>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
 }

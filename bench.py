@@ -25,7 +25,8 @@ import numpy as np  # noqa: E402
 
 L, D, IN_W, T_FRAMES = 48, 25, 39, 300
 F = 8 * IN_W + D  # 337 segment features (io/CRF_InFtrStream_SeqMultiWindow.cpp:77-78)
-PEAK = {"mfma_f64_tflops": 78.6, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md (HBM); fp64 MFMA: SURVEY 8d vendor peak
+PEAK = {"mfma_f64_tflops": 78.6, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md (HBM); fp64 MFMA: vendor peak
+MEASURED_MFMA_F64_TFLOPS = 48.5  # tools/mfma_f64_peak.hip on this pool: sustained v_mfma_f64_16x16x4_f64 rate
 
 
 def n_segs(T, Dm):
@@ -156,8 +157,13 @@ def main():
         bound, work, unit, peak = phases[dom]
         ms, nl = tm[dom]
         achieved = work / (ms / 1e3)
-        roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 5), "traffic": None,
+        kernels = {"scores": "k_scores_mfma (+ k_lin_prefix_* in factored mode)",
+                   "expf": "k_expf_mfma (+ k_lin_expf_z, k_suffix_avg in factored mode)",
+                   "fwd_bwd": "k_dp_wave + k_post_state + k_xi_factors"}
+        roofline = {"kernel": dom, "kernels_in_phase": kernels[dom], "bound": bound, "achieved": round(achieved, 4),
+                    "peak": peak, "unit": unit, "frac": round(achieved / peak, 5), "traffic": None,
+                    "peak_measured": MEASURED_MFMA_F64_TFLOPS if bound == "mfma" else 6290.0,
+                    "frac_of_measured": round(achieved / (MEASURED_MFMA_F64_TFLOPS if bound == "mfma" else 6290.0), 5),
                     "launches": int(nl), "avg_launch_ms": round(ms / max(1, nl), 4),
                     "phase_ms": {k: round(v[0], 3) for k, v in tm.items()}}
         out = {
@@ -170,7 +176,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: segmental CRF forward-backward, 48 labels, max-seg-len 25, "
                                    "39-dim x 300-frame utterances, stdstate map (lambda_len 18528)",
-                       "utts_per_rank_per_step": U, "global_minibatch": U * world,
+                       "utts_per_rank_per_step": U, "global_minibatch": U * world, "precision": args.precision,
                        "parallelism": "dp%d" % world},
             "roofline": roofline,
         }

@@ -212,6 +212,28 @@ def test_chunking_is_invisible():
     e1.close(); e2.close()
 
 
+def test_two_lane_pipeline_equals_single_lane(monkeypatch):
+    """batches of >= 64 utterances are cut into >= 4 chunks that alternate between two HIP streams
+    (DP of one chunk overlaps the contractions of the other); the result must not depend on it."""
+    kw = dict(L=6, D=4, in_w=3, Ts=[5 + (7 * i) % 11 for i in range(80)], seed=77)
+    res = []
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("SCRF_LANES", lanes)
+        for prec in (0, 2):
+            c = Case(precision=prec, **kw)
+            eng = c.engine(); b = c.batch(eng)
+            numer, zx = eng.fb_batch(b)
+            res.append((numer, zx, eng.get_grad(), eng.batch_sums()))
+            b.close(); eng.close()
+    for i in (0, 1):
+        n1, z1, g1, s1 = res[i]; n2, z2, g2, s2 = res[i + 2]
+        assert np.array_equal(n1, n2) and np.array_equal(z1, z2)
+        np.testing.assert_allclose(g1, g2, rtol=1e-12, atol=1e-12 * np.abs(g1).max())
+        np.testing.assert_allclose(s1, s2, rtol=1e-12)
+    og, on, oz = Case(**kw).oracle_gradient()
+    assert np.abs(res[2][2] - og).max() / np.abs(og).max() < 1e-9
+
+
 def test_minibatch_reduce_and_optimizer_step():
     c = Case(L=4, D=3, in_w=2, Ts=[6, 5, 8], seed=33)
     eng = c.engine(); b = c.batch(eng)

@@ -771,7 +771,7 @@ struct PhaseTimer {
 };
 
 // windows + exact scores of a chunk (both training and decode start here)
-static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool fast = false) {
+static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool fast = false, int f32 = 0) {
   const ScrfLayout& l = h->lay;
   const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
   ScrfBatchView bv = b->view();
@@ -815,11 +815,11 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   }
   PhaseTimer tm(h, PH_SCORE, cb.st);
   uint32_t nl = 1;
-  if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S);
+  if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, nullptr, f32);
   else launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
   if (l.use_tf) {
     launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
-    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M);
+    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, nullptr, f32);
     else launch_scores_exact(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
     nl += 2;
   } else if (!h->m0_valid) {
@@ -893,6 +893,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
   Need nd{true, true, false, false};
   ScrfBatchView bv = b->view();
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
+  const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
   nd.factored = h->cfg.train_precision == SCRF_PREC_FACTORED && factored_ok(h, b);
 
   // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
@@ -930,7 +931,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     int rc = carve(h, b, u0, u1, nd, &cb, lane);
     if (rc != SCRF_OK) return rc;
     const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
-    rc = run_scores(h, b, u0, u1, cb, fast);
+    rc = run_scores(h, b, u0, u1, cb, fast, f32);
     if (rc != SCRF_OK) return rc;
     {
       PhaseTimer tm(h, PH_FB, cb.st);
@@ -951,11 +952,11 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
         launch_expf_mfma(cb.st, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
                          spec_lin(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 3;
-      } else if (fast) launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s);
+      } else if (fast) launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
       else launch_expf_gemm(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
       if (l.use_tf) {
         launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
-        if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t);
+        if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32);
         else launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
         nl += 2;
       }

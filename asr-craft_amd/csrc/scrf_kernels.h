@@ -37,10 +37,10 @@ void launch_add(hipStream_t st, double* y, const double* x, uint32_t n);
 // scrf_mfma.hip: fp64 MFMA contractions (FAST training precision)
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
-                        double* out, const ScrfLinEpilogue* le = nullptr);
+                        double* out, const ScrfLinEpilogue* le = nullptr, int f32 = 0);
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
-                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
+                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int f32 = 0);
 
 // scrf_dp.hip: wavefront-per-utterance DP and the parallel posterior kernels
 int dp_wave_supported(const ScrfLayout& lay);

@@ -29,6 +29,13 @@ struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 
 // Software pipeline: while the MFMAs of chunk i run from LDS, the global loads of chunk i+1
 // are in flight into registers (8 x 16 B of X and 6 x 8 B of lambda per thread).
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+// F32 = 1 (train_precision FAST32): v_mfma_f32_16x16x4_f32 -- an exact f32 FMA chain at ~3x the
+// sustained rate of the f64 MFMA on this chip; lambda is rounded to f32 at staging, the K-sum
+// runs in f32 (error ~1e-7 * sum|x*w|), bias and the linear epilogue are added in f64.
+// D layout of the f32 form: row = 4*(lane>>4) + reg (the f64 form: (lane>>4) + 4*reg).
+template <int F32>
 __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      const double* __restrict__ lambda, ScrfLayout lay,
@@ -48,11 +55,17 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
   const int use_b = sp.use_bias;
   const double bv = sp.bias;
 
-  v4f64 acc[4][3];
+  v4f64 acc[F32 ? 1 : 4][F32 ? 1 : 3];
+  v4f32 acc32[F32 ? 4 : 1][F32 ? 3 : 1];
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+  for (int m = 0; m < (F32 ? 1 : 4); m++)
 #pragma unroll
-    for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < (F32 ? 1 : 3); n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < (F32 ? 4 : 1); m++)
+#pragma unroll
+    for (int n = 0; n < (F32 ? 3 : 1); n++) acc32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+  float* Wsf = (float*)Ws;  // F32: the lambda image holds floats, row stride 2*SM_WS floats
 
   // staging coordinates: 8 threads cover one row's 32-float chunk, 32 rows per pass, 8 passes
   const uint32_t sq = tid & 7, sr = tid >> 3;
@@ -107,7 +120,8 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const uint32_t idx = tid + k * 256;
-      Ws[(idx % SM_KC) * SM_WS + idx / SM_KC] = wr_[k];
+      if (F32) Wsf[(idx % SM_KC) * (2 * SM_WS) + idx / SM_KC] = (float)wr_[k];
+      else Ws[(idx % SM_KC) * SM_WS + idx / SM_KC] = wr_[k];
     }
   };
 
@@ -145,14 +159,30 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
     if (f0 + SM_KC < nfe) load_chunk(f0 + SM_KC);
 #pragma unroll
     for (int ks = 0; ks < SM_KC / 4; ks++) {
-      double b[3];
+      if (F32) {
+        float b[3];
 #pragma unroll
-      for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SM_WS + n * 16 + li];
+        for (int n = 0; n < 3; n++) b[n] = Wsf[(ks * 4 + lk) * (2 * SM_WS) + n * 16 + li];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const double a = (double)Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
+        for (int m = 0; m < 4; m++) {
+          const float a = Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
 #pragma unroll
-        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < 3; n++)
+            acc32[F32 ? m : 0][F32 ? n : 0] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc32[F32 ? m : 0][F32 ? n : 0], 0, 0, 0);
+        }
+      } else {
+        double b[3];
+#pragma unroll
+        for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SM_WS + n * 16 + li];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const double a = (double)Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
+#pragma unroll
+          for (int n = 0; n < 3; n++)
+            acc[F32 ? 0 : m][F32 ? 0 : n] =
+                __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -167,10 +197,10 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
     for (int m = 0; m < 4; m++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const uint32_t rl = wave * 64 + m * 16 + lk + 4 * r;
+        const uint32_t rl = wave * 64 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
         const uint64_t row = row0 + rl;
         if (row >= n_rows) continue;
-        double v = acc[m][n][r] + bias;
+        double v = (F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r]) + bias;
         if (le.P) {
           // + sum_k P[pos_k][k][o] + (CA[first+d] - CA[first]) / d   (scrf_factored.hip)
           const uint32_t first = row_first[rl], d = row_dur[rl];
@@ -189,13 +219,17 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
 
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
-                        double* out, const ScrfLinEpilogue* le) {
+                        double* out, const ScrfLinEpilogue* le, int f32) {
   if (n_rows == 0 || n_out == 0) return;
   dim3 grid((uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS), (n_out + SM_NO - 1) / SM_NO);
   ScrfLinEpilogue none;
   memset(&none, 0, sizeof(none));
-  hipLaunchKernelGGL(k_scores_mfma, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out,
-                     le ? *le : none);
+  if (f32)
+    hipLaunchKernelGGL(k_scores_mfma<1>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out,
+                       le ? *le : none);
+  else
+    hipLaunchKernelGGL(k_scores_mfma<0>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out,
+                       le ? *le : none);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -206,7 +240,9 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 // narrow contractions (factorised max/min/dur block, per-frame projections) use fewer waves.
 // KC = rows per staged chunk (KC/4 MFMA k-steps): 32 for the wide tile, 64 for narrow tiles so
 // that the staging/barrier cost per MFMA stays low when few wavefronts share one R tile.
-template <int HAS_XROW, int NW, int EM_KC>
+// F32 = 1: operands rounded to f32 (R is in [-1,1]), v_mfma_f32_16x16x4_f32 within a staged chunk of
+// EM_KC rows, chunk results flushed into f64 accumulators (so the K = millions-of-rows sum is f64).
+template <int HAS_XROW, int NW, int EM_KC, int F32>
 __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
@@ -312,17 +348,43 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     store_chunk(r0);
     __syncthreads();
     if (r0 + EM_KC < r_end) load_chunk(r0 + EM_KC);
-#pragma unroll
-    for (int ks = 0; ks < EM_KC / 4; ks++) {
-      double a[3], b[3];
-#pragma unroll
-      for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
-#pragma unroll
-      for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wave * 48 + n * 16 + li];
+    if (F32) {
+      v4f32 c32[3][3];
 #pragma unroll
       for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 3; n++) c32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < EM_KC / 4; ks++) {
+        float a[3], b[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) a[m] = (float)Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
+#pragma unroll
+        for (int n = 0; n < 3; n++) b[n] = Xs[(ks * 4 + lk) * XS + wave * 48 + n * 16 + li];
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+          for (int n = 0; n < 3; n++) c32[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], c32[m][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[m][n][r] += (double)c32[m][n][r];
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < EM_KC / 4; ks++) {
+        double a[3], b[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
+#pragma unroll
+        for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wave * 48 + n * 16 + li];
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+          for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -337,13 +399,13 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     for (int m = 0; m < 3; m++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const uint32_t o = o0 + m * 16 + lk + 4 * r;
+        const uint32_t o = o0 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
         if (o < n_out) slab[((uint64_t)blockIdx.z * n_out + o) * nfun + col] = acc[m][n][r] * sc;
       }
   }
 }
 
-template <int NW, int KC>
+template <int NW, int KC, int F32>
 static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                 const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
@@ -351,25 +413,35 @@ static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out,
   dim3 grid((nfun + 48 * NW - 1) / (48 * NW), (n_out + EM_NO - 1) / EM_NO, n_chunks);
   const size_t sm = sizeof(double) * KC * EM_NO + sizeof(float) * KC * (48 * NW + 16);
   if (xrow) {
-    hipFuncSetAttribute((const void*)k_expf_mfma<1, NW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+    hipFuncSetAttribute((const void*)k_expf_mfma<1, NW, KC, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab);
   } else {
-    hipFuncSetAttribute((const void*)k_expf_mfma<0, NW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+    hipFuncSetAttribute((const void*)k_expf_mfma<0, NW, KC, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab);
   }
 }
 
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
-                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+                      uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int f32) {
   if (n_rows == 0 || n_chunks == 0) return;
   const uint32_t nfun = sp.nfun();
   const uint32_t tiles = (nfun + 47) / 48;  // 48-column wave tiles needed
-  if (tiles <= 1) launch_expf_mfma_nw<1, 32>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else if (tiles <= 2) launch_expf_mfma_nw<2, 64>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else if (tiles <= 3) launch_expf_mfma_nw<3, 64>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else if (tiles <= 4) launch_expf_mfma_nw<4, 64>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
-  else launch_expf_mfma_nw<8, 32>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+#define EXPF_ARGS st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab
+  if (f32) {
+    if (tiles <= 1) launch_expf_mfma_nw<1, 32, 1>(EXPF_ARGS);
+    else if (tiles <= 2) launch_expf_mfma_nw<2, 64, 1>(EXPF_ARGS);
+    else if (tiles <= 3) launch_expf_mfma_nw<3, 64, 1>(EXPF_ARGS);
+    else if (tiles <= 4) launch_expf_mfma_nw<4, 64, 1>(EXPF_ARGS);
+    else launch_expf_mfma_nw<8, 32, 1>(EXPF_ARGS);
+  } else {
+    if (tiles <= 1) launch_expf_mfma_nw<1, 32, 0>(EXPF_ARGS);
+    else if (tiles <= 2) launch_expf_mfma_nw<2, 64, 0>(EXPF_ARGS);
+    else if (tiles <= 3) launch_expf_mfma_nw<3, 64, 0>(EXPF_ARGS);
+    else if (tiles <= 4) launch_expf_mfma_nw<4, 64, 0>(EXPF_ARGS);
+    else launch_expf_mfma_nw<8, 32, 0>(EXPF_ARGS);
+  }
+#undef EXPF_ARGS
 }

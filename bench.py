@@ -62,8 +62,8 @@ def main():
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the collective path)")
-    ap.add_argument("--precision", choices=["exact", "fast", "factored"], default="factored",
-                    help="exact: reference-order unfused fp64; fast: fp64 MFMA; factored: fp64 MFMA + recipe-factorised contraction")
+    ap.add_argument("--precision", choices=["exact", "fast", "factored", "fast32"], default="factored",
+                    help="exact: reference-order unfused fp64; fast: fp64 MFMA; factored: fp64 MFMA + recipe-factorised contraction; fast32: f32 MFMA contractions (opt-in)")
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     args = ap.parse_args()
 
@@ -90,7 +90,7 @@ def main():
     # synthetic data of the config-2 shape; every rank owns a different contiguous utterance range
     frames, labels, off = synth.make_batch(U, T_FRAMES, IN_W, L, D, seed=1234 + 100003 * rank)
     cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank, scratch_bytes=args.scratch_gib << 30,
-                               precision={"exact": 0, "fast": 1, "factored": 2}[args.precision])
+                               precision={"exact": 0, "fast": 1, "factored": 2, "fast32": 3}[args.precision])
     eng = scrf_amd.Engine(cfg)
     lam = synth.make_lambda(eng.lambda_len)
     eng.set_lambda(lam)

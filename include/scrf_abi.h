@@ -71,8 +71,14 @@ enum scrf_map_type { SCRF_STDSTATE = 0, SCRF_STDTRANS = 1 };
  *          per-frame projections instead of the dense product; only max/min/one-hot-duration
  *          columns use the dense MFMA kernels.  Applies to single-stream segment-recipe batches
  *          without transition features, otherwise the engine silently uses FAST.  The window
- *          average is formed in fp64 instead of the reference's float running sum (~1e-7 rel). */
-enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FACTORED = 2 };
+ *          average is formed in fp64 instead of the reference's float running sum (~1e-7 rel).
+ *  FAST32 : like FAST but the two dense contractions run on the f32 MFMA (exact f32 FMA chain,
+ *          ~3x the sustained f64-MFMA rate of the chip): lambda and the posteriors are rounded to
+ *          f32 as operands, scores sum in f32 over the feature axis, expected counts sum in f32
+ *          inside 32/64-row chunks and in f64 across chunks.  The DP recursion, log-partition and
+ *          posteriors stay f64.  Measured deviation <= ~1e-6 relative on gradients (contract 1e-4).
+ *          Not the default of anything; opt-in. */
+enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FACTORED = 2, SCRF_PREC_FAST32 = 3 };
 
 /* Mirrors CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) plus the model fields
  * CRFTrain sets on CRF_Model (CRFTrain/src/Main.cpp:539-597). */

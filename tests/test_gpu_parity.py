@@ -133,6 +133,22 @@ def test_fb_batch_gradient_factored_precision(ci):
     b.close(); eng.close()
 
 
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_fb_batch_gradient_fast32_precision(ci):
+    """FAST32 (opt-in): both dense contractions on the f32 MFMA, f64 everywhere else.  The bound
+    asserted here (1e-5) is what demonstrates the 1e-4 contract for this mode."""
+    c = Case(seed=100 + ci, precision=3, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-5 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-6 * np.abs(ozx).max()
+    err = np.abs(g - og).max() / np.abs(og).max()
+    assert err <= REL_CONTRACT and err <= 1e-5, err
+    b.close(); eng.close()
+
+
 def test_lattice_arcs_bit_exact(case):
     c, eng, b = case
     for u, T in enumerate(c.Ts):
@@ -227,9 +243,13 @@ def test_two_lane_pipeline_equals_single_lane(monkeypatch):
             b.close(); eng.close()
     for i in (0, 1):
         n1, z1, g1, s1 = res[i]; n2, z2, g2, s2 = res[i + 2]
-        assert np.array_equal(n1, n2) and np.array_equal(z1, z2)
-        np.testing.assert_allclose(g1, g2, rtol=1e-12, atol=1e-12 * np.abs(g1).max())
-        np.testing.assert_allclose(s1, s2, rtol=1e-12)
+        if i == 0:   # EXACT: per-utterance scalars do not depend on the chunking at all
+            assert np.array_equal(n1, n2) and np.array_equal(z1, z2)
+        else:        # FACTORED: the running prefix of the average block starts at the chunk's first frame
+            np.testing.assert_allclose(n1, n2, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(z1, z2, rtol=1e-11)
+        np.testing.assert_allclose(g1, g2, rtol=1e-9, atol=1e-10 * np.abs(g1).max())
+        np.testing.assert_allclose(s1, s2, rtol=1e-10)
     og, on, oz = Case(**kw).oracle_gradient()
     assert np.abs(res[2][2] - og).max() / np.abs(og).max() < 1e-9
 

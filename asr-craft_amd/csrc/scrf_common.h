@@ -95,4 +95,26 @@ struct ScrfLinEpilogue {
   uint32_t u0, u1;
 };
 
+// Fused window synthesis (scrf_fused.hip).  Row tiles are described once per batch on the host:
+// score tiles are the windows of TB = 256/D whole frames, expected-count tiles any 64 consecutive
+// windows of an utterance.
+struct ScrfTileDesc {
+  uint64_t row_abs;   // batch row of the tile's first window (seg_off[u] + r0)
+  uint64_t fr_abs;    // batch index of the first raw frame staged (frame_off[u] + t0 - back)
+  uint32_t r0;        // first row inside the utterance
+  uint32_t t0;        // first frame whose windows the tile touches
+  uint16_t back;      // min(t0, D-1): frames staged before t0
+  uint16_t nfr;       // frames touched
+  uint16_t nrows;
+  uint16_t pad_;
+};
+struct ScrfFusedArgs {
+  const float* frames;        // stream-0 raw frames of the batch, [sum T][W]
+  const ScrfTileDesc* tiles;  // all tiles of the batch
+  uint64_t tile0;             // first tile of the chunk
+  uint64_t row_base;          // seg_off[u0], frame_off[u0] of the chunk
+  uint64_t frame_base;
+  uint32_t TB, W;
+};
+
 #endif  // SCRF_COMMON_H_

@@ -82,6 +82,7 @@ struct scrf_engine_s {
   double* d_sums2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 2;
+  bool fuse_windows = true;
   std::string err;
   bool timing = false;
   hipEvent_t ev[SCRF_N_PHASES + 1][2];
@@ -113,6 +114,10 @@ struct scrf_batch_s {
   double* d_numer = nullptr;
   double* d_zx = nullptr;
   int* d_status = nullptr;
+  // fused window synthesis: row tiles of the score kernel [0] and of the expected-count kernel [1]
+  bool fused_ok = false;
+  std::vector<uint64_t> tile_off[2];
+  ScrfTileDesc* d_tiles[2] = {nullptr, nullptr};
   ScrfBatchView view() const {
     ScrfBatchView v;
     v.U = U; v.T = d_T; v.frame_off = d_frame_off; v.seg_off = d_seg_off; v.arc_off = d_arc_off;
@@ -198,7 +203,8 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   h->lay = lay;
   h->device = cfg->device_id;
   if (h->cfg.scratch_bytes == 0) h->cfg.scratch_bytes = 8ull << 30;
-  if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knob
+  if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knobs
+  if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
   memset(h->ms, 0, sizeof(h->ms));
   memset(h->nlaunch, 0, sizeof(h->nlaunch));
 #define CRCHK(call)                                                                          \
@@ -412,6 +418,7 @@ extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows);
   for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
   hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
+  hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]);
   delete b;
   return SCRF_OK;
 }
@@ -502,13 +509,56 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
         so[u + 1] = so[u] + utts[u].T + pad;
       }
       BCHK(upload(h, &b->d_sframe_off[s], so.data(), n + 1));
-      BCHK(upload<float>(h, &b->d_frames[s], nullptr, so[n] * recipes[s].in_width));
+      BCHK(upload<float>(h, &b->d_frames[s], nullptr, so[n] * recipes[s].in_width + 64));  // tail pad: wide loads may over-read 12 B
       HIPCHK(h, hipStreamSynchronize(h->stream));
       for (uint32_t u = 0; u < n; u++) {
         hipError_t e = hipMemcpyAsync(b->d_frames[s] + so[u] * recipes[s].in_width, utts[u].frames[s],
                                       sizeof(float) * (so[u + 1] - so[u]) * recipes[s].in_width, hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "frame upload failed: %s", hipGetErrorString(e)); }
       }
+    }
+  }
+  // fused window synthesis: one segment-recipe stream without context whose window is exactly
+  // the state feature range, no transition features
+  if (!by_windows && n_streams == 1 && !lay.use_tf && lay.use_sf && recipes[0].extract_seg_ftr &&
+      !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 && lay.nsfe == 8 * recipes[0].in_width + lay.D &&
+      lay.nsfe == lay.F && fused_supported(lay, recipes[0].in_width)) {
+    b->fused_ok = true;
+    // score tiles: the windows of TB whole frames; expected-count tiles: 64 consecutive windows
+    const uint32_t D = lay.D, TB = SCRF_FUSED_ROWS_SCORES / D;
+    for (int k = 0; k < 2; k++) {
+      std::vector<ScrfTileDesc> td;
+      b->tile_off[k].assign(n + 1, 0);
+      for (uint32_t u = 0; u < n; u++) {
+        const uint32_t T = b->T[u];
+        const uint64_t nseg = scrf_seg_base(T, D);
+        uint32_t t = 0;
+        for (uint64_t r0 = 0; r0 < nseg;) {
+          ScrfTileDesc q;
+          memset(&q, 0, sizeof(q));
+          uint32_t t_end;   // one past the last frame touched
+          uint64_t r1;
+          if (k == 0) {
+            t_end = std::min(T, t + TB);
+            r1 = scrf_seg_base(t_end, D);
+          } else {
+            while (scrf_seg_base(t + 1, D) <= r0) t++;
+            r1 = std::min(nseg, r0 + SCRF_FUSED_ROWS_EXPF);
+            t_end = t;
+            while (scrf_seg_base(t_end, D) < r1) t_end++;
+          }
+          q.r0 = (uint32_t)r0; q.t0 = t; q.back = (uint16_t)std::min(t, D - 1);
+          q.nfr = (uint16_t)(t_end - t); q.nrows = (uint16_t)(r1 - r0);
+          q.row_abs = b->seg_off[u] + r0;
+          q.fr_abs = b->frame_off[u] + t - q.back;
+          td.push_back(q);
+          r0 = r1;
+          if (k == 0) t = t_end;
+        }
+        b->tile_off[k][u + 1] = td.size();
+      }
+      BCHK(upload(h, &b->d_tiles[k], td.data(), td.size()));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
     }
   }
   BCHK(upload<double>(h, &b->d_numer, nullptr, n));
@@ -575,6 +625,7 @@ struct ChunkBufs {
   double* slab_atb = nullptr;
   uint32_t nch_atb = 0;
   uint64_t rpc_atb = 0;
+  bool fused = false;        // window synthesis fused into the contractions (no X)
   // recipe-factorised path
   bool factored = false;
   uint32_t XF = 0;           // row width of X (num_feas, or 2W+D for the factored image)
@@ -589,7 +640,7 @@ struct ChunkBufs {
   uint64_t rpc_l = 0;
 };
 
-struct Need { bool fb, post, beta, vit; bool factored = false; };
+struct Need { bool fb, post, beta, vit; bool factored = false; bool fused = false; };
 
 // recipe-factorised path: one segment-recipe stream without context whose window is exactly the
 // state feature range, no transition features
@@ -604,6 +655,12 @@ static ScrfGemmSpec spec_mm(const ScrfLayout& l, uint32_t W) {
   return ScrfGemmSpec{0, 0, 2 * W + l.D, (uint32_t)l.use_sb, l.sbv, 6 * W, 0};
 }
 static ScrfGemmSpec spec_lin(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0.0, 0, W}; }
+// fused path: the five sampled blocks as per-frame projections (outputs (k, label), k < 5), and
+// the dense column groups [avg | max | min | onehot(d)] + bias
+static ScrfGemmSpec spec_samples(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0.0, 0, W}; }
+static ScrfGemmSpec spec_dense(const ScrfLayout& l, uint32_t W) {
+  return ScrfGemmSpec{0, 0, 3 * W + l.D, (uint32_t)l.use_sb, l.sbv, 5 * W, 0};
+}
 
 static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t nfr, uint64_t nseg, const Need& nd) {
   const ScrfLayout& l = h->lay;
@@ -618,6 +675,9 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
       tot += pad256((nfr + nutt) * 6 * l.L * sizeof(double)) + pad256((nfr + nutt) * 8);  // Z, slot rows
       tot += pad256((size_t)256 * 6 * l.L * W0 * sizeof(double));  // slab of the final contraction
     }
+  } else if (nd.fused) {
+    tot += pad256(nfr * 5 * l.L * sizeof(double));                // P (scores) / Z (counts)
+    if (nd.post) tot += pad256((size_t)256 * 5 * l.L * W0 * sizeof(double));
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
   tot += pad256(nseg * l.L * sizeof(double));                       // S
   if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
@@ -642,7 +702,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
         tot += pad256(nutt * LL * sizeof(double));
       }
       const uint64_t rpc_s = expf_rows_per_chunk(nseg);
-      uint64_t nch_s = (nseg + rpc_s - 1) / rpc_s;
+      uint64_t nch_s = nd.fused ? 512 : (nseg + rpc_s - 1) / rpc_s;
       tot += pad256(nch_s * l.L * l.nsf * sizeof(double));
     }
   }
@@ -692,8 +752,19 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       cb->nch_l = (uint32_t)((nslots + cb->rpc_l - 1) / cb->rpc_l);
       cb->slab_l = a.take<double>((size_t)256 * 6 * l.L * W0);
     }
+  } else if (nd.fused) {
+    const uint32_t W0 = b->recipe[0].in_width;
+    cb->X = nullptr;
+    cb->P = a.take<double>(nfr * 5 * l.L);
+    cb->Z = cb->P;  // the projections are dead once the scores exist
+    if (nd.post) {
+      cb->rpc_l = ((nfr + 255) / 256 + 31) & ~31ull;
+      cb->nch_l = (uint32_t)((nfr + cb->rpc_l - 1) / cb->rpc_l);
+      cb->slab_l = a.take<double>((size_t)256 * 5 * l.L * W0);
+    }
   } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
+  cb->fused = nd.fused;
   cb->S = a.take<double>(nseg * l.L);
   if (l.use_tf) {
     cb->M = a.take<double>(nfr * LL);
@@ -741,7 +812,8 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       }
       cb->rpc_s = expf_rows_per_chunk(nseg);
       cb->nch_s = (uint32_t)((nseg + cb->rpc_s - 1) / cb->rpc_s);
-      cb->slab_s = a.take<double>((size_t)cb->nch_s * l.L * l.nsf);
+      if (nd.fused) cb->nch_s = fused_expf_blocks(b->tile_off[1][u1] - b->tile_off[1][u0]);
+      cb->slab_s = a.take<double>((size_t)(nd.fused ? 512 : cb->nch_s) * l.L * l.nsf);
     }
   }
   if (nd.vit) {
@@ -769,6 +841,19 @@ struct PhaseTimer {
     h->nlaunch[ph] += launches;
   }
 };
+
+static ScrfFusedArgs fused_args(scrf_handle h, scrf_batch b, uint32_t u0, int which) {
+  ScrfFusedArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.frames = b->d_frames[0];
+  fa.tiles = b->d_tiles[which];
+  fa.tile0 = b->tile_off[which][u0];
+  fa.row_base = b->seg_off[u0];
+  fa.frame_base = b->frame_off[u0];
+  fa.W = b->recipe[0].in_width;
+  fa.TB = SCRF_FUSED_ROWS_SCORES / h->lay.D;
+  return fa;
+}
 
 // windows + exact scores of a chunk (both training and decode start here)
 static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool fast = false, int f32 = 0) {
@@ -799,6 +884,18 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
       nl += 2;
     }
     tm.stop(nl);
+    HIPCHK(h, hipGetLastError());
+    return SCRF_OK;
+  }
+  if (cb.fused) {
+    PhaseTimer tm(h, PH_SCORE, cb.st);
+    const uint32_t W0 = b->recipe[0].in_width;
+    ScrfFusedArgs fa = fused_args(h, b, u0, 0);
+    // per-frame projections of the five sampled blocks, then the dense part + gather
+    launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
+                       spec_samples(W0), 5 * l.L, cb.P);
+    launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32);
+    tm.stop(2);
     HIPCHK(h, hipGetLastError());
     return SCRF_OK;
   }
@@ -895,6 +992,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
   const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
   nd.factored = h->cfg.train_precision == SCRF_PREC_FACTORED && factored_ok(h, b);
+  nd.fused = fast && !nd.factored && b->fused_ok && h->fuse_windows;
 
   // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
   // at least four chunks so that both streams always have work
@@ -952,6 +1050,14 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
         launch_expf_mfma(cb.st, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
                          spec_lin(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 3;
+      } else if (cb.fused) {
+        const uint32_t W0 = b->recipe[0].in_width;
+        ScrfFusedArgs fa = fused_args(h, b, u0, 1);
+        launch_expf_fused(cb.st, fa, l, cb.AD, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
+        launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.AD, cb.Z);
+        launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
+                         spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
+        nl += 2;
       } else if (fast) launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
       else launch_expf_gemm(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
       if (l.use_tf) {
@@ -968,6 +1074,10 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
         const uint32_t W0 = b->recipe[0].in_width;
         launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_mm(l, W0), cb.grad);
         launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 6 * l.L, l, spec_lin(W0), cb.grad);
+      } else if (cb.fused) {
+        const uint32_t W0 = b->recipe[0].in_width;
+        launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
+        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 5 * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
       if (l.use_tf) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
       else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad);

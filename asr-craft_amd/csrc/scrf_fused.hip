@@ -1,0 +1,681 @@
+// scrf_fused.hip -- the two state contractions with the segment-window synthesis fused in.
+//
+// Why: the window image X is 9.7 MB per config-2 utterance (7200 windows x 337 floats) against
+// 47 KB of raw frames.  Materialising it costs 12.5 ms per 4096 utterances to write, as much again
+// per contraction to read back, and 337-deep fp64 MFMA contractions of 12 ms each.  The recipe
+// (io/CRF_InFtrStream_SeqMultiWindow.cpp:556-884) has structure:
+//
+//   x(t,d) = [ F[b+s_0(d)] .. F[b+s_4(d)] | avg | max | min | onehot(d) ],  b = t-d+1,
+//            s_k(d) = ceil(float(0.1 d) * (2k+1)) - 1
+//
+// * the five sampled blocks are COPIES of raw frames, so their share of the score is a sum of
+//   per-frame projections P[f][k][o] = F[f] . W_k[o] (one small MFMA contraction over frames), and
+//   their share of the expected counts is Z_k^T F with Z_k[f][o] = sum of R over the windows whose
+//   k-th sample is frame f.  Both are exact re-associations of the same fp64 products.
+// * avg / max / min are rebuilt per row tile in LDS from the raw frames with the reference's float
+//   arithmetic (running sum from the last frame backwards, divided by the length) and contracted
+//   on the MFMA there; the one-hot duration block and the bias are an epilogue add in the score
+//   kernel and two more column groups of the expected-count kernel.
+//
+// X never exists in HBM and the dense depth drops from 8W+D to 3W (scores) / 3W+D+1 (counts).
+#include "scrf_kernels.h"
+
+#include <math.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+#define FU_GC 40        // columns per dense chunk of the score kernel
+#define FU_XS 42        // float row stride of the chunk image (== 2 mod 4: conflict-free A fragments)
+#define FU_WS 49        // row stride of the transposed lambda image
+#define FU_ROWS SCRF_FUSED_ROWS_SCORES
+#define FE_ROWS SCRF_FUSED_ROWS_EXPF
+#define FE_RS 50        // double row stride of the R image
+
+__host__ __device__ inline uint32_t fu_sample_step(uint32_t d, int k) {
+  const float ot = (float)((double)d * 0.1);
+  return (uint32_t)ceilf(ot * (float)(2 * k + 1)) - 1u;
+}
+__device__ __forceinline__ uint32_t fu_div(uint32_t i, uint32_t magic) { return __umulhi(i, magic); }
+__device__ __forceinline__ uint32_t fu_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+// A row tile (ScrfTileDesc, built on the host with the batch): rows [r0, r0+nrows) of an utterance,
+// touching frames t0 .. t0+nfr-1; raw frames are staged from f0 = t0 - back.
+struct FuTile {
+  uint32_t t0, nfr, nrows, f0, r0;
+  uint64_t row0;  // chunk-relative row of the tile's first window
+  uint64_t fr0;   // chunk-relative index of frame f0
+};
+__device__ __forceinline__ FuTile fu_tile(const ScrfFusedArgs& fa, const ScrfTileDesc& q) {
+  FuTile ft;
+  ft.t0 = q.t0; ft.nfr = q.nfr; ft.nrows = q.nrows; ft.f0 = q.t0 - q.back; ft.r0 = q.r0;
+  ft.row0 = q.row_abs - fa.row_base;
+  ft.fr0 = q.fr_abs - fa.frame_base;
+  return ft;
+}
+
+// Window statistics of one (frame, column): the values F[t-j][c], j = 0 .. nd-1, are read from LDS
+// in one batch (no load sits inside the dependent chain), then walked with compile-time durations.
+// The window average is sum / d in float: q0 = sum * y, r = fma(-q0, d, sum), q = fma(r, y, q0) with
+// y the correctly rounded 1/d (a compile-time constant here) is the correctly rounded quotient
+// (Markstein), i.e. the same float as the reference's division, at a third of the instructions.
+// Results for durations outside [d_lo, d_hi] go to `dump` (a spare LDS row) instead of a branch.
+template <int DMAX>
+__device__ __forceinline__ void fu_load_vals(const float* last, uint32_t W, uint32_t nd, float (&v)[DMAX]) {
+#pragma unroll
+  for (int j = 0; j < DMAX; j++) v[j] = *(last - min((uint32_t)j, nd - 1) * W);
+}
+template <int DMAX>
+__device__ __forceinline__ void fu_scan_avg(const float (&v)[DMAX], float* o, uint32_t stride, uint32_t d_lo,
+                                            uint32_t d_hi, float* dump) {
+  float a = 0.0f;
+#pragma unroll
+  for (int j = 0; j < DMAX; j++) {
+    a = __fadd_rn(a, v[j]);
+    const float df = (float)(j + 1), y = 1.0f / df;
+    const float q0 = __fmul_rn(a, y);
+    const float q = __fmaf_rn(__fmaf_rn(-q0, df, a), y, q0);
+    float* w = ((uint32_t)(j + 1) >= d_lo && (uint32_t)(j + 1) <= d_hi) ? o + j * stride : dump;
+    *w = q;
+  }
+}
+template <int DMAX, int IS_MAX>
+__device__ __forceinline__ void fu_scan_ext(const float (&v)[DMAX], float* o, uint32_t stride, uint32_t d_lo,
+                                            uint32_t d_hi, float* dump) {
+  float a = v[0];
+#pragma unroll
+  for (int j = 0; j < DMAX; j++) {
+    if (IS_MAX) { if (v[j] > a) a = v[j]; } else { if (v[j] < a) a = v[j]; }
+    float* w = ((uint32_t)(j + 1) >= d_lo && (uint32_t)(j + 1) <= d_hi) ? o + j * stride : dump;
+    *w = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scores_fused: S[row][o] = dense(avg|max|min) + sum_k P[b+s_k(d)][k][o] + lambda_dur[d][o] + bias.
+// Workgroup (512 threads) = the windows of TB = 256/D whole frames (<= 256 rows); wave w owns rows
+// [32w, 32w+32) x 48 outputs (2 x 3 MFMA tiles).  The three dense groups are rebuilt 40 columns at
+// a time (one thread per (frame, column)); the next chunk's lambda slice is fetched under the MFMAs.
+// After the last chunk the tile's rows of P are staged over the dead operand images for the gather.
+// ------------------------------------------------------------------------------------------
+#define FU_NT 512
+template <int DMAX, int F32>
+__global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, ScrfLayout lay,
+                                                           const double* __restrict__ lambda,
+                                                           const double* __restrict__ P, uint32_t n_out,
+                                                           double* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const uint32_t W = fa.W, D = lay.D;
+  const uint32_t nfmax = fa.TB + D - 1;
+  float* Xg = (float*)fsm;                                              // [256 + dump row][FU_XS]
+  double* Wg = (double*)(fsm + sizeof(float) * (FU_ROWS + 1) * FU_XS);  // [40][FU_WS] (floats when F32)
+  double* Pl = (double*)fsm;                                            // [nfmax][5][48], aliases Xg/Wg
+  size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS;
+  const size_t pb = sizeof(double) * nfmax * 240;
+  if (pb > opn) opn = pb;
+  float* fr = (float*)(fsm + ((opn + 15) & ~(size_t)15));               // [nfmax][W]
+  uint16_t* rfirst = (uint16_t*)(fr + nfmax * W);
+  uint16_t* rbase = rfirst + FU_ROWS;
+  uint8_t* rdur = (uint8_t*)(rbase + FU_ROWS);
+  uint8_t* steps = rdur + FU_ROWS;                                      // [D][5]
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t o0 = blockIdx.y * 48;
+  const FuTile ft = fu_tile(fa, fa.tiles[fa.tile0 + blockIdx.x]);
+  float* Wgf = (float*)Wg;
+  const uint32_t cpg = (W + FU_GC - 1) / FU_GC;  // chunks per group
+  // lambda chunk prefetch registers: element e = tid + 512*q of the [48][40] chunk
+  double wp[4];
+  auto load_w = [&](uint32_t ci) {
+    const uint32_t ty = ci / cpg, c0 = (ci % cpg) * FU_GC;
+    const uint32_t nc = min((uint32_t)FU_GC, W - c0);
+    const uint32_t woff = (5 + ty) * W + c0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t e = tid + FU_NT * q, ol = e / FU_GC, c = e % FU_GC;
+      wp[q] = (e < 48 * FU_GC && o0 + ol < n_out && c < nc) ? lambda[lay.state_idx(o0 + ol) + woff + c] : 0.0;
+    }
+  };
+  load_w(0);
+
+  // stage raw frames f0 .. t0+nfr-1 (loads batched ahead of the LDS stores), decode rows
+  {
+    const float* src = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
+    const uint32_t n = (ft.t0 + ft.nfr - ft.f0) * W;
+    for (uint32_t i0 = 0; i0 < n; i0 += 4 * FU_NT) {
+      float tmp[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) tmp[q] = (i0 + tid + FU_NT * q < n) ? src[i0 + tid + FU_NT * q] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (i0 + tid + FU_NT * q < n) fr[i0 + tid + FU_NT * q] = tmp[q];
+    }
+    for (uint32_t i = tid; i < ft.nfr * D; i += FU_NT) {
+      const uint32_t tl = i / D, d = i % D + 1;
+      const uint32_t t = ft.t0 + tl;
+      if (d <= scrf_node_max_dur(t, D)) {
+        const uint32_t row = (uint32_t)(scrf_seg_base(t, D) - ft.r0) + d - 1;
+        rfirst[row] = (uint16_t)(t - d + 1 - ft.f0);
+        rdur[row] = (uint8_t)d;
+      }
+    }
+    for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
+    for (uint32_t i = tid; i < D * 5; i += FU_NT) steps[i] = (uint8_t)fu_sample_step(i / 5 + 1, i % 5);
+    // rows past the tile and pad columns of the chunk image stay zero for the whole kernel
+    for (uint32_t i = tid; i < (FU_ROWS + 1) * FU_XS; i += FU_NT) Xg[i] = 0.0f;
+  }
+  __syncthreads();
+
+  v4f64 acc[F32 ? 1 : 2][F32 ? 1 : 3];
+  v4f32 acc32[F32 ? 2 : 1][F32 ? 3 : 1];
+#pragma unroll
+  for (int m = 0; m < (F32 ? 1 : 2); m++)
+#pragma unroll
+    for (int n = 0; n < (F32 ? 1 : 3); n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < (F32 ? 2 : 1); m++)
+#pragma unroll
+    for (int n = 0; n < (F32 ? 3 : 1); n++) acc32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+
+  float* dump = Xg + FU_ROWS * FU_XS + FU_GC;   // pad column of the spare row: never an operand
+  for (uint32_t ci = 0; ci < 3 * cpg; ci++) {
+    const uint32_t ty = ci / cpg, c0 = (ci % cpg) * FU_GC;   // 0 avg, 1 max, 2 min
+    const uint32_t nc = min((uint32_t)FU_GC, W - c0);
+    // a narrower last chunk of a group leaves stale columns behind: clear them
+    if (nc < FU_GC && cpg > 1)
+      for (uint32_t i = tid; i < ft.nrows * (FU_GC - nc); i += FU_NT) {
+        const uint32_t row = i / (FU_GC - nc), c = nc + i % (FU_GC - nc);
+        Xg[row * FU_XS + c] = 0.0f;
+      }
+    for (uint32_t i = tid; i < ft.nfr * nc; i += FU_NT) {
+      const uint32_t tl = i / nc, c = i % nc;
+      const uint32_t t = ft.t0 + tl;
+      const uint32_t nd = scrf_node_max_dur(t, D);
+      float v[DMAX];
+      fu_load_vals<DMAX>(fr + (t - ft.f0) * W + c0 + c, W, nd, v);
+      float* o = Xg + rbase[tl] * FU_XS + c;
+      if (ty == 0) fu_scan_avg<DMAX>(v, o, FU_XS, 1, nd, dump);
+      else if (ty == 1) fu_scan_ext<DMAX, 1>(v, o, FU_XS, 1, nd, dump);
+      else fu_scan_ext<DMAX, 0>(v, o, FU_XS, 1, nd, dump);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t e = tid + FU_NT * q, ol = e / FU_GC, c = e % FU_GC;
+      if (e < 48 * FU_GC) {
+        if (F32) Wgf[c * (2 * FU_WS) + ol] = (float)wp[q];
+        else Wg[c * FU_WS + ol] = wp[q];
+      }
+    }
+    __syncthreads();
+    if (ci + 1 < 3 * cpg) load_w(ci + 1);   // lands under the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < FU_GC / 4; ks++) {
+      if (F32) {
+        float b[3];
+#pragma unroll
+        for (int n = 0; n < 3; n++) b[n] = Wgf[(ks * 4 + lk) * (2 * FU_WS) + n * 16 + li];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const float a = Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
+#pragma unroll
+          for (int n = 0; n < 3; n++)
+            acc32[F32 ? m : 0][F32 ? n : 0] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc32[F32 ? m : 0][F32 ? n : 0], 0, 0, 0);
+        }
+      } else {
+        double b[3];
+#pragma unroll
+        for (int n = 0; n < 3; n++) b[n] = Wg[(ks * 4 + lk) * FU_WS + n * 16 + li];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const double a = (double)Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
+#pragma unroll
+          for (int n = 0; n < 3; n++)
+            acc[F32 ? 0 : m][F32 ? 0 : n] =
+                __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // stage the tile's projections: Pl[f - f0][k][ol] = P[frame f][k * n_out + o0 + ol]; threads
+  // 0..239 and 240..479 take alternate frames, four frames in flight per thread
+  {
+    const uint32_t nf = ft.t0 + ft.nfr - ft.f0;
+    const uint32_t half = tid / 240, e = tid % 240, k = e / 48, ol = e % 48;
+    const double* src = P + ft.fr0 * (uint64_t)(5 * n_out) + k * n_out + o0 + ol;
+    const bool live = tid < 480 && o0 + ol < n_out;
+    for (uint32_t f0 = half; f0 < nf; f0 += 8) {
+      double tmp[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) tmp[q] = (live && f0 + 2 * q < nf) ? src[(uint64_t)(f0 + 2 * q) * 5 * n_out] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (tid < 480 && f0 + 2 * q < nf) Pl[(f0 + 2 * q) * 240 + e] = tmp[q];
+    }
+  }
+  __syncthreads();
+  // epilogue: + sampled-frame projections + one-hot duration weight + bias (all fp64), write S
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t rl = wave * 32 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
+      if (rl >= ft.nrows) continue;
+      const uint32_t d = rdur[rl], b0 = rfirst[rl];
+      const uint8_t* sp = steps + (d - 1) * 5;
+      const uint32_t q0 = (b0 + sp[0]) * 240, q1 = (b0 + sp[1]) * 240 + 48, q2 = (b0 + sp[2]) * 240 + 96,
+                     q3 = (b0 + sp[3]) * 240 + 144, q4 = (b0 + sp[4]) * 240 + 192;
+#pragma unroll
+      for (int n = 0; n < 3; n++) {
+        const uint32_t ol = n * 16 + li, o = o0 + ol;
+        if (o >= n_out) continue;
+        const double* wl = lambda + lay.state_idx(o) + 8 * W;  // duration block, then the bias weight
+        const double lin = (((Pl[q0 + ol] + Pl[q1 + ol]) + Pl[q2 + ol]) + Pl[q3 + ol]) + Pl[q4 + ol];
+        const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
+        double s = (v + lin) + wl[d - 1];
+        if (lay.use_sb) s += wl[D] * lay.sbv;
+        S[(ft.row0 + rl) * n_out + o] = s;
+      }
+    }
+}
+
+static size_t fused_scores_smem(uint32_t W, uint32_t D) {
+  const uint32_t TB = FU_ROWS / D, nfmax = TB + D - 1;
+  size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS;
+  const size_t pb = sizeof(double) * nfmax * 240;
+  if (pb > opn) opn = pb;
+  opn = (opn + 15) & ~(size_t)15;
+  return opn + sizeof(float) * nfmax * W + sizeof(uint16_t) * 2 * FU_ROWS + FU_ROWS + D * 5 + 64;
+}
+
+template <int DMAX, int F32>
+static void launch_scores_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
+                                  const double* P, uint64_t n_tiles, double* S) {
+  const size_t sm = fused_scores_smem(fa.W, lay.D);
+  dim3 grid((uint32_t)n_tiles, (lay.L + 47) / 48);
+  hipFuncSetAttribute((const void*)k_scores_fused<DMAX, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL((k_scores_fused<DMAX, F32>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S);
+}
+
+void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
+                         const double* P, uint64_t n_tiles, double* S, int f32) {
+  if (n_tiles == 0) return;
+#define FS_GO(N)                                                                        \
+  do {                                                                                  \
+    if (f32) launch_scores_fused_t<N, 1>(st, fa, lay, lambda, P, n_tiles, S);            \
+    else launch_scores_fused_t<N, 0>(st, fa, lay, lambda, P, n_tiles, S);                \
+  } while (0)
+  if (lay.D <= 12) FS_GO(12);
+  else if (lay.D <= 25) FS_GO(25);
+  else FS_GO(40);
+#undef FS_GO
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lin_z: Z[f][k][o] = sum_d R[(t = f + off_k(d), d)][o], off_k(d) = d - 1 - s_k(d): the windows
+// whose k-th sampled frame is f.  One thread per (utterance, k, o) walks the utterance once with a
+// private ring of D partial sums in LDS; frame f is final once t = f + D - 1 has been added.
+// The adds are LDS ds_add_f64 (no return, so they pipeline); every address belongs to one thread
+// and LDS operations of a wave complete in order, so the sum order is fixed (t, then d ascending).
+// The next frame's R rows are fetched into registers while the current ones are added.
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_lin_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0,
+                                               const double* __restrict__ R, double* __restrict__ Z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const uint32_t D = lay.D, L = lay.L;
+  double* ring = (double*)fsm;                         // [D][256]
+  const uint32_t tid = threadIdx.x;
+  const uint32_t u = u0 + blockIdx.x;
+  const uint32_t T = bv.T[u];
+  const uint32_t k = tid / 48, ol = tid % 48, o = blockIdx.y * 48 + ol;
+  if (k >= 5 || o >= L) return;
+  for (uint32_t s = 0; s < D; s++) ring[s * 256 + tid] = 0.0;
+  // off_k(d) is non-decreasing in d with steps of 0 or 1: bit d-1 set = off_k(d) > off_k(d-1)
+  uint64_t inc = 0;
+  {
+    uint32_t prev = 0;
+    for (uint32_t d = 2; d <= D; d++) {
+      const uint32_t of = d - 1 - fu_sample_step(d, (int)k);
+      if (of != prev) inc |= 1ull << (d - 1);
+      prev = of;
+    }
+  }
+  const double* Ru = R + (bv.seg_off[u] - bv.seg_off[u0]) * (uint64_t)L + o;
+  double* Zu = Z + (bv.frame_off[u] - bv.frame_off[u0]) * (uint64_t)(5 * L) + k * L + o;
+  double* rg = ring + tid;
+  double r[DMAX], rn[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; d++) r[d] = (d < 1) ? Ru[0] : 0.0;   // frame 0 has one window
+  uint32_t tm = 0;  // t mod D
+  for (uint32_t t = 0; t < T; t++) {
+    const uint32_t nd = scrf_node_max_dur(t, D);
+    const uint32_t nd1 = (t + 1 < T) ? scrf_node_max_dur(t + 1, D) : 0;
+    const double* Rn = Ru + scrf_seg_base(t + 1, D) * (uint64_t)L;
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) rn[d] = ((uint32_t)d < nd1) ? Rn[(uint64_t)d * L] : 0.0;
+    uint32_t s = tm;
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) {
+      if ((uint32_t)d < nd) {
+        if (d > 0 && ((inc >> d) & 1)) s = s ? s - 1 : D - 1;
+        __hip_atomic_fetch_add(rg + s * 256, r[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    // frame f = t - (D-1) can receive nothing more: its slot is the one t+1 will reuse
+    const uint32_t sn = (tm + 1 == D) ? 0 : tm + 1;
+    if (t + 1 >= D) {
+      Zu[(uint64_t)(t + 1 - D) * (5 * L)] = rg[sn * 256];
+      rg[sn * 256] = 0.0;
+    }
+    tm = sn;
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) r[d] = rn[d];
+  }
+  // flush the frames still open: f = max(0, T-D+1) .. T-1
+  for (uint32_t f = (T >= D) ? T - D + 1 : 0; f < T; f++) Zu[(uint64_t)f * (5 * L)] = rg[(f % D) * 256];
+}
+
+void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                  const double* R, double* Z) {
+  if (n_utts == 0) return;
+  const size_t sm = sizeof(double) * lay.D * 256 + 16;
+  dim3 grid(n_utts, (lay.L + 47) / 48);
+#define LZ_GO(N)                                                                                          \
+  do {                                                                                                    \
+    hipFuncSetAttribute((const void*)k_lin_z<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);   \
+    hipLaunchKernelGGL(k_lin_z<N>, grid, dim3(256), sm, st, lay, bv, u0, R, Z);                           \
+  } while (0)
+  if (lay.D <= 8) LZ_GO(8);
+  else if (lay.D <= 16) LZ_GO(16);
+  else if (lay.D <= 25) LZ_GO(25);
+  else if (lay.D <= 32) LZ_GO(32);
+  else LZ_GO(40);
+#undef LZ_GO
+}
+
+// ------------------------------------------------------------------------------------------
+// k_expf_fused: slab[block][o][f] = sum_rows R[row][o] * x[row][f] over the dense column groups
+// f in [avg | max | min | onehot(d) | bias]   (M = outputs, N = columns, K = rows).
+// Persistent workgroups (256 threads, two per CU) walk 64-row tiles (any 64 consecutive windows of
+// an utterance); the dense columns of the tile are rebuilt in LDS, R is staged through LDS once
+// per tile.  The next tile's R and raw frames are fetched into registers under the MFMAs (issued
+// after the barrier: a barrier drains outstanding loads on gfx9).  The 3 x n_ct output tiles are
+// dealt round-robin to the 4 waves (slot q = wave + 4j -> output tile q % 3, column tile q / 3);
+// the partial sums stay in registers for the whole launch.  The k-loop is software pipelined by
+// hand: operands of step ks+1 are in flight while the MFMAs of step ks issue.
+// ------------------------------------------------------------------------------------------
+#define FE_NT 256
+#define FE_NRP 12       // R elements per thread in prefetch registers (64*48 / 256)
+#define FE_NFP 6        // raw-frame floats per thread held in prefetch registers
+
+// one wave's share of a tile: slot j = output tile (wave + j) % 3 (== (wave + 4j) % 3), column tile
+// (wave + 4j) / 3.  The three R^T fragments are loaded in the wave's rotation, so slot j always
+// multiplies register a[j % 3]; every LDS address is a per-slot base + a compile-time offset.
+template <int NT, int F32, uint32_t XS>
+__device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, uint32_t wave, uint32_t lk,
+                                             uint32_t li, uint32_t n_ot, v4f64* acc, v4f32* acc32) {
+  const float* ap32[3];
+  const double* ap[3];
+  const float* bp[NT];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const uint32_t n = (wave + i) % 3;
+    ap[i] = Rs + lk * FE_RS + n * 16 + li;
+    ap32[i] = (const float*)Rs + lk * (2 * FE_RS) + n * 16 + li;
+  }
+  // slots past the last output tile repeat its column tile (their sums are never written)
+#pragma unroll
+  for (int j = 0; j < NT; j++) bp[j] = Xs + lk * XS + li + (min(wave + 4 * j, n_ot - 1) / 3) * 16;
+  double a_n[3];
+  float af_n[3], b_n[NT];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { if (F32) af_n[i] = *ap32[i]; else a_n[i] = *ap[i]; }
+#pragma unroll
+  for (int j = 0; j < NT; j++) b_n[j] = *bp[j];
+#pragma unroll
+  for (int ks = 0; ks < FE_ROWS / 4; ks++) {
+    double a[3], bd[F32 ? 1 : NT];
+    float af[3], b[F32 ? NT : 1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { a[i] = a_n[i]; af[i] = af_n[i]; }
+#pragma unroll
+    for (int j = 0; j < NT; j++) { if (F32) b[F32 ? j : 0] = b_n[j]; else bd[F32 ? 0 : j] = (double)b_n[j]; }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < FE_ROWS / 4) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        if (F32) af_n[i] = ap32[i][(ks + 1) * 4 * (2 * FE_RS)];
+        else a_n[i] = ap[i][(ks + 1) * 4 * FE_RS];
+      }
+#pragma unroll
+      for (int j = 0; j < NT; j++) b_n[j] = bp[j][(ks + 1) * 4 * XS];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      if (F32) acc32[F32 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j % 3], b[F32 ? j : 0], acc32[F32 ? j : 0], 0, 0, 0);
+      else acc[F32 ? 0 : j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j % 3], bd[F32 ? 0 : j], acc[F32 ? 0 : j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NT, int DMAX, int F32>
+__global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R,
+                                                         uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
+                                                         uint32_t nfmax, double* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const uint32_t W = fa.W, D = lay.D;
+  // row stride of the column image: 80 / 144 / 208 == 16 (mod 64), so the 4 k-rows of a B fragment
+  // hit disjoint banks, and compile-time, so every operand address is base + immediate
+  constexpr uint32_t xs = (NT == 4 ? 5 : NT == 7 ? 9 : 13) * 16;
+  float* Xs = (float*)fsm;                                    // [64 + dump row][xs]
+  double* Rs = (double*)(Xs + (FE_ROWS + 1) * xs);            // [64][FE_RS] (floats when F32)
+  float* Rsf = (float*)Rs;
+  float* fr = (float*)(Rs + FE_ROWS * FE_RS);                 // [nfmax][W]
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t o0 = blockIdx.y * 48;
+  const uint32_t mW = fu_magic(W);
+  const uint32_t ncol = 3 * W + D + (lay.use_sb ? 1 : 0);
+  const uint32_t n_ot = 3 * n_ct;
+
+  for (uint32_t i = tid; i < (FE_ROWS + 1) * xs; i += FE_NT) Xs[i] = 0.0f;
+
+  v4f64 acc[F32 ? 1 : NT];
+  v4f32 acc32[F32 ? NT : 1];
+#pragma unroll
+  for (int j = 0; j < (F32 ? 1 : NT); j++) acc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < (F32 ? NT : 1); j++) acc32[j] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+
+  // prefetch registers: R element e = tid + 256*q of the [64][48] tile, raw-frame float tid + 256*q
+  double rp[FE_NRP];
+  float fp[FE_NFP];
+  const uint32_t nfw = nfmax * W;
+  auto prefetch = [&](const FuTile& t) {
+#pragma unroll
+    for (int q = 0; q < FE_NRP; q++) {
+      const uint32_t e = tid + FE_NT * q, row = e / 48, ol = e % 48;
+      rp[q] = (row < t.nrows && o0 + ol < n_out) ? R[(t.row0 + row) * n_out + o0 + ol] : 0.0;
+    }
+    const float* src = fa.frames + (fa.frame_base + t.fr0) * (uint64_t)W;
+    const uint32_t n = (t.t0 + t.nfr - t.f0) * W;
+#pragma unroll
+    for (int q = 0; q < FE_NFP; q++) fp[q] = (tid + FE_NT * q < n) ? src[tid + FE_NT * q] : 0.0f;
+  };
+  uint64_t tile = blockIdx.x;
+  FuTile ft, nft;
+  ScrfTileDesc dn;   // descriptor of the tile after next
+  if (tile < n_tiles) {
+    ft = fu_tile(fa, fa.tiles[fa.tile0 + tile]);
+    prefetch(ft);
+    if (tile + gridDim.x < n_tiles) dn = fa.tiles[fa.tile0 + tile + gridDim.x];
+  }
+  uint32_t dur_prev = 0;   // thread tid < 64: duration whose one-hot column is set in row tid
+  float* dump = Xs + FE_ROWS * xs;
+  __syncthreads();
+  while (tile < n_tiles) {
+    // stage: raw frames f0 .. t0+nfr-1, R, the rows' one-hot duration and bias columns
+    {
+#pragma unroll
+      for (int q = 0; q < FE_NFP; q++) if (tid + FE_NT * q < nfw) fr[tid + FE_NT * q] = fp[q];
+      if (nfw > FE_NT * FE_NFP) {   // very wide streams: the rest comes straight from memory
+        const float* src = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
+        const uint32_t n = (ft.t0 + ft.nfr - ft.f0) * W;
+        for (uint32_t i = tid + FE_NT * FE_NFP; i < n; i += FE_NT) fr[i] = src[i];
+      }
+#pragma unroll
+      for (int q = 0; q < FE_NRP; q++) {
+        const uint32_t e = tid + FE_NT * q, row = e / 48, ol = e % 48;
+        if (F32) Rsf[row * (2 * FE_RS) + ol] = (float)rp[q];
+        else Rs[row * FE_RS + ol] = rp[q];
+      }
+      if (tid < ft.nrows) {
+        const uint32_t r = ft.r0 + tid;
+        uint32_t t = ft.t0;
+        while ((uint32_t)scrf_seg_base(t + 1, D) <= r) t++;
+        const uint32_t d = r - (uint32_t)scrf_seg_base(t, D) + 1;
+        float* xr = Xs + tid * xs + 3 * W;
+        if (dur_prev) xr[dur_prev - 1] = 0.0f;
+        xr[d - 1] = 1.0f;
+        dur_prev = d;
+        if (lay.use_sb) xr[D] = 1.0f;
+      }
+    }
+    __syncthreads();
+    // rebuild avg | max | min of the tile's rows: thread = (frame, column); only rows inside the
+    // tile are kept
+    for (uint32_t i = tid; i < ft.nfr * W; i += FE_NT) {
+      const uint32_t tl = fu_div(i, mW), c = i - tl * W;
+      const uint32_t t = ft.t0 + tl;
+      const uint32_t nd = scrf_node_max_dur(t, D);
+      const int32_t lbase = (int32_t)scrf_seg_base(t, D) - (int32_t)ft.r0;
+      const uint32_t d_lo = lbase < 0 ? (uint32_t)(1 - lbase) : 1u;
+      const uint32_t d_hi = min(nd, (uint32_t)((int32_t)ft.nrows - lbase));
+      float v[DMAX];
+      fu_load_vals<DMAX>(fr + (t - ft.f0) * W + c, W, nd, v);
+      float* o = Xs + lbase * (int32_t)xs + c;   // row of d = 1 (may lie before the tile: dumped)
+      fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dump + c);
+      fu_scan_ext<DMAX, 1>(v, o + W, xs, d_lo, d_hi, dump + W + c);
+      fu_scan_ext<DMAX, 0>(v, o + 2 * W, xs, d_lo, d_hi, dump + 2 * W + c);
+    }
+    __syncthreads();
+    // next tile's R and frames, and the descriptor after that, are fetched under the MFMAs
+    const uint64_t ntile = tile + gridDim.x;
+    if (ntile < n_tiles) {
+      nft = fu_tile(fa, dn);
+      prefetch(nft);
+      if (ntile + gridDim.x < n_tiles) {
+        // a vector load on purpose: a scalar load would share lgkmcnt with the LDS operand reads
+        // below and stall the first MFMA for a full memory round trip
+        uint64_t ti = fa.tile0 + ntile + gridDim.x;
+        asm volatile("" : "+v"(ti));
+        dn = fa.tiles[ti];
+      }
+    }
+    fe_mfma_tile<NT, F32, xs>(Rs, Xs, wave, lk, li, n_ot, acc, acc32);
+    __syncthreads();
+    tile = ntile;
+    ft = nft;
+  }
+  // slab[blockIdx.x][o][f]
+  double* out = slab + (uint64_t)blockIdx.x * n_out * ncol;
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const uint32_t q = wave + 4 * j;
+    if (q >= n_ot) continue;
+    const uint32_t n = q % 3, ct = q / 3;
+    const uint32_t f = ct * 16 + li;
+    if (f >= ncol) continue;
+    const double sc = (lay.use_sb && f == 3 * W + D) ? lay.sbv : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t o = o0 + n * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
+      if (o >= n_out) continue;
+      const double v = F32 ? (double)acc32[F32 ? j : 0][r] : acc[F32 ? 0 : j][r];
+      out[(uint64_t)o * ncol + f] = v * sc;
+    }
+  }
+}
+
+// column tiles needed, and the row stride of the kernel instantiation that serves them (NCT * 16)
+static uint32_t fused_expf_xs(const ScrfLayout& lay, uint32_t W, uint32_t* n_ct) {
+  const uint32_t ncol = 3 * W + lay.D + (lay.use_sb ? 1 : 0);
+  *n_ct = (ncol + 15) / 16;
+  return (*n_ct <= 5 ? 5 : *n_ct <= 9 ? 9 : 13) * 16;
+}
+
+// most raw frames a 64-row tile can need (t_last - f0 + 1), by walking the tiles of a long utterance
+static uint32_t fused_expf_nfmax(uint32_t D) {
+  const uint32_t T = 3 * D + FE_ROWS + 8;
+  const uint64_t nseg = scrf_seg_base(T, D);
+  uint32_t best = 1, t = 0;
+  for (uint64_t r0 = 0; r0 < nseg; r0 += FE_ROWS) {
+    while (scrf_seg_base(t + 1, D) <= r0) t++;
+    uint32_t tl = t;
+    const uint64_t rl = (r0 + FE_ROWS < nseg ? r0 + FE_ROWS : nseg) - 1;
+    while (scrf_seg_base(tl + 1, D) <= rl) tl++;
+    const uint32_t f0 = t - (t < D - 1 ? t : D - 1);
+    if (tl - f0 + 1 > best) best = tl - f0 + 1;
+  }
+  return best;
+}
+
+static size_t fused_expf_smem(const ScrfLayout& lay, uint32_t W) {
+  uint32_t n_ct;
+  const uint32_t xs = fused_expf_xs(lay, W, &n_ct);
+  return sizeof(float) * (FE_ROWS + 1) * xs + sizeof(double) * FE_ROWS * FE_RS +
+         sizeof(float) * fused_expf_nfmax(lay.D) * W + 64;
+}
+
+int fused_supported(const ScrfLayout& lay, uint32_t W) {
+  uint32_t n_ct;
+  fused_expf_xs(lay, W, &n_ct);
+  if (lay.D < 2 || lay.D > 40 || W < 1 || n_ct > 13) return 0;
+  if (fused_expf_smem(lay, W) > 80 * 1024) return 0;
+  if (sizeof(double) * lay.D * 256 + 16 > 80 * 1024) return 0;
+  return fused_scores_smem(W, lay.D) <= 80 * 1024;
+}
+
+uint32_t fused_expf_blocks(uint64_t n_tiles) {
+  static const uint32_t nb = getenv("SCRF_EXPF_BLOCKS") ? (uint32_t)atoi(getenv("SCRF_EXPF_BLOCKS")) : 512u;  // experiment knob (<= 512)
+  return (uint32_t)(n_tiles < nb ? n_tiles : nb);
+}
+
+template <int NT, int DMAX, int F32>
+static void launch_expf_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
+                                uint64_t n_tiles, uint32_t n_ct, size_t sm, double* slab) {
+  hipFuncSetAttribute((const void*)k_expf_fused<NT, DMAX, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  dim3 grid(fused_expf_blocks(n_tiles), (lay.L + 47) / 48);
+  hipLaunchKernelGGL((k_expf_fused<NT, DMAX, F32>), grid, dim3(FE_NT), sm, st, fa, lay, R, lay.L, n_tiles, n_ct,
+                     fused_expf_nfmax(lay.D), slab);
+}
+
+// slab: [fused_expf_blocks(n_tiles)][L][3W + D + bias]
+void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
+                       uint64_t n_tiles, double* slab, int f32) {
+  if (n_tiles == 0) return;
+  uint32_t n_ct;
+  fused_expf_xs(lay, fa.W, &n_ct);
+  const size_t sm = fused_expf_smem(lay, fa.W);
+#define FE_GO2(N, DM)                                                                             \
+  do {                                                                                            \
+    if (f32) launch_expf_fused_t<N, DM, 1>(st, fa, lay, R, n_tiles, n_ct, sm, slab);              \
+    else launch_expf_fused_t<N, DM, 0>(st, fa, lay, R, n_tiles, n_ct, sm, slab);                  \
+  } while (0)
+#define FE_GO(N)                                  \
+  do {                                            \
+    if (lay.D <= 12) FE_GO2(N, 12);               \
+    else if (lay.D <= 25) FE_GO2(N, 25);          \
+    else FE_GO2(N, 40);                           \
+  } while (0)
+  if (n_ct <= 5) FE_GO(4);
+  else if (n_ct <= 9) FE_GO(7);
+  else FE_GO(10);
+#undef FE_GO
+#undef FE_GO2
+}

@@ -76,4 +76,16 @@ void launch_lin_expf_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, 
 void launch_suffix_avg(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                        double* Z, uint64_t* slot_row);
 
+// scrf_fused.hip: state contractions with the window synthesis fused in (X never materialised)
+#define SCRF_FUSED_ROWS_SCORES 256
+#define SCRF_FUSED_ROWS_EXPF 64
+int fused_supported(const ScrfLayout& lay, uint32_t W);
+uint32_t fused_expf_blocks(uint64_t n_tiles);
+void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
+                         const double* P, uint64_t n_tiles, double* S, int f32);
+void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                  const double* R, double* Z);
+void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
+                       uint64_t n_tiles, double* slab, int f32);
+
 #endif  // SCRF_KERNELS_H_

@@ -149,6 +149,37 @@ def test_fb_batch_gradient_fast32_precision(ci):
     b.close(); eng.close()
 
 
+FUSED_SHAPES = [
+    dict(L=3, D=3, in_w=2, Ts=[1, 2, 3, 4, 7]),
+    dict(L=50, D=5, in_w=45, Ts=[1, 13, 40, 77]),       # two output groups, two column chunks per group
+    dict(L=7, D=32, in_w=5, Ts=[31, 32, 33, 100]),      # D = rows of an expected-count tile
+    dict(L=48, D=25, in_w=39, Ts=[300, 57]),            # config-2 shape
+]
+
+
+@pytest.mark.parametrize("si", range(len(FUSED_SHAPES)))
+def test_fused_window_synthesis_equals_materialised_windows(si, monkeypatch):
+    """FAST / FAST32 rebuild the window vectors inside both contractions (no X in HBM) when the
+    input is one segment-recipe stream; SCRF_FUSE=0 forces the materialised-X kernels.  Window
+    values are the same floats either way, so the two differ by summation order only."""
+    for prec, tol in ((1, 1e-11), (3, 1e-5)):
+        res = []
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("SCRF_FUSE", fuse)
+            c = Case(seed=300 + si, precision=prec, **FUSED_SHAPES[si])
+            eng = c.engine(); b = c.batch(eng)
+            numer, zx = eng.fb_batch(b)
+            res.append((numer, zx, eng.get_grad()))
+            b.close(); eng.close()
+        (n1, z1, g1), (n2, z2, g2) = res
+        scale = np.abs(g2).max()
+        np.testing.assert_allclose(n1, n2, rtol=tol, atol=tol * max(1, np.abs(n2).max()))
+        np.testing.assert_allclose(z1, z2, rtol=tol)
+        assert np.abs(g1 - g2).max() <= 10 * tol * scale
+        og, on, oz = c.oracle_gradient()
+        assert np.abs(g1 - og).max() / np.abs(og).max() <= max(1e-9, tol)
+
+
 def test_lattice_arcs_bit_exact(case):
     c, eng, b = case
     for u, T in enumerate(c.Ts):

@@ -33,7 +33,7 @@ struct ScrfLayout {
 // Which slice of the window vector / weight block a contraction covers.
 //   kind 0: outputs = labels,            woff(o) = state_idx(o) + wadd
 //   kind 1: outputs = (p,c) pairs,       woff(o) = trans_idx(o / L, o % L) + wadd
-//   kind 2: outputs = (group k, label),  woff(o) = state_idx(o % L) + (o / L) * rw + wadd   (per-frame projections)
+//   kind 2: outputs = (group k, label),  woff(o) = state_idx(o % L) + (o / L) * rw + wadd   (per-frame projections of the sampled blocks)
 struct ScrfGemmSpec {
   uint32_t kind;
   uint32_t fs;        // first X column used
@@ -82,17 +82,6 @@ struct ScrfBatchView {
   const uint64_t* seg_off;    // [U+1]
   const uint64_t* arc_off;    // [U+1]
   const uint32_t* labels;     // [sum T] or nullptr
-};
-
-// Fused linear epilogue of the factorised score kernel: out += sum_k P[first+step_k(d)][k][o]
-// + (CA[first+d] - CA[first]) / d.  P: [frames][6L]; CA: [frames+1][L] running prefix of the
-// average-block projections over the chunk's frames; steps: [D][5] sample offsets.
-struct ScrfLinEpilogue {
-  const double* P;
-  const double* CA;
-  const uint8_t* steps;
-  ScrfBatchView bv;
-  uint32_t u0, u1;
 };
 
 // Fused window synthesis (scrf_fused.hip).  Row tiles are described once per batch on the host:

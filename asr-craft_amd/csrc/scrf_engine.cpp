@@ -626,35 +626,15 @@ struct ChunkBufs {
   uint32_t nch_atb = 0;
   uint64_t rpc_atb = 0;
   bool fused = false;        // window synthesis fused into the contractions (no X)
-  // recipe-factorised path
-  bool factored = false;
-  uint32_t XF = 0;           // row width of X (num_feas, or 2W+D for the factored image)
-  double* P = nullptr;       // [nfr][6L]
-  double* CA = nullptr;      // [nfr+1][L] running prefix of the average-block projections
-  double* blocksum = nullptr;
-  uint8_t* steps = nullptr;  // [D][5] sample offsets
-  double* Z = nullptr;       // [nfr+nutt][6L]
-  uint64_t* slot_row = nullptr;
+  double* P = nullptr;       // [nfr][5L] per-frame projections of the sampled blocks
+  double* Z = nullptr;       // [nfr][5L] per-frame sums of R over the windows sampling the frame
   double* slab_l = nullptr;
   uint32_t nch_l = 0;
   uint64_t rpc_l = 0;
 };
 
-struct Need { bool fb, post, beta, vit; bool factored = false; bool fused = false; };
+struct Need { bool fb, post, beta, vit; bool fused = false; };
 
-// recipe-factorised path: one segment-recipe stream without context whose window is exactly the
-// state feature range, no transition features
-static bool factored_ok(scrf_handle h, scrf_batch b) {
-  const ScrfLayout& l = h->lay;
-  if (b->mode != 1 || b->n_streams != 1 || l.use_tf || !l.use_sf || l.D <= 1 || l.D > 64) return false;
-  const scrf_stream_recipe& r = b->recipe[0];
-  if (!r.extract_seg_ftr || r.left_ctx || r.right_ctx) return false;
-  return l.sfs == 0 && l.nsfe == 8 * r.in_width + l.D && l.nsfe == l.F;
-}
-static ScrfGemmSpec spec_mm(const ScrfLayout& l, uint32_t W) {
-  return ScrfGemmSpec{0, 0, 2 * W + l.D, (uint32_t)l.use_sb, l.sbv, 6 * W, 0};
-}
-static ScrfGemmSpec spec_lin(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0.0, 0, W}; }
 // fused path: the five sampled blocks as per-frame projections (outputs (k, label), k < 5), and
 // the dense column groups [avg | max | min | onehot(d)] + bias
 static ScrfGemmSpec spec_samples(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0.0, 0, W}; }
@@ -667,15 +647,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   const size_t LL = (size_t)l.L * l.L;
   size_t tot = 0;
   const uint32_t W0 = b->mode == 1 ? b->recipe[0].in_width : 0;
-  if (nd.factored) {
-    tot += pad256(nseg * (2 * W0 + l.D) * sizeof(float));          // X_mm
-    tot += pad256(nfr * 6 * l.L * sizeof(double));                // P
-    tot += pad256((nfr + 1) * l.L * sizeof(double)) + pad256(((nfr + 255) / 256 + 1) * l.L * sizeof(double)) + 4096;  // CA, block sums, steps
-    if (nd.post) {
-      tot += pad256((nfr + nutt) * 6 * l.L * sizeof(double)) + pad256((nfr + nutt) * 8);  // Z, slot rows
-      tot += pad256((size_t)256 * 6 * l.L * W0 * sizeof(double));  // slab of the final contraction
-    }
-  } else if (nd.fused) {
+  if (nd.fused) {
     tot += pad256(nfr * 5 * l.L * sizeof(double));                // P (scores) / Z (counts)
     if (nd.post) tot += pad256((size_t)256 * 5 * l.L * W0 * sizeof(double));
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
@@ -734,25 +706,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   cb->st = lane ? h->stream2 : h->stream;
   cb->grad = lane ? h->d_grad2 : h->d_grad;
   cb->sums = lane ? h->d_sums2 : h->d_sums;
-  cb->XF = l.F;
-  cb->factored = nd.factored;
-  if (nd.factored) {
-    const uint32_t W0 = b->recipe[0].in_width;
-    cb->XF = 2 * W0 + l.D;
-    cb->X = a.take<float>(nseg * cb->XF);
-    cb->P = a.take<double>(nfr * 6 * l.L);
-    cb->CA = a.take<double>((nfr + 1) * l.L);
-    cb->blocksum = a.take<double>(((nfr + 255) / 256 + 1) * l.L);
-    cb->steps = a.take<uint8_t>(5 * 64 > l.D * 5 ? 5 * 64 : l.D * 5);
-    if (nd.post) {
-      const uint64_t nslots = nfr + nutt;
-      cb->Z = a.take<double>(nslots * 6 * l.L);
-      cb->slot_row = a.take<uint64_t>(nslots);
-      cb->rpc_l = ((nslots + 255) / 256 + 31) & ~31ull;
-      cb->nch_l = (uint32_t)((nslots + cb->rpc_l - 1) / cb->rpc_l);
-      cb->slab_l = a.take<double>((size_t)256 * 6 * l.L * W0);
-    }
-  } else if (nd.fused) {
+  if (nd.fused) {
     const uint32_t W0 = b->recipe[0].in_width;
     cb->X = nullptr;
     cb->P = a.take<double>(nfr * 5 * l.L);
@@ -860,33 +814,6 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   const ScrfLayout& l = h->lay;
   const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
   ScrfBatchView bv = b->view();
-  if (cb.factored) {
-    const scrf_stream_recipe& r = b->recipe[0];
-    const uint32_t W0 = r.in_width;
-    {
-      PhaseTimer tm(h, PH_WIN, cb.st);
-      launch_windows_mm(cb.st, b->d_frames[0], b->d_sframe_off[0], bv, u0, u1, nfr, W0, l.D, cb.X, cb.XF);
-      tm.stop(1);
-    }
-    PhaseTimer tm(h, PH_SCORE, cb.st);
-    uint32_t nl = 5;
-    // linear part: per-frame projections of the 5 sample blocks and the average block + its prefix
-    launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
-                       spec_lin(W0), 6 * l.L, cb.P);
-    launch_lin_prefix(cb.st, l, nfr, cb.P, cb.CA, cb.blocksum, cb.steps);
-    // dense part [max | min | one-hot dur] + bias, the linear part gathered in its epilogue
-    ScrfLinEpilogue le{cb.P, cb.CA, cb.steps, bv, u0, u1};
-    launch_scores_mfma(cb.st, cb.X, cb.XF, nullptr, nseg, h->d_lambda, l, spec_mm(l, W0), l.L, cb.S, &le);
-    if (!h->m0_valid) {
-      launch_scores_exact(cb.st, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
-      launch_exp_m(cb.st, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
-      h->m0_valid = true;
-      nl += 2;
-    }
-    tm.stop(nl);
-    HIPCHK(h, hipGetLastError());
-    return SCRF_OK;
-  }
   if (cb.fused) {
     PhaseTimer tm(h, PH_SCORE, cb.st);
     const uint32_t W0 = b->recipe[0].in_width;
@@ -912,11 +839,11 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   }
   PhaseTimer tm(h, PH_SCORE, cb.st);
   uint32_t nl = 1;
-  if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, nullptr, f32);
+  if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32);
   else launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
   if (l.use_tf) {
     launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
-    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, nullptr, f32);
+    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, f32);
     else launch_scores_exact(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
     nl += 2;
   } else if (!h->m0_valid) {
@@ -991,8 +918,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
   ScrfBatchView bv = b->view();
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
   const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
-  nd.factored = h->cfg.train_precision == SCRF_PREC_FACTORED && factored_ok(h, b);
-  nd.fused = fast && !nd.factored && b->fused_ok && h->fuse_windows;
+  nd.fused = fast && b->fused_ok && h->fuse_windows;
 
   // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
   // at least four chunks so that both streams always have work
@@ -1041,16 +967,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     {
       PhaseTimer tm(h, PH_EXPF, cb.st);
       uint32_t nl = 1;
-      if (cb.factored) {
-        const uint32_t W0 = b->recipe[0].in_width;
-        const uint64_t nslots = nfr + nutt;
-        launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, cb.XF, nullptr, nseg, l, spec_mm(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s);
-        launch_lin_expf_z(cb.st, l, bv, u0, u1, nslots, cb.AD, cb.Z, cb.steps);
-        launch_suffix_avg(cb.st, l, bv, u0, (uint32_t)nutt, cb.Z, cb.slot_row);
-        launch_expf_mfma(cb.st, cb.Z, 6 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, cb.slot_row, nslots, l,
-                         spec_lin(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
-        nl += 3;
-      } else if (cb.fused) {
+      if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
         ScrfFusedArgs fa = fused_args(h, b, u0, 1);
         launch_expf_fused(cb.st, fa, l, cb.AD, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
@@ -1070,11 +987,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     }
     {
       PhaseTimer tm(h, PH_REDUCE, cb.st);
-      if (cb.factored) {
-        const uint32_t W0 = b->recipe[0].in_width;
-        launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_mm(l, W0), cb.grad);
-        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 6 * l.L, l, spec_lin(W0), cb.grad);
-      } else if (cb.fused) {
+      if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
         launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
         launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 5 * l.L, l, spec_samples(W0), cb.grad);

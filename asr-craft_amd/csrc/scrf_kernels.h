@@ -37,7 +37,7 @@ void launch_add(hipStream_t st, double* y, const double* x, uint32_t n);
 // scrf_mfma.hip: fp64 MFMA contractions (FAST training precision)
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
-                        double* out, const ScrfLinEpilogue* le = nullptr, int f32 = 0);
+                        double* out, int f32 = 0);
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int f32 = 0);
@@ -65,16 +65,6 @@ void launch_add_trans_counts(hipStream_t st, const uint32_t* counts, const ScrfL
 void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
                     uint64_t n_frames, const uint32_t* next_lab, const double* A, const double* B, const double* E,
                     const double* mshift, double* XI);
-
-// scrf_factored.hip: recipe-factorised contractions
-void launch_windows_mm(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
-                       uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, float* X, uint32_t F);
-void launch_lin_prefix(hipStream_t st, const ScrfLayout& lay, uint64_t n_frames, const double* P, double* CA,
-                       double* blocksum, uint8_t* steps);
-void launch_lin_expf_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
-                       uint64_t n_slots, const double* R, double* Z, const uint8_t* steps);
-void launch_suffix_avg(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
-                       double* Z, uint64_t* slot_row);
 
 // scrf_fused.hip: state contractions with the window synthesis fused in (X never materialised)
 #define SCRF_FUSED_ROWS_SCORES 256

@@ -39,13 +39,9 @@ template <int F32>
 __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      const double* __restrict__ lambda, ScrfLayout lay,
-                                                     ScrfGemmSpec sp, uint32_t n_out, double* __restrict__ out,
-                                                     ScrfLinEpilogue le) {
+                                                     ScrfGemmSpec sp, uint32_t n_out, double* __restrict__ out) {
   __shared__ float Xs[SM_ROWS * SM_XS];
   __shared__ double Ws[SM_KC * SM_WS];
-  __shared__ uint32_t row_first[SM_ROWS];  // fused linear epilogue: chunk frame row of the window start
-  __shared__ uint32_t row_dur[SM_ROWS];    //                        and the window length d
-  __shared__ uint8_t stp_s[5 * 64];        //                        sample offsets [D][5]
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint64_t row0 = (uint64_t)blockIdx.x * SM_ROWS;
@@ -125,33 +121,6 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
     }
   };
 
-  if (le.P) {
-    // decode this workgroup's rows once: row -> (utterance, end frame t, duration d)
-    const uint64_t row = row0 + tid;
-    uint32_t first = 0, dur = 1;
-    if (row < n_rows) {
-      uint32_t lo = le.u0, hi = le.u1;
-      const uint64_t grow = le.bv.seg_off[le.u0] + row;
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (le.bv.seg_off[mid] <= grow) lo = mid; else hi = mid; }
-      const uint64_t r = grow - le.bv.seg_off[lo];  // row inside the utterance
-      const uint32_t D = lay.D;
-      const uint64_t tri = (uint64_t)D * (D + 1) / 2;
-      uint32_t t;
-      if (r < tri) {  // t < D: seg_base(t) = t(t+1)/2
-        t = (uint32_t)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
-        while ((uint64_t)t * (t + 1) / 2 > r) t--;
-        while ((uint64_t)(t + 1) * (t + 2) / 2 <= r) t++;
-        dur = (uint32_t)(r - (uint64_t)t * (t + 1) / 2) + 1;
-      } else {
-        t = D + (uint32_t)((r - tri) / D);
-        dur = (uint32_t)((r - tri) % D) + 1;
-      }
-      first = (uint32_t)(le.bv.frame_off[lo] - le.bv.frame_off[le.u0]) + t - dur + 1;
-    }
-    row_first[tid] = first;
-    row_dur[tid] = dur;
-    for (uint32_t i = tid; i < lay.D * 5 && i < 5 * 64; i += 256) stp_s[i] = le.steps[i];
-  }
   if (nfe > 0) load_chunk(0);
   for (uint32_t f0 = 0; f0 < nfe; f0 += SM_KC) {
     store_chunk(f0);
@@ -201,17 +170,6 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
         const uint64_t row = row0 + rl;
         if (row >= n_rows) continue;
         double v = (F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r]) + bias;
-        if (le.P) {
-          // + sum_k P[pos_k][k][o] + (CA[first+d] - CA[first]) / d   (scrf_factored.hip)
-          const uint32_t first = row_first[rl], d = row_dur[rl];
-          const size_t PL = (size_t)6 * lay.L;
-          const double* Pf = le.P + (size_t)first * PL + o;
-          double lin = 0.0;
-#pragma unroll
-          for (int k = 0; k < 5; k++) lin += Pf[(size_t)stp_s[(d - 1) * 5 + k] * PL + (size_t)k * lay.L];
-          const double* Ca = le.CA + (size_t)first * lay.L + o;
-          v += lin + (Ca[(size_t)d * lay.L] - Ca[0]) / (double)d;
-        }
         out[row * n_out + o] = v;
       }
   }
@@ -219,17 +177,13 @@ __global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X
 
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
-                        double* out, const ScrfLinEpilogue* le, int f32) {
+                        double* out, int f32) {
   if (n_rows == 0 || n_out == 0) return;
   dim3 grid((uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS), (n_out + SM_NO - 1) / SM_NO);
-  ScrfLinEpilogue none;
-  memset(&none, 0, sizeof(none));
   if (f32)
-    hipLaunchKernelGGL(k_scores_mfma<1>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out,
-                       le ? *le : none);
+    hipLaunchKernelGGL(k_scores_mfma<1>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
   else
-    hipLaunchKernelGGL(k_scores_mfma<0>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out,
-                       le ? *le : none);
+    hipLaunchKernelGGL(k_scores_mfma<0>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # asr-craft_amd/
 LAB_BAD = 0xFFFFFFFF
 STDFRAME, STDSEG, STDSEG_NO_DUR, STDSEG_NO_DUR_NO_TRANSFTR, STDSEG_NO_DUR_NO_SEGTRANSFTR = range(5)
 STDSTATE, STDTRANS = 0, 1
-PREC_EXACT, PREC_FAST = 0, 1
+PREC_EXACT, PREC_FAST, PREC_FAST32 = 0, 1, 2
 ABI_VERSION = 1
 MAX_STREAMS = 3
 N_PHASES = 7

@@ -26,7 +26,6 @@ import numpy as np  # noqa: E402
 L, D, IN_W, T_FRAMES = 48, 25, 39, 300
 F = 8 * IN_W + D  # 337 segment features (io/CRF_InFtrStream_SeqMultiWindow.cpp:77-78)
 PEAK = {"mfma_f64_tflops": 78.6, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md (HBM); fp64 MFMA: vendor peak
-MEASURED_MFMA_F64_TFLOPS = 48.5  # tools/mfma_f64_peak.hip on this pool: sustained v_mfma_f64_16x16x4_f64 rate
 
 
 def n_segs(T, Dm):
@@ -62,8 +61,8 @@ def main():
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the collective path)")
-    ap.add_argument("--precision", choices=["exact", "fast", "factored", "fast32"], default="factored",
-                    help="exact: reference-order unfused fp64; fast: fp64 MFMA; factored: fp64 MFMA + recipe-factorised contraction; fast32: f32 MFMA contractions (opt-in)")
+    ap.add_argument("--precision", choices=["exact", "fast", "fast32"], default="fast",
+                    help="exact: reference-order unfused fp64; fast: fp64 MFMA, window synthesis fused into the contractions; fast32: f32 MFMA contractions (opt-in)")
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     args = ap.parse_args()
 
@@ -90,7 +89,7 @@ def main():
     # synthetic data of the config-2 shape; every rank owns a different contiguous utterance range
     frames, labels, off = synth.make_batch(U, T_FRAMES, IN_W, L, D, seed=1234 + 100003 * rank)
     cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank, scratch_bytes=args.scratch_gib << 30,
-                               precision={"exact": 0, "fast": 1, "factored": 2, "fast32": 3}[args.precision])
+                               precision={"exact": 0, "fast": 1, "fast32": 2}[args.precision])
     eng = scrf_amd.Engine(cfg)
     lam = synth.make_lambda(eng.lambda_len)
     eng.set_lambda(lam)
@@ -157,13 +156,11 @@ def main():
         bound, work, unit, peak = phases[dom]
         ms, nl = tm[dom]
         achieved = work / (ms / 1e3)
-        kernels = {"scores": "k_scores_mfma (+ k_lin_prefix_* in factored mode)",
-                   "expf": "k_expf_mfma (+ k_lin_expf_z, k_suffix_avg in factored mode)",
+        kernels = {"scores": "k_scores_fused + k_scores_mfma (per-frame projections)",
+                   "expf": "k_expf_fused + k_lin_z + k_expf_mfma (per-frame sums)",
                    "fwd_bwd": "k_dp_wave + k_post_state + k_xi_factors"}
         roofline = {"kernel": dom, "kernels_in_phase": kernels[dom], "bound": bound, "achieved": round(achieved, 4),
                     "peak": peak, "unit": unit, "frac": round(achieved / peak, 5), "traffic": None,
-                    "peak_measured": MEASURED_MFMA_F64_TFLOPS if bound == "mfma" else 6290.0,
-                    "frac_of_measured": round(achieved / (MEASURED_MFMA_F64_TFLOPS if bound == "mfma" else 6290.0), 5),
                     "launches": int(nl), "avg_launch_ms": round(ms / max(1, nl), 4),
                     "phase_ms": {k: round(v[0], 3) for k, v in tm.items()}}
         out = {

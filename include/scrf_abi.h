@@ -65,20 +65,19 @@ enum scrf_map_type { SCRF_STDSTATE = 0, SCRF_STDTRANS = 1 };
  *  EXACT : fp64, ascending feature order, unfused multiply-then-add == the reference's
  *          CRF_StdFeatureMap::computeStateArrayValue bit for bit (needed for bit-identical
  *          lattice arcs / Viterbi).  Always used by the decode entry points.
- *  FAST  : fp64 MFMA (v_mfma_f64_16x16x4_f64); sums reordered, results within 1e-4 rel.
- *  FACTORED : FAST plus the recipe-factorised contraction: the window columns that are linear in
- *          the raw frames (5 sampled frames + average of the standard segment recipe) go through
- *          per-frame projections instead of the dense product; only max/min/one-hot-duration
- *          columns use the dense MFMA kernels.  Applies to single-stream segment-recipe batches
- *          without transition features, otherwise the engine silently uses FAST.  The window
- *          average is formed in fp64 instead of the reference's float running sum (~1e-7 rel).
+ *  FAST  : fp64 MFMA (v_mfma_f64_16x16x4_f64); sums reordered, results within 1e-4 rel (measured
+ *          <= 1e-9).  When the batch is one segment-recipe stream without context frames and the
+ *          model has no transition features, the window vectors are never materialised: the five
+ *          sampled-frame blocks are contracted per frame (an exact re-association of the same
+ *          fp64 products) and avg/max/min are rebuilt in LDS with the reference's float
+ *          arithmetic (scrf_fused.hip).
  *  FAST32 : like FAST but the two dense contractions run on the f32 MFMA (exact f32 FMA chain,
- *          ~3x the sustained f64-MFMA rate of the chip): lambda and the posteriors are rounded to
+ *          twice the f64-MFMA rate of the chip): lambda and the posteriors are rounded to
  *          f32 as operands, scores sum in f32 over the feature axis, expected counts sum in f32
  *          inside 32/64-row chunks and in f64 across chunks.  The DP recursion, log-partition and
  *          posteriors stay f64.  Measured deviation <= ~1e-6 relative on gradients (contract 1e-4).
  *          Not the default of anything; opt-in. */
-enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FACTORED = 2, SCRF_PREC_FAST32 = 3 };
+enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FAST32 = 2 };
 
 /* Mirrors CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) plus the model fields
  * CRFTrain sets on CRF_Model (CRFTrain/src/Main.cpp:539-597). */

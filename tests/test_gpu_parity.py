@@ -117,27 +117,10 @@ def test_fb_batch_gradient_fast_precision(ci):
 
 
 @pytest.mark.parametrize("ci", range(len(CASES)))
-def test_fb_batch_gradient_factored_precision(ci):
-    """FACTORED training precision: sample/avg columns through per-frame projections, max/min/dur
-    columns through the dense MFMA kernels.  The window average is formed in fp64 instead of the
-    reference's float running sum, hence the looser (still 100x inside the contract) bound."""
-    c = Case(seed=100 + ci, precision=2, **CASES[ci])
-    eng = c.engine(); b = c.batch(eng)
-    numer, zx = eng.fb_batch(b)
-    g = eng.get_grad()
-    og, onumer, ozx = c.oracle_gradient()
-    assert np.abs(numer - onumer).max() <= 1e-6 * max(1, np.abs(onumer).max())
-    assert np.abs(zx - ozx).max() <= 1e-7 * np.abs(ozx).max()
-    err = np.abs(g - og).max() / np.abs(og).max()
-    assert err <= REL_CONTRACT and err <= 1e-6, err
-    b.close(); eng.close()
-
-
-@pytest.mark.parametrize("ci", range(len(CASES)))
 def test_fb_batch_gradient_fast32_precision(ci):
     """FAST32 (opt-in): both dense contractions on the f32 MFMA, f64 everywhere else.  The bound
     asserted here (1e-5) is what demonstrates the 1e-4 contract for this mode."""
-    c = Case(seed=100 + ci, precision=3, **CASES[ci])
+    c = Case(seed=100 + ci, precision=2, **CASES[ci])
     eng = c.engine(); b = c.batch(eng)
     numer, zx = eng.fb_batch(b)
     g = eng.get_grad()
@@ -162,7 +145,7 @@ def test_fused_window_synthesis_equals_materialised_windows(si, monkeypatch):
     """FAST / FAST32 rebuild the window vectors inside both contractions (no X in HBM) when the
     input is one segment-recipe stream; SCRF_FUSE=0 forces the materialised-X kernels.  Window
     values are the same floats either way, so the two differ by summation order only."""
-    for prec, tol in ((1, 1e-11), (3, 1e-5)):
+    for prec, tol in ((1, 1e-11), (2, 1e-5)):
         res = []
         for fuse in ("1", "0"):
             monkeypatch.setenv("SCRF_FUSE", fuse)
@@ -266,7 +249,7 @@ def test_two_lane_pipeline_equals_single_lane(monkeypatch):
     res = []
     for lanes in ("1", "2"):
         monkeypatch.setenv("SCRF_LANES", lanes)
-        for prec in (0, 2):
+        for prec in (0, 1):
             c = Case(precision=prec, **kw)
             eng = c.engine(); b = c.batch(eng)
             numer, zx = eng.fb_batch(b)
@@ -276,9 +259,9 @@ def test_two_lane_pipeline_equals_single_lane(monkeypatch):
         n1, z1, g1, s1 = res[i]; n2, z2, g2, s2 = res[i + 2]
         if i == 0:   # EXACT: per-utterance scalars do not depend on the chunking at all
             assert np.array_equal(n1, n2) and np.array_equal(z1, z2)
-        else:        # FACTORED: the running prefix of the average block starts at the chunk's first frame
-            np.testing.assert_allclose(n1, n2, rtol=1e-9, atol=1e-9)
-            np.testing.assert_allclose(z1, z2, rtol=1e-11)
+        else:        # FAST (fused): scores do not depend on the chunking either, MFMA sums are per row
+            np.testing.assert_allclose(n1, n2, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(z1, z2, rtol=1e-13)
         np.testing.assert_allclose(g1, g2, rtol=1e-9, atol=1e-10 * np.abs(g1).max())
         np.testing.assert_allclose(s1, s2, rtol=1e-10)
     og, on, oz = Case(**kw).oracle_gradient()
@@ -341,7 +324,7 @@ def test_full_size_config2_utterances():
     frames, labels, off = synth.make_batch(U, T, in_w, L, D)
     F = 8 * in_w + D
     lam = synth.make_lambda(L * (F + 1 + L))
-    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F, precision=2)); eng.set_lambda(lam)
+    eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=F, precision=1)); eng.set_lambda(lam)
     fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
     ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
     b = eng.batch_from_frames(fl, ll)
@@ -354,11 +337,11 @@ def test_full_size_config2_utterances():
         X = orc.windows(fl[u], D)
         rc, og, on, oz = orc.seg_build_gradient(ocfg, olay, lam, X, ll[u], T, grad=og)
         assert rc == 0
-        assert abs(on - numer[u]) <= 1e-6 * abs(on) and abs(oz - zx[u]) <= 1e-7 * abs(oz)
+        assert abs(on - numer[u]) <= 1e-10 * abs(on) and abs(oz - zx[u]) <= 1e-11 * abs(oz)
     eng.zero_grad()
     b2 = eng.batch_from_frames(fl[:2], ll[:2])
     eng.fb_batch(b2)
-    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() < 1e-6
+    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() < 1e-9
     # property: sum over labels of the state-bias gradient = (#true segments) - E[#segments]; and the
     # expected number of segment ends per utterance equals 1 at the last frame => bias grads are finite
     # and transition-bias gradient mass = state mass minus one segment per utterance

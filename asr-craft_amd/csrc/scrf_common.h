@@ -84,6 +84,15 @@ struct ScrfBatchView {
   const uint32_t* labels;     // [sum T] or nullptr
 };
 
+// Outputs of the scaled linear-domain recursion (scrf_dplin.hip): mantissa vectors [frames][L] and
+// per-frame log-scales [frames].
+struct ScrfDpLin {
+  double* a;    double* ga;    // exp(alpha[t][l])  = a * exp(ga)
+  double* p;    double* gp;    // exp(aPT[t][l])    = p * exp(gp)   (alpha plus transition)
+  double* b;    double* gb;    // exp(beta[t][l])   = b * exp(gb)
+  double* sd;   double* gsd;   // exp(sd[t][l])     = sd * exp(gsd) (sum over next durations)
+};
+
 // Fused window synthesis (scrf_fused.hip).  Row tiles are described once per batch on the host:
 // score tiles are the windows of TB = 256/D whole frames, expected-count tiles any 64 consecutive
 // windows of an utterance.

@@ -13,54 +13,7 @@
 //  * posteriors (gamma, xi) need no recursion: they are separate fully parallel kernels.
 // Reference arithmetic being reproduced: nodes/CRF_StdSegStateNode_WithoutDurLab_WithoutSegTransFtr.cpp
 //   computeAlpha :123-245, computeAlphaPlusTrans :1077-1108, computeBeta :395-466, computeExpF :616-949.
-#include "scrf_kernels.h"
-
-#include <float.h>
-#include <math.h>
-
-#define DP_WPB 6  // wavefronts (utterances) per workgroup
-
-__device__ __forceinline__ double rdlane(double v, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// exp(x) for x <= 0 (including -inf -> 0): the log-sum-exp terms are always max-shifted, so the
-// overflow/NaN handling of the library exp is dead weight in the recursion's inner loop.
-// Cody-Waite reduction by ln2 (hi/lo) + degree-13 Taylor/Horner on |r| <= ln2/2 (truncation
-// 4e-18), scaled with v_ldexp_f64 (which flushes to 0 below the subnormal range): ~1 ulp.
-__device__ __forceinline__ double exp_nonpos(double x) {
-  x = fmax(x, -1000.0);  // also maps -inf; exp(-1000) underflows to 0 through ldexp
-  const double k = rint(x * 1.4426950408889634);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;                 // 1/13!
-  p = fma(p, r, 2.0876756987868100e-09);             // 1/12!
-  p = fma(p, r, 2.5052108385441720e-08);             // 1/11!
-  p = fma(p, r, 2.7557319223985888e-07);             // 1/10!
-  p = fma(p, r, 2.7557319223985893e-06);             // 1/9!
-  p = fma(p, r, 2.4801587301587302e-05);             // 1/8!
-  p = fma(p, r, 1.9841269841269841e-04);             // 1/7!
-  p = fma(p, r, 1.3888888888888889e-03);             // 1/6!
-  p = fma(p, r, 8.3333333333333332e-03);             // 1/5!
-  p = fma(p, r, 4.1666666666666664e-02);             // 1/4!
-  p = fma(p, r, 1.6666666666666666e-01);             // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
-}
+#include "scrf_dp_common.h"
 
 // E = exp(M - max(M)), its transpose, and the shift; one workgroup per L x L matrix
 __global__ void k_exp_m(const double* __restrict__ M, uint32_t L, double* __restrict__ E,
@@ -89,24 +42,6 @@ void launch_exp_m(hipStream_t st, const double* M, uint32_t L, uint64_t n_mat, d
                   double* mshift) {
   if (n_mat == 0) return;
   hipLaunchKernelGGL(k_exp_m, dim3((uint32_t)n_mat), dim3(256), 0, st, M, L, E, ET, mshift);
-}
-
-// sum_c bcast(a, c) * Em[c*L + lc]; four partial sums break the FMA dependency chain.
-// AS = address space of Em is known at compile time (LDS or global), never a flat pointer.
-template <class PTR>
-__device__ __forceinline__ double matvec_bcast(const double a, PTR Em, const int L, const int lc) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int c = 0;
-  for (; c + 4 <= L; c += 4) {
-    const double e0 = Em[(c + 0) * L + lc], e1 = Em[(c + 1) * L + lc];
-    const double e2 = Em[(c + 2) * L + lc], e3 = Em[(c + 3) * L + lc];
-    s0 = fma(rdlane(a, c + 0), e0, s0);
-    s1 = fma(rdlane(a, c + 1), e1, s1);
-    s2 = fma(rdlane(a, c + 2), e2, s2);
-    s3 = fma(rdlane(a, c + 3), e3, s3);
-  }
-  for (; c < L; c++) s0 = fma(rdlane(a, c), Em[c * L + lc], s0);
-  return (s0 + s1) + (s2 + s3);
 }
 
 template <int DMAX, int MPF>

@@ -1,0 +1,428 @@
+// scrf_dplin.hip -- scaled linear-domain forward/backward for L <= 64 labels (training path).
+//
+// The log-domain recursion (scrf_dp.hip, and the reference: nodes/CRF_StdSegStateNode_WithoutDurLab_
+// WithoutSegTransFtr.cpp computeAlpha :123-245, computeBeta :395-466, computeExpF :616-949) spends
+// D exp() per label per frame inside a serial chain.  Here every quantity is carried as a
+// mantissa vector times exp(scalar log-scale), the scalar being per frame:
+//
+//   es[row][l] = exp(S[row][l] - smax[row]),  smax[row] = max_l S[row][l]            (k_exp_rows)
+//   exp(aPT[t'][l]) = p[t'][l] * exp(gp[t'])          exp(alpha[t][l]) = a[t][l] * exp(ga[t])
+//   a[t][l] = sum_d c_d * p[t-d][l] * es[(t,d)][l],   c_d = exp(gp[t-d] + smax[(t,d)] - ga[t]),
+//   ga[t]   = max_d (gp[t-d] + smax[(t,d)])           (one exp per (t, d), not per (t, d, l))
+//   p[t][n] = 2^-k * sum_c a[t][c] * E[c][n],         gp[t] = ga[t] + shift + k ln2   (k: exponent of the max)
+//
+// and symmetrically backwards.  These are the reference's sums with the exponentials factored;
+// results differ from the log-domain recursion by rounding only (~1e-15 relative).  Terms more
+// than ~700 nats below their row's / frame's maximum flush to zero instead of to ~1e-300: they are
+// below the resolution of every output.  A frame whose whole vector flushes (transition scores
+// spanning > ~700 nats) raises SCRF_ERR_NUMERIC like the reference's log(0) check.
+//
+// The alpha-with-duration array (N_seg x L) is never written: gamma is rebuilt from p, es and
+// beta in k_post_lin, R = Y - gamma overwrites es in place.
+#include "scrf_dp_common.h"
+
+#define LN2_HI 6.93147180369123816490e-01
+#define LN2_LO 1.90821492927058770002e-10
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// largest high word over the wave of a non-negative double vector: orders like the values do (to
+// 32 bits), costs what a float max costs, and keeps the full double exponent range
+__device__ __forceinline__ int wave_max_hi(double v) {
+  int h = __double2hiint(v);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) h = max(h, __shfl_xor(h, o));
+  return h;
+}
+// unbiased binary exponent from a high word; *bad = zero / subnormal / inf / nan
+__device__ __forceinline__ int hi_exp(int h, int* bad) {
+  if (h < 0x00100000 || h >= 0x7ff00000) *bad = 1;
+  return ((h >> 20) & 0x7ff) - 1023;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_true_scores: s_true[f] = S[(t, ld)][al] for labelled frames (the numerator's state term,
+// gradbuilder :388-469), read before the scores are exponentiated in place.
+// ------------------------------------------------------------------------------------------
+__global__ void k_true_scores(ScrfLayout lay, ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0,
+                              uint64_t n_frames, const double* __restrict__ S, double* __restrict__ s_true) {
+  const uint64_t fi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (fi >= n_frames) return;
+  const uint32_t L = lay.L, D = lay.D;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  const uint32_t u = frame_u[gf];
+  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  const uint32_t lab = bv.labels ? bv.labels[gf] : SCRF_LAB_BAD;
+  double v = 0.0;
+  if (lab != SCRF_LAB_BAD && lab < L * D) {
+    const uint32_t al = lab % L, ld = lab / L + 1;
+    if (ld <= scrf_node_max_dur(t, D))
+      v = S[((bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D) + ld - 1) * L + al];
+  }
+  s_true[fi] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exp_rows: in place S[row][:] -> exp(S[row][:] - smax[row]); 16 lanes per row, L <= 64.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_exp_rows(double* __restrict__ S, uint64_t n_rows, uint32_t L,
+                                                  double* __restrict__ smax) {
+  const uint64_t row = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const uint32_t sub = threadIdx.x & 15;
+  if (row >= n_rows) return;
+  double* p = S + row * L;
+  double v[4];
+  double m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t l = sub + 16 * j;
+    v[j] = (l < L) ? p[l] : -INFINITY;
+    m = fmax(m, v[j]);
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) m = fmax(m, shfl_f64(m, (int)((threadIdx.x & 63) ^ o)));
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t l = sub + 16 * j;
+    if (l < L) p[l] = exp_nonpos(v[j] - m);
+  }
+  if (sub == 0) smax[row] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_dp_lin: one wavefront per (utterance, direction); lane = label.
+// Outputs per frame: a (alpha mantissa), ga; p (alpha-plus-trans mantissa), gp; b (beta mantissa),
+// gb; sd (sum over durations, mantissa), gsd.
+// ------------------------------------------------------------------------------------------
+template <int DMAX, int MPF>
+__global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
+    ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
+    const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
+    const double* __restrict__ mshift, double* __restrict__ a_g, double* __restrict__ ga_g,
+    double* __restrict__ p_g, double* __restrict__ gp_g, double* __restrict__ b_g, double* __restrict__ gb_g,
+    double* __restrict__ sd_g, double* __restrict__ gsd_g, double* __restrict__ zx_out, int* __restrict__ status) {
+  extern __shared__ double dsm[];
+  const int L = lay.L, D = lay.D;
+  const int LL = L * L;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
+  const uint32_t ul = (blockIdx.x >> 1) * DP_WPB + wave;
+  double* Es = dsm;                                         // [L*L] (time-invariant transitions only)
+  double* ring = dsm + (MPF ? 0 : LL) + (size_t)wave * D * L;  // [D][L] mantissas, private to this wavefront
+  if (!MPF) {
+    const double* src = dir ? ET : E;
+    for (int i = threadIdx.x; i < LL; i += blockDim.x) Es[i] = src[i];
+    __syncthreads();
+  }
+  if (ul >= n_utts) return;
+  const uint32_t u = u0 + ul;
+  const int T = (int)bv.T[u];
+  if (T == 0) return;
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* ESu = ES + s_base * L;
+  const double* smu = smax + s_base;
+  const bool act = lane < L;
+  const int lc = act ? lane : L - 1;  // clamped label: idle lanes shadow the last label
+  const double sh0 = MPF ? 0.0 : mshift[0];
+  int err = 0;
+  double gslot = 0.0;  // lane j: log-scale of the vector in ring slot j
+
+  if (dir == 0) {
+    // ---------------------------------------------------------------- forward
+    double* au = a_g + f_base * L;
+    double* pu = p_g + f_base * L;
+    double a = ESu[lc];        // node 0: the only window is the initial segment of length 1
+    double ga = smu[0];
+    if (act) au[lane] = a;
+    if (lane == 0) ga_g[f_base] = ga;
+    int rpos = D - 1;
+    for (int t = 1; t < T; t++) {
+      rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      const uint64_t base = scrf_seg_base(t, D);
+      const bool full = (nd == DMAX) && (np == DMAX);  // steady state: every duration has a predecessor
+      // the nd windows ending at t: independent of the recursion, issued first
+      double es[DMAX];
+      if (full) {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) es[d0] = ESu[(base + d0) * L + lc];
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          const double x = ESu[(base + (d0 < nd ? d0 : 0)) * L + lc];
+          es[d0] = (d0 < nd) ? x : 0.0;
+        }
+      }
+      const double smx = smu[base + (lane < nd ? lane : 0)];
+      // transition out of node t-1: p = 2^-k * (a . E)
+      double usum, sh = sh0;
+      if (MPF) {
+        usum = matvec_bcast(a, E + (f_base + t) * (size_t)LL, L, lc);
+        sh = mshift[f_base + t];
+      } else {
+        usum = matvec_bcast(a, Es, L, lc);
+      }
+      const int k = hi_exp(wave_max_hi(act ? usum : 0.0), &err);
+      const double p = ldexp(usum, -k);
+      const double gp = ga + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      ring[rpos * L + lc] = p;  // idle lanes rewrite lane L-1's value with the same number
+      if (lane == rpos) gslot = gp;
+      if (act) pu[(size_t)(t - 1) * L + lane] = p;
+      if (lane == 0) gp_g[f_base + t - 1] = gp;
+      // per-duration scales: lane d0 looks at predecessor node t-1-d0 (ring slot rpos-d0)
+      int myslot = rpos - lane;
+      if (myslot < 0) myslot += D;
+      const double gprev = shfl_f64(gslot, (lane < np) ? myslot : 0);
+      double x = (lane < np) ? gprev + smx : smx;   // lane == np (< nd): the initial segment
+      x = (lane < nd) ? x : -INFINITY;
+      const double G = (double)wave_max_f32((float)x);
+      const double c = exp_nonpos(x - G);
+      double acc0 = 0.0, acc1 = 0.0;
+      if (full) {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = rpos - d0;
+          slot += (slot < 0) ? D : 0;
+          const double pv = (d0 == 0) ? p : ring[slot * L + lc];
+          const double w = es[d0] * rdlane(c, d0);
+          if (d0 & 1) acc1 = fma(pv, w, acc1); else acc0 = fma(pv, w, acc0);
+        }
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = rpos - d0;
+          if (slot < 0) slot += D;
+          const double r = (d0 == 0) ? p : ring[(d0 < np ? slot : rpos) * L + lc];
+          const double pv = (d0 < np) ? r : 1.0;
+          const double w = es[d0] * rdlane(c, d0);
+          if (d0 & 1) acc1 = fma(pv, w, acc1); else acc0 = fma(pv, w, acc0);
+        }
+      }
+      a = acc0 + acc1;
+      ga = G;
+      if (act) au[(size_t)t * L + lane] = a;
+      if (lane == 0) ga_g[f_base + t] = ga;
+    }
+    // Zx = log sum_l exp(alpha[T-1][l])  (computeAlphaSum)
+    const double tot = wave_sum_f64(act ? a : 0.0);
+    const double Zx = ga + log(tot);
+    if (!(Zx == Zx) || isinf(Zx)) err = 1;
+    if (lane == 0) zx_out[u] = Zx;
+  } else {
+    // ---------------------------------------------------------------- backward
+    double* bu = b_g + f_base * L;
+    double* sdu = sd_g + f_base * L;
+    int tpos = (T - 1) % D;
+    ring[tpos * L + lc] = 1.0;  // setTailBeta: beta[T-1] = 0
+    if (lane == tpos) gslot = 0.0;
+    if (act) { bu[(size_t)(T - 1) * L + lane] = 1.0; sdu[(size_t)(T - 1) * L + lane] = 0.0; }
+    if (lane == 0) { gb_g[f_base + T - 1] = 0.0; gsd_g[f_base + T - 1] = 0.0; }
+    for (int t = T - 2; t >= 0; t--) {
+      const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+      tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
+      // window (t+1+d0, d0+1): starts at t+1, ends at node t+1+d0
+      const bool full = (nn == DMAX) && (t + 1 >= D);
+      double es[DMAX];
+      const uint64_t sb = scrf_seg_base(t + 1, D);
+      uint64_t myrow;
+      if (full) {
+        // every node t+1.. carries D windows, so the window sits at row seg_base(t+1) + d0*(D+1)
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) es[d0] = ESu[(sb + (uint64_t)d0 * (DMAX + 1)) * L + lc];
+        myrow = sb + (uint64_t)(lane < nn ? lane : 0) * (DMAX + 1);
+      } else {
+        uint64_t r = sb;
+        myrow = sb;
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          const bool ok = d0 < nn;
+          const double x = ESu[(ok ? r + d0 : 0) * L + lc];
+          es[d0] = ok ? x : 0.0;
+          if (lane == d0 && ok) myrow = r + d0;
+          r += scrf_node_max_dur(t + 1 + d0, D);
+        }
+      }
+      const double smx = smu[myrow];
+      int myslot = tpos + lane + 1;  // node t + d0 + 1
+      if (myslot >= D) myslot -= D;
+      const double gnext = shfl_f64(gslot, (lane < nn) ? myslot : 0);
+      const double x = (lane < nn) ? gnext + smx : -INFINITY;
+      const double G = (double)wave_max_f32((float)x);
+      const double c = exp_nonpos(x - G);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        int slot = tpos + d0 + 1;
+        if (slot >= D) slot -= D;
+        const double bv_ = ring[((d0 < nn) ? slot : tpos) * L + lc];
+        const double w = es[d0] * rdlane(c, d0);   // es = 0 past nn
+        if (d0 & 1) acc1 = fma((d0 < nn) ? bv_ : 0.0, w, acc1); else acc0 = fma((d0 < nn) ? bv_ : 0.0, w, acc0);
+      }
+      const double sd = acc0 + acc1;
+      double w, sh = sh0;
+      if (MPF) {
+        w = matvec_bcast(sd, ET + (f_base + t + 1) * (size_t)LL, L, lc);
+        sh = mshift[f_base + t + 1];
+      } else {
+        w = matvec_bcast(sd, Es, L, lc);
+      }
+      const int k = hi_exp(wave_max_hi(act ? w : 0.0), &err);
+      const double b = ldexp(w, -k);
+      const double gb = G + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      ring[tpos * L + lc] = b;
+      if (lane == tpos) gslot = gb;
+      if (act) { sdu[(size_t)t * L + lane] = sd; bu[(size_t)t * L + lane] = b; }
+      if (lane == 0) { gsd_g[f_base + t] = G; gb_g[f_base + t] = gb; }
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicMax(&status[u], SCRF_ERR_NUMERIC);
+}
+
+void launch_true_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                        uint64_t n_frames, const double* S, double* s_true) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_true_scores, dim3((uint32_t)((n_frames + 255) / 256)), dim3(256), 0, st, lay, bv, frame_u, u0,
+                     n_frames, S, s_true);
+}
+void launch_exp_rows(hipStream_t st, double* S, uint64_t n_rows, uint32_t L, double* smax) {
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(k_exp_rows, dim3((uint32_t)((n_rows + 15) / 16)), dim3(256), 0, st, S, n_rows, L, smax);
+}
+
+void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                   const double* ES, const double* smax, const double* E, const double* ET, const double* mshift,
+                   int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
+  if (n_utts == 0) return;
+  const uint32_t nblk = 2 * ((n_utts + DP_WPB - 1) / DP_WPB);
+  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * lay.D * lay.L);
+#define DL_LAUNCH2(DM, MPF)                                                                                    \
+  do {                                                                                                         \
+    hipFuncSetAttribute((const void*)k_dp_lin<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \
+    hipLaunchKernelGGL((k_dp_lin<DM, MPF>), dim3(nblk), dim3(DP_WPB * 64), sm, st, lay, bv, u0, n_utts, ES, smax, \
+                       E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);               \
+  } while (0)
+#define DL_LAUNCH(DM)                     \
+  do {                                    \
+    if (m_per_frame) DL_LAUNCH2(DM, 1);   \
+    else DL_LAUNCH2(DM, 0);               \
+  } while (0)
+  if (lay.D <= 1) DL_LAUNCH(1);
+  else if (lay.D <= 4) DL_LAUNCH(4);
+  else if (lay.D <= 10) DL_LAUNCH(10);
+  else if (lay.D <= 16) DL_LAUNCH(16);
+  else if (lay.D <= 25) DL_LAUNCH(25);
+  else DL_LAUNCH(32);
+#undef DL_LAUNCH
+#undef DL_LAUNCH2
+}
+
+// ------------------------------------------------------------------------------------------
+// k_post_lin: R = Y - gamma over es (in place),
+//   gamma[(t,d)][l] = p[t-d][l] * es[(t,d)][l] * b[t][l] * exp(gp[t-d] + smax[(t,d)] + gb[t] - Zx)
+// (computeExpF :673-702), plus the per-frame numerator term.  One workgroup per frame.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_lin(ScrfLayout lay, ScrfBatchView bv, const uint32_t* __restrict__ frame_u,
+                                                  uint32_t u0, const uint32_t* __restrict__ next_lab,
+                                                  const double* __restrict__ s_true, const double* __restrict__ M,
+                                                  int m_per_frame, double* __restrict__ ES,
+                                                  const double* __restrict__ smax, ScrfDpLin o,
+                                                  const double* __restrict__ zx, double* __restrict__ numer_f,
+                                                  int* __restrict__ status) {
+  __shared__ double fs[64];
+  const uint32_t L = lay.L, D = lay.D;
+  const uint64_t fi = blockIdx.x;  // frame index inside the chunk
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  const uint32_t u = frame_u[gf];
+  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  const uint32_t T = bv.T[u];
+  const uint64_t row0 = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
+  const uint32_t nd = scrf_node_max_dur(t, D), np = scrf_num_prev(t, D);
+  const double Zx = zx[u];
+  const uint32_t lab = bv.labels ? bv.labels[gf] : SCRF_LAB_BAD;
+  uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD;
+  int err = 0;
+  if (lab != SCRF_LAB_BAD) {
+    if (lab >= L * D) err = SCRF_ERR_BAD_LABEL;
+    al = lab % L;
+    ld = lab / L + 1;
+  }
+  const double LN_MAX = 709.782712893384;
+  if (threadIdx.x < nd) {
+    const uint32_t d0 = threadIdx.x;
+    const double x = ((d0 < np) ? o.gp[fi - 1 - d0] : 0.0) + smax[row0 + d0] + o.gb[fi] - Zx;
+    if (x >= LN_MAX) err = SCRF_ERR_NUMERIC;
+    fs[d0] = exp(x);
+  }
+  __syncthreads();
+  const double* bt = o.b + fi * L;
+  for (uint32_t idx = threadIdx.x; idx < nd * L; idx += blockDim.x) {
+    const uint32_t d0 = idx / L, l = idx - d0 * L;
+    const double pv = (d0 < np) ? o.p[(fi - 1 - d0) * L + l] : 1.0;
+    const double g = (pv * ES[(row0 + d0) * L + l]) * (bt[l] * fs[d0]);
+    const double y = (l == al && d0 + 1 == ld) ? 1.0 : 0.0;
+    ES[(row0 + d0) * L + l] = y - g;
+  }
+  if (threadIdx.x == 0) {
+    double nodeLi = 0.0;
+    if (lab != SCRF_LAB_BAD && err == 0) {
+      if (ld <= nd) nodeLi += s_true[fi];
+      const uint32_t nl = next_lab[gf];
+      if (t + 1 < T && nl != SCRF_LAB_BAD) {
+        if (nl >= L * D) err = SCRF_ERR_BAD_LABEL;
+        else {
+          const double* Mn = M + (m_per_frame ? (fi + 1) * (size_t)L * L : 0);
+          nodeLi += Mn[(size_t)al * L + nl % L];
+        }
+      }
+    }
+    numer_f[fi] = nodeLi;
+  }
+  if (err) atomicMax(&status[u], err);
+}
+
+void launch_post_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                     uint64_t n_frames, const uint32_t* next_lab, const double* s_true, const double* M,
+                     int m_per_frame, double* ES, const double* smax, const ScrfDpLin& o, const double* zx,
+                     double* numer_f, int* status) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_post_lin, dim3((uint32_t)n_frames), dim3(256), 0, st, lay, bv, frame_u, u0, next_lab, s_true, M,
+                     m_per_frame, ES, smax, o, zx, numer_f, status);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_xi_lin: transition posteriors xi[t][c][n] = a[t][c] * exp(M[t+1][c][n]) * B[t][n] with
+//   B[t][n] = sd[t][n] * exp(ga[t] + gsd[t] - Zx)   (computeExpF :773-776); B overwrites sd.
+// ------------------------------------------------------------------------------------------
+__global__ void k_xi_lin(ScrfLayout lay, ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0,
+                         uint64_t n_frames, ScrfDpLin o, const double* __restrict__ zx) {
+  const uint32_t L = lay.L;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_frames * L) return;
+  const uint64_t fi = i / L;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  const uint32_t u = frame_u[gf];
+  const bool last = (gf + 1 == bv.frame_off[u + 1]);
+  o.sd[i] = last ? 0.0 : o.sd[i] * exp(o.ga[fi] + o.gsd[fi] - zx[u]);
+}
+void launch_xi_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                   uint64_t n_frames, const ScrfDpLin& o, const double* zx) {
+  if (n_frames == 0) return;
+  const uint64_t n = n_frames * lay.L;
+  hipLaunchKernelGGL(k_xi_lin, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, lay, bv, frame_u, u0, n_frames, o, zx);
+}
+
+// parity hook: alpha = log(a) + ga, beta = log(b) + gb
+__global__ void k_lin_to_log(uint64_t n_frames, uint32_t L, const double* __restrict__ m, const double* __restrict__ g,
+                             double* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_frames * L) return;
+  out[i] = log(m[i]) + g[i / L];
+}
+void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const double* m, const double* g, double* out) {
+  if (n_frames == 0) return;
+  const uint64_t n = n_frames * L;
+  hipLaunchKernelGGL(k_lin_to_log, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n_frames, L, m, g, out);
+}

@@ -83,6 +83,7 @@ struct scrf_engine_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 2;
   bool fuse_windows = true;
+  bool lin_dp = true;
   std::string err;
   bool timing = false;
   hipEvent_t ev[SCRF_N_PHASES + 1][2];
@@ -105,6 +106,7 @@ struct scrf_batch_s {
   uint32_t* d_labels = nullptr;
   uint32_t* d_next_lab = nullptr;      // [sum T] label of the next labelled frame (gradbuilder :436-444)
   uint32_t* d_trans_counts = nullptr;  // [L*L] observed (c -> n) transitions of the whole batch
+  uint32_t* d_frame_u = nullptr;       // [sum T] utterance of each frame
   float* d_windows = nullptr;
   uint32_t n_streams = 0;
   scrf_stream_recipe recipe[SCRF_MAX_STREAMS];
@@ -205,6 +207,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (h->cfg.scratch_bytes == 0) h->cfg.scratch_bytes = 8ull << 30;
   if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knobs
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   memset(h->ms, 0, sizeof(h->ms));
   memset(h->nlaunch, 0, sizeof(h->nlaunch));
 #define CRCHK(call)                                                                          \
@@ -415,7 +418,7 @@ extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   if (!b) return SCRF_OK;
   if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
   hipFree(b->d_T); hipFree(b->d_frame_off); hipFree(b->d_seg_off); hipFree(b->d_arc_off);
-  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows);
+  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u);
   for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
   hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
   hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]);
@@ -469,6 +472,12 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   BCHK(upload(h, &b->d_frame_off, b->frame_off.data(), n + 1));
   BCHK(upload(h, &b->d_seg_off, b->seg_off.data(), n + 1));
   BCHK(upload(h, &b->d_arc_off, b->arc_off.data(), n + 1));
+  {
+    std::vector<uint32_t> fu(NF);
+    for (uint32_t u = 0; u < n; u++) std::fill(fu.begin() + b->frame_off[u], fu.begin() + b->frame_off[u + 1], u);
+    BCHK(upload(h, &b->d_frame_u, fu.data(), NF));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   if (have_labels) {
     std::vector<uint32_t> lab(NF);
     for (uint32_t u = 0; u < n; u++) memcpy(&lab[b->frame_off[u]], utts[u].labels, sizeof(uint32_t) * utts[u].T);
@@ -622,6 +631,12 @@ struct ChunkBufs {
   double* fA = nullptr;      // [nfr][L] xi factors
   double* fB = nullptr;
   double* numer_f = nullptr; // [nfr]
+  // scaled linear-domain recursion (training path of the wavefront DP)
+  bool lin = false;
+  ScrfDpLin dl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* smax = nullptr;    // [nseg] row maxima of the scores
+  double* s_true = nullptr;  // [nfr] score of the labelled window ending at each frame
+  double* R = nullptr;       // [nseg][L] Y - gamma: cb.S (linear path) or cb.AD
   double* slab_atb = nullptr;
   uint32_t nch_atb = 0;
   uint64_t rpc_atb = 0;
@@ -654,14 +669,22 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   tot += pad256(nseg * l.L * sizeof(double));                       // S
   if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
   if (nd.fb) {
-    tot += pad256(nseg * l.L * sizeof(double));                     // AD
-    tot += pad256(nfr * l.L * sizeof(double));                      // alpha
-    if (nd.beta || dp_wave_supported(l)) tot += pad256(nfr * l.L * sizeof(double));
-    if (dp_wave_supported(l)) {
-      tot += pad256(nfr * l.L * sizeof(double));                    // sd
+    const bool wave = dp_wave_supported(l);
+    if (wave && nd.post && h->lin_dp) {
+      // scaled linear-domain recursion: no alpha-with-duration array
+      tot += pad256(nseg * sizeof(double)) + pad256(nfr * sizeof(double));               // smax, s_true
+      tot += 4 * pad256(nfr * l.L * sizeof(double)) + 4 * pad256(nfr * sizeof(double));  // a, p, b, sd + log-scales
+    } else {
+      tot += pad256(nseg * l.L * sizeof(double));                     // AD
+      tot += pad256(nfr * l.L * sizeof(double));                      // alpha
+      if (nd.beta || wave) tot += pad256(nfr * l.L * sizeof(double));
+      if (wave) tot += pad256(nfr * l.L * sizeof(double));            // sd
+      if (wave && nd.post) tot += 2 * pad256(nfr * l.L * sizeof(double));  // A, B
+    }
+    if (wave) {
       if (l.use_tf) tot += 2 * pad256(nfr * LL * sizeof(double)) + pad256(nfr * sizeof(double));  // E, ET, shift
       if (nd.post) {
-        tot += 2 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * sizeof(double));  // A, B, numer_f
+        tot += pad256(nfr * sizeof(double));                          // numer_f
         if (!l.use_tf) tot += pad256(((nfr + 511) / 512) * LL * sizeof(double));
       }
     }
@@ -729,12 +752,30 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     cb->m_per_frame = 0;
   }
   if (nd.fb) {
-    cb->AD = a.take<double>(nseg * l.L);
-    cb->alpha = a.take<double>(nfr * l.L);
     cb->wave = dp_wave_supported(l);
-    if (nd.beta || cb->wave) cb->beta = a.take<double>(nfr * l.L);
+    cb->lin = cb->wave && nd.post && h->lin_dp;
+    if (cb->lin) {
+      cb->smax = a.take<double>(nseg);
+      cb->s_true = a.take<double>(nfr);
+      cb->dl.a = a.take<double>(nfr * l.L);  cb->dl.ga = a.take<double>(nfr);
+      cb->dl.p = a.take<double>(nfr * l.L);  cb->dl.gp = a.take<double>(nfr);
+      cb->dl.b = a.take<double>(nfr * l.L);  cb->dl.gb = a.take<double>(nfr);
+      cb->dl.sd = a.take<double>(nfr * l.L); cb->dl.gsd = a.take<double>(nfr);
+      cb->R = cb->S;              // R = Y - gamma overwrites the exponentiated scores
+      cb->fA = cb->dl.a;          // xi factors: a, and sd rescaled in place
+      cb->fB = cb->dl.sd;
+    } else {
+      cb->AD = a.take<double>(nseg * l.L);
+      cb->R = cb->AD;
+      cb->alpha = a.take<double>(nfr * l.L);
+      if (nd.beta || cb->wave) cb->beta = a.take<double>(nfr * l.L);
+      if (cb->wave) cb->sd = a.take<double>(nfr * l.L);
+      if (cb->wave && nd.post) {
+        cb->fA = a.take<double>(nfr * l.L);
+        cb->fB = a.take<double>(nfr * l.L);
+      }
+    }
     if (cb->wave) {
-      cb->sd = a.take<double>(nfr * l.L);
       if (l.use_tf) {
         cb->E = a.take<double>(nfr * LL);
         cb->ET = a.take<double>(nfr * LL);
@@ -743,8 +784,6 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
         cb->E = h->d_e0; cb->ET = h->d_et0; cb->msh = h->d_msh0;
       }
       if (nd.post) {
-        cb->fA = a.take<double>(nfr * l.L);
-        cb->fB = a.take<double>(nfr * l.L);
         cb->numer_f = a.take<double>(nfr);
         if (!l.use_tf) {
           cb->rpc_atb = 512;
@@ -873,6 +912,25 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
     nl = 1;
   } else {
     if (cb.m_per_frame) { launch_exp_m(cb.st, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh); nl++; }
+    if (cb.lin) {
+      const uint64_t nseg = b->seg_off[u1] - b->seg_off[u0];
+      launch_true_scores(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.S, cb.s_true);
+      launch_exp_rows(cb.st, cb.S, nseg, l.L, cb.smax);
+      launch_dp_lin(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.smax, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.dl,
+                    b->d_zx, b->d_status);
+      launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
+                      cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
+      launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
+      launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
+      nl += 6;
+      if (l.use_tf) {
+        launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
+        nl++;
+      }
+      if (nl_out) *nl_out = nl;
+      HIPCHK(h, hipGetLastError());
+      return SCRF_OK;
+    }
     launch_dp_wave(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
                    cb.beta, cb.sd, b->d_zx, b->d_status);
     nl++;
@@ -970,13 +1028,13 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
       if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
         ScrfFusedArgs fa = fused_args(h, b, u0, 1);
-        launch_expf_fused(cb.st, fa, l, cb.AD, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
-        launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.AD, cb.Z);
+        launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
+        launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z);
         launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
                          spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 2;
-      } else if (fast) launch_expf_mfma(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
-      else launch_expf_gemm(cb.st, cb.AD, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+      } else if (fast) launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
+      else launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
       if (l.use_tf) {
         launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
         if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32);

@@ -66,6 +66,21 @@ void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uin
                     uint64_t n_frames, const uint32_t* next_lab, const double* A, const double* B, const double* E,
                     const double* mshift, double* XI);
 
+// scrf_dplin.hip: scaled linear-domain forward/backward + posteriors (training path, L <= 64)
+void launch_true_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                        uint64_t n_frames, const double* S, double* s_true);
+void launch_exp_rows(hipStream_t st, double* S, uint64_t n_rows, uint32_t L, double* smax);
+void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                   const double* ES, const double* smax, const double* E, const double* ET, const double* mshift,
+                   int m_per_frame, const ScrfDpLin& o, double* zx, int* status);
+void launch_post_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                     uint64_t n_frames, const uint32_t* next_lab, const double* s_true, const double* M,
+                     int m_per_frame, double* ES, const double* smax, const ScrfDpLin& o, const double* zx,
+                     double* numer_f, int* status);
+void launch_xi_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                   uint64_t n_frames, const ScrfDpLin& o, const double* zx);
+void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const double* m, const double* g, double* out);
+
 // scrf_fused.hip: state contractions with the window synthesis fused in (X never materialised)
 #define SCRF_FUSED_ROWS_SCORES 256
 #define SCRF_FUSED_ROWS_EXPF 64

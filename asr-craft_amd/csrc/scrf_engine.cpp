@@ -633,6 +633,7 @@ struct ChunkBufs {
   double* numer_f = nullptr; // [nfr]
   // scaled linear-domain recursion (training path of the wavefront DP)
   bool lin = false;
+  bool es_ready = false;     // cb.S already holds exp(S - smax) (written by the fused score kernel)
   ScrfDpLin dl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* smax = nullptr;    // [nseg] row maxima of the scores
   double* s_true = nullptr;  // [nfr] score of the labelled window ending at each frame
@@ -860,7 +861,10 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     // per-frame projections of the five sampled blocks, then the dense part + gather
     launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
                        spec_samples(W0), 5 * l.L, cb.P);
-    launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32);
+    // on the linear-domain path the epilogue already exponentiates the rows (L <= 48)
+    cb.es_ready = cb.lin && l.L <= 48;
+    launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32,
+                        cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels);
     tm.stop(2);
     HIPCHK(h, hipGetLastError());
     return SCRF_OK;
@@ -914,15 +918,18 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
     if (cb.m_per_frame) { launch_exp_m(cb.st, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh); nl++; }
     if (cb.lin) {
       const uint64_t nseg = b->seg_off[u1] - b->seg_off[u0];
-      launch_true_scores(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.S, cb.s_true);
-      launch_exp_rows(cb.st, cb.S, nseg, l.L, cb.smax);
+      if (!cb.es_ready) {
+        launch_true_scores(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.S, cb.s_true);
+        launch_exp_rows(cb.st, cb.S, nseg, l.L, cb.smax);
+        nl += 2;
+      }
       launch_dp_lin(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.smax, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.dl,
                     b->d_zx, b->d_status);
       launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
                       cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
       launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
       launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
-      nl += 6;
+      nl += 4;
       if (l.use_tf) {
         launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
         nl++;

@@ -22,6 +22,8 @@
 
 #include <math.h>
 #include <string.h>
+#include <utility>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -54,6 +56,29 @@ __device__ __forceinline__ FuTile fu_tile(const ScrfFusedArgs& fa, const ScrfTil
   ft.row0 = q.row_abs - fa.row_base;
   ft.fr0 = q.fr_abs - fa.frame_base;
   return ft;
+}
+
+// exp(x) for x <~ 0 (Cody-Waite + degree-13 Horner, ~1 ulp; flushes to 0 below -745)
+__device__ __forceinline__ double fu_exp(double x) {
+  x = fmax(x, -1000.0);
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;
+  p = fma(p, r, 2.0876756987868100e-09);
+  p = fma(p, r, 2.5052108385441720e-08);
+  p = fma(p, r, 2.7557319223985888e-07);
+  p = fma(p, r, 2.7557319223985893e-06);
+  p = fma(p, r, 2.4801587301587302e-05);
+  p = fma(p, r, 1.9841269841269841e-04);
+  p = fma(p, r, 1.3888888888888889e-03);
+  p = fma(p, r, 8.3333333333333332e-03);
+  p = fma(p, r, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
 }
 
 // Window statistics of one (frame, column): the values F[t-j][c], j = 0 .. nd-1, are read from LDS
@@ -101,11 +126,16 @@ __device__ __forceinline__ void fu_scan_ext(const float (&v)[DMAX], float* o, ui
 // After the last chunk the tile's rows of P are staged over the dead operand images for the gather.
 // ------------------------------------------------------------------------------------------
 #define FU_NT 512
+// smax != nullptr (n_out <= 48 only): the epilogue writes exp(S - smax[row]) instead of S, with
+// smax[row] the float-rounded row maximum, and the labelled windows' scores to s_true -- the inputs
+// of the linear-domain recursion (scrf_dplin.hip), saving a read-modify-write pass over S.
 template <int DMAX, int F32>
 __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, ScrfLayout lay,
                                                            const double* __restrict__ lambda,
                                                            const double* __restrict__ P, uint32_t n_out,
-                                                           double* __restrict__ S) {
+                                                           double* __restrict__ S, double* __restrict__ smax,
+                                                           double* __restrict__ s_true,
+                                                           const uint32_t* __restrict__ labels) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const uint32_t W = fa.W, D = lay.D;
   const uint32_t nfmax = fa.TB + D - 1;
@@ -261,21 +291,46 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const uint32_t rl = wave * 32 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
-      if (rl >= ft.nrows) continue;
+      if (rl >= ft.nrows) continue;   // uniform over the 16 lanes that share the row
       const uint32_t d = rdur[rl], b0 = rfirst[rl];
       const uint8_t* sp = steps + (d - 1) * 5;
       const uint32_t q0 = (b0 + sp[0]) * 240, q1 = (b0 + sp[1]) * 240 + 48, q2 = (b0 + sp[2]) * 240 + 96,
                      q3 = (b0 + sp[3]) * 240 + 144, q4 = (b0 + sp[4]) * 240 + 192;
+      double sv[3];
 #pragma unroll
       for (int n = 0; n < 3; n++) {
         const uint32_t ol = n * 16 + li, o = o0 + ol;
+        sv[n] = -INFINITY;
         if (o >= n_out) continue;
         const double* wl = lambda + lay.state_idx(o) + 8 * W;  // duration block, then the bias weight
         const double lin = (((Pl[q0 + ol] + Pl[q1 + ol]) + Pl[q2 + ol]) + Pl[q3 + ol]) + Pl[q4 + ol];
         const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
-        double s = (v + lin) + wl[d - 1];
-        if (lay.use_sb) s += wl[D] * lay.sbv;
-        S[(ft.row0 + rl) * n_out + o] = s;
+        double sc = (v + lin) + wl[d - 1];
+        if (lay.use_sb) sc += wl[D] * lay.sbv;
+        sv[n] = sc;
+      }
+      if (smax) {
+        // row maximum over the 16 lanes that share this row (and the 3 output tiles), as a float
+        float mx = fmaxf(fmaxf((float)sv[0], (float)sv[1]), (float)sv[2]);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const double ref = (double)mx;
+        const uint32_t lab = labels ? labels[fa.frame_base + ft.fr0 + b0 + d - 1] : SCRF_LAB_BAD;
+        const bool mine = lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d;
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+          const uint32_t o = o0 + n * 16 + li;
+          if (o >= n_out) continue;
+          if (mine && lab % n_out == o) s_true[ft.fr0 + b0 + d - 1] = sv[n];
+          S[(ft.row0 + rl) * n_out + o] = fu_exp(sv[n] - ref);
+        }
+        if (li == 0) smax[ft.row0 + rl] = ref;
+      } else {
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+          const uint32_t o = o0 + n * 16 + li;
+          if (o < n_out) S[(ft.row0 + rl) * n_out + o] = sv[n];
+        }
       }
     }
 }
@@ -291,20 +346,24 @@ static size_t fused_scores_smem(uint32_t W, uint32_t D) {
 
 template <int DMAX, int F32>
 static void launch_scores_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
-                                  const double* P, uint64_t n_tiles, double* S) {
+                                  const double* P, uint64_t n_tiles, double* S, double* smax, double* s_true,
+                                  const uint32_t* labels) {
   const size_t sm = fused_scores_smem(fa.W, lay.D);
   dim3 grid((uint32_t)n_tiles, (lay.L + 47) / 48);
   hipFuncSetAttribute((const void*)k_scores_fused<DMAX, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((k_scores_fused<DMAX, F32>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S);
+  hipLaunchKernelGGL((k_scores_fused<DMAX, F32>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S, smax, s_true,
+                     labels);
 }
 
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
-                         const double* P, uint64_t n_tiles, double* S, int f32) {
+                         const double* P, uint64_t n_tiles, double* S, int f32, double* smax, double* s_true,
+                         const uint32_t* labels) {
   if (n_tiles == 0) return;
+  if (lay.L > 48) smax = nullptr;   // a row spans several workgroups: the caller runs k_exp_rows instead
 #define FS_GO(N)                                                                        \
   do {                                                                                  \
-    if (f32) launch_scores_fused_t<N, 1>(st, fa, lay, lambda, P, n_tiles, S);            \
-    else launch_scores_fused_t<N, 0>(st, fa, lay, lambda, P, n_tiles, S);                \
+    if (f32) launch_scores_fused_t<N, 1>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels);   \
+    else launch_scores_fused_t<N, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels);       \
   } while (0)
   if (lay.D <= 12) FS_GO(12);
   else if (lay.D <= 25) FS_GO(25);
@@ -314,79 +373,96 @@ void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayo
 
 // ------------------------------------------------------------------------------------------
 // k_lin_z: Z[f][k][o] = sum_d R[(t = f + off_k(d), d)][o], off_k(d) = d - 1 - s_k(d): the windows
-// whose k-th sampled frame is f.  One thread per (utterance, k, o) walks the utterance once with a
-// private ring of D partial sums in LDS; frame f is final once t = f + D - 1 has been added.
-// The adds are LDS ds_add_f64 (no return, so they pipeline); every address belongs to one thread
-// and LDS operations of a wave complete in order, so the sum order is fixed (t, then d ascending).
-// The next frame's R rows are fetched into registers while the current ones are added.
+// whose k-th sampled frame is f.  Thread = (utterance, output o): walks the utterance once.  off_k(d) is a compile-time table, so the partial sums of
+// the frames still open live in REGISTERS: a window of off_k(D)+1 doubles per k that slides by one
+// frame per step (no LDS, no atomics).  Sum order: t ascending, then d ascending.
 // ------------------------------------------------------------------------------------------
+constexpr int fu_step_c(int d, int k) {
+  const float ot = (float)((double)d * 0.1);
+  const float x = ot * (float)(2 * k + 1);
+  int c = (int)x;
+  if ((float)c < x) c++;
+  return c - 1;
+}
+constexpr int fu_off_c(int d, int k) { return d - 1 - fu_step_c(d, k); }
+template <int K, int DMAX>
+struct LzWin {
+  static constexpr int MO = fu_off_c(DMAX, K);   // frames a window of length <= DMAX can reach back
+  double v[MO + 1];                              // v[j]: partial sum of frame t - j
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j <= MO; j++) v[j] = 0.0;
+  }
+  // the indices are template constants (a pack expansion): the window is a set of named registers
+  template <int... D0>
+  __device__ __forceinline__ void add_seq(const double (&r)[DMAX], std::integer_sequence<int, D0...>) {
+    ((v[std::integral_constant<int, fu_off_c(D0 + 1, K)>::value] += r[D0]), ...);
+  }
+  __device__ __forceinline__ void add(const double (&r)[DMAX]) { add_seq(r, std::make_integer_sequence<int, DMAX>{}); }
+  // after frame t: frame t - MO is final; slide by one frame
+  __device__ __forceinline__ void retire(double* Zk, int t, size_t zstride) {
+    if (t >= MO) Zk[(size_t)(t - MO) * zstride] = v[MO];
+#pragma unroll
+    for (int j = MO; j >= 1; j--) v[j] = v[j - 1];
+    v[0] = 0.0;
+  }
+  // after the last frame T-1 (already slid): v[j] holds frame T - j, j = 1 .. MO
+  __device__ __forceinline__ void flush(double* Zk, int T, size_t zstride) {
+#pragma unroll
+    for (int j = 1; j <= MO; j++)
+      if (T - j >= 0) Zk[(size_t)(T - j) * zstride] = v[j];
+  }
+};
+
 template <int DMAX>
-__global__ __launch_bounds__(256) void k_lin_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0,
-                                               const double* __restrict__ R, double* __restrict__ Z) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+__device__ __forceinline__ void lz_load(const double* Ru, uint32_t L, uint32_t D, int t, int T, double (&r)[DMAX]) {
+  const uint32_t nd = (t < T) ? scrf_node_max_dur((uint32_t)t, D) : 0;
+  const double* Rt = Ru + scrf_seg_base((uint32_t)(t < T ? t : 0), D) * (uint64_t)L;
+#pragma unroll
+  for (int d0 = 0; d0 < DMAX; d0++) r[d0] = ((uint32_t)d0 < nd) ? Rt[(uint64_t)d0 * L] : 0.0;
+}
+
+// one wavefront per (utterance, 64 outputs): every R row is loaded exactly once and feeds the five
+// sample positions; the next frame's rows are in flight under the adds of the current one
+template <int DMAX>
+__global__ __launch_bounds__(64, 2) void k_lin_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0,
+                                                 const double* __restrict__ R, double* __restrict__ Z) {
   const uint32_t D = lay.D, L = lay.L;
-  double* ring = (double*)fsm;                         // [D][256]
-  const uint32_t tid = threadIdx.x;
   const uint32_t u = u0 + blockIdx.x;
-  const uint32_t T = bv.T[u];
-  const uint32_t k = tid / 48, ol = tid % 48, o = blockIdx.y * 48 + ol;
-  if (k >= 5 || o >= L) return;
-  for (uint32_t s = 0; s < D; s++) ring[s * 256 + tid] = 0.0;
-  // off_k(d) is non-decreasing in d with steps of 0 or 1: bit d-1 set = off_k(d) > off_k(d-1)
-  uint64_t inc = 0;
-  {
-    uint32_t prev = 0;
-    for (uint32_t d = 2; d <= D; d++) {
-      const uint32_t of = d - 1 - fu_sample_step(d, (int)k);
-      if (of != prev) inc |= 1ull << (d - 1);
-      prev = of;
-    }
-  }
+  const int T = (int)bv.T[u];
+  const uint32_t o = blockIdx.y * 64 + threadIdx.x;
+  if (o >= L) return;
   const double* Ru = R + (bv.seg_off[u] - bv.seg_off[u0]) * (uint64_t)L + o;
-  double* Zu = Z + (bv.frame_off[u] - bv.frame_off[u0]) * (uint64_t)(5 * L) + k * L + o;
-  double* rg = ring + tid;
+  double* Zu = Z + (bv.frame_off[u] - bv.frame_off[u0]) * (uint64_t)(5 * L) + o;
+  LzWin<0, DMAX> w0; LzWin<1, DMAX> w1; LzWin<2, DMAX> w2; LzWin<3, DMAX> w3; LzWin<4, DMAX> w4;
+  w0.clear(); w1.clear(); w2.clear(); w3.clear(); w4.clear();
+  const size_t zs = (size_t)5 * L;
   double r[DMAX], rn[DMAX];
+  lz_load<DMAX>(Ru, L, D, 0, T, r);
+#pragma unroll 1
+  for (int t = 0; t < T; t++) {
+    lz_load<DMAX>(Ru, L, D, t + 1, T, rn);
+    w0.add(r); w1.add(r); w2.add(r); w3.add(r); w4.add(r);
+    w0.retire(Zu, t, zs);
+    w1.retire(Zu + L, t, zs);
+    w2.retire(Zu + 2 * (size_t)L, t, zs);
+    w3.retire(Zu + 3 * (size_t)L, t, zs);
+    w4.retire(Zu + 4 * (size_t)L, t, zs);
 #pragma unroll
-  for (int d = 0; d < DMAX; d++) r[d] = (d < 1) ? Ru[0] : 0.0;   // frame 0 has one window
-  uint32_t tm = 0;  // t mod D
-  for (uint32_t t = 0; t < T; t++) {
-    const uint32_t nd = scrf_node_max_dur(t, D);
-    const uint32_t nd1 = (t + 1 < T) ? scrf_node_max_dur(t + 1, D) : 0;
-    const double* Rn = Ru + scrf_seg_base(t + 1, D) * (uint64_t)L;
-#pragma unroll
-    for (int d = 0; d < DMAX; d++) rn[d] = ((uint32_t)d < nd1) ? Rn[(uint64_t)d * L] : 0.0;
-    uint32_t s = tm;
-#pragma unroll
-    for (int d = 0; d < DMAX; d++) {
-      if ((uint32_t)d < nd) {
-        if (d > 0 && ((inc >> d) & 1)) s = s ? s - 1 : D - 1;
-        __hip_atomic_fetch_add(rg + s * 256, r[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-    // frame f = t - (D-1) can receive nothing more: its slot is the one t+1 will reuse
-    const uint32_t sn = (tm + 1 == D) ? 0 : tm + 1;
-    if (t + 1 >= D) {
-      Zu[(uint64_t)(t + 1 - D) * (5 * L)] = rg[sn * 256];
-      rg[sn * 256] = 0.0;
-    }
-    tm = sn;
-#pragma unroll
-    for (int d = 0; d < DMAX; d++) r[d] = rn[d];
+    for (int d0 = 0; d0 < DMAX; d0++) r[d0] = rn[d0];
   }
-  // flush the frames still open: f = max(0, T-D+1) .. T-1
-  for (uint32_t f = (T >= D) ? T - D + 1 : 0; f < T; f++) Zu[(uint64_t)f * (5 * L)] = rg[(f % D) * 256];
+  w0.flush(Zu, T, zs);
+  w1.flush(Zu + L, T, zs);
+  w2.flush(Zu + 2 * (size_t)L, T, zs);
+  w3.flush(Zu + 3 * (size_t)L, T, zs);
+  w4.flush(Zu + 4 * (size_t)L, T, zs);
 }
 
 void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                   const double* R, double* Z) {
   if (n_utts == 0) return;
-  const size_t sm = sizeof(double) * lay.D * 256 + 16;
-  dim3 grid(n_utts, (lay.L + 47) / 48);
-#define LZ_GO(N)                                                                                          \
-  do {                                                                                                    \
-    hipFuncSetAttribute((const void*)k_lin_z<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);   \
-    hipLaunchKernelGGL(k_lin_z<N>, grid, dim3(256), sm, st, lay, bv, u0, R, Z);                           \
-  } while (0)
+  dim3 grid(n_utts, (lay.L + 63) / 64);
+#define LZ_GO(N) hipLaunchKernelGGL(k_lin_z<N>, grid, dim3(64), 0, st, lay, bv, u0, R, Z)
   if (lay.D <= 8) LZ_GO(8);
   else if (lay.D <= 16) LZ_GO(16);
   else if (lay.D <= 25) LZ_GO(25);
@@ -637,7 +713,6 @@ int fused_supported(const ScrfLayout& lay, uint32_t W) {
   fused_expf_xs(lay, W, &n_ct);
   if (lay.D < 2 || lay.D > 40 || W < 1 || n_ct > 13) return 0;
   if (fused_expf_smem(lay, W) > 80 * 1024) return 0;
-  if (sizeof(double) * lay.D * 256 + 16 > 80 * 1024) return 0;
   return fused_scores_smem(W, lay.D) <= 80 * 1024;
 }
 

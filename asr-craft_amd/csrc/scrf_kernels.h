@@ -87,7 +87,8 @@ void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const doub
 int fused_supported(const ScrfLayout& lay, uint32_t W);
 uint32_t fused_expf_blocks(uint64_t n_tiles);
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
-                         const double* P, uint64_t n_tiles, double* S, int f32);
+                         const double* P, uint64_t n_tiles, double* S, int f32, double* smax = nullptr,
+                         double* s_true = nullptr, const uint32_t* labels = nullptr);
 void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                   const double* R, double* Z);
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,

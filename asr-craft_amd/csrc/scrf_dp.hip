@@ -360,44 +360,57 @@ void launch_xi_factors(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, 
                      n_frames, alpha_g, sd_g, zx, A, B);
 }
 
-// bias-only transitions: C[z][c][n] = sum_{frames of K-chunk z} A[f][c] * B[f][n]
-#define ATB_KT 32
+// bias-only transitions: C[z][c][n] = sum_{frames of K-chunk z} A[f][c] * B[f][n]  (A^T B, K = frames)
+// on the fp64 MFMA: one wavefront per K-chunk holds the LT x LT output tiles in registers and
+// streams its frames four at a time straight from memory (each operand fragment is four 128-byte
+// row pieces); the next group's fragments are in flight under the MFMAs.
+typedef double atb_v4f64 __attribute__((ext_vector_type(4)));
+template <int LT>
 __global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const double* __restrict__ B, uint32_t L,
-                                             uint64_t n_frames, uint64_t rows_per_chunk, double* __restrict__ slab) {
-  extern __shared__ double absm[];
-  double* As = absm;                       // [ATB_KT][L]
-  double* Bs = absm + (size_t)ATB_KT * L;  // [ATB_KT][L]
-  const uint32_t LL = L * L;
-  const uint64_t r_begin = (uint64_t)blockIdx.x * rows_per_chunk;
+                                             uint64_t n_frames, uint64_t rows_per_chunk, uint32_t n_chunks,
+                                             double* __restrict__ slab) {
+  const uint32_t lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const uint32_t z = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (z >= n_chunks) return;
+  const uint64_t r_begin = (uint64_t)z * rows_per_chunk;
   const uint64_t r_end = min(n_frames, r_begin + rows_per_chunk);
-  const uint32_t per = (LL + 255) / 256;  // outputs per thread, idx = tid + k*256
-  double acc[16];
+  atb_v4f64 acc[LT][LT];
 #pragma unroll
-  for (int k = 0; k < 16; k++) acc[k] = 0.0;
-  for (uint64_t r0 = r_begin; r0 < r_end; r0 += ATB_KT) {
-    const uint32_t kt = (uint32_t)min((uint64_t)ATB_KT, r_end - r0);
-    for (uint32_t i = threadIdx.x; i < kt * L; i += 256) {
-      As[i] = A[r0 * L + i];
-      Bs[i] = B[r0 * L + i];
+  for (int i = 0; i < LT; i++)
+#pragma unroll
+    for (int j = 0; j < LT; j++) acc[i][j] = (atb_v4f64){0.0, 0.0, 0.0, 0.0};
+  double a_n[LT], b_n[LT];
+  auto load = [&](uint64_t f0) {
+    const uint64_t f = f0 + lk;
+#pragma unroll
+    for (int i = 0; i < LT; i++) {
+      const uint32_t c = i * 16 + li;
+      const bool ok = f < r_end && c < L;
+      a_n[i] = ok ? A[f * L + c] : 0.0;
+      b_n[i] = ok ? B[f * L + c] : 0.0;
     }
-    __syncthreads();
+  };
+  load(r_begin);
+  for (uint64_t f0 = r_begin; f0 < r_end; f0 += 4) {
+    double a[LT], b[LT];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const uint32_t idx = threadIdx.x + k * 256;
-      if ((uint32_t)k < per && idx < LL) {
-        const uint32_t c = idx / L, n = idx - c * L;
-        double s = acc[k];
-        for (uint32_t r = 0; r < kt; r++) s = fma(As[r * L + c], Bs[r * L + n], s);
-        acc[k] = s;
+    for (int i = 0; i < LT; i++) { a[i] = a_n[i]; b[i] = b_n[i]; }
+    if (f0 + 4 < r_end) load(f0 + 4);
+#pragma unroll
+    for (int i = 0; i < LT; i++)
+#pragma unroll
+      for (int j = 0; j < LT; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  double* out = slab + (size_t)z * L * L;
+#pragma unroll
+  for (int i = 0; i < LT; i++)
+#pragma unroll
+    for (int j = 0; j < LT; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t c = i * 16 + lk + 4 * r, n = j * 16 + li;
+        if (c < L && n < L) out[(size_t)c * L + n] = acc[i][j][r];
       }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const uint32_t idx = threadIdx.x + k * 256;
-    if ((uint32_t)k < per && idx < LL) slab[(size_t)blockIdx.x * LL + idx] = acc[k];
-  }
 }
 // grad[trans_idx(c,n)] -= tbv * exp(M0[c][n]) * sum_z C[z][c][n]   (expected transition-bias counts)
 __global__ void k_reduce_atb(const double* __restrict__ slab, uint32_t n_chunks, const double* __restrict__ M0,
@@ -409,12 +422,18 @@ __global__ void k_reduce_atb(const double* __restrict__ slab, uint32_t n_chunks,
   for (uint32_t z = 0; z < n_chunks; z++) s += slab[(size_t)z * LL + i];
   grad[lay.trans_idx(i / lay.L, i % lay.L) + lay.ntfe] -= lay.tbv * exp(M0[i]) * s;
 }
-int atb_supported(const ScrfLayout& lay) { return lay.L * lay.L <= 16 * 256; }
+int atb_supported(const ScrfLayout& lay) { return lay.L <= 64; }
 void launch_atb(hipStream_t st, const ScrfLayout& lay, const double* A, const double* B, uint64_t n_frames,
                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad) {
   if (n_frames == 0 || n_chunks == 0 || !lay.use_tb) return;
-  const size_t sm = sizeof(double) * 2 * ATB_KT * lay.L;
-  hipLaunchKernelGGL(k_atb, dim3(n_chunks), dim3(256), sm, st, A, B, lay.L, n_frames, rows_per_chunk, slab);
+  const dim3 grid((n_chunks + 3) / 4);
+  const uint32_t lt = (lay.L + 15) / 16;
+#define ATB_GO(N) hipLaunchKernelGGL(k_atb<N>, grid, dim3(256), 0, st, A, B, lay.L, n_frames, rows_per_chunk, n_chunks, slab)
+  if (lt <= 1) ATB_GO(1);
+  else if (lt == 2) ATB_GO(2);
+  else if (lt == 3) ATB_GO(3);
+  else ATB_GO(4);
+#undef ATB_GO
   const uint32_t LL = lay.L * lay.L;
   hipLaunchKernelGGL(k_reduce_atb, dim3((LL + 255) / 256), dim3(256), 0, st, slab, n_chunks, M0, lay, grad);
 }

@@ -601,6 +601,12 @@ static uint64_t expf_rows_per_chunk(uint64_t nseg) {
   return rpc < EXPF_ROWS_PER_CHUNK ? EXPF_ROWS_PER_CHUNK : rpc;
 }
 
+// K-chunks of the transition-bias contraction: one wavefront each, about 1024 of them
+static uint64_t atb_rows_per_chunk(uint64_t nfr) {
+  uint64_t rpc = ((nfr + 1023) / 1024 + 3) & ~3ull;
+  return rpc < 64 ? 64 : rpc;
+}
+
 struct ChunkBufs {
   hipStream_t st = nullptr;  // stream of the lane this chunk runs on
   double* grad = nullptr;    // gradient / batch sums this lane accumulates into
@@ -686,7 +692,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
       if (l.use_tf) tot += 2 * pad256(nfr * LL * sizeof(double)) + pad256(nfr * sizeof(double));  // E, ET, shift
       if (nd.post) {
         tot += pad256(nfr * sizeof(double));                          // numer_f
-        if (!l.use_tf) tot += pad256(((nfr + 511) / 512) * LL * sizeof(double));
+        if (!l.use_tf) tot += pad256(((nfr + atb_rows_per_chunk(nfr) - 1) / atb_rows_per_chunk(nfr)) * LL * sizeof(double));
       }
     }
     if (nd.post) {
@@ -787,7 +793,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       if (nd.post) {
         cb->numer_f = a.take<double>(nfr);
         if (!l.use_tf) {
-          cb->rpc_atb = 512;
+          cb->rpc_atb = atb_rows_per_chunk(nfr);
           cb->nch_atb = (uint32_t)((nfr + cb->rpc_atb - 1) / cb->rpc_atb);
           cb->slab_atb = a.take<double>((size_t)cb->nch_atb * LL);
         }

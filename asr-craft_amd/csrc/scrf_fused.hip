@@ -139,14 +139,17 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const uint32_t W = fa.W, D = lay.D;
   const uint32_t nfmax = fa.TB + D - 1;
+  // operand images (live until the last MFMA) and, over them, the gather tables of the epilogue
   float* Xg = (float*)fsm;                                              // [256 + dump row][FU_XS]
   double* Wg = (double*)(fsm + sizeof(float) * (FU_ROWS + 1) * FU_XS);  // [40][FU_WS] (floats when F32)
-  double* Pl = (double*)fsm;                                            // [nfmax][5][48], aliases Xg/Wg
-  size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS;
-  const size_t pb = sizeof(double) * nfmax * 240;
+  float* fr = (float*)(Wg + FU_GC * FU_WS);                             // [nfmax][W]
+  double* Pl = (double*)fsm;                                            // [nfmax][5][48]
+  double* Dt = Pl + nfmax * 240;                                        // [D+1][48] duration weights, bias term
+  size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
+  const size_t pb = sizeof(double) * (nfmax * 240 + (D + 1) * 48);
   if (pb > opn) opn = pb;
-  float* fr = (float*)(fsm + ((opn + 15) & ~(size_t)15));               // [nfmax][W]
-  uint16_t* rfirst = (uint16_t*)(fr + nfmax * W);
+  uint32_t* labs = (uint32_t*)(fsm + ((opn + 15) & ~(size_t)15));       // [TB] labels of the tile's frames
+  uint16_t* rfirst = (uint16_t*)(labs + fa.TB);
   uint16_t* rbase = rfirst + FU_ROWS;
   uint8_t* rdur = (uint8_t*)(rbase + FU_ROWS);
   uint8_t* steps = rdur + FU_ROWS;                                      // [D][5]
@@ -190,7 +193,10 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         rdur[row] = (uint8_t)d;
       }
     }
-    for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
+    for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) {
+      rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
+      labs[tl] = labels ? labels[fa.frame_base + ft.fr0 + (ft.t0 - ft.f0) + tl] : SCRF_LAB_BAD;
+    }
     for (uint32_t i = tid; i < D * 5; i += FU_NT) steps[i] = (uint8_t)fu_sample_step(i / 5 + 1, i % 5);
     // rows past the tile and pad columns of the chunk image stay zero for the whole kernel
     for (uint32_t i = tid; i < (FU_ROWS + 1) * FU_XS; i += FU_NT) Xg[i] = 0.0f;
@@ -269,19 +275,42 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     }
     __syncthreads();
   }
-  // stage the tile's projections: Pl[f - f0][k][ol] = P[frame f][k * n_out + o0 + ol]; threads
-  // 0..239 and 240..479 take alternate frames, four frames in flight per thread
+  // stage the tile's projections, Pl[f - f0][k][ol] = P[frame f][k * n_out + o0 + ol] (threads 0..239
+  // and 240..479 take alternate frames, nine frames in flight per thread), and the per-duration
+  // weights + bias term of the 48 outputs
   {
     const uint32_t nf = ft.t0 + ft.nfr - ft.f0;
     const uint32_t half = tid / 240, e = tid % 240, k = e / 48, ol = e % 48;
     const double* src = P + ft.fr0 * (uint64_t)(5 * n_out) + k * n_out + o0 + ol;
     const bool live = tid < 480 && o0 + ol < n_out;
-    for (uint32_t f0 = half; f0 < nf; f0 += 8) {
-      double tmp[4];
+    double dtv[3];
 #pragma unroll
-      for (int q = 0; q < 4; q++) tmp[q] = (live && f0 + 2 * q < nf) ? src[(uint64_t)(f0 + 2 * q) * 5 * n_out] : 0.0;
+    for (int q = 0; q < 3; q++) {
+      const uint32_t i = tid + FU_NT * q, dd = i / 48, oo = i % 48;
+      double v = 0.0;
+      if (dd <= D && o0 + oo < n_out) {
+        v = lambda[lay.state_idx(o0 + oo) + 8 * W + dd];
+        if (dd == D) v = lay.use_sb ? v * lay.sbv : 0.0;
+      }
+      dtv[q] = v;
+    }
+    for (uint32_t f0 = half; f0 < nf; f0 += 18) {
+      double tmp[9];
 #pragma unroll
-      for (int q = 0; q < 4; q++) if (tid < 480 && f0 + 2 * q < nf) Pl[(f0 + 2 * q) * 240 + e] = tmp[q];
+      for (int q = 0; q < 9; q++) tmp[q] = (live && f0 + 2 * q < nf) ? src[(uint64_t)(f0 + 2 * q) * 5 * n_out] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 9; q++) if (tid < 480 && f0 + 2 * q < nf) Pl[(f0 + 2 * q) * 240 + e] = tmp[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) if (tid + FU_NT * q < (D + 1) * 48) Dt[tid + FU_NT * q] = dtv[q];
+    for (uint32_t i = tid + 3 * FU_NT; i < (D + 1) * 48; i += FU_NT) {   // D > 31 only
+      const uint32_t dd = i / 48, oo = i % 48;
+      double v = 0.0;
+      if (o0 + oo < n_out) {
+        v = lambda[lay.state_idx(o0 + oo) + 8 * W + dd];
+        if (dd == D) v = lay.use_sb ? v * lay.sbv : 0.0;
+      }
+      Dt[i] = v;
     }
   }
   __syncthreads();
@@ -302,12 +331,9 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         const uint32_t ol = n * 16 + li, o = o0 + ol;
         sv[n] = -INFINITY;
         if (o >= n_out) continue;
-        const double* wl = lambda + lay.state_idx(o) + 8 * W;  // duration block, then the bias weight
         const double lin = (((Pl[q0 + ol] + Pl[q1 + ol]) + Pl[q2 + ol]) + Pl[q3 + ol]) + Pl[q4 + ol];
         const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
-        double sc = (v + lin) + wl[d - 1];
-        if (lay.use_sb) sc += wl[D] * lay.sbv;
-        sv[n] = sc;
+        sv[n] = ((v + lin) + Dt[(d - 1) * 48 + ol]) + Dt[D * 48 + ol];
       }
       if (smax) {
         // row maximum over the 16 lanes that share this row (and the 3 output tiles), as a float
@@ -315,7 +341,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         const double ref = (double)mx;
-        const uint32_t lab = labels ? labels[fa.frame_base + ft.fr0 + b0 + d - 1] : SCRF_LAB_BAD;
+        const uint32_t lab = labs[b0 + d - 1 - (ft.t0 - ft.f0)];
         const bool mine = lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d;
 #pragma unroll
         for (int n = 0; n < 3; n++) {
@@ -337,11 +363,11 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 
 static size_t fused_scores_smem(uint32_t W, uint32_t D) {
   const uint32_t TB = FU_ROWS / D, nfmax = TB + D - 1;
-  size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS;
-  const size_t pb = sizeof(double) * nfmax * 240;
+  size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
+  const size_t pb = sizeof(double) * (nfmax * 240 + (D + 1) * 48);
   if (pb > opn) opn = pb;
   opn = (opn + 15) & ~(size_t)15;
-  return opn + sizeof(float) * nfmax * W + sizeof(uint16_t) * 2 * FU_ROWS + FU_ROWS + D * 5 + 64;
+  return opn + sizeof(uint32_t) * TB + sizeof(uint16_t) * 2 * FU_ROWS + FU_ROWS + D * 5 + 64;
 }
 
 template <int DMAX, int F32>

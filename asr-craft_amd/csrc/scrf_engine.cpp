@@ -591,7 +591,7 @@ extern "C" int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, ui
 // ---------------------------------------------------------------------------------------------
 // chunk planning and the per-chunk pipeline
 // ---------------------------------------------------------------------------------------------
-enum { PH_WIN = 0, PH_SCORE = 1, PH_FB = 2, PH_EXPF = 3, PH_REDUCE = 4, PH_VIT = 5, PH_ALL = 6 };
+enum { PH_WIN = 0, PH_SCORE = 1, PH_FB = 2, PH_EXPF = 3, PH_REDUCE = 4, PH_VIT = 5, PH_ALL = 6, PH_K_SCORE = 7, PH_K_DP = 8, PH_K_EXPF = 9 };
 #define EXPF_ROWS_PER_CHUNK 4096ull
 // split-K plan of the state expected-count contraction: about 1024 K-chunks (2 per CU-slot
 // of the 512-thread MFMA kernel), at least 4096 rows each
@@ -869,8 +869,12 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
                        spec_samples(W0), 5 * l.L, cb.P);
     // on the linear-domain path the epilogue already exponentiates the rows (L <= 48)
     cb.es_ready = cb.lin && l.L <= 48;
-    launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32,
-                        cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels);
+    {
+      PhaseTimer tk(h, PH_K_SCORE, cb.st);
+      launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32,
+                          cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels);
+      tk.stop(1);
+    }
     tm.stop(2);
     HIPCHK(h, hipGetLastError());
     return SCRF_OK;
@@ -888,8 +892,12 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   }
   PhaseTimer tm(h, PH_SCORE, cb.st);
   uint32_t nl = 1;
-  if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32);
-  else launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+  {
+    PhaseTimer tk(h, PH_K_SCORE, cb.st);
+    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32);
+    else launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+    tk.stop(1);
+  }
   if (l.use_tf) {
     launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
     if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, f32);
@@ -929,8 +937,12 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
         launch_exp_rows(cb.st, cb.S, nseg, l.L, cb.smax);
         nl += 2;
       }
-      launch_dp_lin(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.smax, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.dl,
-                    b->d_zx, b->d_status);
+      {
+        PhaseTimer tk(h, PH_K_DP, cb.st);
+        launch_dp_lin(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.smax, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.dl,
+                      b->d_zx, b->d_status);
+        tk.stop(1);
+      }
       launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
                       cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
       launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
@@ -944,8 +956,12 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
       HIPCHK(h, hipGetLastError());
       return SCRF_OK;
     }
-    launch_dp_wave(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
-                   cb.beta, cb.sd, b->d_zx, b->d_status);
+    {
+      PhaseTimer tk(h, PH_K_DP, cb.st);
+      launch_dp_wave(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
+                     cb.beta, cb.sd, b->d_zx, b->d_status);
+      tk.stop(1);
+    }
     nl++;
     if (post) {
       launch_post_state(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.beta,
@@ -1041,13 +1057,21 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
       if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
         ScrfFusedArgs fa = fused_args(h, b, u0, 1);
-        launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
+        {
+          PhaseTimer tk(h, PH_K_EXPF, cb.st);
+          launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
+          tk.stop(1);
+        }
         launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z);
         launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
                          spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 2;
-      } else if (fast) launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
-      else launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+      } else {
+        PhaseTimer tk(h, PH_K_EXPF, cb.st);
+        if (fast) launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
+        else launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+        tk.stop(1);
+      }
       if (l.use_tf) {
         launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
         if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32);

@@ -12,8 +12,8 @@ STDSTATE, STDTRANS = 0, 1
 PREC_EXACT, PREC_FAST, PREC_FAST32 = 0, 1, 2
 ABI_VERSION = 1
 MAX_STREAMS = 3
-N_PHASES = 7
-PHASES = ("windows", "scores", "fwd_bwd", "expf", "reduce", "viterbi", "total")
+N_PHASES = 10
+PHASES = ("windows", "scores", "fwd_bwd", "expf", "reduce", "viterbi", "total", "k_scores", "k_dp", "k_expf")
 
 ARC_DTYPE = np.dtype([("src", "<i4"), ("ilabel", "<i4"), ("olabel", "<i4"), ("w", "<f4"), ("dst", "<i4")])
 

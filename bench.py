@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 
 L, D, IN_W, T_FRAMES = 48, 25, 39, 300
 F = 8 * IN_W + D  # 337 segment features (io/CRF_InFtrStream_SeqMultiWindow.cpp:77-78)
-PEAK = {"mfma_f64_tflops": 78.6, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md (HBM); fp64 MFMA: vendor peak
+PEAK = {"mfma_f64_tflops": 78.6, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
 
 
 def n_segs(T, Dm):
@@ -135,34 +135,68 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: one extra instrumented step (HIP events on the
-        # engine's stream around every phase), outside the timed region
+        # ---- roofline of the dominant kernel: three extra instrumented steps (HIP events on the
+        # engine's stream around every phase and around the three big kernels), kept outside the
+        # timed region because the per-phase event waits would perturb `value`
         eng.set_lambda(lam)
         eng.enable_timing(True)
-        eng.zero_grad()
-        eng.fb_batch(batch, want_scalars=False)
-        eng.synchronize()
-        tm = eng.last_timing()
+        acc = {}
+        N_INSTR = 3
+        for _ in range(N_INSTR):
+            eng.zero_grad()
+            eng.fb_batch(batch, want_scalars=False)
+            eng.synchronize()
+            for k, (ms_, nl_) in eng.last_timing().items():
+                a_ = acc.setdefault(k, [0.0, 0])
+                a_[0] += ms_; a_[1] += nl_
+        tm = {k: (v[0], v[1]) for k, v in acc.items()}
         eng.enable_timing(False)
         nseg = n_segs(T_FRAMES, D)
-        flops_gemm = 2.0 * nseg * L * F * U          # per phase: scores or expected counts
-        bytes_dp = (8.0 * (5 * nseg * L + 4 * T_FRAMES * L)) * U
-        phases = {
-            "scores": ("mfma", flops_gemm / 1e12, "TFLOP/s", PEAK["mfma_f64_tflops"]),
-            "expf": ("mfma", flops_gemm / 1e12, "TFLOP/s", PEAK["mfma_f64_tflops"]),
-            "fwd_bwd": ("hbm", bytes_dp / 1e9, "GB/s", PEAK["hbm_gbs"]),
+        # algorithmic work per utterance: dense flops of the two state contractions
+        # (2 per MAC, bias excluded); bytes the recursion has to move (S read by the forward and
+        # by the backward sweep, alpha / alpha-plus-trans / beta / sum-over-durations written)
+        flops_gemm = 2.0 * nseg * L * F
+        bytes_dp = 8.0 * (2 * nseg * L + 4 * T_FRAMES * L)
+        mfma_peak = PEAK["mfma_f32_tflops"] if args.precision == "fast32" else PEAK["mfma_f64_tflops"]
+        kern = {
+            "k_scores": ("k_scores_fused" if args.precision != "exact" else "k_scores_exact", "mfma",
+                         flops_gemm / 1e12, "TFLOP/s", mfma_peak),
+            "k_expf": ("k_expf_fused" if args.precision != "exact" else "k_expf_gemm", "mfma",
+                       flops_gemm / 1e12, "TFLOP/s", mfma_peak),
+            "k_dp": ("k_dp_lin", "hbm", bytes_dp / 1e9, "GB/s", PEAK["hbm_gbs"]),
         }
-        dom = max(phases, key=lambda k: tm[k][0])
-        bound, work, unit, peak = phases[dom]
+        dom = max(kern, key=lambda k: tm[k][0])
+        kname, bound, work_per_utt, unit, peak = kern[dom]
         ms, nl = tm[dom]
-        achieved = work / (ms / 1e3)
-        kernels = {"scores": "k_scores_fused + k_scores_mfma (per-frame projections)",
-                   "expf": "k_expf_fused + k_lin_z + k_expf_mfma (per-frame sums)",
-                   "fwd_bwd": "k_dp_wave + k_post_state + k_xi_factors"}
-        roofline = {"kernel": dom, "kernels_in_phase": kernels[dom], "bound": bound, "achieved": round(achieved, 4),
-                    "peak": peak, "unit": unit, "frac": round(achieved / peak, 5), "traffic": None,
-                    "launches": int(nl), "avg_launch_ms": round(ms / max(1, nl), 4),
-                    "phase_ms": {k: round(v[0], 3) for k, v in tm.items()}}
+        nl = max(1, int(nl))
+        avg_ms = ms / nl                       # average duration of one launch of that kernel
+        per_step = max(1, nl // N_INSTR)       # launches per step (1 unless the batch had to be chunked)
+        work = work_per_utt * U / per_step     # algorithmic work of one launch
+        achieved = work / (avg_ms / 1e3)
+        # what the fused kernels actually execute on the MFMA: the sampled-frame blocks are
+        # re-associated into per-frame projections, so only 3W (scores) / 3W+D+1 (counts) of the
+        # 8W+D columns go through the dense product (DESIGN.md "roofline accounting")
+        executed = None
+        if bound == "mfma" and args.precision != "exact":
+            cols = 3 * IN_W if dom == "k_scores" else 3 * IN_W + D + 1
+            executed = 2.0 * nseg * L * cols * U / per_step / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):   # HBM bytes per utterance from separate rocprofv3 --pmc passes (profiles/README.md)
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            ent = tj.get(args.precision, {}).get(kname)
+            if ent:
+                traffic = round(ent["bytes_per_utt"] * U / per_step)
+        roofline = {"kernel": kname, "bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 5), "traffic": traffic,
+                    "algorithmic_per_launch": round(work, 6), "launches_per_step": per_step,
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "kernel_ms": {k: round(tm[k][0] / max(1, tm[k][1]), 3) for k in kern},
+                    "phase_ms": {k: round(v[0] / N_INSTR, 3) for k, v in tm.items() if not k.startswith("k_")}}
+        if executed is not None:
+            roofline["executed_per_launch"] = round(executed, 6)
+            roofline["frac_executed"] = round(executed / (avg_ms / 1e3) / peak, 5)
         out = {
             "metric": "utterances/sec SCRF forward-backward (TIMIT-shape)",
             "value": round(U * world * args.steps / dt, 2),

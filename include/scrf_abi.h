@@ -227,8 +227,11 @@ int scrf_sgd_step(scrf_handle h, double lr_or_eta, int use_adagrad, double eps);
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event time (ms) of the phases of the last scrf_fb_batch / scrf_viterbi_batch on the
  * engine stream: [0] windows, [1] scores, [2] forward-backward+posteriors, [3] expected
- * counts (ExpF GEMM), [4] reduce, [5] viterbi, [6] whole call; n_launch[i] = kernel launches. */
-#define SCRF_N_PHASES 7
+ * counts (ExpF GEMM), [4] reduce, [5] viterbi, [6] whole call; n_launch[i] = kernel launches.
+ * [7] [8] [9] time single kernels inside phases 1-3, events recorded on the stream the kernel is
+ * launched on: the state score kernel, the forward/backward recursion, the state expected-count
+ * kernel (the three that dominate a step). */
+#define SCRF_N_PHASES 10
 int scrf_last_timing(scrf_handle h, float* ms, uint32_t* n_launch);
 int scrf_enable_timing(scrf_handle h, int on);
 

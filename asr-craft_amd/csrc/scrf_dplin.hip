@@ -28,13 +28,53 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+// wave-wide max on the DPP path (no LDS crossbar round trips): quad permutes, row shifts and the
+// two row broadcasts leave the result in lane 63, which is then read back as a scalar
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, dpp_i32<0xb1, 0xf>(v, v));    // quad_perm:[1,0,3,2]
+  v = max(v, dpp_i32<0x4e, 0xf>(v, v));    // quad_perm:[2,3,0,1]
+  v = max(v, dpp_i32<0x114, 0xf>(v, v));   // row_shr:4
+  v = max(v, dpp_i32<0x118, 0xf>(v, v));   // row_shr:8
+  v = max(v, dpp_i32<0x142, 0xa>(v, v));   // row_bcast:15
+  v = max(v, dpp_i32<0x143, 0xc>(v, v));   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// float max through the integer path: for x >= 0 the bit pattern orders like the value; negative
+// values are mapped to the mirrored order first (standard total-order trick)
+__device__ __forceinline__ float wave_max_f32_dpp(float x) {
+  int b = __float_as_int(x);
+  b = b >= 0 ? b : (int)(0x80000000u - (unsigned)b);   // monotone map of floats onto signed ints
+  int m = wave_max_i32(b);
+  m = m >= 0 ? m : (int)(0x80000000u - (unsigned)m);
+  return __int_as_float(m);
+}
 // largest high word over the wave of a non-negative double vector: orders like the values do (to
 // 32 bits), costs what a float max costs, and keeps the full double exponent range
-__device__ __forceinline__ int wave_max_hi(double v) {
-  int h = __double2hiint(v);
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) h = max(h, __shfl_xor(h, o));
-  return h;
+__device__ __forceinline__ int wave_max_hi(double v) { return wave_max_i32(__double2hiint(v)); }
+
+// sum_c a[c] * Em[c*L + lc] with the a-vector broadcast through a private LDS line: one uniform
+// 16-byte read serves two labels, against two v_readlane + hazard padding per label
+template <class PTR>
+__device__ __forceinline__ double matvec_lds(const double a, double* abuf, PTR Em, const int L, const int lc,
+                                             const int lane) {
+  abuf[lane] = a;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int c = 0;
+  for (; c + 8 <= L; c += 8) {
+    const double2 a01 = *(const double2*)(abuf + c), a23 = *(const double2*)(abuf + c + 2);
+    const double2 a45 = *(const double2*)(abuf + c + 4), a67 = *(const double2*)(abuf + c + 6);
+    const double e0 = Em[(c + 0) * L + lc], e1 = Em[(c + 1) * L + lc], e2 = Em[(c + 2) * L + lc];
+    const double e3 = Em[(c + 3) * L + lc], e4 = Em[(c + 4) * L + lc], e5 = Em[(c + 5) * L + lc];
+    const double e6 = Em[(c + 6) * L + lc], e7 = Em[(c + 7) * L + lc];
+    s0 = fma(a01.x, e0, s0); s1 = fma(a01.y, e1, s1); s2 = fma(a23.x, e2, s2); s3 = fma(a23.y, e3, s3);
+    s0 = fma(a45.x, e4, s0); s1 = fma(a45.y, e5, s1); s2 = fma(a67.x, e6, s2); s3 = fma(a67.y, e7, s3);
+  }
+  for (; c < L; c++) s0 = fma(abuf[c], Em[c * L + lc], s0);
+  return (s0 + s1) + (s2 + s3);
 }
 // unbiased binary exponent from a high word; *bad = zero / subnormal / inf / nan
 __device__ __forceinline__ int hi_exp(int h, int* bad) {
@@ -110,7 +150,9 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
   const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
   const uint32_t ul = (blockIdx.x >> 1) * DP_WPB + wave;
   double* Es = dsm;                                         // [L*L] (time-invariant transitions only)
-  double* ring = dsm + (MPF ? 0 : LL) + (size_t)wave * D * L;  // [D][L] mantissas, private to this wavefront
+  double* ring = dsm + (MPF ? 0 : LL) + (size_t)wave * (D * L + 128);  // [D][L] mantissas, private to this wavefront
+  double* abuf = ring + D * L;   // [64] broadcast line of the matvec operand
+  double* cbuf = abuf + 64;      // [64] broadcast line of the per-duration scales
   if (!MPF) {
     const double* src = dir ? ET : E;
     for (int i = threadIdx.x; i < LL; i += blockDim.x) Es[i] = src[i];
@@ -160,10 +202,10 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       // transition out of node t-1: p = 2^-k * (a . E)
       double usum, sh = sh0;
       if (MPF) {
-        usum = matvec_bcast(a, E + (f_base + t) * (size_t)LL, L, lc);
+        usum = matvec_lds(a, abuf, E + (f_base + t) * (size_t)LL, L, lc, lane);
         sh = mshift[f_base + t];
       } else {
-        usum = matvec_bcast(a, Es, L, lc);
+        usum = matvec_lds(a, abuf, Es, L, lc, lane);
       }
       const int k = hi_exp(wave_max_hi(act ? usum : 0.0), &err);
       const double p = ldexp(usum, -k);
@@ -178,8 +220,9 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       const double gprev = shfl_f64(gslot, (lane < np) ? myslot : 0);
       double x = (lane < np) ? gprev + smx : smx;   // lane == np (< nd): the initial segment
       x = (lane < nd) ? x : -INFINITY;
-      const double G = (double)wave_max_f32((float)x);
+      const double G = (double)wave_max_f32_dpp((float)x);
       const double c = exp_nonpos(x - G);
+      cbuf[lane] = c;
       double acc0 = 0.0, acc1 = 0.0;
       if (full) {
 #pragma unroll
@@ -187,7 +230,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
           int slot = rpos - d0;
           slot += (slot < 0) ? D : 0;
           const double pv = (d0 == 0) ? p : ring[slot * L + lc];
-          const double w = es[d0] * rdlane(c, d0);
+          const double w = es[d0] * cbuf[d0];
           if (d0 & 1) acc1 = fma(pv, w, acc1); else acc0 = fma(pv, w, acc0);
         }
       } else {
@@ -197,7 +240,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
           if (slot < 0) slot += D;
           const double r = (d0 == 0) ? p : ring[(d0 < np ? slot : rpos) * L + lc];
           const double pv = (d0 < np) ? r : 1.0;
-          const double w = es[d0] * rdlane(c, d0);
+          const double w = es[d0] * cbuf[d0];
           if (d0 & 1) acc1 = fma(pv, w, acc1); else acc0 = fma(pv, w, acc0);
         }
       }
@@ -250,24 +293,25 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       if (myslot >= D) myslot -= D;
       const double gnext = shfl_f64(gslot, (lane < nn) ? myslot : 0);
       const double x = (lane < nn) ? gnext + smx : -INFINITY;
-      const double G = (double)wave_max_f32((float)x);
+      const double G = (double)wave_max_f32_dpp((float)x);
       const double c = exp_nonpos(x - G);
+      cbuf[lane] = c;
       double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
       for (int d0 = 0; d0 < DMAX; d0++) {
         int slot = tpos + d0 + 1;
         if (slot >= D) slot -= D;
         const double bv_ = ring[((d0 < nn) ? slot : tpos) * L + lc];
-        const double w = es[d0] * rdlane(c, d0);   // es = 0 past nn
+        const double w = es[d0] * cbuf[d0];   // es = 0 past nn
         if (d0 & 1) acc1 = fma((d0 < nn) ? bv_ : 0.0, w, acc1); else acc0 = fma((d0 < nn) ? bv_ : 0.0, w, acc0);
       }
       const double sd = acc0 + acc1;
       double w, sh = sh0;
       if (MPF) {
-        w = matvec_bcast(sd, ET + (f_base + t + 1) * (size_t)LL, L, lc);
+        w = matvec_lds(sd, abuf, ET + (f_base + t + 1) * (size_t)LL, L, lc, lane);
         sh = mshift[f_base + t + 1];
       } else {
-        w = matvec_bcast(sd, Es, L, lc);
+        w = matvec_lds(sd, abuf, Es, L, lc, lane);
       }
       const int k = hi_exp(wave_max_hi(act ? w : 0.0), &err);
       const double b = ldexp(w, -k);
@@ -297,7 +341,7 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
                    int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
   if (n_utts == 0) return;
   const uint32_t nblk = 2 * ((n_utts + DP_WPB - 1) / DP_WPB);
-  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * lay.D * lay.L);
+  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * (lay.D * lay.L + 128));
 #define DL_LAUNCH2(DM, MPF)                                                                                    \
   do {                                                                                                         \
     hipFuncSetAttribute((const void*)k_dp_lin<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \

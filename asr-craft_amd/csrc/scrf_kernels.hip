@@ -536,12 +536,20 @@ void launch_reduce_xiacc(hipStream_t st, const double* xi_acc, uint32_t n_utts, 
   hipLaunchKernelGGL(k_reduce_xiacc, dim3((LL + 255) / 256), dim3(256), 0, st, xi_acc, n_utts, lay, grad);
 }
 
-// sums of numer/zx over a range, accumulated into sums3 = {numer, zx, n_utts}
+// sums of numer/zx over a range, accumulated into sums3 = {numer, zx, n_utts}; 64 lanes take
+// contiguous slices, lane partials are combined in lane order (fixed, reproducible)
 __global__ void k_batch_sums(const double* __restrict__ numer, const double* __restrict__ zx, uint32_t n,
                              double* __restrict__ sums3) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (uint32_t i = 0; i < n; i++) { a += numer[i]; b += zx[i]; }
+  __shared__ double pa[64], pb[64];
+  const uint32_t per = (n + 63) / 64, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+  double a = 0.0, b = 0.0;
+  for (uint32_t i = i0; i < i1; i++) { a += numer[i]; b += zx[i]; }
+  pa[threadIdx.x] = a;
+  pb[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0.0; b = 0.0;
+    for (int j = 0; j < 64; j++) { a += pa[j]; b += pb[j]; }
     sums3[0] += a;
     sums3[1] += b;
     sums3[2] += (double)n;

@@ -294,7 +294,11 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       }
       dtv[q] = v;
     }
-    for (uint32_t f0 = half; f0 < nf; f0 += 18) {
+    // sample position k reaches back at most off_k(D) = D - 1 - s_k(D) frames before the tile's
+    // first frame: older rows of its block are never gathered, so they are not fetched
+    const uint32_t back = ft.t0 - ft.f0, reach = D - 1 - fu_sample_step(D, (int)(k < 5 ? k : 4));
+    const uint32_t fbeg = back > reach ? back - reach : 0;
+    for (uint32_t f0 = fbeg + half; f0 < nf; f0 += 18) {
       double tmp[9];
 #pragma unroll
       for (int q = 0; q < 9; q++) tmp[q] = (live && f0 + 2 * q < nf) ? src[(uint64_t)(f0 + 2 * q) * 5 * n_out] : 0.0;

@@ -81,7 +81,7 @@ struct scrf_engine_s {
   double* d_grad2 = nullptr;
   double* d_sums2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int n_lanes = 2;
+  int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
   bool lin_dp = true;
   std::string err;

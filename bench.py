@@ -66,6 +66,11 @@ def main():
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     args = ap.parse_args()
 
+    # the JSON line must be the only thing on stdout: until it is printed, file descriptor 1 points
+    # at stderr, so that library banners (RCCL prints one under NCCL_DEBUG=VERSION) do not mix in
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import scrf_amd
     from scrf_amd import synth
@@ -220,8 +225,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -39,6 +39,8 @@ if __name__ == "__main__":
     # config 3 shape: L=48 D=10, 144-dim frames, +-6 context transition features (lambda_len 4,371,216)
     for prec in (0, 1):
         run("cfg3", prec, L=48, D=10, in_w=144, Ts=[120, 304, 200, 260], trans_ctx=6, seed=3, lam_scale=0.01)
+    # config 3 shape at a minibatch that fills the chip: 64 utterances of ~300 frames
+    run("cfg3x64", 1, L=48, D=10, in_w=144, Ts=[304] * 64, trans_ctx=6, seed=4, lam_scale=0.01)
     # config 5 shape: L=200 D=40, 123-dim frames (generic workgroup-per-utterance DP kernel)
-    for prec in (0, 1, 2):
+    for prec in (0, 1):
         run("cfg5", prec, L=200, D=40, in_w=123, Ts=[300, 500], seed=5, lam_scale=0.01)

@@ -242,6 +242,33 @@ def test_chunking_is_invisible():
     e1.close(); e2.close()
 
 
+def test_fused_path_chunking_and_log_domain_fallback(monkeypatch):
+    """the fused FAST path must not depend on how the batch is cut into chunks (chunk-relative tile,
+    row and frame offsets), and the scaled linear-domain recursion must agree with the log-domain
+    kernels (SCRF_LINDP=0) to rounding."""
+    kw = dict(L=6, D=5, in_w=4, Ts=[1, 2, 4, 5, 6, 9, 17, 30, 3, 12], seed=41, precision=1)
+    c1 = Case(**kw); c2 = Case(scratch_bytes=1 << 15, **kw)
+    e1, e2 = c1.engine(), c2.engine()
+    b1, b2 = c1.batch(e1), c2.batch(e2)
+    n1, z1 = e1.fb_batch(b1); n2, z2 = e2.fb_batch(b2)
+    np.testing.assert_allclose(n1, n2, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(z1, z2, rtol=1e-13)
+    g1, g2 = e1.get_grad(), e2.get_grad()
+    np.testing.assert_allclose(g1, g2, rtol=1e-11, atol=1e-12 * np.abs(g1).max())
+    og, on, oz = c1.oracle_gradient()
+    assert np.abs(g1 - og).max() / np.abs(og).max() <= 1e-9
+    assert np.abs(n1 - on).max() <= 1e-11 * max(1, np.abs(on).max()) and np.abs(z1 - oz).max() <= 1e-11 * np.abs(oz).max()
+    for x in (b1, b2): x.close()
+    e1.close(); e2.close()
+    monkeypatch.setenv("SCRF_LINDP", "0")
+    c3 = Case(**kw); e3 = c3.engine(); b3 = c3.batch(e3)
+    n3, z3 = e3.fb_batch(b3); g3 = e3.get_grad()
+    np.testing.assert_allclose(z1, z3, rtol=1e-12)
+    np.testing.assert_allclose(n1, n3, rtol=1e-12, atol=1e-12)
+    assert np.abs(g1 - g3).max() <= 1e-10 * np.abs(g1).max()
+    b3.close(); e3.close()
+
+
 def test_two_lane_pipeline_equals_single_lane(monkeypatch):
     """batches of >= 64 utterances are cut into >= 4 chunks that alternate between two HIP streams
     (DP of one chunk overlaps the contractions of the other); the result must not depend on it."""

@@ -640,6 +640,7 @@ struct ChunkBufs {
   // scaled linear-domain recursion (training path of the wavefront DP)
   bool lin = false;
   bool es_ready = false;     // cb.S already holds exp(S - smax) (written by the fused score kernel)
+  bool z_ready = false;      // cb.Z already holds the per-frame sums of R (written by k_post_z)
   ScrfDpLin dl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* smax = nullptr;    // [nseg] row maxima of the scores
   double* s_true = nullptr;  // [nfr] score of the labelled window ending at each frame
@@ -943,8 +944,15 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
                       b->d_zx, b->d_status);
         tk.stop(1);
       }
-      launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
-                      cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
+      if (cb.fused) {
+        // posterior pass and the per-frame sums of R in one walk (R is not read back for Z)
+        launch_post_z(cb.st, l, bv, u0, (uint32_t)nutt, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S, cb.smax,
+                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z);
+        cb.z_ready = true;
+      } else {
+        launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
+                        cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
+      }
       launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
       launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
       nl += 4;
@@ -1062,7 +1070,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
           launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
           tk.stop(1);
         }
-        launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z);
+        if (!cb.z_ready) launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z);
         launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
                          spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 2;

@@ -502,6 +502,133 @@ void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint3
 }
 
 // ------------------------------------------------------------------------------------------
+// k_post_z: the posterior pass and k_lin_z in one walk (linear-domain path, scrf_dplin.hip):
+//   R[(t,d)][o] = Y - p[t-d][o] * es[(t,d)][o] * b[t][o] * exp(gp[t-d] + smax[(t,d)] + gb[t] - Zx)
+// overwrites es in place (computeExpF :673-702) and is folded into the five register windows of
+// Z on the spot, so R is written once and not read back for the per-frame sums.  One wavefront
+// per (utterance, 64 outputs); the last D alpha-plus-trans vectors sit in an LDS ring; the D
+// scale factors of a frame are computed by lanes 0..D-1 and broadcast through LDS.
+// Also produces the per-frame numerator terms (gradbuilder :388-469).
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0,
+                                                  const uint32_t* __restrict__ next_lab,
+                                                  const double* __restrict__ s_true, const double* __restrict__ M,
+                                                  int m_per_frame, double* __restrict__ ES,
+                                                  const double* __restrict__ smax, ScrfDpLin o_,
+                                                  const double* __restrict__ zx, double* __restrict__ numer_f,
+                                                  int* __restrict__ status, double* __restrict__ Z) {
+  __shared__ double pring[DMAX * 64];
+  __shared__ double fsb[64];
+  const uint32_t D = lay.D, L = lay.L;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t o = blockIdx.y * 64 + lane;
+  const bool act = o < L;
+  const uint32_t oc = act ? o : L - 1;
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0], s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const uint64_t gf0 = bv.frame_off[u];
+  double* ESu = ES + s_base * L + oc;
+  const double* smu = smax + s_base;
+  double* Zu = Z + f_base * (uint64_t)(5 * L) + oc;
+  const double Zx = zx[u];
+  const double LN_MAX = 709.782712893384;
+  LzWin<0, DMAX> w0; LzWin<1, DMAX> w1; LzWin<2, DMAX> w2; LzWin<3, DMAX> w3; LzWin<4, DMAX> w4;
+  w0.clear(); w1.clear(); w2.clear(); w3.clear(); w4.clear();
+  const size_t zs = (size_t)5 * L;
+  int err = 0;
+  int slot = 0;   // ring slot that will receive p[t]
+#pragma unroll 1
+  for (int t = 0; t < T; t++) {
+    const uint32_t nd = scrf_node_max_dur((uint32_t)t, D), np = scrf_num_prev((uint32_t)t, D);
+    const uint64_t row0 = scrf_seg_base((uint32_t)t, D);
+    double r[DMAX];
+#pragma unroll
+    for (int d0 = 0; d0 < DMAX; d0++) r[d0] = ((uint32_t)d0 < nd) ? ESu[(row0 + d0) * L] : 0.0;
+    const double b = o_.b[(f_base + t) * L + oc];
+    const double pnew = (t + 1 < T) ? o_.p[(f_base + t) * L + oc] : 0.0;
+    // scale factor of duration d0 = lane
+    {
+      double x = -INFINITY;
+      if (lane < nd) {
+        x = ((lane < np) ? o_.gp[f_base + t - 1 - lane] : 0.0) + smu[row0 + lane] + o_.gb[f_base + t] - Zx;
+        if (x >= LN_MAX) err = SCRF_ERR_NUMERIC;
+      }
+      fsb[lane] = (lane < nd) ? exp(x) : 0.0;
+    }
+    const uint32_t lab = bv.labels ? bv.labels[gf0 + t] : SCRF_LAB_BAD;
+    uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD;
+    if (lab != SCRF_LAB_BAD) {
+      if (lab >= L * D) err = SCRF_ERR_BAD_LABEL;
+      al = lab % L;
+      ld = lab / L + 1;
+    }
+#pragma unroll
+    for (int d0 = 0; d0 < DMAX; d0++) {
+      int ps = slot - 1 - d0;            // ring slot of p[t-1-d0]
+      if (ps < 0) ps += (int)D;
+      const double pv = ((uint32_t)d0 < np) ? pring[(((uint32_t)d0 < np) ? ps : 0) * 64 + lane] : 1.0;
+      const double g = (pv * r[d0]) * (b * fsb[d0]);
+      const double y = (o == al && (uint32_t)d0 + 1 == ld) ? 1.0 : 0.0;
+      const double rv = ((uint32_t)d0 < nd) ? y - g : 0.0;
+      if (act && (uint32_t)d0 < nd) ESu[(row0 + d0) * L] = rv;
+      r[d0] = rv;
+    }
+    w0.add(r); w1.add(r); w2.add(r); w3.add(r); w4.add(r);
+    if (act) {
+      w0.retire(Zu, t, zs);
+      w1.retire(Zu + L, t, zs);
+      w2.retire(Zu + 2 * (size_t)L, t, zs);
+      w3.retire(Zu + 3 * (size_t)L, t, zs);
+      w4.retire(Zu + 4 * (size_t)L, t, zs);
+    } else {
+      w0.retire(Zu, -1000000, zs); w1.retire(Zu, -1000000, zs); w2.retire(Zu, -1000000, zs);
+      w3.retire(Zu, -1000000, zs); w4.retire(Zu, -1000000, zs);
+    }
+    pring[slot * 64 + lane] = pnew;
+    slot = (slot + 1 == (int)D) ? 0 : slot + 1;
+    if (lane == 0 && blockIdx.y == 0) {
+      double nodeLi = 0.0;
+      if (lab != SCRF_LAB_BAD && err == 0) {
+        if (ld <= nd) nodeLi += s_true[f_base + t];
+        const uint32_t nl = next_lab[gf0 + t];
+        if (t + 1 < T && nl != SCRF_LAB_BAD) {
+          if (nl >= L * D) err = SCRF_ERR_BAD_LABEL;
+          else {
+            const double* Mn = M + (m_per_frame ? (f_base + t + 1) * (size_t)L * L : 0);
+            nodeLi += Mn[(size_t)al * L + nl % L];
+          }
+        }
+      }
+      numer_f[f_base + t] = nodeLi;
+    }
+  }
+  if (act) {
+    w0.flush(Zu, T, zs);
+    w1.flush(Zu + L, T, zs);
+    w2.flush(Zu + 2 * (size_t)L, T, zs);
+    w3.flush(Zu + 3 * (size_t)L, T, zs);
+    w4.flush(Zu + 4 * (size_t)L, T, zs);
+  }
+  if (__any(err != 0) && lane == 0) atomicMax(&status[u], err > 0 ? err : SCRF_ERR_NUMERIC);
+}
+
+void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                   const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
+                   const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z) {
+  if (n_utts == 0) return;
+  dim3 grid(n_utts, (lay.L + 63) / 64);
+#define PZ_GO(N) hipLaunchKernelGGL(k_post_z<N>, grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z)
+  if (lay.D <= 8) PZ_GO(8);
+  else if (lay.D <= 16) PZ_GO(16);
+  else if (lay.D <= 25) PZ_GO(25);
+  else if (lay.D <= 32) PZ_GO(32);
+  else PZ_GO(40);
+#undef PZ_GO
+}
+
+// ------------------------------------------------------------------------------------------
 // k_expf_fused: slab[block][o][f] = sum_rows R[row][o] * x[row][f] over the dense column groups
 // f in [avg | max | min | onehot(d) | bias]   (M = outputs, N = columns, K = rows).
 // Persistent workgroups (256 threads, two per CU) walk 64-row tiles (any 64 consecutive windows of

@@ -91,6 +91,9 @@ void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayo
                          double* s_true = nullptr, const uint32_t* labels = nullptr);
 void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                   const double* R, double* Z);
+void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                   const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
+                   const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z);
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                        uint64_t n_tiles, double* slab, int f32);
 

@@ -661,37 +661,53 @@ __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, 
   // slots past the last output tile repeat its column tile (their sums are never written)
 #pragma unroll
   for (int j = 0; j < NT; j++) bp[j] = Xs + lk * XS + li + (min(wave + 4 * j, n_ot - 1) / 3) * 16;
-  double a_n[3];
-  float af_n[3], b_n[NT];
+  // software pipeline, two steps deep: while the MFMAs of step ks issue, the B operands of step
+  // ks+1 are converted fp32 -> fp64 and the raw operands of step ks+2 are loaded.  The group
+  // barriers pin the interleaving (one MFMA, one conversion, one or two LDS reads) so that the
+  // matrix pipe does not idle behind a block of conversions and loads at every step.
+  constexpr int NKS = FE_ROWS / 4;
+  double a_c[3], a_n[3], bd_c[F32 ? 1 : NT], bd_n[F32 ? 1 : NT];
+  float af_c[3], af_n[3], b_c[F32 ? NT : 1], b_r[NT];
 #pragma unroll
-  for (int i = 0; i < 3; i++) { if (F32) af_n[i] = *ap32[i]; else a_n[i] = *ap[i]; }
+  for (int i = 0; i < 3; i++) { if (F32) af_c[i] = *ap32[i]; else a_c[i] = *ap[i]; }
 #pragma unroll
-  for (int j = 0; j < NT; j++) b_n[j] = *bp[j];
+  for (int j = 0; j < NT; j++) { const float x = *bp[j]; if (F32) b_c[F32 ? j : 0] = x; else bd_c[F32 ? 0 : j] = (double)x; }
 #pragma unroll
-  for (int ks = 0; ks < FE_ROWS / 4; ks++) {
-    double a[3], bd[F32 ? 1 : NT];
-    float af[3], b[F32 ? NT : 1];
+  for (int i = 0; i < 3; i++) { if (F32) af_n[i] = ap32[i][4 * (2 * FE_RS)]; else a_n[i] = ap[i][4 * FE_RS]; }
 #pragma unroll
-    for (int i = 0; i < 3; i++) { a[i] = a_n[i]; af[i] = af_n[i]; }
+  for (int j = 0; j < NT; j++) b_r[j] = bp[j][4 * XS];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < NT; j++) { if (F32) b[F32 ? j : 0] = b_n[j]; else bd[F32 ? 0 : j] = (double)b_n[j]; }
-    __builtin_amdgcn_sched_barrier(0);
-    if (ks + 1 < FE_ROWS / 4) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        if (F32) af_n[i] = ap32[i][(ks + 1) * 4 * (2 * FE_RS)];
-        else a_n[i] = ap[i][(ks + 1) * 4 * FE_RS];
-      }
-#pragma unroll
-      for (int j = 0; j < NT; j++) b_n[j] = bp[j][(ks + 1) * 4 * XS];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int ks = 0; ks < NKS; ks++) {
+    double a_nn[3];
+    float af_nn[3];
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      if (F32) acc32[F32 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j % 3], b[F32 ? j : 0], acc32[F32 ? j : 0], 0, 0, 0);
-      else acc[F32 ? 0 : j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j % 3], bd[F32 ? 0 : j], acc[F32 ? 0 : j], 0, 0, 0);
+      if (F32) acc32[F32 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_c[j % 3], b_c[F32 ? j : 0], acc32[F32 ? j : 0], 0, 0, 0);
+      else acc[F32 ? 0 : j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_c[j % 3], bd_c[F32 ? 0 : j], acc[F32 ? 0 : j], 0, 0, 0);
+      // operand j of step ks+1: convert; of step ks+2: load
+      if (!F32) bd_n[F32 ? 0 : j] = (double)b_r[j];
+      const float held = b_r[j];
+      if (ks + 2 < NKS) b_r[j] = bp[j][(ks + 2) * 4 * XS];
+      if (F32) b_c[F32 ? j : 0] = held;   // (consumed by the next step's MFMA j, after this step's)
+      if (j < 3 && ks + 2 < NKS) {
+        if (F32) af_nn[j] = ap32[j][(ks + 2) * 4 * (2 * FE_RS)]; else a_nn[j] = ap[j][(ks + 2) * 4 * FE_RS];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+      if (!F32) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // one conversion
+      if (j < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // its LDS reads
+      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { a_c[i] = a_n[i]; af_c[i] = af_n[i]; a_n[i] = a_nn[i]; af_n[i] = af_nn[i]; }
+    if (!F32) {
+#pragma unroll
+      for (int j = 0; j < NT; j++) bd_c[F32 ? 0 : j] = bd_n[F32 ? 0 : j];
+    }
   }
 }
 

@@ -672,7 +672,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   const uint32_t W0 = b->mode == 1 ? b->recipe[0].in_width : 0;
   if (nd.fused) {
     tot += pad256(nfr * 5 * l.L * sizeof(double));                // P (scores) / Z (counts)
-    if (nd.post) tot += pad256((size_t)256 * 5 * l.L * W0 * sizeof(double));
+    if (nd.post) tot += pad256((size_t)512 * 5 * l.L * W0 * sizeof(double));
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
   tot += pad256(nseg * l.L * sizeof(double));                       // S
   if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
@@ -743,9 +743,9 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     cb->P = a.take<double>(nfr * 5 * l.L);
     cb->Z = cb->P;  // the projections are dead once the scores exist
     if (nd.post) {
-      cb->rpc_l = ((nfr + 255) / 256 + 31) & ~31ull;
+      cb->rpc_l = ((nfr + 511) / 512 + 31) & ~31ull;   // <= 512 K-chunks of whole 4-frame groups
       cb->nch_l = (uint32_t)((nfr + cb->rpc_l - 1) / cb->rpc_l);
-      cb->slab_l = a.take<double>((size_t)256 * 5 * l.L * W0);
+      cb->slab_l = a.take<double>((size_t)512 * 5 * l.L * W0);
     }
   } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
@@ -866,8 +866,11 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     const uint32_t W0 = b->recipe[0].in_width;
     ScrfFusedArgs fa = fused_args(h, b, u0, 0);
     // per-frame projections of the five sampled blocks, then the dense part + gather
-    launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
-                       spec_samples(W0), 5 * l.L, cb.P);
+    if (pframe_supported(W0))
+      launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, 5 * l.L, cb.P);
+    else
+      launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
+                         spec_samples(W0), 5 * l.L, cb.P);
     // on the linear-domain path the epilogue already exponentiates the rows (L <= 48)
     cb.es_ready = cb.lin && l.L <= 48;
     {
@@ -1071,8 +1074,11 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
           tk.stop(1);
         }
         if (!cb.z_ready) launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z);
-        launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
-                         spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
+        if (pframe_supported(W0))
+          launch_ztf(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l);
+        else
+          launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
+                           spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
         nl += 2;
       } else {
         PhaseTimer tk(h, PH_K_EXPF, cb.st);

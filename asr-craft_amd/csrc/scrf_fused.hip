@@ -58,27 +58,30 @@ __device__ __forceinline__ FuTile fu_tile(const ScrfFusedArgs& fa, const ScrfTil
   return ft;
 }
 
-// exp(x) for x <~ 0 (Cody-Waite + degree-13 Horner, ~1 ulp; flushes to 0 below -745)
-__device__ __forceinline__ double fu_exp(double x) {
-  x = fmax(x, -1000.0);
-  const double k = rint(x * 1.4426950408889634);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;
-  p = fma(p, r, 2.0876756987868100e-09);
-  p = fma(p, r, 2.5052108385441720e-08);
-  p = fma(p, r, 2.7557319223985888e-07);
-  p = fma(p, r, 2.7557319223985893e-06);
-  p = fma(p, r, 2.4801587301587302e-05);
-  p = fma(p, r, 1.9841269841269841e-04);
-  p = fma(p, r, 1.3888888888888889e-03);
-  p = fma(p, r, 8.3333333333333332e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
+// exp(x) for x <~ 0 (Cody-Waite + degree-13 Horner, ~1 ulp; flushes to 0 below -745).  The
+// coefficients live in constant memory so that they are read into scalar registers once instead of
+// being re-materialised as 64-bit literals (two v_mov each) at every use.
+__constant__ double FU_EXPC[18] = {
+    1.4426950408889634, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+    1.6059043836821613e-10, 2.0876756987868100e-09, 2.5052108385441720e-08, 2.7557319223985888e-07,
+    2.7557319223985893e-06, 2.4801587301587302e-05, 1.9841269841269841e-04, 1.3888888888888889e-03,
+    8.3333333333333332e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, 0.5, 1.0, 1.0, -1000.0};
+struct FuExpC { double c[18]; };
+__device__ __forceinline__ FuExpC fu_exp_consts() {
+  FuExpC k;
+#pragma unroll
+  for (int i = 0; i < 18; i++) k.c[i] = FU_EXPC[i];
+  return k;
+}
+__device__ __forceinline__ double fu_exp(double x, const FuExpC& k) {
+  x = fmax(x, k.c[17]);
+  const double n = rint(x * k.c[0]);
+  double r = fma(n, k.c[1], x);
+  r = fma(n, k.c[2], r);
+  double p = k.c[3];
+#pragma unroll
+  for (int i = 4; i <= 16; i++) p = fma(p, r, k.c[i]);
+  return ldexp(p, (int)n);
 }
 
 // Window statistics of one (frame, column): the values F[t-j][c], j = 0 .. nd-1, are read from LDS
@@ -318,48 +321,66 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     }
   }
   __syncthreads();
-  // epilogue: + sampled-frame projections + one-hot duration weight + bias (all fp64), write S
+  // epilogue: + sampled-frame projections + one-hot duration weight + bias (all fp64), write S.
+  // Branch-free per row: every lane gathers (rows past the tile and outputs past n_out read valid
+  // table entries and are masked at the stores), so the 18 LDS reads of a row are in flight together.
+  double dbias[3];
+#pragma unroll
+  for (int n = 0; n < 3; n++) dbias[n] = Dt[D * 48 + n * 16 + li];
+  const FuExpC ek = fu_exp_consts();
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const uint32_t rl = wave * 32 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
-      if (rl >= ft.nrows) continue;   // uniform over the 16 lanes that share the row
-      const uint32_t d = rdur[rl], b0 = rfirst[rl];
+      const bool valid = rl < ft.nrows;
+      const uint32_t rc = valid ? rl : 0;
+      const uint32_t d = rdur[rc], b0 = rfirst[rc];
       const uint8_t* sp = steps + (d - 1) * 5;
       const uint32_t q0 = (b0 + sp[0]) * 240, q1 = (b0 + sp[1]) * 240 + 48, q2 = (b0 + sp[2]) * 240 + 96,
                      q3 = (b0 + sp[3]) * 240 + 144, q4 = (b0 + sp[4]) * 240 + 192;
+      double pv[3][5], dt[3];
+#pragma unroll
+      for (int n = 0; n < 3; n++) {
+        const uint32_t ol = n * 16 + li;
+        pv[n][0] = Pl[q0 + ol]; pv[n][1] = Pl[q1 + ol]; pv[n][2] = Pl[q2 + ol];
+        pv[n][3] = Pl[q3 + ol]; pv[n][4] = Pl[q4 + ol];
+        dt[n] = Dt[(d - 1) * 48 + ol];
+      }
       double sv[3];
 #pragma unroll
       for (int n = 0; n < 3; n++) {
-        const uint32_t ol = n * 16 + li, o = o0 + ol;
-        sv[n] = -INFINITY;
-        if (o >= n_out) continue;
-        const double lin = (((Pl[q0 + ol] + Pl[q1 + ol]) + Pl[q2 + ol]) + Pl[q3 + ol]) + Pl[q4 + ol];
+        const double lin = (((pv[n][0] + pv[n][1]) + pv[n][2]) + pv[n][3]) + pv[n][4];
         const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
-        sv[n] = ((v + lin) + Dt[(d - 1) * 48 + ol]) + Dt[D * 48 + ol];
+        sv[n] = ((v + lin) + dt[n]) + dbias[n];
       }
       if (smax) {
-        // row maximum over the 16 lanes that share this row (and the 3 output tiles), as a float
-        float mx = fmaxf(fmaxf((float)sv[0], (float)sv[1]), (float)sv[2]);
+        // row maximum over the 16 lanes that share this row (and the 3 output tiles), as a float,
+        // on the DPP path: quad permutes, then the half-row and row mirrors
+        float mx = -INFINITY;
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        for (int n = 0; n < 3; n++) mx = fmaxf(mx, (o0 + n * 16 + li < n_out) ? (float)sv[n] : -INFINITY);
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xb1, 0xf, 0xf, false)));
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4e, 0xf, 0xf, false)));
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x141, 0xf, 0xf, false)));
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x140, 0xf, 0xf, false)));
         const double ref = (double)mx;
         const uint32_t lab = labs[b0 + d - 1 - (ft.t0 - ft.f0)];
-        const bool mine = lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d;
+        const bool mine = valid && lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d;
+        double* Srow = S + (ft.row0 + rc) * n_out + o0 + li;
 #pragma unroll
         for (int n = 0; n < 3; n++) {
           const uint32_t o = o0 + n * 16 + li;
-          if (o >= n_out) continue;
+          const double e = fu_exp(sv[n] - ref, ek);
           if (mine && lab % n_out == o) s_true[ft.fr0 + b0 + d - 1] = sv[n];
-          S[(ft.row0 + rl) * n_out + o] = fu_exp(sv[n] - ref);
+          if (valid && o < n_out) Srow[n * 16] = e;
         }
-        if (li == 0) smax[ft.row0 + rl] = ref;
+        if (valid && li == 0) smax[ft.row0 + rl] = ref;
       } else {
 #pragma unroll
         for (int n = 0; n < 3; n++) {
           const uint32_t o = o0 + n * 16 + li;
-          if (o < n_out) S[(ft.row0 + rl) * n_out + o] = sv[n];
+          if (valid && o < n_out) S[(ft.row0 + rl) * n_out + o] = sv[n];
         }
       }
     }

@@ -163,6 +163,29 @@ def test_fused_window_synthesis_equals_materialised_windows(si, monkeypatch):
         assert np.abs(g1 - og).max() / np.abs(og).max() <= max(1e-9, tol)
 
 
+@pytest.mark.parametrize("prec", [0, 1, 2])
+def test_more_than_64_labels_takes_the_workgroup_recursion(prec):
+    """L > 64 does not fit the wavefront-per-utterance kernels: the workgroup-per-utterance log-domain
+    recursion (k_fb) and the generic posterior path serve it, with the fused contractions when the
+    stream qualifies (several 48-output groups per row)."""
+    c = Case(L=70, D=3, in_w=4, Ts=[1, 2, 5, 9, 14], seed=61, precision=prec)
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, on, oz = c.oracle_gradient()
+    tol = 1e-9 if prec < 2 else 1e-5
+    assert np.abs(numer - on).max() <= tol * max(1, np.abs(on).max())
+    assert np.abs(zx - oz).max() <= tol * np.abs(oz).max()
+    assert np.abs(g - og).max() / np.abs(og).max() <= tol
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol)
+    b.close(); eng.close()
+
+
 def test_lattice_arcs_bit_exact(case):
     c, eng, b = case
     for u, T in enumerate(c.Ts):

@@ -216,6 +216,17 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": roofline,
         }
+        # decode half of the metric: best-path labels of the same resident batch; scores
+        # always in the reference's exact operation order (bit-identical labels), one untimed call first
+        eng.viterbi_batch(batch)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        eng.viterbi_batch(batch)
+        eng.synchronize()
+        dtv = time.perf_counter() - t1
+        out["decode"] = {"metric": "utterances/sec SCRF Viterbi decode (TIMIT-shape), labels copied to host",
+                         "value": round(U / dtv, 1), "unit": "utterances/s", "ms_per_batch": round(1e3 * dtv, 2),
+                         "dtype": "f64 exact-order scores, f32 tropical recursion"}
         if not args.no_cpu_baseline:
             cb, _ = cpu_baseline(frames, labels, off, lam)
             out["cpu_baseline"] = cb

@@ -120,6 +120,9 @@ void launch_frame_rows(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t u
 // k_scores_exact: out[row][o] = sum_f (double)x[row][fs+f] * lambda[woff(o)+f]  (+ bias), the
 // reference's sequential unfused chain.  block = (64 rows) x (4 output groups of NL outputs).
 // ------------------------------------------------------------------------------------------
+// The NL weights a wavefront needs per feature are wave-uniform: they are fetched through the scalar
+// cache straight into SGPR operands of the multiplies (no LDS traffic for lambda); only the window
+// values go through LDS.
 #define SC_FC 32
 template <int NL>
 __global__ __launch_bounds__(256) void k_scores_exact(const float* __restrict__ X, uint32_t F,
@@ -127,8 +130,7 @@ __global__ __launch_bounds__(256) void k_scores_exact(const float* __restrict__ 
                                                       const double* __restrict__ lambda, ScrfLayout lay,
                                                       int is_trans, uint32_t n_out, double* __restrict__ out) {
   __shared__ float Xs[64][SC_FC + 1];
-  __shared__ double Ws[4 * NL][SC_FC];
-  const uint32_t tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const uint32_t tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y), tid = ty * 64 + tx;
   const uint64_t row0 = (uint64_t)blockIdx.x * 64;
   const uint32_t o0 = blockIdx.y * 4 * NL;
   const uint32_t L = lay.L;
@@ -138,8 +140,13 @@ __global__ __launch_bounds__(256) void k_scores_exact(const float* __restrict__ 
   const double bv = is_trans ? lay.tbv : lay.sbv;
 
   double acc[NL];
+  const double* wp[NL];   // wave-uniform: weight block of output o0 + ty*NL + k (clamped to a valid one)
 #pragma unroll
-  for (int k = 0; k < NL; k++) acc[k] = 0.0;
+  for (int k = 0; k < NL; k++) {
+    acc[k] = 0.0;
+    const uint32_t o = min(o0 + ty * NL + k, n_out - 1);
+    wp[k] = lambda + (is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o));
+  }
 
   for (uint32_t f0 = 0; f0 < nfe; f0 += SC_FC) {
     const uint32_t fc = min((uint32_t)SC_FC, nfe - f0);
@@ -152,21 +159,20 @@ __global__ __launch_bounds__(256) void k_scores_exact(const float* __restrict__ 
       }
       Xs[r][c] = v;
     }
-    for (uint32_t idx = tid; idx < 4 * NL * SC_FC; idx += 256) {
-      uint32_t ol = idx / SC_FC, c = idx % SC_FC;
-      uint32_t o = o0 + ol;
-      double w = 0.0;
-      if (o < n_out && c < fc) {
-        uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
-        w = lambda[woff + f0 + c];
-      }
-      Ws[ol][c] = w;
-    }
     __syncthreads();
-    for (uint32_t c = 0; c < fc; c++) {
-      const double xv = (double)Xs[tx][c];
+    if (fc == SC_FC) {
+#pragma unroll 8
+      for (uint32_t c = 0; c < SC_FC; c++) {
+        const double xv = (double)Xs[tx][c];
 #pragma unroll
-      for (int k = 0; k < NL; k++) acc[k] = __dadd_rn(acc[k], __dmul_rn(xv, Ws[ty * NL + k][c]));
+        for (int k = 0; k < NL; k++) acc[k] = __dadd_rn(acc[k], __dmul_rn(xv, wp[k][f0 + c]));
+      }
+    } else {
+      for (uint32_t c = 0; c < fc; c++) {
+        const double xv = (double)Xs[tx][c];
+#pragma unroll
+        for (int k = 0; k < NL; k++) acc[k] = __dadd_rn(acc[k], __dmul_rn(xv, wp[k][f0 + c]));
+      }
     }
     __syncthreads();
   }
@@ -176,10 +182,7 @@ __global__ __launch_bounds__(256) void k_scores_exact(const float* __restrict__ 
       uint32_t o = o0 + ty * NL + k;
       if (o < n_out) {
         double v = acc[k];
-        if (use_b) {
-          uint32_t woff = is_trans ? lay.trans_idx(o / L, o % L) : lay.state_idx(o);
-          v = __dadd_rn(v, __dmul_rn(lambda[woff + nfe], bv));
-        }
+        if (use_b) v = __dadd_rn(v, __dmul_rn(wp[k][nfe], bv));
         out[(row0 + tx) * n_out + o] = v;
       }
     }

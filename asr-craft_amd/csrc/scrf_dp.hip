@@ -372,6 +372,8 @@ __global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const
   const uint32_t lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t z = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (z >= n_chunks) return;
+  // L > 64: the output is cut into 64 x 64 blocks, blockIdx.y = (row block, column block)
+  const uint32_t nb = (L + 63) / 64, c0 = (blockIdx.y / nb) * 64, n0 = (blockIdx.y % nb) * 64;
   const uint64_t r_begin = (uint64_t)z * rows_per_chunk;
   const uint64_t r_end = min(n_frames, r_begin + rows_per_chunk);
   atb_v4f64 acc[LT][LT];
@@ -384,10 +386,9 @@ __global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const
     const uint64_t f = f0 + lk;
 #pragma unroll
     for (int i = 0; i < LT; i++) {
-      const uint32_t c = i * 16 + li;
-      const bool ok = f < r_end && c < L;
-      a_n[i] = ok ? A[f * L + c] : 0.0;
-      b_n[i] = ok ? B[f * L + c] : 0.0;
+      const uint32_t c = c0 + i * 16 + li, n = n0 + i * 16 + li;
+      a_n[i] = (f < r_end && c < L) ? A[f * L + c] : 0.0;
+      b_n[i] = (f < r_end && n < L) ? B[f * L + n] : 0.0;
     }
   };
   load(r_begin);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const
     for (int j = 0; j < LT; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const uint32_t c = i * 16 + lk + 4 * r, n = j * 16 + li;
+        const uint32_t c = c0 + i * 16 + lk + 4 * r, n = n0 + j * 16 + li;
         if (c < L && n < L) out[(size_t)c * L + n] = acc[i][j][r];
       }
 }
@@ -422,12 +423,13 @@ __global__ void k_reduce_atb(const double* __restrict__ slab, uint32_t n_chunks,
   for (uint32_t z = 0; z < n_chunks; z++) s += slab[(size_t)z * LL + i];
   grad[lay.trans_idx(i / lay.L, i % lay.L) + lay.ntfe] -= lay.tbv * exp(M0[i]) * s;
 }
-int atb_supported(const ScrfLayout& lay) { return lay.L <= 64; }
+int atb_supported(const ScrfLayout& lay) { return lay.L <= 256; }
 void launch_atb(hipStream_t st, const ScrfLayout& lay, const double* A, const double* B, uint64_t n_frames,
                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad) {
   if (n_frames == 0 || n_chunks == 0 || !lay.use_tb) return;
-  const dim3 grid((n_chunks + 3) / 4);
-  const uint32_t lt = (lay.L + 15) / 16;
+  const uint32_t nb = (lay.L + 63) / 64;
+  const dim3 grid((n_chunks + 3) / 4, nb * nb);
+  const uint32_t lt = lay.L > 64 ? 4 : (lay.L + 15) / 16;
 #define ATB_GO(N) hipLaunchKernelGGL(k_atb<N>, grid, dim3(256), 0, st, A, B, lay.L, n_frames, rows_per_chunk, n_chunks, slab)
   if (lt <= 1) ATB_GO(1);
   else if (lt == 2) ATB_GO(2);

@@ -105,7 +105,7 @@ __global__ void k_true_scores(ScrfLayout lay, ScrfBatchView bv, const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_exp_rows: in place S[row][:] -> exp(S[row][:] - smax[row]); 16 lanes per row, L <= 64.
+// k_exp_rows: in place S[row][:] -> exp(S[row][:] - smax[row]); 16 lanes per row, L <= 256.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_exp_rows(double* __restrict__ S, uint64_t n_rows, uint32_t L,
                                                   double* __restrict__ smax) {
@@ -113,21 +113,11 @@ __global__ __launch_bounds__(256) void k_exp_rows(double* __restrict__ S, uint64
   const uint32_t sub = threadIdx.x & 15;
   if (row >= n_rows) return;
   double* p = S + row * L;
-  double v[4];
   double m = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t l = sub + 16 * j;
-    v[j] = (l < L) ? p[l] : -INFINITY;
-    m = fmax(m, v[j]);
-  }
+  for (uint32_t l = sub; l < L; l += 16) m = fmax(m, p[l]);
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) m = fmax(m, shfl_f64(m, (int)((threadIdx.x & 63) ^ o)));
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t l = sub + 16 * j;
-    if (l < L) p[l] = exp_nonpos(v[j] - m);
-  }
+  for (uint32_t l = sub; l < L; l += 16) p[l] = exp_nonpos(p[l] - m);
   if (sub == 0) smax[row] = m;
 }
 
@@ -325,6 +315,205 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
   if (__any(err != 0) && lane == 0) atomicMax(&status[u], SCRF_ERR_NUMERIC);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_dp_lin_mw: the same recursion for 64 < L <= 256: one workgroup of NW = ceil(L/64) wavefronts per
+// (utterance, direction), lane = label.  The vector that feeds the L x L transition step is
+// exchanged through LDS (two barriers per frame, one more for the wave maxima); everything a lane
+// needs for the duration step is its own column of the ring, so that part needs no barrier.  The
+// transition matrix stays in memory (L2-resident): rows are read coalesced.
+// ------------------------------------------------------------------------------------------
+template <int DMAX, int MPF>
+__global__ __launch_bounds__(256) void k_dp_lin_mw(
+    ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
+    const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
+    const double* __restrict__ mshift, double* __restrict__ a_g, double* __restrict__ ga_g,
+    double* __restrict__ p_g, double* __restrict__ gp_g, double* __restrict__ b_g, double* __restrict__ gb_g,
+    double* __restrict__ sd_g, double* __restrict__ gsd_g, double* __restrict__ zx_out, int* __restrict__ status) {
+  extern __shared__ double dsm[];
+  const int L = lay.L, D = lay.D;
+  const size_t LL = (size_t)L * L;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
+  const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
+  const uint32_t u = u0 + (blockIdx.x >> 1);
+  double* ring = dsm;                 // [D][L] mantissas of the last D alpha-plus-trans / beta vectors
+  double* abuf = ring + (((size_t)D * L + 1) & ~(size_t)1);  // [64*NW] operand of the transition step (16-byte aligned)
+  double* gring = abuf + 64 * NW;     // [D] log-scales of the ring slots
+  double* cbuf = gring + 64;          // [NW][64] per-duration scales, one line per wavefront
+  int* red = (int*)(cbuf + 64 * NW);  // [NW] wave maxima (high words)
+  double* redd = (double*)(red + 8);  // [NW] partial sums (Zx)
+  const int T = (int)bv.T[u];
+  if (T == 0) return;
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* ESu = ES + s_base * L;
+  const double* smu = smax + s_base;
+  const int l = tid;
+  const bool act = l < L;
+  const int lc = act ? l : L - 1;
+  const double sh0 = MPF ? 0.0 : mshift[0];
+  double* cw = cbuf + wave * 64;
+  int err = 0;
+
+  // sum_c v[c] * Em[c*L + lc], v exchanged through abuf (caller places the barriers)
+  auto matvec = [&](const double* Em) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= L; c += 4) {
+      const double2 a01 = *(const double2*)(abuf + c), a23 = *(const double2*)(abuf + c + 2);
+      s0 = fma(a01.x, Em[(size_t)(c + 0) * L + lc], s0);
+      s1 = fma(a01.y, Em[(size_t)(c + 1) * L + lc], s1);
+      s2 = fma(a23.x, Em[(size_t)(c + 2) * L + lc], s2);
+      s3 = fma(a23.y, Em[(size_t)(c + 3) * L + lc], s3);
+    }
+    for (; c < L; c++) s0 = fma(abuf[c], Em[(size_t)c * L + lc], s0);
+    return (s0 + s1) + (s2 + s3);
+  };
+  // exponent of the workgroup-wide maximum of a non-negative vector
+  auto block_exp = [&](double v) {
+    const int h = wave_max_hi(act ? v : 0.0);
+    if (lane == 0) red[wave] = h;
+    __syncthreads();
+    int m = red[0];
+    for (int w = 1; w < NW; w++) m = max(m, red[w]);
+    return hi_exp(m, &err);
+  };
+
+  if (dir == 0) {
+    // ---------------------------------------------------------------- forward
+    double* au = a_g + f_base * L;
+    double* pu = p_g + f_base * L;
+    double a = ESu[lc];
+    double ga = smu[0];
+    if (act) au[l] = a;
+    if (tid == 0) ga_g[f_base] = ga;
+    int rpos = D - 1;
+    for (int t = 1; t < T; t++) {
+      rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      const uint64_t base = scrf_seg_base(t, D);
+      double es[DMAX];
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        const double x = ESu[(base + (d0 < nd ? d0 : 0)) * L + lc];
+        es[d0] = (d0 < nd) ? x : 0.0;
+      }
+      const double smx = smu[base + (lane < nd ? lane : 0)];
+      abuf[tid] = act ? a : 0.0;
+      __syncthreads();
+      const double usum = matvec(MPF ? E + (f_base + t) * LL : E);
+      const double sh = MPF ? mshift[f_base + t] : sh0;
+      const int k = block_exp(usum);           // (barrier inside: abuf is free again after it)
+      const double p = ldexp(usum, -k);
+      const double gp = ga + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      ring[(size_t)rpos * L + lc] = p;
+      if (tid == 0) { gring[rpos] = gp; gp_g[f_base + t - 1] = gp; }
+      if (act) pu[(size_t)(t - 1) * L + l] = p;
+      __syncthreads();                          // gring[rpos] visible to every wavefront
+      int myslot = rpos - lane;
+      if (myslot < 0) myslot += D;
+      double x = (lane < np) ? gring[(lane < np) ? myslot : 0] + smx : smx;
+      x = (lane < nd) ? x : -INFINITY;
+      const double G = (double)wave_max_f32_dpp((float)x);
+      cw[lane] = exp_nonpos(x - G);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        int slot = rpos - d0;
+        if (slot < 0) slot += D;
+        const double r = (d0 == 0) ? p : ring[(size_t)(d0 < np ? slot : rpos) * L + lc];
+        const double pv = (d0 < np) ? r : 1.0;
+        const double w = es[d0] * cw[d0];
+        if (d0 & 1) acc1 = fma(pv, w, acc1); else acc0 = fma(pv, w, acc0);
+      }
+      a = acc0 + acc1;
+      ga = G;
+      if (act) au[(size_t)t * L + l] = a;
+      if (tid == 0) ga_g[f_base + t] = ga;
+    }
+    // Zx = log sum_l exp(alpha[T-1][l])
+    const double part = wave_sum_f64(act ? a : 0.0);
+    if (lane == 0) redd[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < NW; w++) tot += redd[w];
+      const double Zx = ga + log(tot);
+      if (!(Zx == Zx) || isinf(Zx)) err = 1;
+      zx_out[u] = Zx;
+    }
+  } else {
+    // ---------------------------------------------------------------- backward
+    double* bu = b_g + f_base * L;
+    double* sdu = sd_g + f_base * L;
+    int tpos = (T - 1) % D;
+    ring[(size_t)tpos * L + lc] = 1.0;  // setTailBeta: beta[T-1] = 0
+    if (tid == 0) { gring[tpos] = 0.0; gb_g[f_base + T - 1] = 0.0; gsd_g[f_base + T - 1] = 0.0; }
+    if (act) { bu[(size_t)(T - 1) * L + l] = 1.0; sdu[(size_t)(T - 1) * L + l] = 0.0; }
+    __syncthreads();
+    for (int t = T - 2; t >= 0; t--) {
+      const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+      tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
+      double es[DMAX];
+      uint64_t r = scrf_seg_base(t + 1, D), myrow = r;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        const bool ok = d0 < nn;
+        const double x = ESu[(ok ? r + d0 : 0) * L + lc];
+        es[d0] = ok ? x : 0.0;
+        if (lane == d0 && ok) myrow = r + d0;
+        r += scrf_node_max_dur(t + 1 + d0, D);
+      }
+      const double smx = smu[myrow];
+      int myslot = tpos + lane + 1;
+      if (myslot >= D) myslot -= D;
+      const double x = (lane < nn) ? gring[(lane < nn) ? myslot : 0] + smx : -INFINITY;
+      const double G = (double)wave_max_f32_dpp((float)x);
+      cw[lane] = exp_nonpos(x - G);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int d0 = 0; d0 < DMAX; d0++) {
+        int slot = tpos + d0 + 1;
+        if (slot >= D) slot -= D;
+        const double bv_ = ring[(size_t)((d0 < nn) ? slot : tpos) * L + lc];
+        const double w = es[d0] * cw[d0];
+        if (d0 & 1) acc1 = fma((d0 < nn) ? bv_ : 0.0, w, acc1); else acc0 = fma((d0 < nn) ? bv_ : 0.0, w, acc0);
+      }
+      const double sd = acc0 + acc1;
+      abuf[tid] = act ? sd : 0.0;
+      __syncthreads();
+      const double w = matvec(MPF ? ET + (f_base + t + 1) * LL : ET);
+      const double sh = MPF ? mshift[f_base + t + 1] : sh0;
+      const int k = block_exp(w);
+      const double b = ldexp(w, -k);
+      const double gb = G + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      ring[(size_t)tpos * L + lc] = b;
+      if (tid == 0) { gring[tpos] = gb; gsd_g[f_base + t] = G; gb_g[f_base + t] = gb; }
+      if (act) { sdu[(size_t)t * L + l] = sd; bu[(size_t)t * L + l] = b; }
+      __syncthreads();
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicMax(&status[u], SCRF_ERR_NUMERIC);
+}
+
+int dplin_mw_supported(const ScrfLayout& lay) { return lay.L > 64 && lay.L <= 256 && lay.D <= 40; }
+
+template <int DMAX>
+static void launch_dp_lin_mw_t(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                               const double* ES, const double* smax, const double* E, const double* ET,
+                               const double* mshift, int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
+  const uint32_t nw = (lay.L + 63) / 64;
+  const size_t sm = sizeof(double) * ((((size_t)lay.D * lay.L + 1) & ~(size_t)1) + 64 * nw + 64 + 64 * nw + 16);
+  if (m_per_frame) {
+    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, 1>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E,
+                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);
+  } else {
+    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, 0>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E,
+                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);
+  }
+}
+
 void launch_true_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
                         uint64_t n_frames, const double* S, double* s_true) {
   if (n_frames == 0) return;
@@ -340,6 +529,12 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
                    const double* ES, const double* smax, const double* E, const double* ET, const double* mshift,
                    int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
   if (n_utts == 0) return;
+  if (lay.L > 64) {
+    if (lay.D <= 10) launch_dp_lin_mw_t<10>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
+    else if (lay.D <= 25) launch_dp_lin_mw_t<25>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
+    else launch_dp_lin_mw_t<40>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
+    return;
+  }
   const uint32_t nblk = 2 * ((n_utts + DP_WPB - 1) / DP_WPB);
   const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * (lay.D * lay.L + 128));
 #define DL_LAUNCH2(DM, MPF)                                                                                    \

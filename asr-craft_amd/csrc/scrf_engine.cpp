@@ -658,6 +658,13 @@ struct ChunkBufs {
 
 struct Need { bool fb, post, beta, vit; bool fused = false; };
 
+// does the recursion run on the wavefront kernels?  L <= 64: always (log-domain kernels for the
+// hooks, linear-domain for training); 64 < L <= 256: the multi-wavefront linear-domain kernel,
+// training path only
+static bool wave_path(scrf_handle h, bool post) {
+  return dp_wave_supported(h->lay) || (post && h->lin_dp && dplin_mw_supported(h->lay));
+}
+
 // fused path: the five sampled blocks as per-frame projections (outputs (k, label), k < 5), and
 // the dense column groups [avg | max | min | onehot(d)] + bias
 static ScrfGemmSpec spec_samples(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0.0, 0, W}; }
@@ -677,7 +684,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   tot += pad256(nseg * l.L * sizeof(double));                       // S
   if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
   if (nd.fb) {
-    const bool wave = dp_wave_supported(l);
+    const bool wave = wave_path(h, nd.post);
     if (wave && nd.post && h->lin_dp) {
       // scaled linear-domain recursion: no alpha-with-duration array
       tot += pad256(nseg * sizeof(double)) + pad256(nfr * sizeof(double));               // smax, s_true
@@ -701,7 +708,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
         tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
         uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
         tot += pad256((size_t)nch_t * LL * l.ntf * sizeof(double));
-      } else if (!dp_wave_supported(l)) {
+      } else if (!wave_path(h, nd.post)) {
         tot += pad256(nutt * LL * sizeof(double));
       }
       const uint64_t rpc_s = expf_rows_per_chunk(nseg);
@@ -760,7 +767,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     cb->m_per_frame = 0;
   }
   if (nd.fb) {
-    cb->wave = dp_wave_supported(l);
+    cb->wave = wave_path(h, nd.post);
     cb->lin = cb->wave && nd.post && h->lin_dp;
     if (cb->lin) {
       cb->smax = a.take<double>(nseg);
@@ -1116,7 +1123,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     launch_add(h->stream, h->d_grad, h->d_grad2, l.lambda_len);
     launch_add(h->stream, h->d_sums, h->d_sums2, 3);
   }
-  if (!l.use_tf && dp_wave_supported(l)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_grad);
+  if (!l.use_tf && wave_path(h, true)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_grad);
   if (h->timing) {
     hipEventRecord(h->ev[SCRF_N_PHASES][1], h->stream);
     hipEventSynchronize(h->ev[SCRF_N_PHASES][1]);

@@ -164,10 +164,10 @@ def test_fused_window_synthesis_equals_materialised_windows(si, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
-def test_more_than_64_labels_takes_the_workgroup_recursion(prec):
-    """L > 64 does not fit the wavefront-per-utterance kernels: the workgroup-per-utterance log-domain
-    recursion (k_fb) and the generic posterior path serve it, with the fused contractions when the
-    stream qualifies (several 48-output groups per row)."""
+def test_more_than_64_labels(prec):
+    """64 < L <= 256: the multi-wavefront linear-domain recursion (k_dp_lin_mw: one workgroup per
+    utterance and direction, the transition operand exchanged through LDS), the 64 x 64-blocked
+    transition-count contraction, and the fused contractions with several 48-output groups per row."""
     c = Case(L=70, D=3, in_w=4, Ts=[1, 2, 5, 9, 14], seed=61, precision=prec)
     eng = c.engine(); b = c.batch(eng)
     numer, zx = eng.fb_batch(b)
@@ -183,6 +183,18 @@ def test_more_than_64_labels_takes_the_workgroup_recursion(prec):
         oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
         ol, oc = orc.best_path(oa, ons, ofin)
         assert list(labs[u]) == list(ol)
+    b.close(); eng.close()
+
+
+def test_more_than_64_labels_log_domain_fallback(monkeypatch):
+    """SCRF_LINDP=0 sends L > 64 through the workgroup-per-utterance log-domain recursion (k_fb)."""
+    monkeypatch.setenv("SCRF_LINDP", "0")
+    c = Case(L=70, D=3, in_w=4, Ts=[1, 2, 5, 9, 14], seed=61, precision=1)
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    og, on, oz = c.oracle_gradient()
+    assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
+    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() <= 1e-9
     b.close(); eng.close()
 
 

@@ -42,5 +42,6 @@ if __name__ == "__main__":
     # config 3 shape at a minibatch that fills the chip: 64 utterances of ~300 frames
     run("cfg3x64", 1, L=48, D=10, in_w=144, Ts=[304] * 64, trans_ctx=6, seed=4, lam_scale=0.01)
     # config 5 shape: L=200 D=40, 123-dim frames (generic workgroup-per-utterance DP kernel)
+    run("cfg5x32", 1, L=200, D=40, in_w=123, Ts=[2000] * 32, seed=6, lam_scale=0.01)
     for prec in (0, 1):
         run("cfg5", prec, L=200, D=40, in_w=123, Ts=[300, 500], seed=5, lam_scale=0.01)

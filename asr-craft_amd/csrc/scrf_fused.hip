@@ -18,6 +18,10 @@
 //   kernel and two more column groups of the expected-count kernel.
 //
 // X never exists in HBM and the dense depth drops from 8W+D to 3W (scores) / 3W+D+1 (counts).
+//
+// Kernels: k_pframe (P = F W_k), k_scores_fused (dense part + gather of P + exp epilogue),
+// k_post_z (R = Y - gamma and Z in one walk; k_lin_z is the Z-only form), k_expf_fused (dense part
+// of the expected counts), k_ztf (Z^T F).  DESIGN.md 4.1 has the data flow.
 #include "scrf_kernels.h"
 
 #include <math.h>

@@ -18,15 +18,23 @@ int main(int argc, char** argv) {
   } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
   if (!crf.readFromFile(a.str("weight_file").c_str())) { std::cerr << "ERROR! File " << a.str("weight_file") << " unable to be opened for reading" << std::endl; return -1; }
   CRF_MemoryFeatureStream strm(m.recipes, m.D, m.fmap.nActualLabs);
-  const size_t U = data[0].size();
-  for (size_t u = 0; u < U; u++) {
+  std::vector<uint32_t> sents;
+  try {
+    sents = select_sents(a, "crf_eval_range", data[0].utts.size());
+  } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+  for (uint32_t u : sents) {
     std::vector<std::vector<float> > fr(data.size());
-    for (size_t s = 0; s < data.size(); s++)
-      for (const auto& row : data[s][u]) fr[s].insert(fr[s].end(), row.begin(), row.end());
+    for (size_t s = 0; s < data.size(); s++) fr[s] = data[s].utts[u];
     strm.addUtterance(fr, std::vector<uint32_t>());
   }
+  // crf_output_format=ilab writes QuickNet ILAB (CRFFstDecode/src/Main.cpp:203); the default here
+  // is the same content as ascii `sent pos label` lines
+  const std::string ofmt = a.str("crf_output_format", "ascii");
+  if (ofmt != "ascii" && ofmt != "ilab") { std::cerr << "crf_output_format=" << ofmt << " is not built (ascii|ilab)" << std::endl; return 1; }
+  if (ofmt == "ilab" && !a.has("crf_output_labelfile")) { std::cerr << "crf_output_format=ilab needs crf_output_labelfile" << std::endl; return 1; }
+  std::vector<std::vector<uint32_t> > all_labs;
   std::ofstream out;
-  if (a.has("crf_output_labelfile")) out.open(a.str("crf_output_labelfile").c_str());
+  if (a.has("crf_output_labelfile") && ofmt == "ascii") out.open(a.str("crf_output_labelfile").c_str());
   std::ostream& os = out.is_open() ? (std::ostream&)out : std::cout;
   strm.rewind();
   size_t u = 0;
@@ -42,11 +50,19 @@ int main(int argc, char** argv) {
       }
       float cost = 0;
       std::vector<uint32_t> labs = crf_amd_best_path(&strm, &crf, &cost);
-      for (size_t i = 0; i < labs.size(); i++) os << u << " " << i << " " << labs[i] << "\n";
+      if (ofmt == "ascii")
+        for (size_t i = 0; i < labs.size(); i++) os << u << " " << i << " " << labs[i] << "\n";
+      all_labs.push_back(labs);
     } catch (std::exception& e) {
       std::cerr << "Exception: " << e.what() << std::endl;
+      all_labs.push_back(std::vector<uint32_t>());
     }
     u++;
+  }
+  if (ofmt == "ilab") {
+    try {
+      qn::write_ilab(a.str("crf_output_labelfile"), all_labs);
+    } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
   }
   return 0;
 }

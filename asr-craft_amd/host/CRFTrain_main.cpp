@@ -10,7 +10,10 @@ int main(int argc, char** argv) {
     auto data = load_streams(a, &m);
     if (!a.has("hardtarget_file")) { std::cerr << "hardtarget_file is required" << std::endl; return 1; }
     if (!a.has("out_weight_file")) { std::cerr << "out_weight_file is required" << std::endl; return 1; }
-    auto labs = read_ascii_labs(a.str("hardtarget_file"));
+    auto labs = read_labs(a.str("hardtarget_file"));
+    const std::vector<uint32_t> sents = select_sents(a, "train_sent_range", data[0].utts.size());
+    if (a.has("cv_sent_range") && a.str("cv_sent_range") != "nil" && a.str("cv_sent_range") != "none")
+      std::cout << "NOTE: cv_sent_range=" << a.str("cv_sent_range") << " ignored: the cross-validation pass is not built" << std::endl;
     if (a.str("crf_train_method", "sg") != "sg") { std::cerr << "only crf_train_method=sg is built" << std::endl; return 1; }
     if (a.str("crf_train_order", "seq") != "seq") std::cout << "NOTE: crf_train_order=" << a.str("crf_train_order") << " ignored: sequential presentation (QuickNet's RNG is not reproducible here)" << std::endl;
 
@@ -28,11 +31,11 @@ int main(int argc, char** argv) {
     crf.setInitIter((QNUInt32)a.num("init_iter", 0));
 
     CRF_MemoryFeatureStream all(m.recipes, m.D, m.fmap.nActualLabs);
-    const size_t U = data[0].size();
-    for (size_t u = 0; u < U; u++) {
+    const size_t U = sents.size();
+    for (size_t i = 0; i < U; i++) {
+      const uint32_t u = sents[i];
       std::vector<std::vector<float> > fr(data.size());
-      for (size_t s = 0; s < data.size(); s++)
-        for (const auto& row : data[s][u]) fr[s].insert(fr[s].end(), row.begin(), row.end());
+      for (size_t s = 0; s < data.size(); s++) fr[s] = data[s].utts[u];
       all.addUtterance(fr, u < labs.size() ? labs[u] : std::vector<uint32_t>());
     }
     // `threads` child streams over contiguous ranges (io/CRF_FeatureStreamManager.cpp:425-464)

@@ -2,9 +2,9 @@
 // CRFTrain / CRFFstDecode front-ends (the reference parses the same flag names with QuickNet's
 // QN_initargs, CRFTrain/src/Main.cpp:146-256, CRFFstDecode/src/Main.cpp).  Only the flags that
 // reach the hot path are honoured; the others are accepted and ignored with a notice.
-// Feature files: QuickNet "ascii" pfile layout, one line per frame `sent frame v0 v1 ...`
-// (the layout of the reference's bundled CRFTrain/test*.ascii fixtures); label files
-// `sent frame label`.  Binary pfile/ILAB readers are SURVEY row f1 ("next").
+// Feature files: binary pfile (the reference's default format) or the "ascii" layout, one line
+// per frame `sent frame v0 v1 ...` (the reference's bundled CRFTrain/test*.ascii fixtures); label
+// files: binary ILAB or ascii `sent frame label` (qn_files.h).
 #ifndef CLI_COMMON_H_
 #define CLI_COMMON_H_
 
@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "crf_amd.h"
+#include "qn_files.h"
 
 struct Args {
   std::map<std::string, std::string> kv;
@@ -35,29 +36,47 @@ struct Args {
   double real(const std::string& k, double d) const { return has(k) ? atof(kv.at(k).c_str()) : d; }
 };
 
-// utterances of one ascii stream: [utt][frame][value]
-inline std::vector<std::vector<std::vector<float> > > read_ascii_ftrs(const std::string& path, size_t* width) {
+// one input stream: utts[u] = T x width floats, row-major
+struct FtrData {
+  size_t width = 0;
+  std::vector<std::vector<float> > utts;
+};
+
+inline FtrData read_ascii_ftrs(const std::string& path) {
   std::ifstream f(path.c_str());
   if (!f.is_open()) { std::cerr << "cannot open feature file " << path << std::endl; exit(1); }
-  std::vector<std::vector<std::vector<float> > > utts;
+  FtrData d;
   std::string line;
-  *width = 0;
   while (getline(f, line)) {
     std::istringstream is(line);
     long s, t;
     if (!(is >> s >> t)) continue;
-    std::vector<float> v;
+    if ((size_t)s >= d.utts.size()) d.utts.resize(s + 1);
+    size_t n = 0;
     float x;
-    while (is >> x) v.push_back(x);
-    if (*width == 0) *width = v.size();
-    if (v.size() != *width) { std::cerr << path << ": ragged feature line" << std::endl; exit(1); }
-    if ((size_t)s >= utts.size()) utts.resize(s + 1);
-    utts[s].push_back(v);
+    while (is >> x) { d.utts[s].push_back(x); n++; }
+    if (d.width == 0) d.width = n;
+    if (n != d.width) { std::cerr << path << ": ragged feature line" << std::endl; exit(1); }
   }
-  return utts;
+  return d;
 }
 
-inline std::vector<std::vector<uint32_t> > read_ascii_labs(const std::string& path) {
+// pfile stream (QN_build_ftrstream(format="pfile"), io/CRF_FeatureStreamManager.cpp:138), columns
+// ftr_start .. ftr_start+ftr_count (ftr_count 0 = the rest), one sentence at a time
+inline FtrData read_pfile_ftrs(const std::string& path, uint32_t ftr_start, uint32_t ftr_count) {
+  qn::PFileReader r(path);
+  FtrData d;
+  if (ftr_start > r.info().n_ftrs) qn::fail(path, "ftr_start beyond the file's width");
+  d.width = ftr_count ? ftr_count : r.info().n_ftrs - ftr_start;
+  d.utts.resize(r.num_sents());
+  for (uint32_t s = 0; s < r.num_sents(); s++) r.read_sent(s, &d.utts[s], nullptr, ftr_start, (uint32_t)d.width);
+  return d;
+}
+
+// hardtarget_file: QuickNet ILAB (QN_InLabStream_ILab, io/CRF_FeatureStreamManager.cpp:285) or the
+// ascii `sent frame label` layout of the bundled fixture -- told apart by the magic
+inline std::vector<std::vector<uint32_t> > read_labs(const std::string& path) {
+  if (qn::is_ilab(path)) return qn::read_ilab(path).labels;
   std::ifstream f(path.c_str());
   if (!f.is_open()) { std::cerr << "cannot open label file " << path << std::endl; exit(1); }
   std::vector<std::vector<uint32_t> > utts;
@@ -85,8 +104,8 @@ inline modeltype parse_model_type(const std::string& s) {
 }
 
 // streams (ftr1/ftr2/ftr3) + set_fmap_config of CRFTrain/src/Main.cpp:372-430
-inline std::vector<std::vector<std::vector<std::vector<float> > > > load_streams(const Args& a, CliModel* m) {
-  std::vector<std::vector<std::vector<std::vector<float> > > > data;
+inline std::vector<FtrData> load_streams(const Args& a, CliModel* m) {
+  std::vector<FtrData> data;
   m->D = (uint32_t)a.num("label_maximum_duration", 1);
   m->L = (uint32_t)a.num("crf_label_size", 0);
   m->mtype = parse_model_type(a.str("crf_model_type", "stdframe"));
@@ -95,9 +114,19 @@ inline std::vector<std::vector<std::vector<std::vector<float> > > > load_streams
   for (int k = 1; k <= 3; k++) {
     std::string p = "ftr" + std::to_string(k) + "_";
     if (!a.has(p + "file")) break;
-    if (a.str(p + "format", "ascii") != "ascii") { std::cerr << p << "format: only ascii is built (pfile: next round)" << std::endl; exit(1); }
-    size_t w = 0;
-    data.push_back(read_ascii_ftrs(a.str(p + "file"), &w));
+    const std::string fmt = a.str(p + "format", "pfile");  // the reference's default
+    const uint32_t f0 = (uint32_t)a.num(p + "ftr_start", 0), fc = (uint32_t)a.num(p + "ftr_count", 0);
+    if (fmt == "pfile") {
+      data.push_back(read_pfile_ftrs(a.str(p + "file"), f0, fc));
+    } else if (fmt == "ascii") {
+      if (f0 || fc) { std::cerr << p << "ftr_start/ftr_count need " << p << "format=pfile" << std::endl; exit(1); }
+      data.push_back(read_ascii_ftrs(a.str(p + "file")));
+    } else {
+      std::cerr << p << "format=" << fmt << " is not built (pfile|ascii)" << std::endl;
+      exit(1);
+    }
+    if (data.back().utts.size() != data[0].utts.size()) { std::cerr << p << "file holds " << data.back().utts.size() << " sentences, ftr1_file " << data[0].utts.size() << std::endl; exit(1); }
+    const size_t w = data.back().width;
     scrf_stream_recipe r;
     r.in_width = (uint32_t)w;
     r.left_ctx = (uint32_t)a.num(p + "left_context_len", 0);
@@ -132,6 +161,11 @@ inline std::vector<std::vector<std::vector<std::vector<float> > > > load_streams
   c.durFtrStart = (QNUInt32)a.num("dur_ftr_start", 0);
   c.nActualLabs = (QNUInt32)a.num("num_actual_labs", m->L);
   return data;
+}
+
+// sentences a run works on (train_sent_range / crf_eval_range, QN_Range syntax, qn_files.h)
+inline std::vector<uint32_t> select_sents(const Args& a, const std::string& key, size_t n_sents) {
+  return qn::parse_range(a.str(key, "all"), (uint32_t)n_sents);
 }
 
 #endif  // CLI_COMMON_H_

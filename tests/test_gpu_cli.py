@@ -118,3 +118,71 @@ def test_segmental_gradbuilder_via_read_protocol(tmp_path):
         assert rc == 0
     ref = np.float32(0.05) * g
     np.testing.assert_allclose(np.loadtxt(out), np.array([float("%g" % v) for v in ref]), rtol=2e-5, atol=1e-9)
+
+
+def test_crftrain_and_fstdecode_on_pfile_and_ilab_inputs(tmp_path):
+    """the same runs from binary pfile features + ILAB labels (the reference's
+    default formats) give the same weight files and labels, byte for byte, as from the ascii
+    fixture; train_sent_range / crf_eval_range select sentences; ILAB output."""
+    tool = os.path.join(BIN, "qn_filetool")
+    pf1, pf2, il = str(tmp_path / "f1.pfile"), str(tmp_path / "f2.pfile"), str(tmp_path / "lab.ilab")
+    for src, dst in [("crftrain_test.ascii", pf1), ("crftrain_test.ftr2.ascii", pf2)]:
+        subprocess.check_call([tool, "ascii2pfile", os.path.join(G, src), dst])
+    subprocess.check_call([tool, "ascii2ilab", os.path.join(G, "crftrain_test.lab.ascii"), il])
+    model = ["crf_label_size=48", "crf_model_type=stdframe", "label_maximum_duration=1", "crf_featuremap=stdstate"]
+    train = ["crf_epochs=2", "crf_lr=0.1", "crf_bunch_size=2", "threads=1", "crf_train_order=seq"]
+    outs = {}
+    for tag, ftr, lab, extra in [("ascii", _common_flags(), os.path.join(G, "crftrain_test.lab.ascii"), []),
+                                 ("bin", ["ftr1_file=" + pf1, "ftr2_file=" + pf2] + model, il, ["train_sent_range=all"]),
+                                 ("sub_ascii", _common_flags(), os.path.join(G, "crftrain_test.lab.ascii"), ["train_sent_range=0,2"]),
+                                 ("sub_bin", ["ftr1_file=" + pf1, "ftr1_format=pfile", "ftr2_file=" + pf2, "ftr2_format=pfile"] + model, il, ["train_sent_range=0:2:2"])]:
+        d = tmp_path / tag
+        d.mkdir()
+        out = str(d / "w.out")
+        r = subprocess.run([os.path.join(BIN, "CRFTrain")] + ftr + ["hardtarget_file=" + lab, "out_weight_file=" + out] + train + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = open(out).read()
+    assert outs["ascii"] == outs["bin"] and outs["sub_ascii"] == outs["sub_bin"] and outs["ascii"] != outs["sub_ascii"]
+
+    # feature-column selection: the joined 6-wide stream cut back into its two halves
+    joined = str(tmp_path / "joined.ascii")
+    a, b = np.loadtxt(os.path.join(G, "crftrain_test.ascii")), np.loadtxt(os.path.join(G, "crftrain_test.ftr2.ascii"))
+    with open(joined, "w") as f:
+        for ra, rb in zip(a, b):
+            f.write("%d %d %s\n" % (ra[0], ra[1], " ".join("%.9g" % v for v in list(ra[2:]) + list(rb[2:]))))
+    pj = str(tmp_path / "joined.pfile")
+    subprocess.check_call([tool, "ascii2pfile", joined, pj])
+    w3 = a.shape[1] - 2
+    out = str(tmp_path / "cut.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain"), "ftr1_file=" + pj, "ftr1_ftr_start=0", "ftr1_ftr_count=%d" % w3,
+                        "ftr2_file=" + pj, "ftr2_ftr_start=%d" % w3, "hardtarget_file=" + il, "out_weight_file=" + out] + model + train,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(out).read() == outs["ascii"]
+
+    # decode: ascii labels == ILAB labels, crf_eval_range picks sentences
+    wf = str(tmp_path / "ascii" / "w.out")
+    dec_a, dec_b, dec_c = str(tmp_path / "dec.txt"), str(tmp_path / "dec.ilab"), str(tmp_path / "dec1.txt")
+    for flags in (_common_flags() + ["crf_output_labelfile=" + dec_a],
+                  ["ftr1_file=" + pf1, "ftr2_file=" + pf2] + model + ["crf_output_labelfile=" + dec_b, "crf_output_format=ilab", "crf_eval_range=all"],
+                  ["ftr1_file=" + pf1, "ftr2_file=" + pf2] + model + ["crf_output_labelfile=" + dec_c, "crf_eval_range=1"]):
+        r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + flags + ["weight_file=" + wf], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+    back = str(tmp_path / "dec_back.txt")
+    subprocess.check_call([tool, "ilab2ascii", dec_b, back])
+    assert open(back).read() == open(dec_a).read()
+    one = np.loadtxt(dec_c).astype(int).reshape(-1, 3)
+    full = np.loadtxt(dec_a).astype(int)
+    assert np.array_equal(one[:, 1:], full[full[:, 0] == 1][:, 1:]) and set(one[:, 0]) == {0}
+
+    # errors: label/frame count mismatch and an out-of-range sentence are reported, not ignored
+    bad = str(tmp_path / "bad.ascii")
+    with open(bad, "w") as f:
+        f.write("0 0 1\n0 1 1\n")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + ["hardtarget_file=" + bad, "out_weight_file=" + str(tmp_path / "x.out")] + train,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one label per frame expected" in r.stderr
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + ["hardtarget_file=" + il, "out_weight_file=" + str(tmp_path / "y.out"), "train_sent_range=0:7"] + train,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "selects sentence" in r.stderr

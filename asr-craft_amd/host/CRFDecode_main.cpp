@@ -1,0 +1,127 @@
+// CRFDecode -- Viterbi decode front-end (CRFDecode/src/Main.cpp) for the case the reference
+// decodes against its own free-phone-loop LM (no crf_lm_bin): per utterance the best path from
+// CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode, written as an HTK MLF
+// (crf_output_mlffile + crf_olist + crf_osymbols, Main.cpp:803-835,1176-1330) and, with
+// crf_lat_outdir, as a text arc list `src dst ilabel olabel weight` + `final weight` per
+// utterance (the reference writes OpenFST binaries there).  crf_lm_bin / crf_lm_arpa need an FST
+// library and are refused.
+#include "cli_common.h"
+
+// OpenFST text symbol table: `symbol id` per line
+static std::map<long, std::string> read_symbols(const std::string& path) {
+  std::ifstream f(path.c_str());
+  if (!f.is_open()) { std::cerr << "ERROR: Failed opening file: " << path << std::endl; exit(-1); }
+  std::map<long, std::string> m;
+  std::string sym;
+  long id;
+  while (f >> sym >> id) m[id] = sym;
+  return m;
+}
+
+int main(int argc, char** argv) {
+  Args a(argc, argv);
+  if (a.has("crf_lm_bin") || a.has("crf_lm_arpa")) { std::cerr << "crf_lm_bin / crf_lm_arpa: decoding against an LM FST is not built (free phone loop only)" << std::endl; return 1; }
+  if (!a.has("crf_output_labelfile") && !a.has("crf_output_mlffile")) { std::cerr << "At least one of crf_output_labelfile or crf_output_mlffile must be assigned" << std::endl; return -1; }
+  if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
+  if (!a.has("crf_olist")) { std::cerr << "crf_olist required currently." << std::endl; return -1; }  // Main.cpp:1022-1025
+  if (a.str("crf_decode_mode", "decode") != "decode") { std::cerr << "crf_decode_mode=" << a.str("crf_decode_mode") << " is not built" << std::endl; return 1; }
+  CliModel m;
+  std::vector<FtrData> data;
+  try {
+    data = load_streams(a, &m);
+  } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+  std::vector<std::string> olist;
+  {
+    std::ifstream f(a.str("crf_olist").c_str());
+    if (!f.is_open()) { std::cerr << "ERROR: Failed opening file: " << a.str("crf_olist") << std::endl; return -1; }
+    std::string s;
+    while (getline(f, s)) olist.push_back(s);
+  }
+  std::map<long, std::string> osym;
+  const bool have_osym = a.has("crf_osymbols");
+  if (have_osym) osym = read_symbols(a.str("crf_osymbols"));
+  std::ofstream mlf;
+  if (a.has("crf_output_mlffile")) {
+    mlf.open(a.str("crf_output_mlffile").c_str());
+    mlf << "#!MLF!#" << std::endl;
+  }
+  if (a.has("crf_output_labelfile")) { std::ofstream touch(a.str("crf_output_labelfile").c_str()); }  // opened, never written (Main.cpp:794-801)
+  const bool out_frames = a.num("crf_mlf_output_frames", 0) != 0;
+
+  CRF_Model crf(m.L);
+  crf.setLabMaxDur(m.D);
+  crf.setNActualLabs(m.fmap.nActualLabs);
+  crf.setModelType(m.mtype);
+  std::cout << "LABELS: " << crf.getNLabs() << std::endl;
+  std::cout << "LABEL_MAXIMUM_DURATION: " << crf.getLabMaxDur() << std::endl;
+  std::cout << "ACTUAL_LABELS: " << crf.getNActualLabs() << std::endl;
+  std::vector<uint32_t> sents;
+  try {
+    if (m.mtype == STDFRAME && m.D != 1) throw std::runtime_error("the maximum duration of labels must be 1 for \"stdframe\" CRF model.");
+    if (m.mtype != STDFRAME && m.mtype != STDSEG_NO_DUR_NO_SEGTRANSFTR)
+      throw std::runtime_error("CRF_ViterbiDecoder for CRF models other than \"stdframe\" and \"stdseg_no_dur_no_segtransftr\" have not been implmented.");
+    crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));
+    sents = select_sents(a, "crf_eval_range", data[0].utts.size());
+  } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+  if (!crf.readFromFile(a.str("weight_file").c_str())) { std::cerr << "ERROR: Failed opening file: " << a.str("weight_file") << std::endl; return -1; }
+  CRF_MemoryFeatureStream strm(m.recipes, m.D, m.fmap.nActualLabs);
+  for (uint32_t u : sents) {
+    std::vector<std::vector<float> > fr(data.size());
+    for (size_t s = 0; s < data.size(); s++) fr[s] = data[s].utts[u];
+    strm.addUtterance(fr, std::vector<uint32_t>());
+  }
+  strm.rewind();
+  size_t count = 0;
+  while (strm.nextseg() != QN_SEGID_BAD) {
+    const uint32_t u = sents[count];
+    try {
+      if (u >= olist.size()) throw std::runtime_error("main() in CRFDecode caught exception: eval sentence range goes out of the olist size.");
+      std::cout << "Processing file: " << olist[u] << " (" << u << " in the olist) (" << count << " in the current test set)" << std::endl;
+      CRF_ViterbiDecoder_StdSeg_NoSegTransFtr vd(&strm, &crf);
+      vd.setIfOutputFullFst(a.num("crf_if_output_full_lat", 0) != 0);
+      crf_amd::ArcListFst best_lat;
+      vd.nStateDecode(&best_lat, (crf_amd::ArcListFst*)nullptr, (crf_amd::ArcListFst*)nullptr, a.real("crf_decode_beam", 0.0),
+                      (unsigned)a.num("crf_decode_min_hyp", 0), (unsigned)a.num("crf_decode_max_hyp", 0), (float)a.real("crf_decode_hyp_inc", 0.05));
+      std::cout << "Acoustic model weight (negative log potential) = " << vd.getBestWeight() << ", -Z(X) = " << -1 * vd.getZx()
+                << ", language model weight (negative log probability) = " << 0 << std::endl;
+      if (a.has("crf_lat_outdir")) {
+        const std::string fn = a.str("crf_lat_outdir") + "/" + olist[u] + ".fst.txt";
+        std::ofstream lf(fn.c_str());
+        if (!lf.is_open()) throw std::runtime_error("cannot write " + fn);
+        char buf[64];
+        for (const scrf_arc& c : best_lat.arcs) {
+          snprintf(buf, sizeof buf, "%.9g", (double)c.w);
+          lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << buf << "\n";
+        }
+        snprintf(buf, sizeof buf, "%.9g", (double)best_lat.final_weight);
+        lf << best_lat.final_state << " " << buf << "\n";
+      }
+      if (mlf.is_open()) {
+        // the arc walk of Main.cpp:1176-1330 on the (already linear, epsilon-free on the input side)
+        // best path: `current` counts arcs, a label is printed where a phone starts
+        if (have_osym) { mlf << "\"" << olist[u] << "\"" << std::endl; std::cout << "\"" << olist[u] << "\" : "; }
+        int phnStateStart = 0, current = 0;
+        for (const scrf_arc& c : best_lat.arcs) {
+          if (c.olabel == 0 && c.ilabel != 0) {
+            current++;
+          } else if (c.olabel != 0) {
+            if (c.ilabel != 0) current++;
+            if (have_osym) {
+              if (out_frames) mlf << phnStateStart << "\t" << current << "\t";  // start inclusive, end exclusive
+              const std::string w = osym.count(c.olabel) ? osym[c.olabel] : std::string();
+              mlf << w << std::endl;
+              std::cout << w << " ";
+              phnStateStart = current;
+            }
+          }
+        }
+        if (have_osym) { mlf << "." << std::endl; std::cout << "." << std::endl; }
+      }
+    } catch (std::exception& e) {
+      std::cerr << "Exception: " << e.what() << std::endl;
+      return 0;  // the reference exits with 0 here (Main.cpp:1371-1374)
+    }
+    count++;
+  }
+  return 0;
+}

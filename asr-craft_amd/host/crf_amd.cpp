@@ -547,6 +547,60 @@ int CRF_LatticeBuilder::latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint
   return (int)utts[0].u.T;
 }
 
+// nStateDecode for the free phone loop: device Viterbi, then the arc weights of the backtrace
+// from the node scores -- the reference reads them off the segment's END node
+// (getFullTransValue(prev, cur, dur) = getTransValue + getStateValue of node seg_end, :2262)
+int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decode() {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  const uint32_t T = utts[0].u.T, L = crf->getNActualLabs() ? crf->getNActualLabs() : crf->getNLabs(), D = crf->getLabMaxDur();
+  segs.clear();
+  zx = 0.0;
+  best_weight = 0.0f;
+  if (T == 0) return 0;
+  std::vector<uint32_t> labs(T);
+  uint64_t off[2] = {0, 0};
+  e->check(scrf_viterbi_batch(e->h, g.b, labs.data(), labs.size(), off, &best_weight), "nStateDecode");
+  labs.resize(off[1]);
+  uint64_t n_frames = 0, n_segs = 0;
+  uint32_t nu = 0;
+  uint64_t n_arcs = 0;
+  e->check(scrf_batch_info(e->h, g.b, &nu, &n_frames, &n_segs, &n_arcs), "nStateDecode");
+  std::vector<double> S((size_t)n_segs * L), M((size_t)T * L * L);
+  e->check(scrf_scores(e->h, g.b, 0, S.data(), M.data()), "nStateDecode");
+  e->check(scrf_forward_backward(e->h, g.b, 0, SCRF_PREC_EXACT, nullptr, nullptr, nullptr, &zx), "nStateDecode");
+  auto seg_row = [&](uint32_t t, uint32_t d) -> size_t {  // row of the window of length d ending at t
+    const size_t base = t < D ? (size_t)t * (t + 1) / 2 : (size_t)D * (D + 1) / 2 + (size_t)(t - D) * D;
+    return base + d - 1;
+  };
+  uint32_t at = 0, prev = 0;
+  for (size_t i = 0; i < labs.size(); i++) {
+    Segment sg;
+    sg.phone = labs[i] % L;
+    sg.dur = labs[i] / L + 1;
+    sg.start = at;
+    const uint32_t te = at + sg.dur - 1;
+    if (te >= T) throw runtime_error("nStateDecode: best path runs past the utterance");
+    const double sv = S[seg_row(te, sg.dur) * L + sg.phone];
+    if (i == 0) {
+      sg.weight = (float)(-1 * sv);
+      sg.phone_start = true;
+    } else {
+      sg.weight = (float)(-1 * (M[((size_t)te * L + prev) * L + sg.phone] + sv));
+      sg.phone_start = prev != sg.phone;
+    }
+    segs.push_back(sg);
+    prev = sg.phone;
+    at += sg.dur;
+  }
+  if (at != T) throw runtime_error("nStateDecode: best path does not cover the utterance");
+  return (int)T;
+}
+
 std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* crf, float* cost) {
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();

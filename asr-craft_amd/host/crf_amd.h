@@ -284,6 +284,70 @@ class CRF_LatticeBuilder {
 };
 typedef CRF_LatticeBuilder CRF_LatticeBuilder_StdSeg_WithoutDurLab_WithoutSegTransFtr;
 
+// Viterbi decoder of CRFDecode (decoders/CRF_ViterbiDecoder_StdSeg_NoSegTransFtr.{h,cpp}; used for
+// STDFRAME and STDSEG_NO_DUR_NO_SEGTRANSFTR models, CRFDecode/src/Main.cpp:1059-1077) for the case
+// the reference builds its own free-phone-loop LM (lm_fst == NULL, createFreePhoneLmFst :1270-1350).
+// That LM forbids the same phone twice in a row at the LM level, but the decoder lets a phone
+// continue over several segments through its "internal" transition (l -> l, :246-300), so the
+// hypothesis space is every segmentation x labelling and the weights are the float sums
+// (old + float(-M)) + float(-S) (:286-290, :143-146): the same search as the dense device
+// Viterbi over the lattice.  The per-node hypothesis vectors (viterbiPhnIds / viterbiPointers /
+// viterbiDurs / isPhoneStartBoundary, nodes/CRF_StateNode.h:60-65) exist here in their dense form
+// on the device (best weight, back pointer and duration per frame x label) and bestSegments()
+// is the backtrace (:2204-2290).  The search is exhaustive: a positive beam cannot lose the best
+// path here, whereas the reference's pruned search can.  LM-constrained decoding (lm_fst != NULL)
+// needs an FST library and is refused.
+class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
+ public:
+  CRF_ViterbiDecoder_StdSeg_NoSegTransFtr(CRF_FeatureStream* ftr_strm_in, CRF_Model* crf_in) : ftr_strm(ftr_strm_in), crf(crf_in) {}
+  virtual ~CRF_ViterbiDecoder_StdSeg_NoSegTransFtr() {}
+  void setIfOutputFullFst(bool ifFull) { if_output_full_fst = ifFull; }
+  // one segment of the best path, first to last
+  struct Segment {
+    uint32_t phone, dur, start;  // frames start .. start+dur-1
+    float weight;                // float(-getStateValue) for the first, float(-getFullTransValue) after (:2237,:2262)
+    bool phone_start;            // isPhoneStartBoundary: the previous segment carries another phone
+  };
+  // result_fst: the best path as a chain, one arc per segment, StdArc(phone+1, phone+1 if the phone
+  // starts here else 0, weight, next), final weight Zx (:1967-1971, :2204-2290, after Compose with
+  // the free-phone LM :2294).  Returns the number of frames.
+  template <class Fst>
+  int nStateDecode(Fst* result_fst, Fst* lm_fst, Fst* out_full_fst, double input_beam, unsigned min_hyps = 0, unsigned max_hyps = 0, float beam_inc = 0.05f) {
+    (void)out_full_fst; (void)min_hyps; (void)max_hyps; (void)beam_inc; (void)input_beam;
+    if (lm_fst != nullptr) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: decoding against an LM FST is not built (free phone loop only)");
+    if (if_output_full_fst) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: the full output lattice is not built (use CRF_LatticeBuilder)");
+    const int T = decode();
+    typedef typename Fst::Arc Arc;
+    int cur = result_fst->AddState();
+    result_fst->SetStart(cur);
+    if (segs.empty()) {  // "Could not reach end of utterance" (:2141-2147)
+      int fin = result_fst->AddState();
+      result_fst->AddArc(cur, Arc(0, 0, 8, fin));
+      result_fst->SetFinal(fin, (float)zx);
+      return T;
+    }
+    for (const Segment& g : segs) {
+      int nxt = result_fst->AddState();
+      result_fst->AddArc(cur, Arc((int)g.phone + 1, g.phone_start ? (int)g.phone + 1 : 0, g.weight, nxt));
+      cur = nxt;
+    }
+    result_fst->SetFinal(cur, (float)zx);
+    return T;
+  }
+  const std::vector<Segment>& bestSegments() const { return segs; }
+  double getZx() const { return zx; }
+  float getBestWeight() const { return best_weight; }  // total weight of the best hypothesis (:2133)
+
+ protected:
+  int decode();
+  CRF_FeatureStream* ftr_strm;
+  CRF_Model* crf;
+  bool if_output_full_fst = false;
+  std::vector<Segment> segs;
+  double zx = 0.0;
+  float best_weight = 0.0f;
+};
+
 // best path of CRFFstDecode (ShortestPath -> Project(OUTPUT) -> RmEpsilon -> TopSort -> olabel-1)
 std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* crf, float* cost);
 

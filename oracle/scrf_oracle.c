@@ -893,3 +893,111 @@ done:
   free(first); free(order); free(dist); free(parent);
   return ret;
 }
+
+/* ---- a19: free-phone-loop Viterbi decoder (see scrf_oracle.h) ------------------------------- */
+int orc_free_phone_decode(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                          uint32_t* seg_phone, uint32_t* seg_dur, float* seg_weight,
+                          int32_t* seg_phone_start, uint32_t* n_segs, float* best_weight) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  *n_segs = 0;
+  *best_weight = 99999.0f;
+  if (T == 0) return -1;
+  const float BIG = 99999.0f; /* the decoder's "infinity" */
+  /* hypothesis lists of the nodes: key (phone l, dur d) -> weight, back pointer, start flag */
+  const size_t HN = (size_t)T * L * D;
+  float* hw = (float*)malloc(sizeof(float) * HN);
+  int32_t* hp = (int32_t*)malloc(sizeof(int32_t) * HN);
+  int8_t* hs = (int8_t*)malloc(HN);
+  int8_t* hset = (int8_t*)calloc(HN, 1);
+  /* per node and phone after choose_nState_Best_Seg: weight, chosen dur */
+  float* bw = (float*)malloc(sizeof(float) * (size_t)T * L);
+  uint32_t* bd = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)T * L);
+#define H(t, l, d) (((size_t)(t) * L + (l)) * D + ((d)-1))
+  for (uint32_t t = 0; t < T; t++) {
+    /* expansions entering at node t, pushed to nodes t .. t+D-1 */
+    for (uint32_t l = 0; l < L; l++) {
+      for (int pass = 0; pass < 2; pass++) {            /* cross (all p != l, list order), then internal */
+        const uint32_t p0 = pass == 0 ? 0 : l, p1 = pass == 0 ? L : l + 1;
+        for (uint32_t p = p0; p < p1; p++) {
+          float w;
+          int32_t ptr;
+          int8_t start;
+          if (t == 0) {
+            if (pass == 1 || p != 0) continue;          /* one expansion from the LM start state */
+            w = 0.0f + 0.0f;
+            ptr = -1;
+            start = 1;
+          } else {
+            if (pass == 0 && p == l) continue;
+            if (bw[(size_t)(t - 1) * L + p] >= BIG) continue;
+            const float trans_wt = (float)(-1 * M[((size_t)t * L + p) * L + l]);
+            w = bw[(size_t)(t - 1) * L + p] + trans_wt;
+            ptr = (int32_t)p;
+            start = pass == 0;
+          }
+          for (uint32_t d = 1; d <= D && t + d - 1 < T; d++) {
+            const size_t k = H(t + d - 1, l, d);
+            if (!hset[k] || w < hw[k]) { hset[k] = 1; hw[k] = w; hp[k] = ptr; hs[k] = start; }
+          }
+        }
+      }
+    }
+    /* stateValueUpdate + choose_nState_Best_Seg at node t */
+    const uint64_t base = orc_seg_base(t, D);
+    for (uint32_t l = 0; l < L; l++) {
+      float best = BIG;
+      uint32_t arg = 0;
+      for (uint32_t d = D; d >= 1; d--) {               /* list order: entered at t-d+1, earliest first */
+        const size_t k = H(t, l, d);
+        if (d > t + 1 || !hset[k]) continue;
+        const float phnStateVal = (float)(-1 * S[(base + d - 1) * L + l]);
+        hw[k] = hw[k] + phnStateVal;
+        if (arg == 0 || hw[k] < best) { best = hw[k]; arg = d; }
+      }
+      bw[(size_t)t * L + l] = arg ? best : BIG;
+      bd[(size_t)t * L + l] = arg;
+    }
+  }
+  /* final: best end hypothesis in list order (:2122-2133) */
+  float min_weight = BIG;
+  int32_t bl = -1;
+  for (uint32_t l = 0; l < L; l++)
+    if (bd[(size_t)(T - 1) * L + l] && bw[(size_t)(T - 1) * L + l] < min_weight) { min_weight = bw[(size_t)(T - 1) * L + l]; bl = (int32_t)l; }
+  int rc = -1;
+  if (bl >= 0) {
+    uint32_t n = 0;
+    int64_t te = (int64_t)T - 1;
+    int32_t l = bl;
+    while (te >= 0) {
+      const uint32_t d = bd[(size_t)te * L + l];
+      const size_t k = H(te, l, d);
+      const int64_t ts = te + 1 - (int64_t)d;
+      const double sv = S[(orc_seg_base((uint32_t)te, D) + d - 1) * L + l];
+      seg_phone[n] = (uint32_t)l;
+      seg_dur[n] = d;
+      if (ts == 0) {
+        seg_weight[n] = (float)(-1 * sv);
+        seg_phone_start[n] = 1;
+      } else {
+        const int32_t p = hp[k];
+        seg_weight[n] = (float)(-1 * (M[((size_t)te * L + p) * L + l] + sv)); /* END node's matrix */
+        seg_phone_start[n] = hs[k];
+        l = p;
+      }
+      n++;
+      te = ts - 1;
+    }
+    for (uint32_t i = 0; i < n / 2; i++) { /* first to last */
+      uint32_t a = seg_phone[i]; seg_phone[i] = seg_phone[n - 1 - i]; seg_phone[n - 1 - i] = a;
+      a = seg_dur[i]; seg_dur[i] = seg_dur[n - 1 - i]; seg_dur[n - 1 - i] = a;
+      float w = seg_weight[i]; seg_weight[i] = seg_weight[n - 1 - i]; seg_weight[n - 1 - i] = w;
+      int32_t b = seg_phone_start[i]; seg_phone_start[i] = seg_phone_start[n - 1 - i]; seg_phone_start[n - 1 - i] = b;
+    }
+    *n_segs = n;
+    *best_weight = min_weight;
+    rc = 0;
+  }
+#undef H
+  free(hw); free(hp); free(hs); free(hset); free(bw); free(bd);
+  return rc;
+}

@@ -188,6 +188,25 @@ int64_t orc_best_path(const orc_arc* arcs, uint64_t n_arcs, uint32_t n_states, i
                       int32_t final_state, uint32_t* out_labels, uint64_t max_out,
                       float* best_cost);
 
+/* ---- a19: CRFDecode's Viterbi decoder, free phone loop ------------------------------------ */
+/* decoders/CRF_ViterbiDecoder_StdSeg_NoSegTransFtr.cpp with lm_fst == NULL (createFreePhoneLmFst
+ * :1270-1350), one state per phone, no pruning (input_beam <= 0), in the reference's own "push"
+ * form: at node t every surviving (phone) hypothesis of node t-1 is expanded across LM arcs to
+ * every OTHER phone (crossStateTransUpdate :435-500, weight old + float(-M[t][p][l]), marks a phone
+ * start) and then to itself (internalStateTransUpdate :246-300, old + float(-M[t][l][l])); each
+ * expansion enters the hypothesis lists of nodes t..t+D-1 under the key (phone, dur), the smaller
+ * weight winning with strict < (CRF_ViterbiNode::addNonEpsVtbState); stateValueUpdate (:116-160)
+ * adds float(-S[t][dur][l]); choose_nState_Best_Seg keeps per phone the best duration in list
+ * order (earliest-entered, i.e. longest, first; strict <).  Node 0 is entered from the LM start
+ * state with weight 0 (:442-445).  Backtrace :2204-2290: one arc per segment, weight
+ * float(-S) for the first and float(-(M + S)) taken from the segment's END node for the others
+ * (getFullTransValue :2262), olabel phone+1 where the phone starts, else 0.
+ * The decoder itself cannot be compiled here (OpenFST absent): parity UNPINNED, ties included.
+ * S [N_seg][L], M [T][L][L].  Outputs hold up to T segments.  Returns 0, or -1 if T == 0. */
+int orc_free_phone_decode(const orc_config* cfg, const double* S, const double* M, uint32_t T,
+                          uint32_t* seg_phone, uint32_t* seg_dur, float* seg_weight,
+                          int32_t* seg_phone_start, uint32_t* n_segs, float* best_weight);
+
 #ifdef __cplusplus
 }
 #endif

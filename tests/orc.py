@@ -264,6 +264,20 @@ def best_path(arcs, n_states, final_state, start=0):
     return out[:n].copy(), cost.value
 
 
+def free_phone_decode(cfg, S, M, T):
+    """CRFDecode's Viterbi decoder with its own free-phone-loop LM: segments (phone, dur, float
+    weight, phone_start) first to last, and the best hypothesis weight."""
+    ph = np.zeros(max(1, T), dtype=np.uint32); du = np.zeros(max(1, T), dtype=np.uint32)
+    w = np.zeros(max(1, T), dtype=np.float32); ps = np.zeros(max(1, T), dtype=np.int32)
+    n = C.c_uint32(); best = C.c_float()
+    rc = lib().orc_free_phone_decode(C.byref(cfg), _p(S), _p(M), C.c_uint32(T), _p(ph), _p(du), _p(w), _p(ps),
+                                     C.byref(n), C.byref(best))
+    if rc != 0:
+        return None, None
+    k = n.value
+    return list(zip(ph[:k].tolist(), du[:k].tolist(), w[:k].tolist(), ps[:k].tolist())), best.value
+
+
 def bench_fb(cfg, lam, frames, labels, frame_off, in_width, n_threads):
     """Threaded CPU forward-backward over packed utterances; returns (rc, grad, numer, zx, seconds)."""
     lam = np.ascontiguousarray(lam, dtype=np.float64)

@@ -186,3 +186,72 @@ def test_crftrain_and_fstdecode_on_pfile_and_ilab_inputs(tmp_path):
     r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + ["hardtarget_file=" + il, "out_weight_file=" + str(tmp_path / "y.out"), "train_sent_range=0:7"] + train,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "selects sentence" in r.stderr
+
+
+def test_crfdecode_free_phone_loop_mlf_and_best_path_chain(tmp_path):
+    """§8 a19 / f2: CRFDecode with the reference's own free-phone-loop LM (no crf_lm_bin): the
+    best-path chain (arc labels, float weights from the END node's scores, final weight Zx) and
+    the MLF against the oracle's push-form restatement of the decoder."""
+    rng = np.random.RandomState(3)
+    L, D, W = 5, 3, 2
+    f = str(tmp_path / "f.ascii"); l = str(tmp_path / "l.ascii")
+    utts = []
+    with open(f, "w") as ff, open(l, "w") as lf:
+        for u, T in enumerate([7, 12, 1, 9]):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T].astype(np.uint32)
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdtrans",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + l, "out_weight_file=" + wf,
+                        "crf_epochs=3", "crf_lr=0.5", "crf_bunch_size=2", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    olist, osym = str(tmp_path / "olist"), str(tmp_path / "osym.txt")
+    names = ["utt_a", "utt_b", "utt_c", "utt_d"]
+    open(olist, "w").write("\n".join(names) + "\n")
+    syms = ["<eps>"] + ["ph%d" % i for i in range(L)]
+    open(osym, "w").write("".join("%s %d\n" % (s, i) for i, s in enumerate(syms)))
+    latdir = tmp_path / "lat"; latdir.mkdir()
+    mlf = str(tmp_path / "out.mlf")
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym,
+                        "crf_output_mlffile=" + mlf, "crf_lat_outdir=" + str(latdir), "crf_mlf_output_frames=1", "crf_eval_range=0,1,3:^0",
+                        "crf_decode_beam=0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F, use_trans_ftrs=True, tfs=0, tfe=F - 1)
+    lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+    assert w.shape[0] == lay.lambda_len
+    want_mlf = ["#!MLF!#"]
+    for u in (0, 1, 3):
+        X = utts[u]; T = X.shape[0]
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(X, D), T)
+        segs, best = orc.free_phone_decode(cfg, S, M, T)
+        rc, _, _, _, zx = orc.seg_forward(cfg, S, M, T)
+        assert rc == 0
+        got = [x.split() for x in open(str(latdir / (names[u] + ".fst.txt"))).read().strip().split("\n")]
+        assert len(got) == len(segs) + 1
+        for i, (p, d, wt, ps) in enumerate(segs):
+            assert [int(v) for v in got[i][:4]] == [i, i + 1, p + 1, p + 1 if ps else 0]
+            assert np.float32(float(got[i][4])) == np.float32(wt)
+        assert int(got[-1][0]) == len(segs) and np.float32(float(got[-1][1])) == np.float32(zx)
+        want_mlf.append('"%s"' % names[u])
+        start = cur = 0
+        for (p, d, wt, ps) in segs:
+            cur += 1
+            if ps:
+                want_mlf.append("%d\t%d\t%s" % (start, cur, syms[p + 1]))
+                start = cur
+        want_mlf.append(".")
+    assert open(mlf).read().strip().split("\n") == want_mlf
+
+    # refusals: an LM FST, a model type the decoder does not cover, a missing olist
+    for extra, rc, msg in [(["crf_lm_bin=x.fst"], 1, "not built"), (["crf_olist="], 255, "crf_olist required")]:
+        args = model + ["weight_file=" + wf, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_olist=" + olist] + extra
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == rc and msg in r.stderr, (r.returncode, r.stderr)

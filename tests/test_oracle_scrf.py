@@ -273,3 +273,34 @@ def test_threaded_cpu_path_matches_serial_and_is_thread_count_invariant():
         rc, tot, nu, zu = orc.seg_build_gradient(cfg, lay, lam, X, labels[int(off[u]):int(off[u + 1])], T, grad=tot)
         assert nu == n1[u] and zu == z1[u]
     assert (tot == g1).all()
+
+
+@pytest.mark.parametrize("L,D,T,trans", [(2, 2, 1, True), (3, 3, 2, True), (3, 2, 6, True), (2, 4, 7, True), (4, 3, 6, False), (5, 1, 5, True)])
+def test_free_phone_decoder_against_enumeration_and_lattice_best_path(L, D, T, trans):
+    """a19: the push-form restatement of CRFDecode's decoder (free phone loop) finds the path the
+    brute-force enumeration and the pull-form shortest path over the CRFFstDecode lattice find;
+    arc weights come from the segment's END node; olabel marks where the phone changes."""
+    cfg, lay, lam, X, _ = _case(L, D, T, 2, trans, seed=70 + T + L, scale=1.0)
+    S, M = orc.seg_scores(cfg, lay, lam, X, T)
+    segs, best = orc.free_phone_decode(cfg, S, M, T)
+    bf = orc.brute_force(S, M, T, L, D)
+    best_sc, best_segs = bf["best"]
+    assert [(l, d) for (_, d, l) in best_segs] == [(p, d) for (p, d, _, _) in segs]
+    assert abs(-best - best_sc) < 1e-4 * max(1, abs(best_sc))
+    if D > 1:
+        arcs, ns, fin = orc.seg_lattice_arcs(cfg, S, M, T)
+    else:
+        arcs, ns, fin = orc.frame_lattice_arcs(cfg, S, M, T)
+    labels, cost = orc.best_path(arcs, ns, fin)
+    assert list(labels) == [p + L * (d - 1) for (p, d, _, _) in segs]
+    if D > 1:
+        assert np.float32(cost) == np.float32(best)  # same float additions in the same order
+    at, prev = 0, None
+    for i, (p, d, w, ps) in enumerate(segs):
+        te = at + d - 1
+        sv = S[orc.seg_base(te, D) + d - 1, p]
+        want = np.float32(-1 * sv) if i == 0 else np.float32(-1 * (M[te, prev * L + p] + sv))
+        assert np.float32(w) == want and ps == (1 if prev is None or prev != p else 0)
+        at, prev = at + d, p
+    assert at == T
+    assert orc.free_phone_decode(cfg, S, M, 0) == (None, None)

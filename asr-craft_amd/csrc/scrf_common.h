@@ -115,4 +115,21 @@ struct ScrfFusedArgs {
   uint32_t TB, W;
 };
 
+// Decode mode of the fused score kernel: instead of the fp64 scores it writes the float arc
+// weights float(-1 * score) the lattice / Viterbi consume, and lists every entry whose float
+// rounding the fp64-MFMA evaluation cannot guarantee to equal the reference-order evaluation's:
+// |fused - reference order| <= (gamma_n + gamma_m) * sum_f |x_f lambda_f| <= bound_scale * xm * w1[o]
+// =: B (constants in scrf_engine.cpp, run_scores), so an entry is safe when float(v - B) == float(v + B).
+// The listed entries (a few per 10^5) are recomputed
+// in reference order by k_decode_fixup; everything else is bit-identical by the bound.
+struct ScrfDecodeOut {
+  float* wneg;          // [rows][n_out]; nullptr = mode off
+  const double* w1;     // [n_out] sum_f |lambda_f| over the label's state block, bias weight included
+  const float* xm_f;    // [frames of the chunk] max(|x|, 1, |bias value|) over the frame's utterance
+  uint32_t* cnt;        // entries appended to `list` (may exceed cap = overflow)
+  uint64_t* list;       // (chunk-relative row << 16) | output
+  uint32_t cap;
+  double bound_scale;   // gamma_n + gamma_m, see above
+};
+
 #endif  // SCRF_COMMON_H_

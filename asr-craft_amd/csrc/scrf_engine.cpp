@@ -84,6 +84,12 @@ struct scrf_engine_s {
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
   bool lin_dp = true;
+  // decode from the fused score kernel's float arc weights + reference-order fix-ups (bit-identical
+  // to the EXACT path by a rounding-error bound, ScrfDecodeOut); SCRF_FAST_DECODE=0 turns it off
+  bool fast_decode = true;
+  double decode_bound_factor = 1.0;   // SCRF_DECODE_BOUND_SCALE (tests widen the screen with it)
+  double* d_w1 = nullptr;
+  uint64_t n_decode_fix = 0, n_decode_fallback = 0;   // entries recomputed / chunks sent back to the EXACT path
   std::string err;
   bool timing = false;
   hipEvent_t ev[SCRF_N_PHASES + 1][2];
@@ -107,6 +113,7 @@ struct scrf_batch_s {
   uint32_t* d_next_lab = nullptr;      // [sum T] label of the next labelled frame (gradbuilder :436-444)
   uint32_t* d_trans_counts = nullptr;  // [L*L] observed (c -> n) transitions of the whole batch
   uint32_t* d_frame_u = nullptr;       // [sum T] utterance of each frame
+  float* d_xm_f = nullptr;             // [sum T] max(|x|, 1, |state bias value|) over the frame's utterance (fused path)
   float* d_windows = nullptr;
   uint32_t n_streams = 0;
   scrf_stream_recipe recipe[SCRF_MAX_STREAMS];
@@ -208,6 +215,8 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knobs
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = atof(e);
   memset(h->ms, 0, sizeof(h->ms));
   memset(h->nlaunch, 0, sizeof(h->nlaunch));
 #define CRCHK(call)                                                                          \
@@ -228,6 +237,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_gsa, nb));
   CRCHK(hipMalloc((void**)&h->d_grad, nb));
   CRCHK(hipMalloc((void**)&h->d_m0, sizeof(double) * lay.L * lay.L));
+  CRCHK(hipMalloc((void**)&h->d_w1, sizeof(double) * lay.L));
   CRCHK(hipMalloc((void**)&h->d_e0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_msh0, sizeof(double)));
@@ -264,7 +274,7 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
+  hipFree(h->d_w1); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -418,7 +428,7 @@ extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   if (!b) return SCRF_OK;
   if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
   hipFree(b->d_T); hipFree(b->d_frame_off); hipFree(b->d_seg_off); hipFree(b->d_arc_off);
-  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u);
+  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u); hipFree(b->d_xm_f);
   for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
   hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
   hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]);
@@ -533,8 +543,21 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
       !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 && lay.nsfe == 8 * recipes[0].in_width + lay.D &&
       lay.nsfe == lay.F && fused_supported(lay, recipes[0].in_width)) {
     b->fused_ok = true;
+    {
+      std::vector<float> xm(NF);
+      const uint32_t W0 = recipes[0].in_width;
+      for (uint32_t u = 0; u < n; u++) {
+        float m = fmaxf(1.0f, (float)fabs(lay.sbv));
+        const float* x = utts[u].frames[0];
+        for (size_t i = 0; i < (size_t)utts[u].T * W0; i++) m = fmaxf(m, fabsf(x[i]));
+        m = nextafterf(m, INFINITY);   // |sbv| was rounded to float
+        std::fill(xm.begin() + b->frame_off[u], xm.begin() + b->frame_off[u + 1], m);
+      }
+      BCHK(upload(h, &b->d_xm_f, xm.data(), NF));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     // score tiles: the windows of TB whole frames; expected-count tiles: 64 consecutive windows
-    const uint32_t D = lay.D, TB = SCRF_FUSED_ROWS_SCORES / D;
+    const uint32_t D = lay.D, TB = fused_scores_tb(recipes[0].in_width, D);
     for (int k = 0; k < 2; k++) {
       std::vector<ScrfTileDesc> td;
       b->tile_off[k].assign(n + 1, 0);
@@ -626,6 +649,11 @@ struct ChunkBufs {
   double* slab_t = nullptr;
   uint16_t* bp_b = nullptr;
   uint16_t* bp_e = nullptr;
+  // fast decode: float arc weights of the fused score kernel + the entries to recompute
+  float* Wn = nullptr;       // [nseg][L]
+  uint64_t* fix_list = nullptr;
+  uint32_t* fix_cnt = nullptr;
+  uint32_t fix_cap = 0;
   uint32_t nch_s = 0, nch_t = 0;
   uint64_t rpc_s = 0, rpc_t = 0;
   // wavefront-per-utterance DP
@@ -656,7 +684,13 @@ struct ChunkBufs {
   uint64_t rpc_l = 0;
 };
 
-struct Need { bool fb, post, beta, vit; bool fused = false; };
+struct Need { bool fb, post, beta, vit; bool fused = false; bool vitfast = false; };
+
+// entries the decode screen may list per chunk before the chunk falls back to the EXACT path
+static uint32_t decode_fix_cap(uint64_t nseg, uint32_t L) {
+  const uint64_t c = nseg * L / 64 + 4096;
+  return (uint32_t)std::min<uint64_t>(c, 1u << 26);
+}
 
 // does the recursion run on the wavefront kernels?  L <= 64: always (log-domain kernels for the
 // hooks, linear-domain for training); 64 < L <= 256: the multi-wavefront linear-domain kernel,
@@ -681,7 +715,8 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
     tot += pad256(nfr * 5 * l.L * sizeof(double));                // P (scores) / Z (counts)
     if (nd.post) tot += pad256((size_t)512 * 5 * l.L * W0 * sizeof(double));
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
-  tot += pad256(nseg * l.L * sizeof(double));                       // S
+  if (nd.vitfast) tot += pad256(nseg * l.L * sizeof(float)) + pad256((size_t)decode_fix_cap(nseg, l.L) * 8) + 256;  // Wn, list, count
+  else tot += pad256(nseg * l.L * sizeof(double));                  // S
   if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
   if (nd.fb) {
     const bool wave = wave_path(h, nd.post);
@@ -757,7 +792,14 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
   cb->fused = nd.fused;
-  cb->S = a.take<double>(nseg * l.L);
+  if (nd.vitfast) {
+    cb->Wn = a.take<float>(nseg * l.L);
+    cb->fix_cap = decode_fix_cap(nseg, l.L);
+    cb->fix_list = a.take<uint64_t>(cb->fix_cap);
+    cb->fix_cnt = a.take<uint32_t>(64);
+  } else {
+    cb->S = a.take<double>(nseg * l.L);
+  }
   if (l.use_tf) {
     cb->M = a.take<double>(nfr * LL);
     cb->xrow_cur = a.take<uint64_t>(nfr);
@@ -859,7 +901,7 @@ static ScrfFusedArgs fused_args(scrf_handle h, scrf_batch b, uint32_t u0, int wh
   fa.row_base = b->seg_off[u0];
   fa.frame_base = b->frame_off[u0];
   fa.W = b->recipe[0].in_width;
-  fa.TB = SCRF_FUSED_ROWS_SCORES / h->lay.D;
+  fa.TB = fused_scores_tb(fa.W, h->lay.D);
   return fa;
 }
 
@@ -878,6 +920,25 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     else
       launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
                          spec_samples(W0), 5 * l.L, cb.P);
+    if (cb.Wn) {
+      // decode: float arc weights + the rounding screen
+      launch_state_l1(cb.st, h->d_lambda, l, h->d_w1);
+      HIPCHK(h, hipMemsetAsync(cb.fix_cnt, 0, sizeof(uint32_t), cb.st));
+      ScrfDecodeOut dz;
+      dz.wneg = cb.Wn; dz.w1 = h->d_w1; dz.xm_f = b->d_xm_f + b->frame_off[u0];
+      dz.cnt = cb.fix_cnt; dz.list = cb.fix_list; dz.cap = cb.fix_cap;
+      // |fused - reference order| <= (gamma_n + gamma_m) * sum_f |x_f lambda_f|, u = 2^-53: n = nsfe + 1
+      // separately rounded products added one by one; m <= 3 W + 8 roundings on any term's way through
+      // the fused evaluation (MFMA accumulation of the 3W dense columns or a W-term P dot, gather and
+      // epilogue adds).  1 % covers gamma's denominator and the rounding of the bound itself.
+      dz.bound_scale = h->decode_bound_factor * 1.01 * 0x1p-53 * (double)(l.nsfe + 1 + 3 * W0 + 8);
+      PhaseTimer tk(h, PH_K_SCORE, cb.st);
+      launch_scores_fused_decode(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], dz);
+      tk.stop(1);
+      tm.stop(3);
+      HIPCHK(h, hipGetLastError());
+      return SCRF_OK;
+    }
     // on the linear-domain path the epilogue already exponentiates the rows (L <= 48)
     cb.es_ready = cb.lin && l.L <= 48;
     {
@@ -1294,19 +1355,67 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   HIPCHK(h, hipMalloc((void**)&d_n, sizeof(uint32_t) * b->U));
   HIPCHK(h, hipMalloc((void**)&d_cost, sizeof(float) * b->U));
   Need nd{false, false, false, true};
+  // fast decode: the fused score kernel writes the float arc weights and lists the entries whose
+  // rounding it cannot guarantee; those are recomputed in reference order.  A chunk whose list
+  // overflows (pathological cancellation) goes through the EXACT path instead.
+  Need ndf = nd;
+  ndf.fused = ndf.vitfast = true;
+  const bool fast = h->fast_decode && b->fused_ok && h->fuse_windows && !frame_model && l.L <= 0xffff;
+  if (getenv("SCRF_DEBUG_DECODE")) fprintf(stderr, "decode: fast_decode %d fused_ok %d fuse_windows %d frame_model %d L %u mode %d\n", (int)h->fast_decode, (int)b->fused_ok, (int)h->fuse_windows, (int)frame_model, l.L, b->mode);
   int rc = SCRF_OK;
   for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK;) {
-    const uint32_t u1 = plan_chunk(h, b, u0, nd);
-    ChunkBufs cb;
-    rc = carve(h, b, u0, u1, nd, &cb);
-    if (rc != SCRF_OK) break;
-    rc = run_scores(h, b, u0, u1, cb);
-    if (rc != SCRF_OK) break;
-    PhaseTimer tm(h, PH_VIT);
-    launch_viterbi(h->stream, l, b->view(), u0, u1 - u0, cb.S, cb.M, cb.m_per_frame, frame_model, cb.bp_b, cb.bp_e,
-                   d_lab, d_n, d_cost);
-    tm.stop(1);
-    u0 = u1;
+    uint32_t u_end = u0;
+    if (fast) {
+      const uint32_t u1 = plan_chunk(h, b, u0, ndf);
+      ChunkBufs cb;
+      rc = carve(h, b, u0, u1, ndf, &cb);
+      if (rc != SCRF_OK) break;
+      if (!h->m0_valid) {  // transition scores carry only the bias: one L x L matrix for every frame
+        launch_scores_exact(cb.st, nullptr, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
+        launch_exp_m(cb.st, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
+        h->m0_valid = true;
+      }
+      rc = run_scores(h, b, u0, u1, cb);
+      if (rc != SCRF_OK) break;
+      uint32_t n_fix = 0;
+      HIPCHK(h, hipMemcpyAsync(&n_fix, cb.fix_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      h->n_decode_fix += n_fix;
+      if (getenv("SCRF_DEBUG_DECODE")) {
+        std::vector<double> w1(l.L); float xm0 = 0;
+        hipMemcpy(w1.data(), h->d_w1, sizeof(double) * l.L, hipMemcpyDeviceToHost);
+        hipMemcpy(&xm0, b->d_xm_f, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "decode chunk %u..%u n_fix %u cap %u w1[0] %g xm %g factor %g\n", u0, u1, n_fix, cb.fix_cap, w1[0], xm0, h->decode_bound_factor);
+      }
+      if (n_fix <= cb.fix_cap) {
+        PhaseTimer tm(h, PH_VIT);
+        launch_decode_fixup(h->stream, b->d_frames[0], b->recipe[0].in_width, b->view(), u0, u1, h->d_lambda, l, cb.fix_cnt,
+                            cb.fix_list, std::min(n_fix, cb.fix_cap), cb.Wn);
+        if (viterbi_fast_supported(l))
+          launch_viterbi_fast(h->stream, l, b->view(), u0, u1 - u0, cb.Wn, cb.M, cb.bp_b, cb.bp_e, d_lab, d_n, d_cost);
+        else
+          launch_viterbi(h->stream, l, b->view(), u0, u1 - u0, nullptr, cb.M, cb.m_per_frame, 0, cb.bp_b, cb.bp_e, d_lab, d_n,
+                         d_cost, cb.Wn);
+        tm.stop(2);
+        u0 = u1;
+        continue;
+      }
+      h->n_decode_fallback++;
+      u_end = u1;  // this range again, through the EXACT path
+    }
+    do {
+      const uint32_t u1 = std::min(fast ? u_end : b->U, plan_chunk(h, b, u0, nd));
+      ChunkBufs cb;
+      rc = carve(h, b, u0, u1, nd, &cb);
+      if (rc != SCRF_OK) break;
+      rc = run_scores(h, b, u0, u1, cb);
+      if (rc != SCRF_OK) break;
+      PhaseTimer tm(h, PH_VIT);
+      launch_viterbi(h->stream, l, b->view(), u0, u1 - u0, cb.S, cb.M, cb.m_per_frame, frame_model, cb.bp_b, cb.bp_e,
+                     d_lab, d_n, d_cost);
+      tm.stop(1);
+      u0 = u1;
+    } while (fast && u0 < u_end && rc == SCRF_OK);
   }
   std::vector<uint32_t> lab, cnt(b->U);
   if (rc == SCRF_OK) {
@@ -1332,6 +1441,19 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
     pos += cnt[u];
   }
   lab_off[b->U] = pos;
+  return SCRF_OK;
+}
+
+extern "C" int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused) {
+  if (!h || !b || !fused) return SCRF_ERR_INVALID;
+  *fused = b->fused_ok && h->fuse_windows ? 1 : 0;
+  return SCRF_OK;
+}
+
+extern "C" int scrf_decode_stats(scrf_handle h, uint64_t* n_recomputed, uint64_t* n_fallback_chunks) {
+  if (!h) return SCRF_ERR_INVALID;
+  if (n_recomputed) *n_recomputed = h->n_decode_fix;
+  if (n_fallback_chunks) *n_fallback_chunks = h->n_decode_fallback;
   return SCRF_OK;
 }
 

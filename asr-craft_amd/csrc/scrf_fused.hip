@@ -136,13 +136,15 @@ __device__ __forceinline__ void fu_scan_ext(const float (&v)[DMAX], float* o, ui
 // smax != nullptr (n_out <= 48 only): the epilogue writes exp(S - smax[row]) instead of S, with
 // smax[row] the float-rounded row maximum, and the labelled windows' scores to s_true -- the inputs
 // of the linear-domain recursion (scrf_dplin.hip), saving a read-modify-write pass over S.
-template <int DMAX, int F32>
+// DEC (decode, F32 == 0 only): write float(-1 * score) and the list of entries to recompute
+// (ScrfDecodeOut, scrf_common.h) instead of S.
+template <int DMAX, int F32, int DEC>
 __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, ScrfLayout lay,
                                                            const double* __restrict__ lambda,
                                                            const double* __restrict__ P, uint32_t n_out,
                                                            double* __restrict__ S, double* __restrict__ smax,
                                                            double* __restrict__ s_true,
-                                                           const uint32_t* __restrict__ labels) {
+                                                           const uint32_t* __restrict__ labels, ScrfDecodeOut dz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const uint32_t W = fa.W, D = lay.D;
   const uint32_t nfmax = fa.TB + D - 1;
@@ -358,7 +360,23 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
         sv[n] = ((v + lin) + dt[n]) + dbias[n];
       }
-      if (smax) {
+      if (DEC) {
+        const double xm = (double)dz.xm_f[ft.fr0 + (ft.t0 - ft.f0)] * dz.bound_scale;   // a tile lies in one utterance
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+          const uint32_t o = o0 + n * 16 + li;
+          if (valid && o < n_out) {
+            const double v = -1 * sv[n];
+            const float w = (float)v;
+            const double B = xm * dz.w1[o];
+            if ((float)(v - B) != w || (float)(v + B) != w) {
+              const uint32_t at = atomicAdd(dz.cnt, 1u);
+              if (at < dz.cap) dz.list[at] = ((ft.row0 + rl) << 16) | o;
+            }
+            dz.wneg[(ft.row0 + rl) * n_out + o] = w;
+          }
+        }
+      } else if (smax) {
         // row maximum over the 16 lanes that share this row (and the 3 output tiles), as a float,
         // on the DPP path: quad permutes, then the half-row and row mirrors
         float mx = -INFINITY;
@@ -390,24 +408,32 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     }
 }
 
-static size_t fused_scores_smem(uint32_t W, uint32_t D) {
-  const uint32_t TB = FU_ROWS / D, nfmax = TB + D - 1;
+static size_t fused_scores_smem_tb(uint32_t W, uint32_t D, uint32_t TB) {
+  const uint32_t nfmax = TB + D - 1;
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
   const size_t pb = sizeof(double) * (nfmax * 240 + (D + 1) * 48);
   if (pb > opn) opn = pb;
   opn = (opn + 15) & ~(size_t)15;
   return opn + sizeof(uint32_t) * TB + sizeof(uint16_t) * 2 * FU_ROWS + FU_ROWS + D * 5 + 64;
 }
+// frames per score tile: as many whole frames as give <= 256 rows and keep the workgroup's LDS
+// (the staged P rows grow with TB + D - 1) within 80 KB, i.e. two workgroups per CU; 0 = no fit
+uint32_t fused_scores_tb(uint32_t W, uint32_t D) {
+  for (uint32_t TB = FU_ROWS / D; TB >= 1; TB--)
+    if (fused_scores_smem_tb(W, D, TB) <= 80 * 1024) return TB;
+  return 0;
+}
+static size_t fused_scores_smem(uint32_t W, uint32_t D) { return fused_scores_smem_tb(W, D, fused_scores_tb(W, D)); }
 
-template <int DMAX, int F32>
+template <int DMAX, int F32, int DEC>
 static void launch_scores_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                                   const double* P, uint64_t n_tiles, double* S, double* smax, double* s_true,
-                                  const uint32_t* labels) {
+                                  const uint32_t* labels, const ScrfDecodeOut& dz) {
   const size_t sm = fused_scores_smem(fa.W, lay.D);
   dim3 grid((uint32_t)n_tiles, (lay.L + 47) / 48);
-  hipFuncSetAttribute((const void*)k_scores_fused<DMAX, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((k_scores_fused<DMAX, F32>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S, smax, s_true,
-                     labels);
+  hipFuncSetAttribute((const void*)k_scores_fused<DMAX, F32, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL((k_scores_fused<DMAX, F32, DEC>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S, smax,
+                     s_true, labels, dz);
 }
 
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
@@ -415,15 +441,25 @@ void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayo
                          const uint32_t* labels) {
   if (n_tiles == 0) return;
   if (lay.L > 48) smax = nullptr;   // a row spans several workgroups: the caller runs k_exp_rows instead
+  ScrfDecodeOut off;
+  memset(&off, 0, sizeof(off));
 #define FS_GO(N)                                                                        \
   do {                                                                                  \
-    if (f32) launch_scores_fused_t<N, 1>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels);   \
-    else launch_scores_fused_t<N, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels);       \
+    if (f32) launch_scores_fused_t<N, 1, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off);   \
+    else launch_scores_fused_t<N, 0, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off);       \
   } while (0)
   if (lay.D <= 12) FS_GO(12);
   else if (lay.D <= 25) FS_GO(25);
   else FS_GO(40);
 #undef FS_GO
+}
+
+void launch_scores_fused_decode(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
+                                const double* P, uint64_t n_tiles, const ScrfDecodeOut& dz) {
+  if (n_tiles == 0) return;
+  if (lay.D <= 12) launch_scores_fused_t<12, 0, 1>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
+  else if (lay.D <= 25) launch_scores_fused_t<25, 0, 1>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
+  else launch_scores_fused_t<40, 0, 1>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1059,7 +1095,7 @@ int fused_supported(const ScrfLayout& lay, uint32_t W) {
   fused_expf_xs(lay, W, &n_ct);
   if (lay.D < 2 || lay.D > 40 || W < 1 || n_ct > 13) return 0;
   if (fused_expf_smem(lay, W) > 80 * 1024) return 0;
-  return fused_scores_smem(W, lay.D) <= 80 * 1024;
+  return fused_scores_tb(W, lay.D) >= 1;
 }
 
 uint32_t fused_expf_blocks(uint64_t n_tiles) {

@@ -26,7 +26,8 @@ void launch_reduce_xiacc(hipStream_t st, const double* xi_acc, uint32_t n_utts, 
 void launch_batch_sums(hipStream_t st, const double* numer, const double* zx, uint32_t n, double* sums3);
 void launch_viterbi(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                     const double* S, const double* M, int m_per_frame, int frame_model, uint16_t* bp_b,
-                    uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost);
+                    uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost,
+                    const float* Wn = nullptr);   // Wn: float(-1 * score) per (segment, label), replaces S
 void launch_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t T, int frame_model, const double* S,
                  const double* M, int m_per_frame, float final_w, scrf_arc* arcs);
 void launch_sgd_step(hipStream_t st, double* lambda, double* lambda_acc, double* gsa, double* grad, uint32_t n,
@@ -84,12 +85,26 @@ void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const doub
 
 // scrf_fused.hip: state contractions with the window synthesis fused in (X never materialised)
 #define SCRF_FUSED_ROWS_SCORES 256
+uint32_t fused_scores_tb(uint32_t W, uint32_t D);   // whole frames per score tile (0: shape not supported)
 #define SCRF_FUSED_ROWS_EXPF 64
 int fused_supported(const ScrfLayout& lay, uint32_t W);
 uint32_t fused_expf_blocks(uint64_t n_tiles);
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                          const double* P, uint64_t n_tiles, double* S, int f32, double* smax = nullptr,
                          double* s_true = nullptr, const uint32_t* labels = nullptr);
+// k_viterbi on float arc weights with one wavefront per utterance (fast decode; L <= 64, constant M)
+int viterbi_fast_supported(const ScrfLayout& lay);
+void launch_viterbi_fast(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const float* Wn,
+                         const double* M, uint16_t* bp_b, uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost);
+// decode mode: float arc weights + the list of entries to recompute (ScrfDecodeOut)
+void launch_scores_fused_decode(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
+                                const double* P, uint64_t n_tiles, const ScrfDecodeOut& dz);
+// w1[o] = sum of |lambda| over label o's state block (features + bias weight)
+void launch_state_l1(hipStream_t st, const double* lambda, const ScrfLayout& lay, double* w1);
+// reference-order recomputation of the listed (row, output) arc weights from the raw frames
+void launch_decode_fixup(hipStream_t st, const float* frames, uint32_t W, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                         const double* lambda, const ScrfLayout& lay, const uint32_t* cnt, const uint64_t* list,
+                         uint32_t cap, float* wneg);
 void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                   const double* R, double* Z);
 int pframe_supported(uint32_t W);

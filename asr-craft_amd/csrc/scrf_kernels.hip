@@ -572,7 +572,7 @@ void launch_batch_sums(hipStream_t st, const double* numer, const double* zx, ui
 // ------------------------------------------------------------------------------------------
 __global__ void k_viterbi(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
                           const double* __restrict__ M, int m_per_frame, int frame_model,
-                          uint16_t* __restrict__ bp_b, uint16_t* __restrict__ bp_e,
+                          const float* __restrict__ Wn, uint16_t* __restrict__ bp_b, uint16_t* __restrict__ bp_e,
                           uint32_t* __restrict__ out_labels, uint32_t* __restrict__ out_n,
                           float* __restrict__ out_cost) {
   extern __shared__ float vsm[];
@@ -583,6 +583,7 @@ __global__ void k_viterbi(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const d
   const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
   const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
   const double* Su = S + s_base * L;
+  const float* Wu = Wn ? Wn + s_base * L : nullptr;   // float(-1 * score) already formed (segment model)
   const size_t LL = (size_t)L * L;
   float* de_prev = vsm;               // [L]
   float* de_cur = de_prev + L;        // [L]
@@ -632,13 +633,13 @@ __global__ void k_viterbi(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const d
         float best = INFINITY;
         int arg = 0;
         if (t < D) {  // from the start state: duration t+1
-          float cst = 0.0f + (float)(-1.0 * Su[(base + t) * L + l]);
+          float cst = 0.0f + (Wu ? Wu[(base + t) * L + l] : (float)(-1.0 * Su[(base + t) * L + l]));
           if (cst < best) { best = cst; arg = t + 1; }
         }
         const int tp0 = (t - D + 1 > 1) ? t - D + 1 : 1;
         for (int tp = tp0; tp <= t; tp++) {
           const int d = t - tp + 1;
-          float cst = db[(tp % D) * L + l] + (float)(-1.0 * Su[(base + d - 1) * L + l]);
+          float cst = db[(tp % D) * L + l] + (Wu ? Wu[(base + d - 1) * L + l] : (float)(-1.0 * Su[(base + d - 1) * L + l]));
           if (cst < best) { best = cst; arg = d; }
         }
         de_cur[l] = best;
@@ -691,14 +692,246 @@ __global__ void k_viterbi(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const d
 
 void launch_viterbi(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                     const double* S, const double* M, int m_per_frame, int frame_model, uint16_t* bp_b,
-                    uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost) {
+                    uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost, const float* Wn) {
   if (n_utts == 0) return;
   int NT = ((int)lay.L + 63) / 64 * 64;
   if (NT > 1024) NT = 1024;
   size_t sm = sizeof(float) * ((size_t)2 * lay.L + (size_t)lay.D * lay.L);
   hipFuncSetAttribute((const void*)k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(k_viterbi, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, S, M, m_per_frame, frame_model,
-                     bp_b, bp_e, out_labels, out_n, out_cost);
+                     frame_model ? nullptr : Wn, bp_b, bp_e, out_labels, out_n, out_cost);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_viterbi_fast: k_viterbi for the fast decode path -- float arc weights already formed, one
+// time-invariant transition matrix, L <= 64: one WAVEFRONT per utterance (lane = label), the
+// float(-M) matrix in LDS for the whole workgroup, the frame's D weights fetched into registers
+// before the boundary step so that their latency hides under it.  Same additions in the same order
+// and the same strict-improvement scans as k_viterbi (bit-identical labels and costs).
+// ------------------------------------------------------------------------------------------
+#define VF_WAVES 4
+template <int DMAX>
+__global__ __launch_bounds__(64 * VF_WAVES) void k_viterbi_fast(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                                                                const float* __restrict__ Wn, const double* __restrict__ M,
+                                                                uint16_t* __restrict__ bp_b, uint16_t* __restrict__ bp_e,
+                                                                uint32_t* __restrict__ out_labels, uint32_t* __restrict__ out_n,
+                                                                float* __restrict__ out_cost) {
+  extern __shared__ float vsm[];
+  const int L = lay.L, D = lay.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* Mf = vsm;                                         // [L][L] float(-1 * M[p][l])
+  float* de_prev = Mf + L * L + wave * (L + D * L);        // [L]
+  float* db = de_prev + L;                                 // [D][L]
+  for (int i = threadIdx.x; i < L * L; i += 64 * VF_WAVES) Mf[i] = (float)(-1.0 * M[i]);
+  __syncthreads();
+  const uint32_t ui = blockIdx.x * VF_WAVES + wave;
+  if (ui >= n_utts) return;
+  const uint32_t u = u0 + ui;
+  const int T = (int)bv.T[u];
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const float* Wu = Wn + s_base * L;
+  uint16_t* bpb = bp_b + f_base * L;
+  uint16_t* bpe = bp_e + f_base * L;
+  uint32_t* outl = out_labels + bv.frame_off[u];
+  if (T == 0) {
+    if (lane == 0) { out_n[u] = 0; out_cost[u] = INFINITY; }
+    return;
+  }
+  const int l = lane < L ? lane : L - 1;   // idle lanes shadow the last label, their stores are masked
+  const bool act = lane < L;
+  for (int t = 0; t < T; t++) {
+    const uint64_t base = scrf_seg_base(t, D);
+    const int nd = t + 1 < D ? t + 1 : D;
+    float wv[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) wv[i] = i < nd ? Wu[(base + i) * L + l] : 0.0f;
+    if (t >= 1) {
+      float best = INFINITY;
+      int arg = 0;
+      for (int p = 0; p < L; p++) {
+        const float cst = de_prev[p] + Mf[p * L + l];
+        if (cst < best) { best = cst; arg = p; }
+      }
+      if (act) { db[(t % D) * L + l] = best; bpb[(size_t)t * L + l] = (uint16_t)arg; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float best = INFINITY;
+    int arg = 0;
+    if (t < D) {  // from the start state: duration t+1
+#pragma unroll
+      for (int i = 0; i < DMAX; i++)
+        if (i == t) { const float cst = 0.0f + wv[i]; if (cst < best) { best = cst; arg = t + 1; } }
+    }
+    // tp ascending = d descending
+#pragma unroll
+    for (int i = DMAX - 1; i >= 0; i--) {
+      const int d = i + 1, tp = t - i;
+      if (d <= nd && tp >= 1) {
+        const float cst = db[(tp % D) * L + l] + wv[i];
+        if (cst < best) { best = cst; arg = d; }
+      }
+    }
+    if (act) { de_prev[l] = best; bpe[(size_t)t * L + l] = (uint16_t)arg; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __threadfence_block();
+  if (lane == 0) {
+    float best = INFINITY;
+    int bl = -1;
+    for (int k = 0; k < L; k++) {
+      const float cst = de_prev[k] + -0.0f;
+      if (cst < best) { best = cst; bl = k; }
+    }
+    uint32_t n = 0;
+    if (bl >= 0) {
+      int t = T - 1, k = bl;
+      while (true) {
+        const int d = bpe[(size_t)t * L + k];
+        outl[n++] = (uint32_t)(k + L * (d - 1));
+        const int ts = t - d + 1;
+        if (ts == 0) break;
+        k = bpb[(size_t)ts * L + k];
+        t = ts - 1;
+      }
+      for (uint32_t i = 0; i < n / 2; i++) {
+        const uint32_t tmp = outl[i];
+        outl[i] = outl[n - 1 - i];
+        outl[n - 1 - i] = tmp;
+      }
+      best = best + 0.0f;  // Times(distance, Final = One)
+    }
+    out_n[u] = n;
+    out_cost[u] = best;
+  }
+}
+
+int viterbi_fast_supported(const ScrfLayout& lay) {
+  return lay.L <= 64 && lay.D >= 2 && lay.D <= 40 && !lay.use_tf &&
+         sizeof(float) * ((size_t)lay.L * lay.L + VF_WAVES * ((size_t)lay.L + (size_t)lay.D * lay.L)) <= 64 * 1024;
+}
+void launch_viterbi_fast(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const float* Wn,
+                         const double* M, uint16_t* bp_b, uint16_t* bp_e, uint32_t* out_labels, uint32_t* out_n, float* out_cost) {
+  if (n_utts == 0) return;
+  const size_t sm = sizeof(float) * ((size_t)lay.L * lay.L + VF_WAVES * ((size_t)lay.L + (size_t)lay.D * lay.L));
+  const dim3 grid((n_utts + VF_WAVES - 1) / VF_WAVES), block(64 * VF_WAVES);
+#define VF_GO(N)                                                                                                         \
+  do {                                                                                                                   \
+    hipFuncSetAttribute((const void*)k_viterbi_fast<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);            \
+    hipLaunchKernelGGL(k_viterbi_fast<N>, grid, block, sm, st, lay, bv, u0, n_utts, Wn, M, bp_b, bp_e, out_labels, out_n, \
+                       out_cost);                                                                                        \
+  } while (0)
+  if (lay.D <= 12) VF_GO(12);
+  else if (lay.D <= 25) VF_GO(25);
+  else VF_GO(40);
+#undef VF_GO
+}
+
+// ------------------------------------------------------------------------------------------
+// fast decode support (ScrfDecodeOut, scrf_common.h)
+// ------------------------------------------------------------------------------------------
+// w1[o] = sum of |lambda| over label o's state block; one wavefront per label
+__global__ void k_state_l1(const double* __restrict__ lambda, ScrfLayout lay, double* __restrict__ w1) {
+  const uint32_t o = blockIdx.x;
+  const double* wp = lambda + lay.state_idx(o);
+  const uint32_t n = lay.nsfe + (lay.use_sb ? 1 : 0);
+  double a = 0.0;
+  for (uint32_t f = threadIdx.x; f < n; f += 64) a += fabs(wp[f]);
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  if (threadIdx.x == 0) w1[o] = a * (1.0 + 1e-12);   // the summation error of the norm itself
+}
+void launch_state_l1(hipStream_t st, const double* lambda, const ScrfLayout& lay, double* w1) {
+  hipLaunchKernelGGL(k_state_l1, dim3(lay.L), dim3(64), 0, st, lambda, lay, w1);
+}
+
+// One wavefront per listed (row, output).  The window vector of the row is rebuilt from the raw
+// frames with k_windows' arithmetic -- lanes over the raw column: float running sum from the LAST
+// frame backwards / length, running max / min, sampled frames; one-hot duration -- into LDS in
+// feature order.  The contraction keeps the reference's order with unfused multiply and add
+// (k_scores_exact): the products of 64 consecutive features are formed in parallel (each is
+// rounded on its own, so that is the same number), then added one after the other in feature
+// order through readlane; bias last.  The arc weight is float(-1 * score).
+#define FX_WAVES 4
+#define FX_MAXF 1024
+__global__ __launch_bounds__(64 * FX_WAVES) void k_decode_fixup(const float* __restrict__ frames, uint32_t W, ScrfBatchView bv,
+                                                                uint32_t u0, uint32_t u1, const double* __restrict__ lambda,
+                                                                ScrfLayout lay, const uint32_t* __restrict__ cnt,
+                                                                const uint64_t* __restrict__ list, uint32_t cap,
+                                                                float* __restrict__ wneg) {
+  __shared__ float xs_all[FX_WAVES][FX_MAXF];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xs = xs_all[wave];
+  const uint32_t n = min(*cnt, cap), D = lay.D, L = lay.L, F = 8 * W + D;
+  const uint64_t tri = (uint64_t)D * (D + 1) / 2;
+  for (uint32_t i = blockIdx.x * FX_WAVES + wave; i < n; i += gridDim.x * FX_WAVES) {
+    const uint64_t row = list[i] >> 16;
+    const uint32_t o = (uint32_t)(list[i] & 0xffff);
+    const uint64_t arow = row + bv.seg_off[u0];
+    const uint32_t u = find_utt(bv.seg_off, u0, u1, arow);
+    const uint64_t r = arow - bv.seg_off[u];
+    uint32_t t, d;
+    if (r < tri) {
+      t = 0;
+      while ((uint64_t)(t + 1) * (t + 2) / 2 <= r) t++;
+      d = (uint32_t)(r - (uint64_t)t * (t + 1) / 2) + 1;
+    } else {
+      t = D + (uint32_t)((r - tri) / D);
+      d = (uint32_t)((r - tri) % D) + 1;
+    }
+    const float* last = frames + (bv.frame_off[u] + t) * (uint64_t)W;
+    const float* first = last - (uint64_t)(d - 1) * W;
+    const float ot = (float)((double)d * 0.1);
+    for (uint32_t c = lane; c < W; c += 64) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const float prod = ot * (float)(2 * k + 1);
+        const uint32_t step = (uint32_t)ceilf(prod) - 1u;
+        xs[k * W + c] = first[(uint64_t)step * W + c];
+      }
+      float acc = 0.0f, mx = last[c], mn = last[c];
+      for (uint32_t w = 0; w < d; w++) {
+        const float v = (last - (uint64_t)w * W)[c];
+        acc = __fadd_rn(acc, v);
+        if (v > mx) mx = v;
+        if (v < mn) mn = v;
+      }
+      xs[5 * W + c] = __fdiv_rn(acc, (float)d);
+      xs[6 * W + c] = mx;
+      xs[7 * W + c] = mn;
+    }
+    for (uint32_t k = lane; k < D; k += 64) xs[8 * W + k] = (k + 1 == d) ? 1.0f : 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    const double* wp = lambda + lay.state_idx(o);
+    double s = 0.0;
+    for (uint32_t f0 = 0; f0 < F; f0 += 64) {
+      const uint32_t f = f0 + lane;
+      const double p = f < F ? __dmul_rn((double)xs[f], wp[f]) : 0.0;
+      const uint32_t m = min(64u, F - f0);
+      if (m == 64) {
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+          const double pj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), j), __builtin_amdgcn_readlane(__double2loint(p), j));
+          s = __dadd_rn(s, pj);
+        }
+      } else {
+        for (uint32_t j = 0; j < m; j++) {
+          const double pj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), j), __builtin_amdgcn_readlane(__double2loint(p), j));
+          s = __dadd_rn(s, pj);
+        }
+      }
+    }
+    if (lay.use_sb) s = __dadd_rn(s, __dmul_rn(wp[lay.nsfe], lay.sbv));
+    if (lane == 0) wneg[row * L + o] = (float)(-1 * s);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+void launch_decode_fixup(hipStream_t st, const float* frames, uint32_t W, ScrfBatchView bv, uint32_t u0, uint32_t u1,
+                         const double* lambda, const ScrfLayout& lay, const uint32_t* cnt, const uint64_t* list,
+                         uint32_t cap, float* wneg) {
+  if (cap == 0) return;
+  const uint32_t blocks = std::min<uint32_t>((cap + FX_WAVES - 1) / FX_WAVES, 4096);
+  hipLaunchKernelGGL(k_decode_fixup, dim3(blocks), dim3(64 * FX_WAVES), 0, st, frames, W, bv, u0, u1, lambda, lay, cnt,
+                     list, cap, wneg);
 }
 
 // ------------------------------------------------------------------------------------------

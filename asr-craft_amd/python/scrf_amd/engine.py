@@ -279,6 +279,17 @@ class Engine:
         self._chk(self.lib.scrf_viterbi_batch(self.h, batch.handle, _p(labs), C.c_uint64(cap), _p(off), _p(cost)))
         return [labs[int(off[u]):int(off[u + 1])].copy() for u in range(batch.n)], cost
 
+    def batch_is_fused(self, batch):
+        f = C.c_int()
+        self._chk(self.lib.scrf_batch_is_fused(self.h, batch.handle, C.byref(f)))
+        return bool(f.value)
+
+    def decode_stats(self):
+        """(arc weights recomputed in reference order, chunks sent back to the EXACT path) since create."""
+        a = C.c_uint64(); b = C.c_uint64()
+        self._chk(self.lib.scrf_decode_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # ---- reduce + optimizer
     def allreduce_grad(self, active=True):
         s = np.zeros(4)

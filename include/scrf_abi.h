@@ -167,6 +167,9 @@ int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n, uint32_t 
 int scrf_batch_destroy(scrf_handle h, scrf_batch b);
 int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, uint64_t* n_frames,
                     uint64_t* n_segs, uint64_t* n_arcs);
+/* 1 if the FAST / decode kernels synthesise this batch's windows on the fly (one segment-recipe
+ * stream, no context, no transition features, shape within the kernels' LDS budget), else 0 */
+int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused);
 
 /* ---- hot path: forward-backward + gradient ------------------------------------------------ */
 /* replaces: CRF_NewGradBuilder_StdSeg_NoDur_NoTrans::buildGradient (trainers/gradbuilders/
@@ -208,6 +211,12 @@ int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int norm, scrf_ar
  * float path weight.  max_labels = capacity of seg_labels (sum of T is always enough). */
 int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
                        uint64_t* lab_off, float* best_cost);
+/* scrf_viterbi_batch on a batch of raw frames takes its float arc weights from the fused fp64-MFMA
+ * score kernel and recomputes, in the reference's operation order, every weight whose float
+ * rounding a rounding-error bound cannot guarantee -- so labels and costs equal
+ * the EXACT path's bit for bit.  Counters since scrf_create: weights recomputed, chunks whose
+ * list overflowed and went through the EXACT path.  SCRF_FAST_DECODE=0 disables the fast path. */
+int scrf_decode_stats(scrf_handle h, uint64_t* n_recomputed, uint64_t* n_fallback_chunks);
 
 /* ---- minibatch reduce + optimizer ------------------------------------------------------------ */
 /* replaces the join/sum/average of CRF_Minibatch_GradAccumulator::accumulateGradient

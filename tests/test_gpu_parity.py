@@ -151,6 +151,7 @@ def test_fused_window_synthesis_equals_materialised_windows(si, monkeypatch):
             monkeypatch.setenv("SCRF_FUSE", fuse)
             c = Case(seed=300 + si, precision=prec, **FUSED_SHAPES[si])
             eng = c.engine(); b = c.batch(eng)
+            assert eng.batch_is_fused(b) == (fuse == "1")
             numer, zx = eng.fb_batch(b)
             res.append((numer, zx, eng.get_grad()))
             b.close(); eng.close()
@@ -217,6 +218,49 @@ def test_viterbi_matches_shortest_path_on_reference_lattice(case):
         ol, oc = orc.best_path(oa, ons, ofin)
         assert list(labs[u]) == list(ol)
         assert np.float32(cost[u]).tobytes() == np.float32(oc).tobytes()
+
+
+@pytest.mark.parametrize("si", range(len(FUSED_SHAPES)))
+def test_fast_decode_is_bit_identical_to_exact_decode(si, monkeypatch):
+    """scrf_viterbi_batch on raw frames takes float arc weights from the fused fp64-MFMA score kernel
+    and recomputes in reference order every weight whose float rounding the error bound cannot
+    guarantee; labels and float path costs must equal the EXACT path's (SCRF_FAST_DECODE=0) bit for
+    bit -- also when the screen is widened so that many entries take the fix-up kernel
+    (SCRF_DECODE_BOUND_SCALE=30), when the list overflows and the chunk falls back to the EXACT
+    path (1e7), and when the batch is cut into several chunks."""
+    kw = dict(seed=500 + si, lam_scale=0.3, **FUSED_SHAPES[si])
+    res = {}
+    for tag, env, scratch in [("exact", {"SCRF_FAST_DECODE": "0"}, 0), ("fast", {}, 0), ("fix", {"SCRF_DECODE_BOUND_SCALE": "30"}, 0),
+                              ("overflow", {"SCRF_DECODE_BOUND_SCALE": "1e7"}, 0), ("chunks", {"SCRF_DECODE_BOUND_SCALE": "30"}, 1 << 16)]:
+        for k in ("SCRF_FAST_DECODE", "SCRF_DECODE_BOUND_SCALE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = Case(scratch_bytes=scratch, **kw)
+        eng = c.engine(); b = c.batch(eng, with_labels=False)
+        assert eng.batch_is_fused(b)
+        labs, cost = eng.viterbi_batch(b)
+        res[tag] = (labs, cost, eng.decode_stats())
+        b.close(); eng.close()
+    el, ec, est = res["exact"]
+    assert est == (0, 0)
+    n_entries = sum(orc.num_segs(T, c.D) for T in c.Ts) * c.L
+    for tag in ("fast", "fix", "overflow", "chunks"):
+        gl, gc, st = res[tag]
+        assert all(list(a) == list(b_) for a, b_ in zip(gl, el)), tag
+        assert gc.tobytes() == ec.tobytes(), tag
+    assert res["fast"][2][1] == 0 and res["fast"][2][0] <= max(8, n_entries // 1000)
+    assert res["fix"][2][1] == 0 and res["fix"][2][0] >= res["fast"][2][0]
+    if n_entries > 8192:
+        assert res["fix"][2][0] > max(res["fast"][2][0], n_entries // 100000)   # the widened screen really feeds the fix-up kernel
+    if n_entries > 8192:
+        assert res["overflow"][2][1] >= 1
+    # and the oracle's shortest path on the oracle's lattice
+    u = len(c.Ts) - 1; T = c.Ts[u]
+    So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+    oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+    ol, oc = orc.best_path(oa, ons, ofin)
+    assert list(res["fast"][0][u]) == list(ol) and np.float32(res["fast"][1][u]).tobytes() == np.float32(oc).tobytes()
 
 
 def test_viterbi_tie_rule_on_zero_weights():

@@ -29,7 +29,10 @@ for u in range(8):
     arcs, ns, fin = eng.lattice_arcs(b, u)
     na += len(arcs)
 dta = (time.perf_counter() - t1) / 8
-print(json.dumps({"metric": "utterances/sec SCRF Viterbi decode (TIMIT-shape)", "value": round(U / dt, 1), "unit": "utterances/s",
+stats = eng.decode_stats()
+print(json.dumps({"decode_path": "fused float weights + reference-order fix-ups" if eng.batch_is_fused(b) and os.environ.get("SCRF_FAST_DECODE", "1") != "0" else "exact scores",
+                  "arc_weights_recomputed_per_batch": stats[0] // (reps + 1), "fallback_chunks": stats[1],
+                  "metric": "utterances/sec SCRF Viterbi decode (TIMIT-shape)", "value": round(U / dt, 1), "unit": "utterances/s",
                   "utts": U, "ms_per_batch": round(1e3 * dt, 2),
                   "phase_ms": {k: round(v[0], 2) for k, v in tm.items() if v[0] > 0},
                   "lattice_arcs": {"arcs_per_utt": na // 8, "ms_per_utt_incl_copy_to_host": round(1e3 * dta, 2)}}))

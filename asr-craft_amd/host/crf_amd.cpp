@@ -112,23 +112,33 @@ void CRF_Model::setLambda(double* v, QNUInt32 n) {
 }
 void CRF_Model::resetLambda() { std::fill(lambda.begin(), lambda.end(), 0.0); }
 
+// one value per line in the stream default format (6 significant digits, "%g"), as the reference's
+// `ofile << lambda[i] << endl` (CRF_Model.cpp); buffered -- a stdtrans TIMIT model has 4.4 M lines
 static bool write_vec(const char* fname, const double* v, size_t n) {
-  std::ofstream o(fname);
-  if (!o.is_open()) throw runtime_error(string("CRF_Model::writeToFile() caught exception: cannot open the file:\n") + fname);
-  for (size_t i = 0; i < n; i++) o << v[i] << std::endl;  // default precision: 6 significant digits
-  if (o.bad() || o.fail()) throw runtime_error(string("CRF_Model::writeToFile() caught exception: errors when writing the weights to the file:\n") + fname);
+  FILE* o = fopen(fname, "w");
+  if (!o) throw runtime_error(string("CRF_Model::writeToFile() caught exception: cannot open the file:\n") + fname);
+  std::vector<char> buf(1 << 20);
+  setvbuf(o, buf.data(), _IOFBF, buf.size());
+  bool ok = true;
+  for (size_t i = 0; i < n && ok; i++) ok = fprintf(o, "%g\n", v[i]) > 0;
+  ok = fclose(o) == 0 && ok;
+  if (!ok) throw runtime_error(string("CRF_Model::writeToFile() caught exception: errors when writing the weights to the file:\n") + fname);
   return true;
 }
 static bool read_vec(const char* fname, double* v, size_t n, double scale) {
-  std::ifstream f(fname);
-  if (!f.is_open()) return false;
+  FILE* f = fopen(fname, "r");
+  if (!f) return false;
+  char line[512];
   for (size_t i = 0; i < n; i++) {
-    string s;
-    getline(f, s);
-    std::istringstream iss(s);
-    iss >> std::dec >> v[i];
-    if (scale != 1.0) v[i] *= scale;
+    double x = 0.0;  // a missing or unparsable line reads as 0, like `iss >> v[i]` on a failed stream
+    if (fgets(line, sizeof line, f)) {
+      char* e = nullptr;
+      x = strtod(line, &e);
+      if (e == line) x = 0.0;
+    }
+    v[i] = scale != 1.0 ? x * scale : x;
   }
+  fclose(f);
   return true;
 }
 bool CRF_Model::writeToFile(const char* fname) { return write_vec(fname, lambda.data(), lambda.size()); }

@@ -1361,7 +1361,6 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   Need ndf = nd;
   ndf.fused = ndf.vitfast = true;
   const bool fast = h->fast_decode && b->fused_ok && h->fuse_windows && !frame_model && l.L <= 0xffff;
-  if (getenv("SCRF_DEBUG_DECODE")) fprintf(stderr, "decode: fast_decode %d fused_ok %d fuse_windows %d frame_model %d L %u mode %d\n", (int)h->fast_decode, (int)b->fused_ok, (int)h->fuse_windows, (int)frame_model, l.L, b->mode);
   int rc = SCRF_OK;
   for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK;) {
     uint32_t u_end = u0;
@@ -1381,12 +1380,6 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
       HIPCHK(h, hipMemcpyAsync(&n_fix, cb.fix_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       h->n_decode_fix += n_fix;
-      if (getenv("SCRF_DEBUG_DECODE")) {
-        std::vector<double> w1(l.L); float xm0 = 0;
-        hipMemcpy(w1.data(), h->d_w1, sizeof(double) * l.L, hipMemcpyDeviceToHost);
-        hipMemcpy(&xm0, b->d_xm_f, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "decode chunk %u..%u n_fix %u cap %u w1[0] %g xm %g factor %g\n", u0, u1, n_fix, cb.fix_cap, w1[0], xm0, h->decode_bound_factor);
-      }
       if (n_fix <= cb.fix_cap) {
         PhaseTimer tm(h, PH_VIT);
         launch_decode_fixup(h->stream, b->d_frames[0], b->recipe[0].in_width, b->view(), u0, u1, h->d_lambda, l, cb.fix_cnt,

@@ -38,26 +38,43 @@ int main(int argc, char** argv) {
   std::ostream& os = out.is_open() ? (std::ostream&)out : std::cout;
   strm.rewind();
   size_t u = 0;
-  while (strm.nextseg() != QN_SEGID_BAD) {
-    try {  // the reference prints the exception and continues with the next utterance (:1052-1054)
-      if (a.has("crf_lat_outdir")) {
+  auto emit = [&](const std::vector<uint32_t>& labs) {
+    if (ofmt == "ascii")
+      for (size_t i = 0; i < labs.size(); i++) os << u << " " << i << " " << labs[i] << "\n";
+    all_labs.push_back(labs);
+    u++;
+  };
+  if (!a.has("crf_lat_outdir")) {
+    // best paths only: whole device batches of utterances (crf_bunch_size of them, default 256)
+    const size_t bunch = (size_t)std::max(1L, a.num("crf_bunch_size", 256));
+    bool at_end = strm.nextseg() == QN_SEGID_BAD;
+    while (!at_end) {
+      try {
+        std::vector<std::vector<uint32_t> > labs;
+        std::vector<float> costs;
+        crf_amd_best_paths(&strm, &crf, bunch, &labs, &costs, &at_end);
+        for (const auto& l : labs) emit(l);
+      } catch (std::exception& e) {
+        std::cerr << "Exception: " << e.what() << std::endl;
+        return -1;
+      }
+    }
+  } else {
+    while (strm.nextseg() != QN_SEGID_BAD) {
+      try {  // the reference prints the exception and continues with the next utterance (:1052-1054)
         crf_amd::ArcListFst fst;
         CRF_LatticeBuilder lb(&strm, &crf);
         lb.buildLattice(&fst, false, (crf_amd::ArcListFst*)nullptr, false);
         std::ofstream lf((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".txt").c_str());
         for (const scrf_arc& c : fst.arcs) lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << c.w << "\n";
         lf << fst.final_state << "\n";
+        float cost = 0;
+        emit(crf_amd_best_path(&strm, &crf, &cost));
+      } catch (std::exception& e) {
+        std::cerr << "Exception: " << e.what() << std::endl;
+        emit(std::vector<uint32_t>());
       }
-      float cost = 0;
-      std::vector<uint32_t> labs = crf_amd_best_path(&strm, &crf, &cost);
-      if (ofmt == "ascii")
-        for (size_t i = 0; i < labs.size(); i++) os << u << " " << i << " " << labs[i] << "\n";
-      all_labs.push_back(labs);
-    } catch (std::exception& e) {
-      std::cerr << "Exception: " << e.what() << std::endl;
-      all_labs.push_back(std::vector<uint32_t>());
     }
-    u++;
   }
   if (ofmt == "ilab") {
     try {

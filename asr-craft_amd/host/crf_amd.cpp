@@ -626,3 +626,28 @@ std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* 
   if (cost) *cost = c;
   return labs;
 }
+
+size_t crf_amd_best_paths(CRF_FeatureStream* ftr_strm, CRF_Model* crf, size_t max_utts,
+                          std::vector<std::vector<uint32_t> >* labels, std::vector<float>* costs, bool* at_end) {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts;
+  utts.reserve(max_utts);
+  *at_end = false;
+  size_t frames = 0;
+  while (utts.size() < max_utts) {
+    utts.emplace_back();
+    grab(ftr_strm, crf, &utts.back());
+    frames += utts.back().u.T;
+    if (ftr_strm->nextseg() == QN_SEGID_BAD) { *at_end = true; break; }
+  }
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  std::vector<uint32_t> labs(frames);
+  std::vector<uint64_t> off(utts.size() + 1, 0);
+  costs->assign(utts.size(), 0.0f);
+  e->check(scrf_viterbi_batch(e->h, g.b, labs.data(), labs.size(), off.data(), costs->data()), "ShortestPath");
+  labels->resize(utts.size());
+  for (size_t u = 0; u < utts.size(); u++) (*labels)[u].assign(labs.begin() + off[u], labs.begin() + off[u + 1]);
+  return utts.size();
+}

@@ -350,5 +350,10 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
 
 // best path of CRFFstDecode (ShortestPath -> Project(OUTPUT) -> RmEpsilon -> TopSort -> olabel-1)
 std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* crf, float* cost);
+// the same for the stream's CURRENT utterance and up to max_utts - 1 following ones in one device
+// batch (the stream is advanced with nextseg(); *at_end is set when it ran out).  Labels and costs
+// are what crf_amd_best_path returns utterance by utterance.
+size_t crf_amd_best_paths(CRF_FeatureStream* ftr_strm, CRF_Model* crf, size_t max_utts,
+                          std::vector<std::vector<uint32_t> >* labels, std::vector<float>* costs, bool* at_end);
 
 #endif  // CRF_AMD_H_

@@ -255,3 +255,38 @@ def test_crfdecode_free_phone_loop_mlf_and_best_path_chain(tmp_path):
         args = model + ["weight_file=" + wf, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_olist=" + olist] + extra
         r = subprocess.run([os.path.join(BIN, "CRFDecode")] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == rc and msg in r.stderr, (r.returncode, r.stderr)
+
+
+def test_crfdecode_frame_model_on_bundled_fixture(tmp_path):
+    """CRFDecode on BASELINE config 1 (frame-level CRF, the reference's bundled fixture): one arc per
+    frame, olabel only where the phone changes, weights float(-(M + S)), final weight Zx."""
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + [
+        "hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + wf, "crf_epochs=3", "crf_lr=0.2",
+        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    olist, osym = str(tmp_path / "olist"), str(tmp_path / "osym.txt")
+    open(olist, "w").write("a\nb\nc\n")
+    open(osym, "w").write("<eps> 0\n" + "".join("p%d %d\n" % (i, i + 1) for i in range(48)))
+    latdir = tmp_path / "lat"; latdir.mkdir()
+    mlf = str(tmp_path / "out.mlf")
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + _common_flags() + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym,
+                        "crf_output_mlffile=" + mlf, "crf_lat_outdir=" + str(latdir), "crf_eval_range=all"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    utts = _fixture()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+    want = ["#!MLF!#"]
+    for u, (X, _) in enumerate(utts):
+        T = X.shape[0]
+        S, M = orc.seg_scores(cfg, lay, w, X, T)
+        segs, _ = orc.free_phone_decode(cfg, S, M, T)
+        assert len(segs) == T and all(d == 1 for (_, d, _, _) in segs)
+        got = [x.split() for x in open(str(latdir / ("abc"[u] + ".fst.txt"))).read().strip().split("\n")]
+        for i, (p, d, wt, ps) in enumerate(segs):
+            assert [int(v) for v in got[i][:4]] == [i, i + 1, p + 1, p + 1 if ps else 0]
+            assert np.float32(float(got[i][4])) == np.float32(wt)
+        want.append('"%s"' % "abc"[u])
+        want += ["p%d" % p for (p, _, _, ps) in segs if ps]
+        want.append(".")
+    assert open(mlf).read().strip().split("\n") == want

@@ -61,13 +61,13 @@ int main(int argc, char** argv) {
     if (m.mtype != STDFRAME && m.mtype != STDSEG_NO_DUR_NO_SEGTRANSFTR)
       throw std::runtime_error("CRF_ViterbiDecoder for CRF models other than \"stdframe\" and \"stdseg_no_dur_no_segtransftr\" have not been implmented.");
     crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));
-    sents = select_sents(a, "crf_eval_range", data[0].utts.size());
+    sents = select_sents(a, "crf_eval_range", data[0].size());
   } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
   if (!crf.readFromFile(a.str("weight_file").c_str())) { std::cerr << "ERROR: Failed opening file: " << a.str("weight_file") << std::endl; return -1; }
   CRF_MemoryFeatureStream strm(m.recipes, m.D, m.fmap.nActualLabs);
   for (uint32_t u : sents) {
     std::vector<std::vector<float> > fr(data.size());
-    for (size_t s = 0; s < data.size(); s++) fr[s] = data[s].utts[u];
+    for (size_t s = 0; s < data.size(); s++) { fr[s] = data[s].get(u); data[s].drop(u); }
     strm.addUtterance(fr, std::vector<uint32_t>());
   }
   strm.rewind();

@@ -20,11 +20,11 @@ int main(int argc, char** argv) {
   CRF_MemoryFeatureStream strm(m.recipes, m.D, m.fmap.nActualLabs);
   std::vector<uint32_t> sents;
   try {
-    sents = select_sents(a, "crf_eval_range", data[0].utts.size());
+    sents = select_sents(a, "crf_eval_range", data[0].size());
   } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
   for (uint32_t u : sents) {
     std::vector<std::vector<float> > fr(data.size());
-    for (size_t s = 0; s < data.size(); s++) fr[s] = data[s].utts[u];
+    for (size_t s = 0; s < data.size(); s++) { fr[s] = data[s].get(u); data[s].drop(u); }
     strm.addUtterance(fr, std::vector<uint32_t>());
   }
   // crf_output_format=ilab writes QuickNet ILAB (CRFFstDecode/src/Main.cpp:203); the default here

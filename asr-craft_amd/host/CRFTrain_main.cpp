@@ -11,7 +11,7 @@ int main(int argc, char** argv) {
     if (!a.has("hardtarget_file")) { std::cerr << "hardtarget_file is required" << std::endl; return 1; }
     if (!a.has("out_weight_file")) { std::cerr << "out_weight_file is required" << std::endl; return 1; }
     auto labs = read_labs(a.str("hardtarget_file"));
-    const std::vector<uint32_t> sents = select_sents(a, "train_sent_range", data[0].utts.size());
+    const std::vector<uint32_t> sents = select_sents(a, "train_sent_range", data[0].size());
     if (a.has("cv_sent_range") && a.str("cv_sent_range") != "nil" && a.str("cv_sent_range") != "none")
       std::cout << "NOTE: cv_sent_range=" << a.str("cv_sent_range") << " ignored: the cross-validation pass is not built" << std::endl;
     if (a.str("crf_train_method", "sg") != "sg") { std::cerr << "only crf_train_method=sg is built" << std::endl; return 1; }
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < U; i++) {
       const uint32_t u = sents[i];
       std::vector<std::vector<float> > fr(data.size());
-      for (size_t s = 0; s < data.size(); s++) fr[s] = data[s].utts[u];
+      for (size_t s = 0; s < data.size(); s++) { fr[s] = data[s].get(u); data[s].drop(u); }
       all.addUtterance(fr, u < labs.size() ? labs[u] : std::vector<uint32_t>());
     }
     // `threads` child streams over contiguous ranges (io/CRF_FeatureStreamManager.cpp:425-464)

@@ -13,6 +13,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -36,10 +37,19 @@ struct Args {
   double real(const std::string& k, double d) const { return has(k) ? atof(kv.at(k).c_str()) : d; }
 };
 
-// one input stream: utts[u] = T x width floats, row-major
+// one input stream: sentence u = T x width floats, row-major.  ascii files are held whole; a pfile is
+// read sentence by sentence on demand (a run over `crf_eval_range=0-399` touches those 400 only)
 struct FtrData {
   size_t width = 0;
-  std::vector<std::vector<float> > utts;
+  std::vector<std::vector<float> > utts;      // ascii: everything; pfile: filled by get()
+  std::shared_ptr<qn::PFileReader> pfile;
+  uint32_t ftr_start = 0;
+  size_t size() const { return utts.size(); }
+  const std::vector<float>& get(size_t u) {
+    if (pfile && utts[u].empty() && pfile->num_frames((uint32_t)u) > 0) pfile->read_sent((uint32_t)u, &utts[u], nullptr, ftr_start, (uint32_t)width);
+    return utts[u];
+  }
+  void drop(size_t u) { if (pfile) std::vector<float>().swap(utts[u]); }  // the stream keeps its own copy
 };
 
 inline FtrData read_ascii_ftrs(const std::string& path) {
@@ -62,14 +72,16 @@ inline FtrData read_ascii_ftrs(const std::string& path) {
 }
 
 // pfile stream (QN_build_ftrstream(format="pfile"), io/CRF_FeatureStreamManager.cpp:138), columns
-// ftr_start .. ftr_start+ftr_count (ftr_count 0 = the rest), one sentence at a time
+// ftr_start .. ftr_start+ftr_count (ftr_count 0 = the rest); sentences are read when first asked for
 inline FtrData read_pfile_ftrs(const std::string& path, uint32_t ftr_start, uint32_t ftr_count) {
-  qn::PFileReader r(path);
   FtrData d;
-  if (ftr_start > r.info().n_ftrs) qn::fail(path, "ftr_start beyond the file's width");
-  d.width = ftr_count ? ftr_count : r.info().n_ftrs - ftr_start;
-  d.utts.resize(r.num_sents());
-  for (uint32_t s = 0; s < r.num_sents(); s++) r.read_sent(s, &d.utts[s], nullptr, ftr_start, (uint32_t)d.width);
+  d.pfile.reset(new qn::PFileReader(path));
+  const qn::PFileInfo& info = d.pfile->info();
+  if (ftr_start > info.n_ftrs) qn::fail(path, "ftr_start beyond the file's width");
+  d.width = ftr_count ? ftr_count : info.n_ftrs - ftr_start;
+  if (ftr_start + d.width > info.n_ftrs) qn::fail(path, "ftr_start + ftr_count beyond the file's width");
+  d.ftr_start = ftr_start;
+  d.utts.resize(d.pfile->num_sents());
   return d;
 }
 

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_wave(
   const int LL = L * L;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
-  const uint32_t ul = (blockIdx.x >> 1) * DP_WPB + wave;
+  const uint32_t ul = (blockIdx.x >> 1) * (blockDim.x >> 6) + wave;   // blockDim.x / 64 utterances per workgroup
   double* Es = dsm;                                         // [L*L] (time-invariant transitions only)
   double* ring = dsm + (MPF ? 0 : LL) + (size_t)wave * D * L;  // [D][L], private to this wavefront
   if (!MPF) {
@@ -221,12 +221,13 @@ void launch_dp_wave(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uin
                     const double* S, const double* E, const double* ET, const double* mshift, int m_per_frame,
                     double* AD, double* alpha_g, double* beta_g, double* sd_g, double* zx, int* status) {
   if (n_utts == 0) return;
-  const uint32_t nblk = 2 * ((n_utts + DP_WPB - 1) / DP_WPB);
-  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * lay.D * lay.L);
+  const uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * (size_t)lay.D * lay.L);
+  const uint32_t nblk = 2 * ((n_utts + wpb - 1) / wpb);
+  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)wpb * lay.D * lay.L);
 #define DP_LAUNCH2(DM, MPF)                                                                                   \
   do {                                                                                                          \
     hipFuncSetAttribute((const void*)k_dp_wave<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \
-    hipLaunchKernelGGL((k_dp_wave<DM, MPF>), dim3(nblk), dim3(DP_WPB * 64), sm, st, lay, bv, u0, n_utts, S, E, ET, \
+    hipLaunchKernelGGL((k_dp_wave<DM, MPF>), dim3(nblk), dim3(wpb * 64), sm, st, lay, bv, u0, n_utts, S, E, ET, \
                        mshift, AD, alpha_g, beta_g, sd_g, zx, status);                                          \
   } while (0)
 #define DP_LAUNCH(DM)                     \

@@ -9,6 +9,13 @@
 #include <math.h>
 
 #define DP_WPB 12  // wavefronts (utterances) per workgroup: 3 per SIMD, one workgroup per CU (6-wave groups do not pair up on a CU)
+// wavefronts per workgroup the LDS allows: 12 when they fit, else 8 / 4 / 2 / 1 (L = 64 with D >= 17 needs that)
+static inline uint32_t dp_waves_per_block(size_t shared_bytes, size_t per_wave_bytes) {
+  const uint32_t opts[5] = {DP_WPB, 8, 4, 2, 1};
+  for (int i = 0; i < 5; i++)
+    if (shared_bytes + opts[i] * per_wave_bytes <= 156 * 1024) return opts[i];
+  return 1;
+}
 
 __device__ __forceinline__ double rdlane(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

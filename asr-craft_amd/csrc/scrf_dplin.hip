@@ -138,7 +138,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
   const int LL = L * L;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
-  const uint32_t ul = (blockIdx.x >> 1) * DP_WPB + wave;
+  const uint32_t ul = (blockIdx.x >> 1) * (blockDim.x >> 6) + wave;   // blockDim.x / 64 utterances per workgroup
   double* Es = dsm;                                         // [L*L] (time-invariant transitions only)
   double* ring = dsm + (MPF ? 0 : LL) + (size_t)wave * (D * L + 128);  // [D][L] mantissas, private to this wavefront
   double* abuf = ring + D * L;   // [64] broadcast line of the matvec operand
@@ -535,12 +535,13 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
     else launch_dp_lin_mw_t<40>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
     return;
   }
-  const uint32_t nblk = 2 * ((n_utts + DP_WPB - 1) / DP_WPB);
-  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)DP_WPB * (lay.D * lay.L + 128));
+  const uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * ((size_t)lay.D * lay.L + 128));
+  const uint32_t nblk = 2 * ((n_utts + wpb - 1) / wpb);
+  const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)wpb * (lay.D * lay.L + 128));
 #define DL_LAUNCH2(DM, MPF)                                                                                    \
   do {                                                                                                         \
     hipFuncSetAttribute((const void*)k_dp_lin<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \
-    hipLaunchKernelGGL((k_dp_lin<DM, MPF>), dim3(nblk), dim3(DP_WPB * 64), sm, st, lay, bv, u0, n_utts, ES, smax, \
+    hipLaunchKernelGGL((k_dp_lin<DM, MPF>), dim3(nblk), dim3(wpb * 64), sm, st, lay, bv, u0, n_utts, ES, smax, \
                        E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);               \
   } while (0)
 #define DL_LAUNCH(DM)                     \

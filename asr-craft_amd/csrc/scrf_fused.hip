@@ -45,7 +45,7 @@ __host__ __device__ inline uint32_t fu_sample_step(uint32_t d, int k) {
   const float ot = (float)((double)d * 0.1);
   return (uint32_t)ceilf(ot * (float)(2 * k + 1)) - 1u;
 }
-__device__ __forceinline__ uint32_t fu_div(uint32_t i, uint32_t magic) { return __umulhi(i, magic); }
+__device__ __forceinline__ uint32_t fu_div(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }   // magic 0: d == 1 (2^32 does not fit)
 __device__ __forceinline__ uint32_t fu_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
 // A row tile (ScrfTileDesc, built on the host with the batch): rows [r0, r0+nrows) of an utterance,
 // touching frames t0 .. t0+nfr-1; raw frames are staged from f0 = t0 - back.

@@ -2,6 +2,8 @@
 inputs.  Bars: bit-exact for window vectors, scores (EXACT mode), lattice arcs and Viterbi label
 sequences; forward log-likelihood and gradients within 1e-4 relative (BASELINE.json) -- the
 tests assert much tighter bounds than the contract wherever the fp64 path allows it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -466,3 +468,30 @@ def test_full_size_config2_utterances():
     ga, gns, gfin = eng.lattice_arcs(b, 0)
     assert ga.tobytes() == oa.tobytes()
     b.close(); b2.close(); eng.close()
+
+
+def test_random_shape_sweep_through_the_fused_and_wavefront_kernels():
+    """tools/fused_shape_sweep.py: 60 seeded random (D, W, L, T...) shapes -- W = 1 (division by
+    magic number), L = 64 with large D (workgroup size chosen by the LDS fit), L just above 48 / 64,
+    D = 2 .. 40, utterances shorter than D: FAST gradient with fused windows == materialised windows
+    (1e-9) == oracle (1e-8, small cases); fast decode == EXACT decode bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fused_shape_sweep.py"), "60", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") == 60
+
+
+@pytest.mark.parametrize("L,D,W", [(64, 25, 3), (64, 32, 2), (3, 5, 1)])
+def test_regressions_found_by_the_shape_sweep(L, D, W, monkeypatch):
+    """L = 64, D >= 17: twelve wavefronts' rings do not fit the LDS (the launch used to fail);
+    W = 1: the expected-count kernel's magic-number division by W."""
+    for prec in (0, 1):
+        c = Case(L=L, D=D, in_w=W, Ts=[2, D, 2 * D + 3], seed=11, precision=prec, lam_scale=0.2)
+        eng = c.engine(); b = c.batch(eng)
+        numer, zx = eng.fb_batch(b)
+        g = eng.get_grad()
+        og, on, oz = c.oracle_gradient()
+        assert np.abs(g - og).max() <= 1e-9 * np.abs(og).max()
+        assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
+        b.close(); eng.close()

@@ -996,6 +996,9 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
   ScrfBatchView bv = b->view();
   uint32_t nl = 0;
   if (!cb.wave) {
+    if (fb_smem_bytes(l, fb_block_threads(l)) > 160 * 1024)
+      return fail(h, SCRF_ERR_INVALID, "labels x maximum duration = %u x %u is too large for the workgroup-per-utterance recursion "
+                  "(its two [D][L] rings must fit 160 KB of LDS; the wavefront kernels cover L <= 256 with D <= 40)", l.L, l.D);
     if (post && cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, cb.st));
     launch_fb(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, post ? cb.XI : nullptr,
               post ? cb.xi_acc : nullptr, b->d_numer, b->d_zx, b->d_status, post ? 1 : 0);

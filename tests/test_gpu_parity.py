@@ -495,3 +495,13 @@ def test_regressions_found_by_the_shape_sweep(L, D, W, monkeypatch):
         assert np.abs(g - og).max() <= 1e-9 * np.abs(og).max()
         assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
         b.close(); eng.close()
+
+
+def test_random_shape_sweep_through_every_path():
+    """tools/general_shape_sweep.py: 60 seeded random cases over stdstate / stdtrans (context stream),
+    EXACT / FAST / FAST32, tiny scratch budgets, L up to 300, D up to 45, W up to 90 -- gradient, Zx,
+    numerator against the oracle within the precision's bound; Viterbi labels and cost bit-identical."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "general_shape_sweep.py"), "60", "7"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]

@@ -26,9 +26,15 @@ def one(kw, prec, scratch):
     e_n = np.abs(numer - on).max() / max(1.0, np.abs(on).max())
     u = len(c.Ts) - 1; T = c.Ts[u]
     So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
-    oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+    if c.ocfg.model_type == orc.STDFRAME:
+        oa, ons, ofin = orc.frame_lattice_arcs(c.ocfg, So, Mo, T)
+    else:
+        oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
     ol, oc = orc.best_path(oa, ons, ofin)
     dec = list(labs[u]) == list(ol) and np.float32(cost[u]).tobytes() == np.float32(oc).tobytes()
+    if len(oa) < 3000000:   # lattice arcs in AddArc order, bit for bit
+        ga, gns, gfin = eng.lattice_arcs(b, u)
+        dec = dec and (gns, gfin) == (ons, ofin) and ga.tobytes() == oa.tobytes()
     b.close(); eng.close()
     ok = e_g <= TOL[prec][0] and e_z <= TOL[prec][1] and e_n <= TOL[prec][1] and dec
     return ok, "grad=%.1e zx=%.1e numer=%.1e decode=%s" % (e_g, e_z, e_n, dec)
@@ -48,8 +54,13 @@ for i in range(n):
     if cost > 3e8:
         L = min(L, 50); W = min(W, 16)
     scratch = int(rng.choice([0, 0, 1 << 16, 1 << 20]))
-    kw = dict(L=L, D=D, in_w=W, Ts=Ts, seed=2000 + i, lam_scale=0.05, trans_ctx=(int(ctx) if ctx > 0 else None))
-    tag = "D=%d W=%d L=%d ctx=%s prec=%d scratch=%d Ts=%s" % (D, W, L, kw["trans_ctx"], prec, scratch, Ts)
+    frame = rng.rand() < 0.2
+    if frame:   # frame-level CRF (BASELINE config 1): D = 1, transition features optional
+        D = 1
+        Ts = [max(1, int(x)) for x in rng.choice([1, 2, 3, 9, 40], size=nu)]
+    kw = dict(L=L, D=D, in_w=W, Ts=Ts, seed=2000 + i, lam_scale=0.05, trans_ctx=(int(ctx) if ctx > 0 else (0 if frame else None)),
+              frame_model=bool(frame))
+    tag = ("frame " if frame else "") + "D=%d W=%d L=%d ctx=%s prec=%d scratch=%d Ts=%s" % (D, W, L, kw["trans_ctx"], prec, scratch, Ts)
     try:
         ok, msg = one(kw, prec, scratch)
     except Exception as e:

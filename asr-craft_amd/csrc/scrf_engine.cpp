@@ -1507,6 +1507,14 @@ extern "C" int scrf_allreduce_grad(scrf_handle h, int active, double* sums4) {
   return SCRF_OK;
 }
 
+extern "C" int scrf_div_grad(scrf_handle h, double d) {
+  if (!h || d == 0.0) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  launch_scale(h->stream, h->d_grad, h->lay.lambda_len, d, 1);
+  HIPCHK(h, hipGetLastError());
+  return SCRF_OK;
+}
+
 extern "C" int scrf_scale_grad(scrf_handle h, double s) {
   if (!h) return SCRF_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));

@@ -416,20 +416,30 @@ void CRF_Minibatch_GradAccumulator::rewindAllAndNextSegs() {
   }
 }
 
+double CRF_Minibatch_GradAccumulator::accumulateGradientOnDevice(double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter) {
+  return accumulate(nullptr, Zx_out, uttCount, isEndOfIter);
+}
 double CRF_Minibatch_GradAccumulator::accumulateGradient(double* grad, double* Zx_out, QNUInt32* uttCount,
                                                          bool* isEndOfIter) {
+  return accumulate(grad, Zx_out, uttCount, isEndOfIter);
+}
+// grad != nullptr: per-stream gradients come to the host and are summed there in stream order, like
+// the reference's join; grad == nullptr: the streams accumulate into the device gradient one after
+// the other (same order, the sums inside one stream's reduction kernels aside) and it is divided there
+double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter) {
   crf_amd::Engine* e = crf->engine();
   const QNUInt32 n = e->lambda_len, N = (QNUInt32)ftrStrms.size();
   *uttCount = 0;
   *Zx_out = 0.0;
-  for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
+  if (grad) for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
+  else e->check(scrf_zero_grad(e->h), "accumulateGradient");
   const QNUInt32 per = minibatch == CRF_UINT32_MAX ? CRF_UINT32_MAX : minibatch / N;
   const QNUInt32 rem = minibatch == CRF_UINT32_MAX ? 0 : minibatch % N;
   int nEnd = 0, nActive = 0;
   for (QNUInt32 s = 0; s < N; s++) if (segids[s] == QN_SEGID_BAD) ++nEnd;
   if (nEnd == (int)N) throw runtime_error("All feature streams are at the end! You don't have any utterances or you forget to rewind all the streams.");
   double totNumer = 0.0;
-  std::vector<double> sgrad(n);
+  std::vector<double> sgrad(grad ? n : 0);
   for (QNUInt32 s = 0; s < N; s++) {  // stream order == the reference's join/sum order
     if (segids[s] == QN_SEGID_BAD) continue;
     const QNUInt32 share = per == CRF_UINT32_MAX ? CRF_UINT32_MAX : per + (s < rem ? 1 : 0);
@@ -442,16 +452,18 @@ double CRF_Minibatch_GradAccumulator::accumulateGradient(double* grad, double* Z
     BatchGuard g{e};
     make_batch(e, ftrStrms[s], utts, &g);
     std::vector<double> numer(utts.size()), zx(utts.size());
-    e->check(scrf_zero_grad(e->h), "accumulateGradient");
+    if (grad) e->check(scrf_zero_grad(e->h), "accumulateGradient");
     e->check(scrf_fb_batch(e->h, g.b, numer.data(), zx.data()), "CRF_Minibatch_GradAccumulator::accumulateGradient()");
-    e->check(scrf_get_grad(e->h, sgrad.data(), n), "accumulateGradient");
+    if (grad) e->check(scrf_get_grad(e->h, sgrad.data(), n), "accumulateGradient");
     ++nActive;
     for (size_t i = 0; i < utts.size(); i++) { totNumer += numer[i]; *Zx_out += zx[i]; }
     *uttCount += (QNUInt32)utts.size();
     if (segids[s] == QN_SEGID_BAD) ++nEnd;
-    for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
+    if (grad) for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
   }
-  for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;  // averaged over ACTIVE STREAMS (reference quirk)
+  // averaged over ACTIVE STREAMS (reference quirk)
+  if (grad) for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;
+  else if (nActive > 1) e->check(scrf_div_grad(e->h, (double)nActive), "accumulateGradient");
   *isEndOfIter = nEnd == (int)N;
   return totNumer;
 }
@@ -475,7 +487,7 @@ void CRF_SGTrainer::train() {
   CRF_Minibatch_GradAccumulator gaccum(crf_ptr, streams);
   gaccum.setMinibatch(minibatch);
   gaccum.setUttReport(uttRpt);
-  std::vector<double> grad(n, 0.0), lambdaAvg(n, 0.0);
+  std::vector<double> lambdaAvg(n, 0.0);
   int iCounter = (int)crf_ptr->getInitIter();
   QNUInt32 uCounter = 0;
   int accCnt = (int)crf_ptr->getPresentations();
@@ -491,7 +503,7 @@ void CRF_SGTrainer::train() {
     QNUInt32 inc = 0;
     bool endOfIter = false;
     double Zx = 0.0;
-    const double numer = gaccum.accumulateGradient(grad.data(), &Zx, &inc, &endOfIter);
+    const double numer = gaccum.accumulateGradientOnDevice(&Zx, &inc, &endOfIter);
     const double logLi = numer - Zx;
     totLogLi += logLi;
     uCounter += inc;
@@ -499,8 +511,6 @@ void CRF_SGTrainer::train() {
       std::cout << " Finished Utt: " << uCounter - 1 << " Batch-Avg Numerator: " << numer / inc << " Batch-Avg Zx: " << Zx / inc
                 << " Batch-Avg LogLi: " << logLi / inc << " Iter-Avg LogLi: " << totLogLi / uCounter << std::endl;
     // update on the device: lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0
-    e->check(scrf_zero_grad(e->h), "sgtrainMinibatch");
-    e->check(scrf_add_grad(e->h, grad.data(), n), "sgtrainMinibatch");
     e->check(scrf_sgd_step(e->h, useAdagrad ? eta : (double)lr, useAdagrad, eps), "sgtrainMinibatch");
     accCnt += (int)inc;
     if (endOfIter) {

@@ -224,8 +224,12 @@ class CRF_Minibatch_GradAccumulator {
   void setUttReport(QNUInt32 r) { uttReport = r; }
   void rewindAllAndNextSegs();
   double accumulateGradient(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
+  // the same minibatch, but the summed and averaged gradient STAYS in the engine's device buffer
+  // (what CRF_SGTrainer uses: no 2 x lambda_len doubles over PCIe per minibatch)
+  double accumulateGradientOnDevice(double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
 
  protected:
+  double accumulate(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
   CRF_Model* crf;
   std::vector<CRF_FeatureStream*> ftrStrms;
   std::vector<QN_SegID> segids;

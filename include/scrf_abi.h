@@ -229,6 +229,9 @@ int scrf_comm_init(scrf_handle h, const void* id128, int rank, int n_ranks);
 int scrf_allreduce_grad(scrf_handle h, int active, double* sums4);
 /* grad *= s  (used with an external all-reduce: s = 1/n_active) */
 int scrf_scale_grad(scrf_handle h, double s);
+/* grad[i] /= d on the device: the `/ nStreams_active` of accumulateGradient (:306-308) for a host that
+ * runs several streams on ONE device and keeps the summed gradient there */
+int scrf_div_grad(scrf_handle h, double d);
 /* replaces CRF_SGTrainer::sgtrainMinibatch's update (trainers/CRF_SGTrainer.cpp:299-325):
  * lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0. */
 int scrf_sgd_step(scrf_handle h, double lr_or_eta, int use_adagrad, double eps);

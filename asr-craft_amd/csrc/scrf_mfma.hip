@@ -35,8 +35,11 @@ typedef float v4f32 __attribute__((ext_vector_type(4)));
 // sustained rate of the f64 MFMA on this chip; lambda is rounded to f32 at staging, the K-sum
 // runs in f32 (error ~1e-7 * sum|x*w|), bias and the linear epilogue are added in f64.
 // D layout of the f32 form: row = 4*(lane>>4) + reg (the f64 form: (lane>>4) + 4*reg).
+// launch bound 2 waves per SIMD: left alone the compiler takes 210 VGPRs + 96 AGPRs for the f64 form
+// (one wavefront per SIMD, matrix pipe 47 % busy at the TIMIT transition scores); capped at 256 it
+// needs 218 with no spills and the second workgroup per CU hides staging and barriers (1.35x)
 template <int F32>
-__global__ __launch_bounds__(256) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
+__global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      const double* __restrict__ lambda, ScrfLayout lay,
                                                      ScrfGemmSpec sp, uint32_t n_out, double* __restrict__ out) {

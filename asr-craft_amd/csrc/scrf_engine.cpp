@@ -1354,6 +1354,11 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   const uint64_t NF = b->frame_off[b->U];
   uint32_t *d_lab = nullptr, *d_n = nullptr;
   float* d_cost = nullptr;
+  struct Release {   // the result buffers go away on every exit path, error returns included
+    uint32_t **a, **b;
+    float** c;
+    ~Release() { hipFree(*a); hipFree(*b); hipFree(*c); }
+  } release{&d_lab, &d_n, &d_cost};
   HIPCHK(h, hipMalloc((void**)&d_lab, sizeof(uint32_t) * NF));
   HIPCHK(h, hipMalloc((void**)&d_n, sizeof(uint32_t) * b->U));
   HIPCHK(h, hipMalloc((void**)&d_cost, sizeof(float) * b->U));
@@ -1422,7 +1427,6 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) rc = fail(h, SCRF_ERR_HIP, "scrf_viterbi_batch: %s", hipGetErrorString(e));
   }
-  hipFree(d_lab); hipFree(d_n); hipFree(d_cost);
   if (rc != SCRF_OK) return rc;
   if (h->timing) {
     hipEventRecord(h->ev[SCRF_N_PHASES][1], h->stream);

@@ -25,10 +25,19 @@ int main(int argc, char** argv) {
     std::cout << "LABEL_MAXIMUM_DURATION: " << crf.getLabMaxDur() << std::endl;
     crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));
     std::cout << "FEATURES: " << crf.getLambdaLen() << std::endl;
-    if (a.has("init_weight_file") && !crf.readFromFile(a.str("init_weight_file").c_str())) { std::cerr << "ERROR! File " << a.str("init_weight_file") << " unable to be opened for reading" << std::endl; return -1; }
-    if (a.has("avg_weight_file")) crf.readAverageFromFile(a.str("avg_weight_file").c_str(), (int)a.num("avg_weight_present", 0));
-    if (a.has("grad_sqr_acc_file")) crf.readGradSqrAccFromFile(a.str("grad_sqr_acc_file").c_str());
-    crf.setInitIter((QNUInt32)a.num("init_iter", 0));
+    // resume flags, nested as in CRFTrain/src/Main.cpp:599-621: the average and AdaGrad accumulators are
+    // only read next to an initial weight file and a positive presentation count
+    if (a.has("init_weight_file")) {
+      if (!crf.readFromFile(a.str("init_weight_file").c_str())) { std::cerr << "ERROR! File " << a.str("init_weight_file") << " unable to be opened for reading.  ABORT!" << std::endl; return -1; }
+      if (a.num("avg_weight_present", 0) > 0) {
+        if (a.has("avg_weight_file") && !crf.readAverageFromFile(a.str("avg_weight_file").c_str(), (int)a.num("avg_weight_present", 0))) {
+          std::cerr << "ERROR! File " << a.str("avg_weight_file") << " unable to be opened for reading.  ABORT!" << std::endl; return -1; }
+        if (a.num("crf_use_adagrad", 0) != 0 && a.has("grad_sqr_acc_file") && !crf.readGradSqrAccFromFile(a.str("grad_sqr_acc_file").c_str())) {
+          std::cerr << "ERROR! File " << a.str("grad_sqr_acc_file") << " unable to be opened for reading.  ABORT!" << std::endl; return -1; }
+      }
+      crf.setInitIter((QNUInt32)a.num("init_iter", 0));
+    }
+    if (a.real("crf_gauss_var", 0.0) != 0.0) { std::cerr << "crf_gauss_var: the Gaussian prior is not built" << std::endl; return 1; }
 
     CRF_MemoryFeatureStream all(m.recipes, m.D, m.fmap.nActualLabs);
     const size_t U = sents.size();
@@ -48,6 +57,8 @@ int main(int argc, char** argv) {
       streams.push_back(views.back().get());
     }
     CRF_SGTrainer tr(&crf, streams, a.str("out_weight_file").c_str());
+    std::cout << "MINIBATCH SIZE: " << a.num("crf_bunch_size", 1) << std::endl;
+    std::cout << "NUMBER OF THREADS: " << N << std::endl;
     tr.setMaxIters((int)a.num("crf_epochs", 10));
     tr.setLR((float)a.real("crf_lr", 0.008));
     tr.setLRDecayRate((float)a.real("crf_lr_decay_rate", 1.0));
@@ -55,6 +66,16 @@ int main(int argc, char** argv) {
     tr.setUseAdagrad(a.num("crf_use_adagrad", 0) != 0);
     tr.setEta(a.real("crf_adagrad_eta", 1.0));
     tr.setUttRpt((QNUInt32)a.num("crf_utt_rpt", 100));
+    {  // a finished run is not repeated (Main.cpp:676-682)
+      const std::string wf = a.str("out_weight_file");
+      const size_t k = wf.find_last_of('/');
+      const std::string done_file = (k == std::string::npos ? std::string(".") : wf.substr(0, k)) + "/.done.train";
+      if (std::ifstream(done_file.c_str()).good()) {
+        std::cout << "The done file has already existed: " << done_file << std::endl;
+        std::cout << "Finished." << std::endl;
+        return 0;
+      }
+    }
     tr.train();
   } catch (std::exception& e) {
     std::cerr << "Exception: " << e.what() << std::endl;

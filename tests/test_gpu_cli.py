@@ -290,3 +290,37 @@ def test_crfdecode_frame_model_on_bundled_fixture(tmp_path):
         want += ["p%d" % p for (p, _, _, ps) in segs if ps]
         want.append(".")
     assert open(mlf).read().strip().split("\n") == want
+
+
+def test_crftrain_resume_and_done_file(tmp_path):
+    """checkpoint / resume surface (CRFTrain/src/Main.cpp:599-621,676-682): a run restarted from the
+    iteration-0 files with init_iter=1 continues where the straight run went (the weight files keep 6
+    significant digits, so the continuation agrees to that resolution); a directory that already holds
+    .done.train is not trained again."""
+    base = _common_flags() + ["hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "crf_lr=0.1", "crf_bunch_size=1",
+                              "threads=1", "crf_use_adagrad=1", "crf_adagrad_eta=0.3", "crf_utt_rpt=1"]
+    d1 = tmp_path / "straight"; d1.mkdir()
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(d1 / "w.out"), "crf_epochs=2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MINIBATCH SIZE: 1" in r.stdout and "NUMBER OF THREADS: 1" in r.stdout
+    # second invocation in the finished directory: nothing is trained
+    r2 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(d1 / "w.out"), "crf_epochs=2"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "The done file has already existed" in r2.stdout and "Iteration: 0" not in r2.stdout
+    # resume from iteration 0 in a fresh directory
+    d2 = tmp_path / "resumed"; d2.mkdir()
+    r3 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(d2 / "w.out"), "crf_epochs=2", "init_iter=1",
+                         "init_weight_file=" + str(d1 / "w.out.i0.out"), "avg_weight_file=" + str(d1 / "w.out.i0.avg.out"), "avg_weight_present=3",
+                         "grad_sqr_acc_file=" + str(d1 / "w.out.i0.gradSqrAcc.out")], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    assert "Iteration: 1 starting" in r3.stdout and "Iteration: 0 starting" not in r3.stdout
+    w1, w2 = np.loadtxt(str(d1 / "w.out")), np.loadtxt(str(d2 / "w.out"))
+    np.testing.assert_allclose(w2, w1, rtol=2e-4, atol=2e-6)
+    a1, a2 = np.loadtxt(str(d1 / "w.out.avg.out")), np.loadtxt(str(d2 / "w.out.avg.out"))
+    np.testing.assert_allclose(a2, a1, rtol=2e-4, atol=2e-6)
+    # a missing resume file is an error, and the Gaussian prior is refused rather than ignored
+    r4 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(tmp_path / "x.out"), "init_weight_file=" + str(tmp_path / "nope")],
+                        capture_output=True, text=True, timeout=300)
+    assert r4.returncode != 0 and "unable to be opened for reading" in r4.stderr
+    r5 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(tmp_path / "y.out"), "crf_gauss_var=1.0"],
+                        capture_output=True, text=True, timeout=300)
+    assert r5.returncode != 0 and "crf_gauss_var" in r5.stderr

@@ -115,6 +115,28 @@ inline modeltype parse_model_type(const std::string& s) {
   return STDFRAME;
 }
 
+// Flags of the reference's argument tables that would change the numbers and that this build does not
+// implement are refused instead of ignored (the remaining unknown names are accepted silently, like
+// logging and scheduling options)
+inline void refuse_unbuilt_flags(const Args& a, uint32_t D) {
+  auto die = [](const std::string& m) { std::cerr << m << std::endl; exit(1); };
+  for (int k = 1; k <= 3; k++) {
+    const std::string p = "ftr" + std::to_string(k) + "_";
+    if (a.num(p + "delta_order", 0) != 0) die(p + "delta_order: delta features are not built");
+    if (a.has(p + "norm_file")) die(p + "norm_file: feature normalisation files are not built");
+    if (a.num(p + "window_offset", 0) != 0) die(p + "window_offset must be 0");
+    const long wl = a.num(p + "window_len", 1);
+    if (wl != 1 && wl != (long)D) die(p + "window_len must be 1 or label_maximum_duration (the segment windows are synthesised from the raw frames)");
+    if (a.num(p + "use_boundary_delta_ftr", 0) != 0) die(p + "use_boundary_delta_ftr is not built");
+  }
+  const long we = a.num("window_extent", 1);
+  if (we != 1 && we != (long)D) die("window_extent must be 1 or label_maximum_duration");
+  if (a.num("hardtarget_window_offset", 0) != 0) die("hardtarget_window_offset must be 0");
+  if (a.num("use_broken_class_label", 0) != 0) die("use_broken_class_label: broken-class labels are not built");
+  if (a.has("crf_objective_function") && a.str("crf_objective_function") != "expf") die("crf_objective_function=" + a.str("crf_objective_function") + " is not built (expf only)");
+  if (a.has("crf_featuremap_file")) die("crf_featuremap_file: file-defined feature maps are not built");
+}
+
 // streams (ftr1/ftr2/ftr3) + set_fmap_config of CRFTrain/src/Main.cpp:372-430
 inline std::vector<FtrData> load_streams(const Args& a, CliModel* m) {
   std::vector<FtrData> data;
@@ -122,6 +144,7 @@ inline std::vector<FtrData> load_streams(const Args& a, CliModel* m) {
   m->L = (uint32_t)a.num("crf_label_size", 0);
   m->mtype = parse_model_type(a.str("crf_model_type", "stdframe"));
   if (m->L == 0) { std::cerr << "crf_label_size is required" << std::endl; exit(1); }
+  refuse_unbuilt_flags(a, m->D);
   m->F = 0;
   for (int k = 1; k <= 3; k++) {
     std::string p = "ftr" + std::to_string(k) + "_";

@@ -324,3 +324,12 @@ def test_crftrain_resume_and_done_file(tmp_path):
     r5 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(tmp_path / "y.out"), "crf_gauss_var=1.0"],
                         capture_output=True, text=True, timeout=300)
     assert r5.returncode != 0 and "crf_gauss_var" in r5.stderr
+
+
+@pytest.mark.parametrize("flag,msg", [("ftr1_delta_order=2", "delta"), ("ftr2_norm_file=n.norms", "norm_file"), ("ftr1_window_len=9", "window_len"),
+                                      ("use_broken_class_label=1", "broken"), ("crf_objective_function=ferr", "expf only"),
+                                      ("hardtarget_window_offset=4", "hardtarget_window_offset"), ("crf_train_method=lbfgs", "crf_train_method")])
+def test_flags_that_would_change_the_numbers_are_refused(tmp_path, flag, msg):
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + ["hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"),
+                        "out_weight_file=" + str(tmp_path / "w.out"), "crf_epochs=1", flag], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and msg in r.stderr and not os.path.exists(str(tmp_path / "w.out"))

@@ -496,6 +496,8 @@ __global__ __launch_bounds__(256) void k_dp_lin_mw(
 }
 
 int dplin_mw_supported(const ScrfLayout& lay) { return lay.L > 64 && lay.L <= 256 && lay.D <= 40; }
+// the one-wavefront-per-utterance form (k_dp_lin): L <= 64, D <= 40 (the log-domain k_dp_wave stops at 32)
+int dplin_supported(const ScrfLayout& lay) { return lay.L <= 64 && lay.D <= 40; }
 
 template <int DMAX>
 static void launch_dp_lin_mw_t(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
@@ -554,7 +556,8 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
   else if (lay.D <= 10) DL_LAUNCH(10);
   else if (lay.D <= 16) DL_LAUNCH(16);
   else if (lay.D <= 25) DL_LAUNCH(25);
-  else DL_LAUNCH(32);
+  else if (lay.D <= 32) DL_LAUNCH(32);
+  else DL_LAUNCH(40);
 #undef DL_LAUNCH
 #undef DL_LAUNCH2
 }

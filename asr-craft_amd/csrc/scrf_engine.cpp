@@ -696,7 +696,7 @@ static uint32_t decode_fix_cap(uint64_t nseg, uint32_t L) {
 // hooks, linear-domain for training); 64 < L <= 256: the multi-wavefront linear-domain kernel,
 // training path only
 static bool wave_path(scrf_handle h, bool post) {
-  return dp_wave_supported(h->lay) || (post && h->lin_dp && dplin_mw_supported(h->lay));
+  return dp_wave_supported(h->lay) || (post && h->lin_dp && (dplin_mw_supported(h->lay) || dplin_supported(h->lay)));
 }
 
 // fused path: the five sampled blocks as per-frame projections (outputs (k, label), k < 5), and

@@ -421,6 +421,9 @@ static size_t fused_scores_smem_tb(uint32_t W, uint32_t D, uint32_t TB) {
 uint32_t fused_scores_tb(uint32_t W, uint32_t D) {
   for (uint32_t TB = FU_ROWS / D; TB >= 1; TB--)
     if (fused_scores_smem_tb(W, D, TB) <= 80 * 1024) return TB;
+  // long durations with wide frames (D = 32 at W = 39): one workgroup per CU, as many frames as fit
+  for (uint32_t TB = FU_ROWS / D; TB >= 1; TB--)
+    if (fused_scores_smem_tb(W, D, TB) <= 156 * 1024) return TB;
   return 0;
 }
 static size_t fused_scores_smem(uint32_t W, uint32_t D) { return fused_scores_smem_tb(W, D, fused_scores_tb(W, D)); }
@@ -1094,7 +1097,7 @@ int fused_supported(const ScrfLayout& lay, uint32_t W) {
   uint32_t n_ct;
   fused_expf_xs(lay, W, &n_ct);
   if (lay.D < 2 || lay.D > 40 || W < 1 || n_ct > 13) return 0;
-  if (fused_expf_smem(lay, W) > 80 * 1024) return 0;
+  if (fused_expf_smem(lay, W) > 156 * 1024) return 0;   // above 80 KB: one workgroup per CU instead of two
   return fused_scores_tb(W, lay.D) >= 1;
 }
 

@@ -69,6 +69,7 @@ void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uin
 
 // scrf_dplin.hip: scaled linear-domain forward/backward + posteriors (training path, L <= 64)
 int dplin_mw_supported(const ScrfLayout& lay);
+int dplin_supported(const ScrfLayout& lay);
 void launch_true_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
                         uint64_t n_frames, const double* S, double* s_true);
 void launch_exp_rows(hipStream_t st, double* S, uint64_t n_rows, uint32_t L, double* smax);

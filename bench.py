@@ -202,6 +202,14 @@ def main():
         if executed is not None:
             roofline["executed_per_launch"] = round(executed, 6)
             roofline["frac_executed"] = round(executed / (avg_ms / 1e3) / peak, 5)
+        # the whole step against SURVEY 8d's per-utterance totals (F_alg = two dense contractions,
+        # B_alg = frames + 3 passes over S + 2 over the recursion arrays): rank-local, timed region
+        step_s = dt / args.steps
+        f_alg = 2.0 * flops_gemm * U
+        b_alg = (4.0 * T_FRAMES * IN_W + 3 * 8.0 * (nseg * L + L * L) + 2 * 8.0 * (nseg * L + 2 * T_FRAMES * L)) * U
+        roofline["step"] = {"algorithmic_tflop": round(f_alg / 1e12, 4), "tflops": round(f_alg / 1e12 / step_s, 2),
+                            "frac_mfma": round(f_alg / 1e12 / step_s / mfma_peak, 4),
+                            "algorithmic_gb": round(b_alg / 1e9, 2), "frac_hbm": round(b_alg / 1e9 / step_s / PEAK["hbm_gbs"], 4)}
         out = {
             "metric": "utterances/sec SCRF forward-backward (TIMIT-shape)",
             "value": round(U * world * args.steps / dt, 2),

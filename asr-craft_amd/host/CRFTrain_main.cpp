@@ -15,7 +15,10 @@ int main(int argc, char** argv) {
     if (a.has("cv_sent_range") && a.str("cv_sent_range") != "nil" && a.str("cv_sent_range") != "none")
       std::cout << "NOTE: cv_sent_range=" << a.str("cv_sent_range") << " ignored: the cross-validation pass is not built" << std::endl;
     if (a.str("crf_train_method", "sg") != "sg") { std::cerr << "only crf_train_method=sg is built" << std::endl; return 1; }
-    if (a.str("crf_train_order", "seq") != "seq") std::cout << "NOTE: crf_train_order=" << a.str("crf_train_order") << " ignored: sequential presentation (QuickNet's RNG is not reproducible here)" << std::endl;
+    // presentation order: seq (default HERE; the reference defaults to random) | random | noreplace
+    const std::string order = a.str("crf_train_order", "seq");
+    if (order != "seq" && order != "random" && order != "noreplace") { std::cerr << "crf_train_order=" << order << " (seq|random|noreplace)" << std::endl; return 1; }
+    if (order != "seq") std::cout << "NOTE: crf_train_order=" << order << ": orders come from std::mt19937_64 seeded like the reference (12345*epoch+seed); QuickNet's generator is not reproducible here, so the sequence differs from the reference's" << std::endl;
 
     CRF_Model crf(m.L);
     crf.setLabMaxDur(m.D);
@@ -40,6 +43,7 @@ int main(int argc, char** argv) {
     if (a.real("crf_gauss_var", 0.0) != 0.0) { std::cerr << "crf_gauss_var: the Gaussian prior is not built" << std::endl; return 1; }
 
     CRF_MemoryFeatureStream all(m.recipes, m.D, m.fmap.nActualLabs);
+    const seqtype trn_seq = order == "seq" ? SEQUENTIAL : (order == "noreplace" ? RANDOM_NO_REPLACE : RANDOM_REPLACE);
     const size_t U = sents.size();
     for (size_t i = 0; i < U; i++) {
       const uint32_t u = sents[i];
@@ -47,6 +51,7 @@ int main(int argc, char** argv) {
       for (size_t s = 0; s < data.size(); s++) { fr[s] = data[s].get(u); data[s].drop(u); }
       all.addUtterance(fr, u < labs.size() ? labs[u] : std::vector<uint32_t>());
     }
+    if (trn_seq != SEQUENTIAL) all.setPresentation(trn_seq, (QNUInt32)a.num("crf_random_seed", 0));
     // `threads` child streams over contiguous ranges (io/CRF_FeatureStreamManager.cpp:425-464)
     const size_t N = (size_t)std::max(1L, a.num("threads", 1));
     std::vector<std::unique_ptr<CRF_MemoryFeatureStream> > views;

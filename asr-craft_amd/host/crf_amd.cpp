@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <random>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -233,17 +234,48 @@ CRF_MemoryFeatureStream* CRF_MemoryFeatureStream::view(size_t start, size_t coun
   v->begin_ = begin_ + start;
   v->end_ = std::min(end_, v->begin_ + count);
   v->cur_ = -1;
+  if (v->mode_ != SEQUENTIAL) { v->epoch_ = 0; v->rewind(); }   // its own order over its own range
   return v;
 }
 
+void CRF_MemoryFeatureStream::setPresentation(seqtype type, QNUInt32 seed) {
+  mode_ = type;
+  seed_ = seed;
+  epoch_ = 0;
+  rewind();   // the RandPresent constructor rewinds once (:38)
+}
+
 QN_SegID CRF_MemoryFeatureStream::nextseg() {
+  if (mode_ != SEQUENTIAL) {
+    if (pos_ >= order_.size()) { cur_ = (long)end_; return QN_SEGID_BAD; }
+    cur_ = (long)(begin_ + order_[pos_++]);
+    frame_ = 0;
+    return (QN_SegID)(cur_ - (long)begin_);
+  }
   long nxt = cur_ < 0 ? (long)begin_ : cur_ + 1;
   if (nxt >= (long)end_) { cur_ = (long)end_; return QN_SEGID_BAD; }
   cur_ = nxt;
   frame_ = 0;
   return (QN_SegID)(cur_ - (long)begin_);
 }
-int CRF_MemoryFeatureStream::rewind() { cur_ = -1; frame_ = 0; return 0; }
+int CRF_MemoryFeatureStream::rewind() {
+  cur_ = -1;
+  frame_ = 0;
+  if (mode_ != SEQUENTIAL) {
+    epoch_++;
+    const size_t n = end_ - begin_;
+    std::mt19937_64 gen(12345ull * epoch_ + seed_);
+    order_.resize(n);
+    if (mode_ == RANDOM_NO_REPLACE) {
+      for (size_t i = 0; i < n; i++) order_[i] = i;
+      for (size_t i = n; i > 1; i--) std::swap(order_[i - 1], order_[gen() % i]);   // Fisher-Yates, spelled out
+    } else {
+      for (size_t i = 0; i < n; i++) order_[i] = n ? gen() % n : 0;
+    }
+    pos_ = 0;
+  }
+  return 0;
+}
 
 bool CRF_MemoryFeatureStream::currentUtterance(Utterance* u) {
   if (cur_ < (long)begin_ || cur_ >= (long)end_) return false;
@@ -492,6 +524,9 @@ void CRF_SGTrainer::train() {
   QNUInt32 uCounter = 0;
   int accCnt = (int)crf_ptr->getPresentations();
   double totLogLi = 0.0;
+  // a resumed run replays the presentation-order generator (CRF_SGTrainer.cpp:88-93)
+  for (int i = 0; i < iCounter; i++)
+    for (CRF_FeatureStream* st_ : streams) st_->rewind();
   gaccum.rewindAllAndNextSegs();
   bool start = true;
   while (iCounter < maxIters) {

@@ -32,6 +32,7 @@ typedef int32_t QNInt32;
 typedef long QN_SegID;
 #define QN_SEGID_BAD (-1L)
 #define CRF_LAB_BAD SCRF_LAB_BAD
+enum seqtype { SEQUENTIAL, RANDOM_NO_REPLACE, RANDOM_REPLACE };   // CRF.h:38
 #define CRF_UINT32_MAX (0xffffffffu)
 
 enum ftrmaptype { STDSTATE, STDTRANS, STDSPARSE, STDSPARSETRANS, INFILE };                       // CRF.h:40
@@ -149,6 +150,12 @@ class CRF_MemoryFeatureStream : public CRF_FeatureStream {
   // frames[s]: (T + lctx_s + rctx_s) x in_width_s, frame_labels: T phone ids (or empty)
   void addUtterance(const std::vector<std::vector<float> >& frames, const std::vector<uint32_t>& frame_labels);
   CRF_MemoryFeatureStream* view(size_t start, size_t count);  // child stream over a contiguous range
+  // presentation order of the utterances (io/CRF_InFtrStream_RandPresent.cpp): a new order at every
+  // rewind(), generator seeded with 12345 * epoch + seed as there (:125-128); RANDOM_REPLACE draws
+  // numUtterances() utterances with replacement, RANDOM_NO_REPLACE a permutation.  The generator is
+  // std::mt19937_64 with a plain modulo draw -- QuickNet's QN_SeqGen_* are not in the tree, so the
+  // ORDER differs from the reference's for the same seed.  Views made afterwards inherit the mode.
+  void setPresentation(seqtype type, QNUInt32 seed);
   size_t numUtterances() const { return end_ - begin_; }
   QN_SegID nextseg() override;
   size_t read(size_t bunch, float* ftr_buf, QNUInt32* lab_buf) override;
@@ -171,6 +178,10 @@ class CRF_MemoryFeatureStream : public CRF_FeatureStream {
   size_t begin_ = 0, end_ = 0, width_ = 0;
   long cur_ = -1;
   uint32_t frame_ = 0;
+  seqtype mode_ = SEQUENTIAL;
+  QNUInt32 seed_ = 0, epoch_ = 0;
+  std::vector<size_t> order_;   // utterance offsets inside [begin_, end_) in presentation order
+  size_t pos_ = 0;
 };
 
 namespace crf_amd {

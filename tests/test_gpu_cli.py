@@ -333,3 +333,64 @@ def test_flags_that_would_change_the_numbers_are_refused(tmp_path, flag, msg):
     r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + ["hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"),
                         "out_weight_file=" + str(tmp_path / "w.out"), "crf_epochs=1", flag], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and msg in r.stderr and not os.path.exists(str(tmp_path / "w.out"))
+
+
+class _MT64:
+    """std::mt19937_64 (the generator behind crf_train_order=random|noreplace)."""
+    def __init__(self, seed):
+        self.mt = [0] * 312
+        self.mt[0] = seed & 0xFFFFFFFFFFFFFFFF
+        for i in range(1, 312):
+            self.mt[i] = (6364136223846793005 * (self.mt[i - 1] ^ (self.mt[i - 1] >> 62)) + i) & 0xFFFFFFFFFFFFFFFF
+        self.i = 312
+
+    def __call__(self):
+        if self.i >= 312:
+            for k in range(312):
+                x = (self.mt[k] & 0xFFFFFFFF80000000) | (self.mt[(k + 1) % 312] & 0x7FFFFFFF)
+                self.mt[k] = self.mt[(k + 156) % 312] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+            self.i = 0
+        y = self.mt[self.i]; self.i += 1
+        y ^= (y >> 29) & 0x5555555555555555
+        y ^= (y << 17) & 0x71D67FFFEDA60000
+        y ^= (y << 37) & 0xFFF7EEE000000000
+        y ^= y >> 43
+        return y & 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.parametrize("order", ["noreplace", "random"])
+def test_crftrain_presentation_orders(tmp_path, order):
+    """crf_train_order=random|noreplace (io/CRF_InFtrStream_RandPresent.cpp): a fresh order per epoch from
+    a generator seeded 12345 * epoch + crf_random_seed; the run equals the oracle's SGD loop fed the
+    same orders (the ORDER itself is this build's: QuickNet's generator is not in the tree)."""
+    assert _MT64(5489)() == 14514284786278117030   # the generator's known first output
+    out = str(tmp_path / "w.out")
+    seed, epochs, lr = 7, 3, 0.1
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + [
+        "hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + out, "crf_epochs=%d" % epochs, "crf_lr=%g" % lr,
+        "crf_bunch_size=1", "threads=1", "crf_train_order=" + order, "crf_random_seed=%d" % seed], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "NOTE: crf_train_order=" + order in r.stdout
+    utts = _fixture(); n = len(utts)
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    lam = np.zeros(lay.lambda_len); acc = np.zeros_like(lam); gsa = np.zeros_like(lam)
+    seen = []
+    for it in range(epochs):
+        gen = _MT64(12345 * (it + 2) + seed)   # one rewind at construction, one before the first iteration
+        if order == "noreplace":
+            seq = list(range(n))
+            for i in range(n, 1, -1):
+                j = gen() % i
+                seq[i - 1], seq[j] = seq[j], seq[i - 1]
+        else:
+            seq = [gen() % n for _ in range(n)]
+        seen.append(seq)
+        for u in seq:
+            X, lab = utts[u]
+            rc, g, _, _ = orc.frame_build_gradient(cfg, lay, lam, X, lab, X.shape[0], grad=np.zeros(lay.lambda_len))
+            assert rc == 0
+            orc.sgd_step(lam, acc, gsa, orc.minibatch_reduce(g[None, :], [1]), np.float32(lr), False, 1e-12)
+    if order == "noreplace":
+        assert all(sorted(s) == list(range(n)) for s in seen)
+    ref = np.array([float("%g" % v) for v in lam])
+    np.testing.assert_allclose(np.loadtxt(out), ref, rtol=2e-5, atol=1e-12)

@@ -216,7 +216,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
-  if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = atof(e);
+  if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = std::max(1.0, atof(e));   // widening only: < 1 would void the bound
   memset(h->ms, 0, sizeof(h->ms));
   memset(h->nlaunch, 0, sizeof(h->nlaunch));
 #define CRCHK(call)                                                                          \

@@ -501,23 +501,36 @@ void launch_expf_gemm(hipStream_t st, const double* A, uint32_t n_out, const flo
   }
 }
 
-// grad[woff(o)+f] += sum_z slab[z][o][f], fixed z order (bit-reproducible)
-__global__ void k_reduce_slabs(const double* __restrict__ slab, uint32_t n_chunks, uint32_t n_out,
-                               ScrfLayout lay, ScrfGemmSpec sp, double* __restrict__ grad) {
+// grad[woff(o)+f] += sum_z slab[z][o][f].  Fixed association (bit-reproducible): the z range is cut into
+// RS_G contiguous groups, each summed in ascending z by one thread, the group sums added in group order.
+#define RS_G 8
+__global__ __launch_bounds__(64 * RS_G) void k_reduce_slabs(const double* __restrict__ slab, uint32_t n_chunks, uint32_t n_out,
+                                                            ScrfLayout lay, ScrfGemmSpec sp, double* __restrict__ grad) {
+  __shared__ double part[RS_G][64];
   const uint32_t nfun = sp.nfun();
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (uint64_t)n_out * nfun) return;
-  uint32_t o = (uint32_t)(i / nfun), f = (uint32_t)(i % nfun);
+  const uint64_t n = (uint64_t)n_out * nfun;
+  const uint32_t tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + tx;
+  const uint32_t per = (n_chunks + RS_G - 1) / RS_G, z0 = g * per, z1 = min(n_chunks, z0 + per);
   double s = 0.0;
-  for (uint32_t z = 0; z < n_chunks; z++) s += slab[(uint64_t)z * n_out * nfun + i];
-  grad[sp.woff(lay, o) + f] += s;
+  if (i < n)
+    for (uint32_t z = z0; z < z1; z++) s += slab[(uint64_t)z * n + i];
+  part[g][tx] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    double t = part[0][tx];
+#pragma unroll
+    for (int k = 1; k < RS_G; k++) t += part[k][tx];
+    const uint32_t o = (uint32_t)(i / nfun), f = (uint32_t)(i % nfun);
+    grad[sp.woff(lay, o) + f] += t;
+  }
 }
 
 void launch_reduce_slabs(hipStream_t st, const double* slab, uint32_t n_chunks, uint32_t n_out,
                          const ScrfLayout& lay, const ScrfGemmSpec& sp, double* grad) {
   uint64_t n = (uint64_t)n_out * sp.nfun();
   if (n == 0 || n_chunks == 0) return;
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, slab, n_chunks, n_out,
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((uint32_t)((n + 63) / 64)), dim3(64 * RS_G), 0, st, slab, n_chunks, n_out,
                      lay, sp, grad);
 }
 

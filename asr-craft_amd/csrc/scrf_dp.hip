@@ -369,7 +369,7 @@ typedef double atb_v4f64 __attribute__((ext_vector_type(4)));
 template <int LT>
 __global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const double* __restrict__ B, uint32_t L,
                                              uint64_t n_frames, uint64_t rows_per_chunk, uint32_t n_chunks,
-                                             double* __restrict__ slab) {
+                                             double* __restrict__ slab, const double* __restrict__ bscale) {
   const uint32_t lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t z = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (z >= n_chunks) return;
@@ -385,11 +385,13 @@ __global__ __launch_bounds__(256) void k_atb(const double* __restrict__ A, const
   double a_n[LT], b_n[LT];
   auto load = [&](uint64_t f0) {
     const uint64_t f = f0 + lk;
+    const double sc = bscale ? (f < r_end ? bscale[f] : 0.0) : 1.0;   // per-frame factor of the B rows (k_xi_scale)
 #pragma unroll
     for (int i = 0; i < LT; i++) {
       const uint32_t c = c0 + i * 16 + li, n = n0 + i * 16 + li;
       a_n[i] = (f < r_end && c < L) ? A[f * L + c] : 0.0;
-      b_n[i] = (f < r_end && n < L) ? B[f * L + n] : 0.0;
+      const double bv_ = (f < r_end && n < L) ? B[f * L + n] : 0.0;
+      b_n[i] = bscale ? bv_ * sc : bv_;
     }
   };
   load(r_begin);
@@ -439,12 +441,13 @@ __global__ __launch_bounds__(64 * RA_G) void k_reduce_atb(const double* __restri
 }
 int atb_supported(const ScrfLayout& lay) { return lay.L <= 256; }
 void launch_atb(hipStream_t st, const ScrfLayout& lay, const double* A, const double* B, uint64_t n_frames,
-                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad) {
+                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad,
+                const double* bscale) {
   if (n_frames == 0 || n_chunks == 0 || !lay.use_tb) return;
   const uint32_t nb = (lay.L + 63) / 64;
   const dim3 grid((n_chunks + 3) / 4, nb * nb);
   const uint32_t lt = lay.L > 64 ? 4 : (lay.L + 15) / 16;
-#define ATB_GO(N) hipLaunchKernelGGL(k_atb<N>, grid, dim3(256), 0, st, A, B, lay.L, n_frames, rows_per_chunk, n_chunks, slab)
+#define ATB_GO(N) hipLaunchKernelGGL(k_atb<N>, grid, dim3(256), 0, st, A, B, lay.L, n_frames, rows_per_chunk, n_chunks, slab, bscale)
   if (lt <= 1) ATB_GO(1);
   else if (lt == 2) ATB_GO(2);
   else if (lt == 3) ATB_GO(3);

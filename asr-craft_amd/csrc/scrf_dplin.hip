@@ -657,6 +657,24 @@ void launch_xi_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, cons
   hipLaunchKernelGGL(k_xi_lin, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, lay, bv, frame_u, u0, n_frames, o, zx);
 }
 
+// bias-only transitions: the per-frame factor of B alone, gsd[t] <- exp(ga[t] + gsd[t] - Zx) (0 at an
+// utterance's last frame); k_atb multiplies it into the sd rows as it loads them (same product, same
+// rounding as k_xi_lin's in-place pass, without the read-modify-write of the [T][L] array)
+__global__ void k_xi_scale(ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0, uint64_t n_frames,
+                           ScrfDpLin o, const double* __restrict__ zx) {
+  const uint64_t fi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (fi >= n_frames) return;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  const uint32_t u = frame_u[gf];
+  const bool last = (gf + 1 == bv.frame_off[u + 1]);
+  o.gsd[fi] = last ? 0.0 : exp(o.ga[fi] + o.gsd[fi] - zx[u]);
+}
+void launch_xi_scale(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                     const ScrfDpLin& o, const double* zx) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_xi_scale, dim3((uint32_t)((n_frames + 255) / 256)), dim3(256), 0, st, bv, frame_u, u0, n_frames, o, zx);
+}
+
 // parity hook: alpha = log(a) + ga, beta = log(b) + gb
 __global__ void k_lin_to_log(uint64_t n_frames, uint32_t L, const double* __restrict__ m, const double* __restrict__ g,
                              double* __restrict__ out) {

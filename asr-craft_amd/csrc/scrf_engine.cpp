@@ -1028,7 +1028,10 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
                         cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
       }
       launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
-      launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
+      // transition posteriors: with transition features the rescaled sd rows are needed as an array; with
+      // bias-only transitions only their per-frame factor is, applied inside the A^T B contraction
+      if (l.use_tf) launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
+      else launch_xi_scale(cb.st, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
       nl += 4;
       if (l.use_tf) {
         launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
@@ -1173,7 +1176,8 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
         launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 5 * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
       if (l.use_tf) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
-      else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad);
+      else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad,
+                                   cb.lin ? cb.dl.gsd : nullptr);
       else launch_reduce_xiacc(cb.st, cb.xi_acc, (uint32_t)nutt, l, cb.grad);
       launch_batch_sums(cb.st, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, cb.sums);
       tm.stop(3);

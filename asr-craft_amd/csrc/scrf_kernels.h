@@ -61,7 +61,8 @@ void launch_xi_factors(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, 
                        uint64_t n_frames, const double* alpha_g, const double* sd_g, const double* zx, double* A,
                        double* B);
 void launch_atb(hipStream_t st, const ScrfLayout& lay, const double* A, const double* B, uint64_t n_frames,
-                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad);
+                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, const double* M0, double* grad,
+                const double* bscale = nullptr);   // bscale[f]: factor of row f of B (linear-domain path)
 void launch_add_trans_counts(hipStream_t st, const uint32_t* counts, const ScrfLayout& lay, double* grad);
 void launch_xi_full(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
                     uint64_t n_frames, const uint32_t* next_lab, const double* A, const double* B, const double* E,
@@ -82,6 +83,8 @@ void launch_post_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, co
                      double* numer_f, int* status);
 void launch_xi_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
                    uint64_t n_frames, const ScrfDpLin& o, const double* zx);
+void launch_xi_scale(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                     const ScrfDpLin& o, const double* zx);
 void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const double* m, const double* g, double* out);
 
 // scrf_fused.hip: state contractions with the window synthesis fused in (X never materialised)

@@ -573,18 +573,19 @@ void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint3
 // A wavefront owns 80 outputs (5 MFMA tiles).  k_pframe keeps its slice of lambda in registers and
 // streams 16-frame tiles; k_ztf streams its frame range four frames at a time.
 // ------------------------------------------------------------------------------------------
+#define PF_MT 4      // output tiles per wavefront (64 outputs)
 template <int KS>   // k-steps: ceil(W / 4)
 __global__ __launch_bounds__(64) void k_pframe(const float* __restrict__ F, uint32_t W, uint64_t n_frames,
                                                uint64_t frames_per_wave, const double* __restrict__ lambda,
                                                ScrfLayout lay, uint32_t n_out, double* __restrict__ P) {
   const uint32_t lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
-  const uint32_t og = blockIdx.y * 80;
+  const uint32_t og = blockIdx.y * (16 * PF_MT);
   const uint64_t f_begin = (uint64_t)blockIdx.x * frames_per_wave;
   const uint64_t f_end = min(n_frames, f_begin + frames_per_wave);
   // B[k = c][j = o]: lane (li = o, lk = c within the k-step)
-  double bw[5][KS];
+  double bw[PF_MT][KS];
 #pragma unroll
-  for (int nt = 0; nt < 5; nt++) {
+  for (int nt = 0; nt < PF_MT; nt++) {
     const uint32_t o = og + nt * 16 + li;
     const uint32_t wo = (o < n_out) ? lay.state_idx(o % lay.L) + (o / lay.L) * W : 0;
 #pragma unroll
@@ -593,32 +594,29 @@ __global__ __launch_bounds__(64) void k_pframe(const float* __restrict__ F, uint
       bw[nt][ks] = (o < n_out && c < W) ? lambda[wo + c] : 0.0;
     }
   }
-  // A[i = frame][k = c]: lane (li = frame, lk = c); the next tile's fragments are fetched before the
-  // current tile's stores are issued (loads and stores share one in-order counter on gfx9)
-  double a_n[KS];
-  auto load_a = [&](uint64_t f0) {
+  // A[i = frame][k = c]: lane (li = frame, lk = c), kept as floats until used; two 16-frame tiles are in
+  // flight while a third is multiplied and stored (loads and stores share one in-order counter on gfx9)
+  float a1[KS], a2[KS];
+  auto load_a = [&](uint64_t f0, float (&a_n)[KS]) {
     const uint64_t f = f0 + li;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       const uint32_t c = ks * 4 + lk;
-      a_n[ks] = (f < f_end && c < W) ? (double)F[f * W + c] : 0.0;
+      a_n[ks] = (f < f_end && c < W) ? F[f * W + c] : 0.0f;
     }
   };
-  load_a(f_begin);
-  for (uint64_t f0 = f_begin; f0 < f_end; f0 += 16) {
-    double a[KS];
+  auto tile = [&](uint64_t f0, const float (&av)[KS]) {
+    v4f64 acc[PF_MT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) a[ks] = a_n[ks];
-    if (f0 + 16 < f_end) load_a(f0 + 16);
-    v4f64 acc[5];
+    for (int nt = 0; nt < PF_MT; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int nt = 0; nt < 5; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int ks = 0; ks < KS; ks++) {
+      const double a = (double)av[ks];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++)
+      for (int nt = 0; nt < PF_MT; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bw[nt][ks], acc[nt], 0, 0, 0);
+    }
 #pragma unroll
-      for (int nt = 0; nt < 5; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], bw[nt][ks], acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < 5; nt++) {
+    for (int nt = 0; nt < PF_MT; nt++) {
       const uint32_t o = og + nt * 16 + li;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -626,16 +624,31 @@ __global__ __launch_bounds__(64) void k_pframe(const float* __restrict__ F, uint
         if (fr_ < f_end && o < n_out) P[fr_ * n_out + o] = acc[nt][r];
       }
     }
+  };
+  load_a(f_begin, a1);
+  load_a(f_begin + 16, a2);
+  for (uint64_t f0 = f_begin; f0 < f_end; f0 += 32) {
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) a[ks] = a1[ks];
+    load_a(f0 + 32, a1);
+    tile(f0, a);
+    if (f0 + 16 < f_end) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) a[ks] = a2[ks];
+      load_a(f0 + 48, a2);
+      tile(f0 + 16, a);
+    }
   }
 }
 
 void launch_pframe(hipStream_t st, const float* F, uint32_t W, uint64_t n_frames, const double* lambda,
                    const ScrfLayout& lay, uint32_t n_out, double* P) {
   if (n_frames == 0) return;
-  // about 2048 wavefronts per 80-output group, whole 16-frame tiles each
-  uint64_t fpw = ((n_frames + 2047) / 2048 + 15) & ~15ull;
+  // about 2048 wavefronts per output group, whole pairs of 16-frame tiles each
+  uint64_t fpw = ((n_frames + 2047) / 2048 + 31) & ~31ull;
   if (fpw < 64) fpw = 64;
-  dim3 grid((uint32_t)((n_frames + fpw - 1) / fpw), (n_out + 79) / 80);
+  dim3 grid((uint32_t)((n_frames + fpw - 1) / fpw), (n_out + 16 * PF_MT - 1) / (16 * PF_MT));
   const uint32_t ks = (W + 3) / 4;
 #define PF_GO(N) hipLaunchKernelGGL(k_pframe<N>, grid, dim3(64), 0, st, F, W, n_frames, fpw, lambda, lay, n_out, P)
   if (ks <= 4) PF_GO(4);
@@ -646,49 +659,62 @@ void launch_pframe(hipStream_t st, const float* F, uint32_t W, uint64_t n_frames
 }
 int pframe_supported(uint32_t W) { return W <= 80; }
 
+#define ZT_MT 4     // output tiles per wavefront (64 outputs): leaves registers for a second prefetch stage
 template <int NT>   // column tiles: ceil(W / 16)
 __global__ __launch_bounds__(64) void k_ztf(const double* __restrict__ Zm, uint32_t n_out, const float* __restrict__ F,
                                             uint32_t W, uint64_t n_frames, uint64_t rows_per_chunk,
                                             double* __restrict__ slab) {
   const uint32_t lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
-  const uint32_t og = blockIdx.y * 80;
+  const uint32_t og = blockIdx.y * (16 * ZT_MT);
   const uint64_t r_begin = (uint64_t)blockIdx.x * rows_per_chunk;
   const uint64_t r_end = min(n_frames, r_begin + rows_per_chunk);
-  v4f64 acc[5][NT];
+  v4f64 acc[ZT_MT][NT];
 #pragma unroll
-  for (int i = 0; i < 5; i++)
+  for (int i = 0; i < ZT_MT; i++)
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  double a_n[5], b_n[NT];
-  auto load = [&](uint64_t f0) {
+  // two groups of four frames are in flight while a third is multiplied
+  double a1[ZT_MT], a2[ZT_MT];
+  float b1[NT], b2[NT];
+  auto load = [&](uint64_t f0, double (&a_n)[ZT_MT], float (&b_n)[NT]) {
     const uint64_t f = f0 + lk;
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < ZT_MT; i++) {
       const uint32_t o = og + i * 16 + li;
       a_n[i] = (f < r_end && o < n_out) ? Zm[f * n_out + o] : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const uint32_t c = j * 16 + li;
-      b_n[j] = (f < r_end && c < W) ? (double)F[f * W + c] : 0.0;
+      b_n[j] = (f < r_end && c < W) ? F[f * W + c] : 0.0f;
     }
   };
-  load(r_begin);
-  for (uint64_t f0 = r_begin; f0 < r_end; f0 += 4) {
-    double a[5], b[NT];
+  load(r_begin, a1, b1);
+  load(r_begin + 4, a2, b2);
+  for (uint64_t f0 = r_begin; f0 < r_end; f0 += 8) {
+    double a[ZT_MT], b[NT];
 #pragma unroll
-    for (int i = 0; i < 5; i++) a[i] = a_n[i];
+    for (int i = 0; i < ZT_MT; i++) a[i] = a1[i];
 #pragma unroll
-    for (int j = 0; j < NT; j++) b[j] = b_n[j];
-    if (f0 + 4 < r_end) load(f0 + 4);
+    for (int j = 0; j < NT; j++) b[j] = (double)b1[j];
+    load(f0 + 8, a1, b1);
 #pragma unroll
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < ZT_MT; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < ZT_MT; i++) a[i] = a2[i];
+#pragma unroll
+    for (int j = 0; j < NT; j++) b[j] = (double)b2[j];
+    load(f0 + 12, a2, b2);
+#pragma unroll
+    for (int i = 0; i < ZT_MT; i++)
 #pragma unroll
       for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
   double* out = slab + (size_t)blockIdx.x * n_out * W;
 #pragma unroll
-  for (int i = 0; i < 5; i++)
+  for (int i = 0; i < ZT_MT; i++)
 #pragma unroll
     for (int j = 0; j < NT; j++)
 #pragma unroll
@@ -702,7 +728,7 @@ __global__ __launch_bounds__(64) void k_ztf(const double* __restrict__ Zm, uint3
 void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F, uint32_t W, uint64_t n_frames,
                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   if (n_frames == 0 || n_chunks == 0) return;
-  dim3 grid(n_chunks, (n_out + 79) / 80);
+  dim3 grid(n_chunks, (n_out + 16 * ZT_MT - 1) / (16 * ZT_MT));
   const uint32_t nt = (W + 15) / 16;
 #define ZT_GO(N) hipLaunchKernelGGL(k_ztf<N>, grid, dim3(64), 0, st, Zm, n_out, F, W, n_frames, rows_per_chunk, slab)
   if (nt <= 1) ZT_GO(1);

@@ -1,5 +1,5 @@
-// CRFDecode -- Viterbi decode front-end (CRFDecode/src/Main.cpp) for the case the reference
-// decodes against its own free-phone-loop LM (no crf_lm_bin): per utterance the best path from
+// CRFDecode -- Viterbi decode front-end (CRFDecode/src/Main.cpp): against the reference's own
+// free-phone-loop LM (no LM given) or against an LM FST in OpenFST text format (crf_lm_txt): per utterance the best path from
 // CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode, written as an HTK MLF
 // (crf_output_mlffile + crf_olist + crf_osymbols, Main.cpp:803-835,1176-1330) and, with
 // crf_lat_outdir, as a text arc list `src dst ilabel olabel weight` + `final weight` per
@@ -20,7 +20,7 @@ static std::map<long, std::string> read_symbols(const std::string& path) {
 
 int main(int argc, char** argv) {
   Args a(argc, argv);
-  if (a.has("crf_lm_bin") || a.has("crf_lm_arpa")) { std::cerr << "crf_lm_bin / crf_lm_arpa: decoding against an LM FST is not built (free phone loop only)" << std::endl; return 1; }
+  if (a.has("crf_lm_bin") || a.has("crf_lm_arpa")) { std::cerr << "crf_lm_bin / crf_lm_arpa: OpenFST binary and ARPA readers are not built; print the LM with `fstprint` and pass it as crf_lm_txt" << std::endl; return 1; }
   if (!a.has("crf_output_labelfile") && !a.has("crf_output_mlffile")) { std::cerr << "At least one of crf_output_labelfile or crf_output_mlffile must be assigned" << std::endl; return -1; }
   if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
   if (!a.has("crf_olist")) { std::cerr << "crf_olist required currently." << std::endl; return -1; }  // Main.cpp:1022-1025
@@ -36,6 +36,15 @@ int main(int argc, char** argv) {
     if (!f.is_open()) { std::cerr << "ERROR: Failed opening file: " << a.str("crf_olist") << std::endl; return -1; }
     std::string s;
     while (getline(f, s)) olist.push_back(s);
+  }
+  // language model: OpenFST text format (tropical weights), numeric labels: ilabel = phone + 1, olabel = word
+  crf_amd::ArcListFst lm;
+  const bool have_lm = a.has("crf_lm_txt");
+  if (have_lm) {
+    try {
+      crf_amd::readFstText(a.str("crf_lm_txt").c_str(), &lm);
+    } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+    std::cout << "LM: " << lm.n_states << " states, " << lm.arcs.size() << " arcs, " << lm.finals.size() << " final" << std::endl;
   }
   std::map<long, std::string> osym;
   const bool have_osym = a.has("crf_osymbols");
@@ -80,7 +89,7 @@ int main(int argc, char** argv) {
       CRF_ViterbiDecoder_StdSeg_NoSegTransFtr vd(&strm, &crf);
       vd.setIfOutputFullFst(a.num("crf_if_output_full_lat", 0) != 0);
       crf_amd::ArcListFst best_lat;
-      vd.nStateDecode(&best_lat, (crf_amd::ArcListFst*)nullptr, (crf_amd::ArcListFst*)nullptr, a.real("crf_decode_beam", 0.0),
+      vd.nStateDecode(&best_lat, have_lm ? &lm : (crf_amd::ArcListFst*)nullptr, (crf_amd::ArcListFst*)nullptr, a.real("crf_decode_beam", 0.0),
                       (unsigned)a.num("crf_decode_min_hyp", 0), (unsigned)a.num("crf_decode_max_hyp", 0), (float)a.real("crf_decode_hyp_inc", 0.05));
       std::cout << "Acoustic model weight (negative log potential) = " << vd.getBestWeight() << ", -Z(X) = " << -1 * vd.getZx()
                 << ", language model weight (negative log probability) = " << 0 << std::endl;

@@ -656,6 +656,237 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decode() {
   return (int)T;
 }
 
+void crf_amd::readFstText(const char* fname, crf_amd::ArcListFst* fst) {
+  std::ifstream f(fname);
+  if (!f.is_open()) throw runtime_error(string("readFstText: cannot open ") + fname);
+  string line;
+  int max_state = -1;
+  bool first = true;
+  while (getline(f, line)) {
+    std::istringstream is(line);
+    std::vector<string> tok;
+    string t;
+    while (is >> t) tok.push_back(t);
+    if (tok.empty()) continue;
+    if (tok.size() >= 4) {
+      const int src = atoi(tok[0].c_str()), dst = atoi(tok[1].c_str());
+      const float w = tok.size() >= 5 ? (float)atof(tok[4].c_str()) : 0.0f;
+      if (first) { fst->start = src; first = false; }
+      fst->arcs.push_back(scrf_arc{src, atoi(tok[2].c_str()), atoi(tok[3].c_str()), w, dst});
+      max_state = std::max(max_state, std::max(src, dst));
+    } else if (tok.size() <= 2) {
+      const int st = atoi(tok[0].c_str());
+      if (first) { fst->start = st; first = false; }
+      fst->SetFinal(st, tok.size() == 2 ? (float)atof(tok[1].c_str()) : 0.0f);
+      max_state = std::max(max_state, st);
+    } else {
+      throw runtime_error(string("readFstText: ") + fname + ": cannot parse line '" + line + "'");
+    }
+  }
+  if (first) throw runtime_error(string("readFstText: ") + fname + " is empty");
+  fst->n_states = max_state + 1;
+}
+
+int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst) {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  const uint32_t T = utts[0].u.T, L = crf->getNActualLabs() ? crf->getNActualLabs() : crf->getNLabs(), D = crf->getLabMaxDur();
+  segs.clear();
+  n_hyps = 0;
+  uint64_t n_frames = 0, n_segs = 0, n_arcs = 0;
+  uint32_t nu = 0;
+  e->check(scrf_batch_info(e->h, g.b, &nu, &n_frames, &n_segs, &n_arcs), "nStateDecode");
+  std::vector<double> S((size_t)n_segs * L), M((size_t)T * L * L);
+  e->check(scrf_scores(e->h, g.b, 0, S.data(), M.data()), "nStateDecode");
+  e->check(scrf_forward_backward(e->h, g.b, 0, SCRF_PREC_EXACT, nullptr, nullptr, nullptr, &zx), "nStateDecode");
+  const float INF = 99999.0f;   // the decoder's "infinity"
+  const int Q = lm.n_states;
+  if (Q <= 0 || lm.start < 0) throw runtime_error("nStateDecode: the LM FST has no start state");
+  if ((size_t)Q * L > (size_t)1 << 24) throw runtime_error("nStateDecode: LM too large for the dense (state, phone) search");
+  // LM arcs per state; labels above the phone inventory are ignored like disambiguation symbols
+  std::vector<std::vector<int> > out(Q);
+  for (size_t i = 0; i < lm.arcs.size(); i++) {
+    const scrf_arc& a = lm.arcs[i];
+    if (a.src < 0 || a.src >= Q || a.dst < 0 || a.dst >= Q) throw runtime_error("nStateDecode: LM arc with a state out of range");
+    out[a.src].push_back((int)i);
+  }
+  std::vector<float> fin(Q, INF);
+  for (const auto& fw : lm.finals) if (fw.first >= 0 && fw.first < Q) fin[fw.first] = std::min(fin[fw.first], fw.second);
+  // epsilon-input closure of every state: (state reached, summed weight, arcs taken), cheapest first found
+  struct Eps { int state; float w; std::vector<int> path; };
+  std::vector<std::vector<Eps> > closure(Q);
+  for (int q = 0; q < Q; q++) {
+    std::vector<Eps>& c = closure[q];
+    c.push_back(Eps{q, 0.0f, {}});
+    for (size_t k = 0; k < c.size(); k++) {
+      const Eps cur = c[k];
+      for (int ai : out[cur.state]) {
+        const scrf_arc& a = lm.arcs[ai];
+        if (a.ilabel != 0) continue;
+        const float w = cur.w + a.w;
+        bool found = false;
+        for (Eps& x : c) if (x.state == a.dst) { found = true; if (w < x.w) { x.w = w; x.path = cur.path; x.path.push_back(ai); } }
+        if (!found) { Eps n{a.dst, w, cur.path}; n.path.push_back(ai); c.push_back(n); }
+        if (c.size() > 4096) throw runtime_error("nStateDecode: epsilon closure of the LM does not terminate");
+      }
+    }
+  }
+  auto seg_row = [&](uint32_t t, uint32_t d) -> size_t {
+    const size_t base = t < D ? (size_t)t * (t + 1) / 2 : (size_t)D * (D + 1) / 2 + (size_t)(t - D) * D;
+    return base + d - 1;
+  };
+  // E[t][q][l]: best weight of starting a segment of phone l at frame t in LM state q; F[t][q][l]: of a
+  // segment of phone l ending at t.  Back pointers: for E the previous (q, p) and the LM arc taken (-1:
+  // internal, -2: from the start); for F the duration.
+  const size_t QL = (size_t)Q * L;
+  std::vector<float> E((size_t)T * QL, INF), F((size_t)T * QL, INF);
+  std::vector<int32_t> Eprev((size_t)T * QL, -1), Earc((size_t)T * QL, -1), Eeps((size_t)T * QL, -1);
+  std::vector<uint16_t> Fdur((size_t)T * QL, 0);
+  for (uint32_t t = 0; t < T; t++) {
+    float* Et = &E[(size_t)t * QL];
+    if (t == 0) {
+      const std::vector<Eps>& c = closure[lm.start];
+      for (size_t k = 0; k < c.size(); k++)
+        for (int ai : out[c[k].state]) {
+          const scrf_arc& a = lm.arcs[ai];
+          if (a.ilabel <= 0 || a.ilabel > (int)L) continue;
+          const size_t idx = (size_t)a.dst * L + (a.ilabel - 1);
+          const float w = (0.0f + c[k].w) + a.w;
+          if (w < Et[idx]) { Et[idx] = w; Eprev[idx] = -1; Earc[idx] = ai; Eeps[idx] = (int32_t)k; }
+        }
+    } else {
+      const float* Fp = &F[(size_t)(t - 1) * QL];
+      const double* Mt = &M[(size_t)t * L * L];
+      float best_prev = INF;
+      if (beam > 0) for (size_t i = 0; i < QL; i++) best_prev = std::min(best_prev, Fp[i]);
+      for (int q = 0; q < Q; q++)
+        for (uint32_t p = 0; p < L; p++) {
+          const float old = Fp[(size_t)q * L + p];
+          if (old >= INF || (beam > 0 && old > best_prev + (float)beam)) continue;
+          n_hyps++;
+          const size_t base = (size_t)t * QL;
+          {  // internal: the phone continues, no LM move
+            const size_t idx = (size_t)q * L + p;
+            const float w = old + (float)(-1 * Mt[(size_t)p * L + p]);
+            if (w < Et[idx]) { Et[idx] = w; Eprev[base + idx] = (int32_t)((size_t)q * L + p); Earc[base + idx] = -1; Eeps[base + idx] = -1; }
+          }
+          const std::vector<Eps>& c = closure[q];
+          for (size_t k = 0; k < c.size(); k++)
+            for (int ai : out[c[k].state]) {
+              const scrf_arc& a = lm.arcs[ai];
+              if (a.ilabel <= 0 || a.ilabel > (int)L) continue;
+              const uint32_t l = (uint32_t)a.ilabel - 1;
+              const size_t idx = (size_t)a.dst * L + l;
+              const float w = ((old + c[k].w) + a.w) + (float)(-1 * Mt[(size_t)p * L + l]);
+              if (w < Et[idx]) { Et[idx] = w; Eprev[base + idx] = (int32_t)((size_t)q * L + p); Earc[base + idx] = ai; Eeps[base + idx] = (int32_t)k; }
+            }
+        }
+    }
+    // segments ending at t: durations in list order (longest = earliest entered first), strict <
+    const uint32_t nd = t + 1 < D ? t + 1 : D;
+    float* Ft = &F[(size_t)t * QL];
+    for (size_t idx = 0; idx < QL; idx++) {
+      const uint32_t l = (uint32_t)(idx % L);
+      float best = INF;
+      uint16_t arg = 0;
+      for (uint32_t d = nd; d >= 1; d--) {
+        const float w0 = E[(size_t)(t - d + 1) * QL + idx];
+        if (w0 >= INF) continue;
+        const float w = w0 + (float)(-1 * S[seg_row(t, d) * L + l]);
+        if (arg == 0 || w < best) { best = w; arg = (uint16_t)d; }
+      }
+      Ft[idx] = arg ? best : INF;
+      Fdur[(size_t)t * QL + idx] = arg;
+    }
+  }
+  // final: LM final states through the epsilon closure
+  float min_weight = INF, fin_w = 0.0f;
+  long best_idx = -1;
+  int fin_eps = -1;
+  if (T > 0) {
+    const float* Fl = &F[(size_t)(T - 1) * QL];
+    for (int q = 0; q < Q; q++)
+      for (size_t k = 0; k < closure[q].size(); k++) {
+        const Eps& c = closure[q][k];
+        if (fin[c.state] >= INF) continue;
+        for (uint32_t l = 0; l < L; l++) {
+          const float f0 = Fl[(size_t)q * L + l];
+          if (f0 >= INF) continue;
+          const float w = (f0 + c.w) + fin[c.state];
+          if (w < min_weight) { min_weight = w; best_idx = (long)((size_t)q * L + l); fin_eps = (int)k; fin_w = c.w + fin[c.state]; }
+        }
+      }
+  }
+  best_weight = min_weight;
+  int cur = result_fst->AddState();
+  result_fst->SetStart(cur);
+  if (best_idx < 0) {  // "Could not reach end of utterance" (:2141-2147)
+    int fs = result_fst->AddState();
+    result_fst->AddArc(cur, crf_amd::ArcListFst::Arc(0, 0, 8, fs));
+    result_fst->SetFinal(fs, (float)zx);
+    return (int)T;
+  }
+  // backtrace, last segment first
+  struct Step { uint32_t phone, dur, start; int arc, eps, q_from, prev_phone; };
+  std::vector<Step> steps;
+  long idx = best_idx;
+  for (long te = (long)T - 1; te >= 0;) {
+    const uint32_t d = Fdur[(size_t)te * QL + idx];
+    const uint32_t ts = (uint32_t)(te + 1 - d);
+    const size_t eidx = (size_t)ts * QL + idx;
+    Step st{(uint32_t)(idx % L), d, ts, Earc[eidx], Eeps[eidx], -1, -1};
+    if (Eprev[eidx] >= 0) { st.q_from = (int)(Eprev[eidx] / L); st.prev_phone = (int)(Eprev[eidx] % L); }
+    else st.q_from = lm.start;
+    steps.push_back(st);
+    if (ts == 0) break;
+    idx = Eprev[eidx];
+    te = (long)ts - 1;
+  }
+  std::reverse(steps.begin(), steps.end());
+  for (const Step& st : steps) {
+    const uint32_t te = st.start + st.dur - 1;
+    const double sv = S[seg_row(te, st.dur) * L + st.phone];
+    Segment sg;
+    sg.phone = st.phone; sg.dur = st.dur; sg.start = st.start;
+    sg.phone_start = st.arc >= 0;
+    float lmw = 0.0f;
+    int olabel = 0;
+    if (st.arc >= 0) {
+      const Eps& c = closure[st.q_from][st.eps];
+      for (int ai : c.path) {  // epsilon-input LM arcs on the way: words and back-off weights
+        const scrf_arc& a = lm.arcs[ai];
+        int nxt = result_fst->AddState();
+        result_fst->AddArc(cur, crf_amd::ArcListFst::Arc(0, a.olabel, a.w, nxt));
+        cur = nxt;
+      }
+      lmw = lm.arcs[st.arc].w;
+      olabel = lm.arcs[st.arc].olabel;
+    }
+    const float ac = st.prev_phone < 0 ? (float)(-1 * sv) : (float)(-1 * (M[((size_t)te * L + st.prev_phone) * L + st.phone] + sv));
+    sg.weight = ac + lmw;
+    segs.push_back(sg);
+    int nxt = result_fst->AddState();
+    result_fst->AddArc(cur, crf_amd::ArcListFst::Arc((int)st.phone + 1, olabel, sg.weight, nxt));
+    cur = nxt;
+  }
+  {
+    const Eps& c = closure[(int)(best_idx / L)][fin_eps];
+    for (int ai : c.path) {
+      const scrf_arc& a = lm.arcs[ai];
+      int nxt = result_fst->AddState();
+      result_fst->AddArc(cur, crf_amd::ArcListFst::Arc(0, a.olabel, a.w, nxt));
+      cur = nxt;
+    }
+    (void)fin_w;
+    result_fst->SetFinal(cur, (float)zx + fin[c.state]);
+  }
+  return (int)T;
+}
+
 std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* crf, float* cost) {
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();

@@ -204,11 +204,15 @@ struct ArcListFst {
   int AddState() { return n_states++; }
   void SetStart(int s) { start = s; }
   void AddArc(int s, const Arc& a) { arcs.push_back(scrf_arc{s, a.ilabel, a.olabel, a.weight, a.nextstate}); }
-  void SetFinal(int s, float w) { final_state = s; final_weight = w; }
+  void SetFinal(int s, float w) { final_state = s; final_weight = w; finals.push_back(std::make_pair(s, w)); }
   int n_states = 0, start = -1, final_state = -1;
   float final_weight = 0;
   std::vector<scrf_arc> arcs;
+  std::vector<std::pair<int, float> > finals;   // every SetFinal call (an LM has many final states)
 };
+// OpenFST text format (what `fstprint` writes with numeric labels): arc lines `src dst ilabel olabel
+// [weight]`, final-state lines `state [weight]`; the start state is the source of the first line.
+void readFstText(const char* fname, ArcListFst* fst);
 
 }  // namespace crf_amd
 
@@ -328,9 +332,9 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   // the free-phone LM :2294).  Returns the number of frames.
   template <class Fst>
   int nStateDecode(Fst* result_fst, Fst* lm_fst, Fst* out_full_fst, double input_beam, unsigned min_hyps = 0, unsigned max_hyps = 0, float beam_inc = 0.05f) {
-    (void)out_full_fst; (void)min_hyps; (void)max_hyps; (void)beam_inc; (void)input_beam;
-    if (lm_fst != nullptr) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: decoding against an LM FST is not built (free phone loop only)");
+    (void)out_full_fst; (void)min_hyps; (void)max_hyps; (void)beam_inc;
     if (if_output_full_fst) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: the full output lattice is not built (use CRF_LatticeBuilder)");
+    if (lm_fst != nullptr) return decodeLm(*lm_fst, input_beam, result_fst);
     const int T = decode();
     typedef typename Fst::Arc Arc;
     int cur = result_fst->AddState();
@@ -353,8 +357,26 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   double getZx() const { return zx; }
   float getBestWeight() const { return best_weight; }  // total weight of the best hypothesis (:2133)
 
+  // LM-constrained decode (lm_fst != NULL), host-side search over the device's node scores.  Same
+  // hypothesis space and float arithmetic as the reference's time-synchronous search (:246-735):
+  // a hypothesis is (LM state, phone); a phone continues over segments through its internal transition
+  // (old + float(-M[t][l][l]), no LM move); a new phone follows an LM arc with ilabel phone+1 after any
+  // epsilon-input arcs ((old + LM weights) + float(-M[t][p][l]), :452-456); float(-S[t][d][l]) is added
+  // at the segment's end (:143-146); strict-improvement updates.  `beam` > 0 drops hypotheses more than
+  // `beam` above the frame's best (the reference's beam adapts between min_hyps and max_hyps; that
+  // schedule is not reproduced), <= 0 searches exhaustively.  Result: one arc per LM epsilon arc that
+  // carries a word (0 : olabel, LM weight), one per segment (phone+1 : LM arc's olabel where the phone
+  // starts else 0, float(-(M+S)) from the END node + the LM arc's weight); final weight Zx + the LM's
+  // final weight.  OpenFST itself is not in the tree: parity with Compose/ShortestPath ordering UNPINNED.
+  template <class Fst> int decodeLm(const Fst&, double, Fst*) {
+    throw std::runtime_error("nStateDecode: an LM FST must be a crf_amd::ArcListFst");
+  }
+  int decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst);
+  size_t lastNumHyps() const { return n_hyps; }   // hypotheses kept, summed over frames (beam diagnostics)
+
  protected:
   int decode();
+  size_t n_hyps = 0;
   CRF_FeatureStream* ftr_strm;
   CRF_Model* crf;
   bool if_output_full_fst = false;

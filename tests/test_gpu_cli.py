@@ -394,3 +394,144 @@ def test_crftrain_presentation_orders(tmp_path, order):
         assert all(sorted(s) == list(range(n)) for s in seen)
     ref = np.array([float("%g" % v) for v in lam])
     np.testing.assert_allclose(np.loadtxt(out), ref, rtol=2e-5, atol=1e-12)
+
+
+def _lm_bruteforce(S, M, T, L, D, arcs, start, finals):
+    """All labelled segmentations x all LM paths (epsilon closure by Bellman-Ford), in double."""
+    Q = 1 + max(max(a[0], a[1]) for a in arcs)
+    out = [[a for a in arcs if a[0] == q] for q in range(Q)]
+
+    def closure(q):
+        best = {q: (0.0, [])}
+        changed = True
+        while changed:
+            changed = False
+            for s, (w, path) in list(best.items()):
+                for a in out[s]:
+                    if a[2] != 0:
+                        continue
+                    nw = w + a[4]
+                    if a[1] not in best or nw < best[a[1]][0] - 1e-15:
+                        best[a[1]] = (nw, path + [a]); changed = True
+        return best
+    clo = [closure(q) for q in range(Q)]
+    best = (float("inf"), None, None)
+
+    def rec(t_next, segs, score):
+        nonlocal best
+        if t_next == T:
+            # LM: dynamic programme over the segments, states -> (cost, words)
+            cur = {start: (0.0, [])}
+            prev_phone = None
+            for (end, d, l) in segs:
+                nxt = {}
+                for q, (c, words) in cur.items():
+                    if prev_phone is not None and l == prev_phone:   # internal transition: no LM move
+                        if q not in nxt or c < nxt[q][0]:
+                            nxt[q] = (c, words)
+                    for s, (we, path) in clo[q].items():
+                        for a in out[s]:
+                            if a[2] == l + 1:
+                                cc = c + we + a[4]
+                                w2 = words + [x[3] for x in path if x[3]] + ([a[3]] if a[3] else [])
+                                if a[1] not in nxt or cc < nxt[a[1]][0]:
+                                    nxt[a[1]] = (cc, w2)
+                cur = nxt; prev_phone = l
+            for q, (c, words) in cur.items():
+                for s, (we, path) in clo[q].items():
+                    if s in finals:
+                        tot = score + c + we + finals[s]
+                        if tot < best[0]:
+                            best = (tot, list(segs), words + [x[3] for x in path if x[3]])
+            return
+        for d in range(1, D + 1):
+            end = t_next + d - 1
+            if end >= T:
+                break
+            row = orc.seg_base(end, D) + d - 1
+            for l in range(L):
+                s = score - S[row, l]
+                if segs:
+                    s -= M[t_next, segs[-1][2] * L + l]
+                rec(end + 1, segs + [(end, d, l)], s)
+    rec(0, [], 0.0)
+    return best
+
+
+def test_crfdecode_against_a_language_model_fst(tmp_path):
+    """f2: CRFDecode with an LM FST (OpenFST text format, epsilon back-off arcs carrying words, a phone
+    that may repeat through the LM or continue through the internal transition): total path weight,
+    segmentation, phones and words against an exhaustive enumeration over all labelled segmentations
+    and all LM paths; a wide beam changes nothing; an unreachable LM gives the error arc."""
+    rng = np.random.RandomState(11)
+    L, D, W = 3, 2, 2
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    Ts = [1, 3, 4, 5]
+    utts = []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdtrans",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=2", "crf_lr=1.0",
+                        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    arcs = [(0, 1, 1, 11, 0.5), (0, 2, 2, 12, 0.2), (1, 2, 2, 12, 0.3), (1, 3, 0, 0, 0.7), (2, 1, 1, 11, 0.1), (2, 2, 2, 13, 0.9),
+            (3, 1, 1, 14, 0.4), (3, 0, 0, 15, 0.25), (2, 3, 3, 16, 0.6), (3, 2, 2, 12, 1.1), (1, 1, 3, 17, 0.35)]
+    finals = {1: 0.05, 2: 0.3}
+    lmf = str(tmp_path / "lm.fst.txt")
+    with open(lmf, "w") as fh:
+        for a in arcs:
+            fh.write("%d %d %d %d %g\n" % a)
+        for s, w in finals.items():
+            fh.write("%d %g\n" % (s, w))
+    olist, osym = str(tmp_path / "olist"), str(tmp_path / "osym.txt")
+    open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
+    open(osym, "w").write("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(11, 18)))
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F, use_trans_ftrs=True, tfs=0, tfe=F - 1); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+    for beam in ("0", "50"):
+        latdir = tmp_path / ("lat" + beam); latdir.mkdir()
+        mlf = str(tmp_path / ("out%s.mlf" % beam))
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym, "crf_lm_txt=" + lmf,
+                            "crf_output_mlffile=" + mlf, "crf_lat_outdir=" + str(latdir), "crf_decode_beam=" + beam], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "LM: 4 states, 11 arcs, 2 final" in r.stdout, r.stdout + r.stderr
+        mlf_utts = open(mlf).read().split('"\n')[1:]
+        totals = [float(x.split("=")[1].split(",")[0]) for x in r.stdout.split("\n") if x.startswith("Acoustic model weight")]
+        assert len(totals) == len(Ts)
+        for u, T in enumerate(Ts):
+            S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+            rc, _, _, _, zx = orc.seg_forward(cfg, S, M, T)
+            tot, segs, words = _lm_bruteforce(S, M, T, L, D, arcs, 0, finals)
+            got = [x.split() for x in open(str(latdir / ("u%d.fst.txt" % u))).read().strip().split("\n")]
+            chain, fin = got[:-1], got[-1]
+            # the search total (transition scores of the segment's FIRST frame, like the reference's search)
+            assert abs(totals[u] - tot) < 2e-4 * max(1.0, abs(tot)), (u, totals[u], tot)
+            # the chain's arcs carry the END node's transition score (the reference's backtrace, :2262)
+            quirk = sum(M[end - d + 1, segs[i - 1][2] * L + l] - M[end, segs[i - 1][2] * L + l] for i, (end, d, l) in enumerate(segs) if i > 0)
+            got_tot = sum(float(x[4]) for x in chain) + (float(fin[1]) - np.float32(zx))
+            assert abs(got_tot - (tot + quirk)) < 2e-4 * max(1.0, abs(tot)), (u, got_tot, tot, quirk)
+            seg_arcs = [x for x in chain if int(x[2]) != 0]
+            assert [int(x[2]) - 1 for x in seg_arcs] == [l for (_, _, l) in segs]
+            assert [int(x[3]) for x in chain if int(x[3]) != 0] == words
+            assert [int(x[0]) for x in chain] == list(range(len(chain))) and int(fin[0]) == len(chain)
+            assert [x for x in mlf_utts[u].split("\n") if x.startswith("w")] == ["w%d" % k for k in words]
+    # an LM without a reachable final state: the reference's "could not reach end of utterance" arc
+    bad = str(tmp_path / "bad.fst.txt")
+    open(bad, "w").write("0 1 1 11 0.5\n2 0.0\n")
+    latdir = tmp_path / "latbad"; latdir.mkdir()
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym, "crf_lm_txt=" + bad,
+                        "crf_output_mlffile=" + str(tmp_path / "bad.mlf"), "crf_lat_outdir=" + str(latdir), "crf_eval_range=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = open(str(latdir / "u1.fst.txt")).read().split("\n")
+    assert got[0].split()[:4] == ["0", "1", "0", "0"] and float(got[0].split()[4]) == 8.0
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_lm_bin=lm.fst"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "fstprint" in r.stderr

@@ -535,3 +535,68 @@ def test_crfdecode_against_a_language_model_fst(tmp_path):
     r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_lm_bin=lm.fst"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "fstprint" in r.stderr
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_crfdecode_lm_random_language_models(tmp_path, seed):
+    """random small LMs (3-5 states, epsilon arcs with words, parallel arcs, phones missing from some
+    states) and random segmental models (L = 3, D = 2..3, T <= 5): the search total, segments, phones
+    and words equal the exhaustive enumeration's."""
+    rng = np.random.RandomState(100 + seed)
+    L, D, W = 3, int(rng.choice([2, 3])), 2
+    Ts = [int(t) for t in rng.choice([1, 2, 3, 4, 5], size=3)]
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    utts = []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdstate",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=2", "crf_lr=1.0",
+                        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    Q = int(rng.randint(3, 6))
+    arcs = []
+    for q in range(Q):   # every state gets a few phone arcs; state 0 covers all phones so that every utterance is decodable
+        for l in (range(L) if q == 0 else rng.choice(L, size=int(rng.randint(1, L + 1)), replace=False)):
+            arcs.append((q, int(rng.randint(0, Q)), int(l) + 1, int(rng.randint(10, 30)), round(float(rng.uniform(0.05, 1.5)), 3)))
+    for _ in range(int(rng.randint(1, 4))):   # epsilon arcs (some with words) back to state 0 or elsewhere
+        a, b = int(rng.randint(0, Q)), int(rng.randint(0, Q))
+        if a != b:
+            arcs.append((a, b, 0, int(rng.choice([0, 40, 41])), round(float(rng.uniform(0.1, 1.0)), 3)))
+    arcs.sort(key=lambda a: a[0] != 0)   # the first line's source is the start state
+    finals = {int(q): round(float(rng.uniform(0.0, 0.5)), 3) for q in range(Q) if q == Q - 1 or rng.rand() < 0.5}
+    lmf = str(tmp_path / "lm.fst.txt")
+    with open(lmf, "w") as fh:
+        for a in arcs:
+            fh.write("%d %d %d %d %g\n" % a)
+        for s_, w_ in finals.items():
+            fh.write("%d %g\n" % (s_, w_))
+    olist = str(tmp_path / "olist")
+    open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
+    latdir = tmp_path / "lat"; latdir.mkdir()
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_lm_txt=" + lmf,
+                        "crf_output_mlffile=" + str(tmp_path / "o.mlf"), "crf_lat_outdir=" + str(latdir)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    totals = [float(x.split("=")[1].split(",")[0]) for x in r.stdout.split("\n") if x.startswith("Acoustic model weight")]
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+    for u, T in enumerate(Ts):
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        tot, segs, words = _lm_bruteforce(S, M, T, L, D, arcs, 0, finals)
+        got = [x.split() for x in open(str(latdir / ("u%d.fst.txt" % u))).read().strip().split("\n")]
+        chain = got[:-1]
+        if segs is None:   # no LM path accepts any labelling of this length
+            assert chain[0][2:4] == ["0", "0"] and float(chain[0][4]) == 8.0
+            continue
+        assert abs(totals[u] - tot) < 2e-4 * max(1.0, abs(tot)), (u, totals[u], tot)
+        seg_arcs = [x for x in chain if int(x[2]) != 0]
+        assert [int(x[2]) - 1 for x in seg_arcs] == [l for (_, _, l) in segs]
+        assert [int(x[3]) for x in chain if int(x[3]) != 0] == words

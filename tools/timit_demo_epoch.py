@@ -80,10 +80,14 @@ def main():
     ap.add_argument("--eta", type=float, default=0.05)
     ap.add_argument("--signal", type=float, default=2.0)
     ap.add_argument("--decode-utts", type=int, default=200)
+    ap.add_argument("--lm-scale", type=float, default=0.1, help="scale of the bigram LM costs (unscaled, -log P per new phone acts as a heavy insertion penalty on top of the CRF's own transition scores)")
     ap.add_argument("--work", default="/tmp/timit_demo")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "timit_demo.json"))
     a = ap.parse_args()
     os.makedirs(a.work, exist_ok=True)
+    for fn in os.listdir(a.work):   # a stale .done.train would make CRFTrain return at once (as the reference does)
+        if fn.startswith(".done.train") or fn.startswith("weights."):
+            os.remove(os.path.join(a.work, fn))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     L, D, W, CTX = 48, 10, 144, 6
     labs = read_ilab(ILAB)[:a.utts]
@@ -131,6 +135,49 @@ def main():
     open(osym, "w").write("<eps> 0\n" + "".join("ph%d %d\n" % (i, i + 1) for i in range(L)))
     t_dec, _ = run([os.path.join(BIN, "CRFDecode"), "weight_file=" + wf, "crf_eval_range=0-%d" % (nd - 1), "crf_olist=" + olist, "crf_osymbols=" + osym,
                     "crf_output_mlffile=" + mlf] + model, os.path.join(a.work, "decode.log"))
+    # CRFDecode against a phone-bigram LM estimated from the (collapsed) training label sequences, add-one
+    # smoothed, as an OpenFST text file: state 0 = start, state p + 1 = last phone p; ilabel = olabel = phone + 1
+    big = np.ones((L + 1, L + 1))   # [previous (L = start)][next (L = end)]
+    for lab in labs:
+        seq = [int(lab[0])] + [int(x) for i, x in enumerate(lab[1:]) if x != lab[i]]
+        big[L, seq[0]] += 1
+        for a_, b_ in zip(seq[:-1], seq[1:]):
+            big[a_, b_] += 1
+        big[seq[-1], L] += 1
+    big[np.arange(L), np.arange(L)] = 0   # a phone does not follow itself at the LM level (it continues internally)
+    big[L, L] = 0
+    cost = a.lm_scale * -np.log(big / big.sum(axis=1, keepdims=True), where=big > 0, out=np.full_like(big, np.inf))
+    lmf = os.path.join(a.work, "bigram.fst.txt")
+    with open(lmf, "w") as fh:
+        for l in range(L):
+            fh.write("0 %d %d %d %.6f\n" % (l + 1, l + 1, l + 1, cost[L, l]))
+        for p_ in range(L):
+            for l in range(L):
+                if l != p_:
+                    fh.write("%d %d %d %d %.6f\n" % (p_ + 1, l + 1, l + 1, l + 1, cost[p_, l]))
+        for p_ in range(L):
+            fh.write("%d %.6f\n" % (p_ + 1, cost[p_, L]))
+    mlf_lm = os.path.join(a.work, "hyp_lm.mlf")
+    n_lm = min(nd, 100)
+    t_lm, _ = run([os.path.join(BIN, "CRFDecode"), "weight_file=" + wf, "crf_eval_range=0-%d" % (n_lm - 1), "crf_olist=" + olist, "crf_osymbols=" + osym,
+                   "crf_output_mlffile=" + mlf_lm, "crf_lm_txt=" + lmf] + model, os.path.join(a.work, "decode_lm.log"))
+
+    def phone_errors(mlf_path, n):
+        # Levenshtein distance between the decoded and the reference (collapsed) phone sequences
+        err = ref_n = 0
+        blocks = open(mlf_path).read().split('"\n')[1:]
+        for u in range(n):
+            hyp = [int(x[2:]) for x in blocks[u].split("\n") if x.startswith("ph")]
+            lab = labs[u]
+            ref = [int(lab[0])] + [int(x) for i, x in enumerate(lab[1:]) if x != lab[i]]
+            dp = list(range(len(hyp) + 1))
+            for i, r_ in enumerate(ref, 1):
+                prev, dp[0] = dp[0], i
+                for j, h_ in enumerate(hyp, 1):
+                    prev, dp[j] = dp[j], min(dp[j] + 1, dp[j - 1] + 1, prev + (r_ != h_))
+            err += dp[-1]; ref_n += len(ref)
+        return err / max(1, ref_n), sum(len([x for x in b.split('\n') if x.startswith('ph')]) for b in blocks[:n]) / max(1, n)
+    (per_free, nph_free), (per_lm, nph_lm) = phone_errors(mlf, n_lm), phone_errors(mlf_lm, n_lm)
     # frame accuracy of the decoded segmentation (CRFFstDecode labels: phone + L * (dur - 1) per segment)
     hit = tot = 0
     phone_seq_equal = 0
@@ -153,7 +200,9 @@ def main():
            "crftrain_wall_s": round(t_train, 2), "crftrain_utt_per_s_incl_file_io": round(U * a.epochs / t_train, 1),
            "iter_avg_logli_trace": avg_logli[:3] + avg_logli[-3:],
            "crffstdecode_wall_s": round(t_fst, 2), "crfdecode_wall_s": round(t_dec, 2), "decoded_utterances": nd,
-           "decoded_frame_accuracy": round(hit / max(1, tot), 4), "crfdecode_mlf_equals_crffstdecode_phones": "%d/%d" % (phone_seq_equal, nd)}
+           "decoded_frame_accuracy": round(hit / max(1, tot), 4), "crfdecode_mlf_equals_crffstdecode_phones": "%d/%d" % (phone_seq_equal, nd),
+           "crfdecode_bigram_lm": {"utterances": n_lm, "lm_scale": a.lm_scale, "wall_s": round(t_lm, 2), "phone_error_rate_free_loop": round(per_free, 4),
+                                   "phone_error_rate_bigram_lm": round(per_lm, 4), "phones_per_utt_free_loop": round(nph_free, 1), "phones_per_utt_bigram_lm": round(nph_lm, 1)}}
     open(a.out, "w").write(json.dumps(res, indent=1) + "\n")
     print(json.dumps(res))
 

@@ -20,7 +20,7 @@ static std::map<long, std::string> read_symbols(const std::string& path) {
 
 int main(int argc, char** argv) {
   Args a(argc, argv);
-  if (a.has("crf_lm_bin") || a.has("crf_lm_arpa")) { std::cerr << "crf_lm_bin / crf_lm_arpa: OpenFST binary and ARPA readers are not built; print the LM with `fstprint` and pass it as crf_lm_txt" << std::endl; return 1; }
+  if (a.has("crf_lm_arpa")) { std::cerr << "crf_lm_arpa: ARPA language models are not built; compile the LM to an FST and pass it as crf_lm_bin, or its `fstprint` text as crf_lm_txt" << std::endl; return 1; }
   if (!a.has("crf_output_labelfile") && !a.has("crf_output_mlffile")) { std::cerr << "At least one of crf_output_labelfile or crf_output_mlffile must be assigned" << std::endl; return -1; }
   if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
   if (!a.has("crf_olist")) { std::cerr << "crf_olist required currently." << std::endl; return -1; }  // Main.cpp:1022-1025
@@ -39,11 +39,31 @@ int main(int argc, char** argv) {
   }
   // language model: OpenFST text format (tropical weights), numeric labels: ilabel = phone + 1, olabel = word
   crf_amd::ArcListFst lm;
-  const bool have_lm = a.has("crf_lm_txt");
+  const bool have_lm = a.has("crf_lm_txt") || a.has("crf_lm_bin");
   if (have_lm) {
     try {
-      crf_amd::readFstText(a.str("crf_lm_txt").c_str(), &lm);
+      if (a.has("crf_lm_txt")) crf_amd::readFstText(a.str("crf_lm_txt").c_str(), &lm);
+      else {
+        std::cout << "Reading in LM fst from file: " << a.str("crf_lm_bin") << std::endl;
+        crf_amd::readFstBinary(a.str("crf_lm_bin").c_str(), &lm);
+      }
     } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+    if (a.has("crf_disambig")) {  // disambiguation symbols become epsilons on the input side (Main.cpp:857-893)
+      std::ifstream df(a.str("crf_disambig").c_str());
+      std::string ln;
+      std::vector<int> ids;
+      while (getline(df, ln))
+        if (!ln.empty()) {
+          const int id = atoi(ln.c_str());
+          if (id == 0) { std::cerr << "ERROR: invalid disambiguation ID (" << ln << ") from " << a.str("crf_disambig") << std::endl; return -1; }
+          ids.push_back(id);
+        }
+      for (scrf_arc& c : lm.arcs)
+        for (int id : ids)
+          if (c.ilabel == id) c.ilabel = 0;
+    } else {
+      std::cout << "crf_disambig is not set: no disambiguation symbols for the decoding graph." << std::endl;
+    }
     std::cout << "LM: " << lm.n_states << " states, " << lm.arcs.size() << " arcs, " << lm.finals.size() << " final" << std::endl;
   }
   std::map<long, std::string> osym;

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <iterator>
+#include <limits>
 #include <random>
 #include <fstream>
 #include <iostream>
@@ -685,6 +687,97 @@ void crf_amd::readFstText(const char* fname, crf_amd::ArcListFst* fst) {
   }
   if (first) throw runtime_error(string("readFstText: ") + fname + " is empty");
   fst->n_states = max_state + 1;
+}
+
+namespace {
+struct BinReader {
+  std::vector<unsigned char> d;
+  size_t at = 0;
+  string name;
+  void need(size_t n) { if (at + n > d.size()) throw runtime_error(name + ": truncated OpenFST file (print it with fstprint and use crf_lm_txt)"); }
+  template <class Tp> Tp get() { need(sizeof(Tp)); Tp v; memcpy(&v, &d[at], sizeof(Tp)); at += sizeof(Tp); return v; }
+  string str() {
+    const int32_t n = get<int32_t>();
+    if (n < 0 || n > 4096) throw runtime_error(name + ": implausible string length in the OpenFST header");
+    need((size_t)n);
+    string s((const char*)&d[at], (size_t)n);
+    at += (size_t)n;
+    return s;
+  }
+};
+}  // namespace
+
+void crf_amd::readFstBinary(const char* fname, crf_amd::ArcListFst* fst) {
+  BinReader r;
+  r.name = fname;
+  {
+    std::ifstream f(fname, std::ios::binary);
+    if (!f.is_open()) throw runtime_error(string("readFstBinary: cannot open ") + fname);
+    r.d.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  }
+  const string hint = " (print it with fstprint and use crf_lm_txt)";
+  if (r.get<int32_t>() != 2125659606) throw runtime_error(r.name + ": not an OpenFST binary file" + hint);
+  const string fst_type = r.str(), arc_type = r.str();
+  const int32_t version = r.get<int32_t>(), flags = r.get<int32_t>();
+  (void)r.get<uint64_t>();  // properties
+  const int64_t start = r.get<int64_t>(), n_states = r.get<int64_t>(), n_arcs = r.get<int64_t>();
+  if (fst_type != "vector") throw runtime_error(r.name + ": FST type '" + fst_type + "' is not 'vector'" + hint);
+  if (arc_type != "standard" && arc_type != "log") throw runtime_error(r.name + ": arc type '" + arc_type + "' is not standard/log" + hint);
+  if (version < 1 || version > 2) throw runtime_error(r.name + ": unsupported vector FST version " + std::to_string(version) + hint);
+  if (flags & 4) throw runtime_error(r.name + ": aligned FST files are not supported" + hint);
+  if (n_states < 0 || n_arcs < 0 || n_states > (1 << 26) || start >= n_states) throw runtime_error(r.name + ": implausible state/arc counts" + hint);
+  for (int side = 0; side < 2; side++) {   // embedded symbol tables (flags 1: input, 2: output) are skipped
+    if (!(flags & (1 << side))) continue;
+    if (r.get<int32_t>() != 2125658996) throw runtime_error(r.name + ": bad symbol table magic" + hint);
+    (void)r.str();
+    (void)r.get<int64_t>();
+    const int64_t n = r.get<int64_t>();
+    if (n < 0 || n > (1 << 26)) throw runtime_error(r.name + ": implausible symbol table size" + hint);
+    for (int64_t i = 0; i < n; i++) { (void)r.str(); (void)r.get<int64_t>(); }
+  }
+  fst->n_states = (int)n_states;
+  fst->start = (int)start;
+  int64_t seen = 0;
+  for (int64_t s = 0; s < n_states; s++) {
+    const float fw = r.get<float>();
+    const int64_t na = r.get<int64_t>();
+    if (na < 0 || seen + na > n_arcs) throw runtime_error(r.name + ": arc counts do not add up" + hint);
+    if (fw == fw && fw < 3.0e38f) fst->SetFinal((int)s, fw);   // +inf (Zero) marks a non-final state
+    for (int64_t k = 0; k < na; k++) {
+      scrf_arc a;
+      a.src = (int32_t)s;
+      a.ilabel = r.get<int32_t>();
+      a.olabel = r.get<int32_t>();
+      a.w = r.get<float>();
+      a.dst = r.get<int32_t>();
+      if (a.dst < 0 || a.dst >= n_states) throw runtime_error(r.name + ": arc to a state out of range" + hint);
+      fst->arcs.push_back(a);
+    }
+    seen += na;
+  }
+  if (seen != n_arcs || r.at != r.d.size()) throw runtime_error(r.name + ": the file does not end where its header says" + hint);
+}
+
+void crf_amd::writeFstBinary(const char* fname, const crf_amd::ArcListFst& fst, const char* arc_type) {
+  std::ofstream f(fname, std::ios::binary);
+  if (!f.is_open()) throw runtime_error(string("writeFstBinary: cannot open ") + fname);
+  auto put = [&](const void* p, size_t n) { f.write((const char*)p, (std::streamsize)n); };
+  auto put_str = [&](const string& s) { const int32_t n = (int32_t)s.size(); put(&n, 4); put(s.data(), s.size()); };
+  const int32_t magic = 2125659606, version = 2, flags = 0;
+  const uint64_t props = 0;
+  const int64_t start = fst.start, ns = fst.n_states, na = (int64_t)fst.arcs.size();
+  put(&magic, 4); put_str("vector"); put_str(arc_type); put(&version, 4); put(&flags, 4); put(&props, 8);
+  put(&start, 8); put(&ns, 8); put(&na, 8);
+  std::vector<std::vector<const scrf_arc*> > out(fst.n_states);
+  for (const scrf_arc& a : fst.arcs) out[a.src].push_back(&a);
+  std::vector<float> fin(fst.n_states, std::numeric_limits<float>::infinity());
+  for (const auto& fw : fst.finals) fin[fw.first] = fw.second;
+  for (int s = 0; s < fst.n_states; s++) {
+    put(&fin[s], 4);
+    const int64_t n = (int64_t)out[s].size();
+    put(&n, 8);
+    for (const scrf_arc* a : out[s]) { put(&a->ilabel, 4); put(&a->olabel, 4); put(&a->w, 4); put(&a->dst, 4); }
+  }
 }
 
 int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst) {

@@ -213,6 +213,17 @@ struct ArcListFst {
 // OpenFST text format (what `fstprint` writes with numeric labels): arc lines `src dst ilabel olabel
 // [weight]`, final-state lines `state [weight]`; the start state is the source of the first line.
 void readFstText(const char* fname, ArcListFst* fst);
+// OpenFST binary `vector` FST over the standard (tropical) or log arc type -- what `crf_lm_bin` names
+// (CRFDecode/src/Main.cpp:844-855 reads a VectorFst<LogArc> and maps it to the tropical semiring with the
+// identity on the float values).  Layout as written by OpenFST 1.x (FstHeader::Write, VectorFst::Write):
+// int32 magic 2125659606 | string fst type | string arc type | int32 version | int32 flags | uint64
+// properties | int64 start | int64 states | int64 arcs | [symbol tables when flags say so] | per state:
+// float final weight (+inf = not final), int64 arc count, arcs {int32 ilabel, int32 olabel, float
+// weight, int32 nextstate}; strings are int32 length + bytes; little-endian.  OpenFST is not in the tree,
+// so this layout is UNPINNED: every redundancy is checked (types, counts, exact file length) and anything
+// unexpected is an error that points at `fstprint` + crf_lm_txt.  writeFstBinary emits the same layout.
+void readFstBinary(const char* fname, ArcListFst* fst);
+void writeFstBinary(const char* fname, const ArcListFst& fst, const char* arc_type = "standard");
 
 }  // namespace crf_amd
 

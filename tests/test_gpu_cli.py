@@ -251,7 +251,7 @@ def test_crfdecode_free_phone_loop_mlf_and_best_path_chain(tmp_path):
     assert open(mlf).read().strip().split("\n") == want_mlf
 
     # refusals: an LM FST, a model type the decoder does not cover, a missing olist
-    for extra, rc, msg in [(["crf_lm_bin=x.fst"], 1, "not built"), (["crf_olist="], 255, "crf_olist required")]:
+    for extra, rc, msg in [(["crf_lm_arpa=x.arpa"], 1, "not built"), (["crf_olist="], 255, "crf_olist required")]:
         args = model + ["weight_file=" + wf, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_olist=" + olist] + extra
         r = subprocess.run([os.path.join(BIN, "CRFDecode")] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == rc and msg in r.stderr, (r.returncode, r.stderr)
@@ -523,6 +523,51 @@ def test_crfdecode_against_a_language_model_fst(tmp_path):
             assert [int(x[3]) for x in chain if int(x[3]) != 0] == words
             assert [int(x[0]) for x in chain] == list(range(len(chain))) and int(fin[0]) == len(chain)
             assert [x for x in mlf_utts[u].split("\n") if x.startswith("w")] == ["w%d" % k for k in words]
+    # the same LM as an OpenFST binary file (layout written here independently of the reader: header, embedded
+    # symbol tables, log arc type) and with a disambiguation symbol (label 9 on an extra arc pair) mapped to epsilon
+    import struct
+
+    def fst_string(x):
+        return struct.pack("<i", len(x)) + x.encode()
+
+    def symtab(name, syms):
+        b = struct.pack("<i", 2125658996) + fst_string(name) + struct.pack("<qq", len(syms), len(syms))
+        for i, sy in enumerate(syms):
+            b += fst_string(sy) + struct.pack("<q", i)
+        return b
+    arcs_b = arcs + [(2, 0, 9, 0, 0.45)]   # 9 = disambiguation symbol -> epsilon back to the start state
+    Qn = 4
+    body = b""
+    for q in range(Qn):
+        mine = [x for x in arcs_b if x[0] == q]
+        body += struct.pack("<f", finals.get(q, float("inf"))) + struct.pack("<q", len(mine))
+        for (_, dst, il, ol, wt) in mine:
+            body += struct.pack("<iifi", il, ol, wt, dst)
+    hdr = struct.pack("<i", 2125659606) + fst_string("vector") + fst_string("log") + struct.pack("<iiQqqq", 2, 3, 0x5, 0, Qn, len(arcs_b))
+    lmb = str(tmp_path / "lm.fst")
+    open(lmb, "wb").write(hdr + symtab("isyms", ["<eps>", "a", "b"]) + symtab("osyms", ["<eps>"]) + body)
+    lmt2 = str(tmp_path / "lm2.fst.txt")
+    with open(lmt2, "w") as fh:
+        for a in arcs + [(2, 0, 0, 0, 0.45)]:
+            fh.write("%d %d %d %d %g\n" % a)
+        for s_, w_ in finals.items():
+            fh.write("%d %g\n" % (s_, w_))
+    dis = str(tmp_path / "disambig.txt"); open(dis, "w").write("9\n")
+    outs = []
+    for flags in (["crf_lm_bin=" + lmb, "crf_disambig=" + dis], ["crf_lm_txt=" + lmt2]):
+        mlf2 = str(tmp_path / ("o%d.mlf" % len(outs)))
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym, "crf_output_mlffile=" + mlf2] + flags,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "LM: 4 states, 12 arcs, 2 final" in r.stdout, r.stdout + r.stderr
+        outs.append((open(mlf2).read(), [x for x in r.stdout.split("\n") if x.startswith("Acoustic model weight")]))
+    assert outs[0] == outs[1]
+    # damaged binary files are refused with the pointer to fstprint
+    raw = open(lmb, "rb").read()
+    for k, mut in enumerate([raw[:-5], b"\0\0\0\0" + raw[4:], raw.replace(b"vector", b"vectoq"), raw + b"\0"]):
+        badb = str(tmp_path / ("bad%d.fst" % k)); open(badb, "wb").write(mut)
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_lm_bin=" + badb],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "fstprint" in r.stderr, (k, r.stderr)
     # an LM without a reachable final state: the reference's "could not reach end of utterance" arc
     bad = str(tmp_path / "bad.fst.txt")
     open(bad, "w").write("0 1 1 11 0.5\n2 0.0\n")
@@ -532,9 +577,9 @@ def test_crfdecode_against_a_language_model_fst(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     got = open(str(latdir / "u1.fst.txt")).read().split("\n")
     assert got[0].split()[:4] == ["0", "1", "0", "0"] and float(got[0].split()[4]) == 8.0
-    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_lm_bin=lm.fst"],
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_output_mlffile=" + str(tmp_path / "x.mlf"), "crf_lm_arpa=lm.arpa"],
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "fstprint" in r.stderr
+    assert r.returncode != 0 and "ARPA" in r.stderr
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

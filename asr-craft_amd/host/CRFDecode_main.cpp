@@ -114,6 +114,7 @@ int main(int argc, char** argv) {
       std::cout << "Acoustic model weight (negative log potential) = " << vd.getBestWeight() << ", -Z(X) = " << -1 * vd.getZx()
                 << ", language model weight (negative log probability) = " << 0 << std::endl;
       if (a.has("crf_lat_outdir")) {
+        crf_amd::writeFstBinary((a.str("crf_lat_outdir") + "/" + olist[u] + ".fst").c_str(), best_lat);   // Main.cpp:1126-1136
         const std::string fn = a.str("crf_lat_outdir") + "/" + olist[u] + ".fst.txt";
         std::ofstream lf(fn.c_str());
         if (!lf.is_open()) throw std::runtime_error("cannot write " + fn);

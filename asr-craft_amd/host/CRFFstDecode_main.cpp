@@ -65,6 +65,9 @@ int main(int argc, char** argv) {
         crf_amd::ArcListFst fst;
         CRF_LatticeBuilder lb(&strm, &crf);
         lb.buildLattice(&fst, false, (crf_amd::ArcListFst*)nullptr, false);
+        // the reference writes the lattice as an OpenFST binary, fst.<n>.final.fst (:832-837); here that file
+        // (layout unpinned, crf_amd.h) plus the same arcs as text
+        crf_amd::writeFstBinary((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".final.fst").c_str(), fst);
         std::ofstream lf((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".txt").c_str());
         for (const scrf_arc& c : fst.arcs) lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << c.w << "\n";
         lf << fst.final_state << "\n";

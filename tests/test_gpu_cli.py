@@ -188,6 +188,36 @@ def test_crftrain_and_fstdecode_on_pfile_and_ilab_inputs(tmp_path):
     assert r.returncode != 0 and "selects sentence" in r.stderr
 
 
+def _read_fst_bin(path):
+    """Independent parser of the OpenFST binary vector-FST layout: (start, [(src, il, ol, w, dst)], {final: w})."""
+    import struct
+    d = open(path, "rb").read()
+    at = 0
+
+    def get(fmt):
+        nonlocal at
+        v = struct.unpack_from("<" + fmt, d, at); at += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def gstr():
+        nonlocal at
+        n = get("i"); x = d[at:at + n].decode(); at += n
+        return x
+    assert get("i") == 2125659606 and gstr() == "vector" and gstr() in ("standard", "log")
+    version, flags, props, start, ns, na = get("iiQqqq")
+    assert version == 2 and flags == 0
+    arcs, fin = [], {}
+    for s_ in range(ns):
+        fw = get("f"); n = get("q")
+        if fw != float("inf"):
+            fin[s_] = fw
+        for _ in range(n):
+            il, ol, w, dst = get("iifi")
+            arcs.append((s_, il, ol, w, dst))
+    assert len(arcs) == na and at == len(d)
+    return start, arcs, fin
+
+
 def test_crfdecode_free_phone_loop_mlf_and_best_path_chain(tmp_path):
     """§8 a19 / f2: CRFDecode with the reference's own free-phone-loop LM (no crf_lm_bin): the
     best-path chain (arc labels, float weights from the END node's scores, final weight Zx) and
@@ -236,6 +266,11 @@ def test_crfdecode_free_phone_loop_mlf_and_best_path_chain(tmp_path):
         assert rc == 0
         got = [x.split() for x in open(str(latdir / (names[u] + ".fst.txt"))).read().strip().split("\n")]
         assert len(got) == len(segs) + 1
+        # the OpenFST binary next to it carries the same chain
+        start, barcs, bfin = _read_fst_bin(str(latdir / (names[u] + ".fst")))
+        assert start == 0 and [(a_[0], a_[4], a_[1], a_[2]) for a_ in barcs] == [tuple(int(v) for v in x[:4]) for x in got[:-1]]
+        assert [np.float32(a_[3]) for a_ in barcs] == [np.float32(float(x[4])) for x in got[:-1]]
+        assert list(bfin.keys()) == [int(got[-1][0])] and np.float32(list(bfin.values())[0]) == np.float32(float(got[-1][1]))
         for i, (p, d, wt, ps) in enumerate(segs):
             assert [int(v) for v in got[i][:4]] == [i, i + 1, p + 1, p + 1 if ps else 0]
             assert np.float32(float(got[i][4])) == np.float32(wt)

@@ -859,7 +859,7 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst&
       for (int q = 0; q < Q; q++)
         for (uint32_t p = 0; p < L; p++) {
           const float old = Fp[(size_t)q * L + p];
-          if (old >= INF || (beam > 0 && old > best_prev + (float)beam)) continue;
+          if (old >= INF || (beam > 0 && !(old < best_prev + beam))) continue;   // pruning(): kept iff weight < min + beam (:1006)
           n_hyps++;
           const size_t base = (size_t)t * QL;
           {  // internal: the phone continues, no LM move

@@ -373,9 +373,9 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   // a hypothesis is (LM state, phone); a phone continues over segments through its internal transition
   // (old + float(-M[t][l][l]), no LM move); a new phone follows an LM arc with ilabel phone+1 after any
   // epsilon-input arcs ((old + LM weights) + float(-M[t][p][l]), :452-456); float(-S[t][d][l]) is added
-  // at the segment's end (:143-146); strict-improvement updates.  `beam` > 0 drops hypotheses more than
-  // `beam` above the frame's best (the reference's beam adapts between min_hyps and max_hyps; that
-  // schedule is not reproduced), <= 0 searches exhaustively.  Result: one arc per LM epsilon arc that
+  // at the segment's end (:143-146); strict-improvement updates.  `beam` > 0 keeps, like pruning()
+  // (:976-1040), the hypotheses of a frame whose weight is < the frame's minimum + beam (min_hyps /
+  // max_hyps / beam_inc are accepted and unused there as well); <= 0 searches exhaustively.  Result: one arc per LM epsilon arc that
   // carries a word (0 : olabel, LM weight), one per segment (phone+1 : LM arc's olabel where the phone
   // starts else 0, float(-(M+S)) from the END node + the LM arc's weight); final weight Zx + the LM's
   // final weight.  OpenFST itself is not in the tree: parity with Compose/ShortestPath ordering UNPINNED.

@@ -558,6 +558,13 @@ def test_crfdecode_against_a_language_model_fst(tmp_path):
             assert [int(x[3]) for x in chain if int(x[3]) != 0] == words
             assert [int(x[0]) for x in chain] == list(range(len(chain))) and int(fin[0]) == len(chain)
             assert [x for x in mlf_utts[u].split("\n") if x.startswith("w")] == ["w%d" % k for k in words]
+    # a narrow beam may lose the best path but never invents a cheaper one
+    exhaustive = totals
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym, "crf_lm_txt=" + lmf,
+                        "crf_output_mlffile=" + str(tmp_path / "narrow.mlf"), "crf_decode_beam=0.3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    narrow = [float(x.split("=")[1].split(",")[0]) for x in r.stdout.split("\n") if x.startswith("Acoustic model weight")]
+    assert len(narrow) == len(exhaustive) and all(n_ >= e_ - 1e-5 for n_, e_ in zip(narrow, exhaustive))
     # the same LM as an OpenFST binary file (layout written here independently of the reader: header, embedded
     # symbol tables, log arc type) and with a disambiguation symbol (label 9 on an extra arc pair) mapped to epsilon
     import struct

@@ -13,11 +13,13 @@ class Case:
     TIMIT demo's ftr2 stream (demo/segmental-timit-demo.cfg.in:21-24)."""
 
     def __init__(self, L, D, in_w, Ts, trans_ctx=None, seed=0, lam_scale=0.3, frame_model=False,
-                 scratch_bytes=0, precision=0):
+                 scratch_bytes=0, precision=0, l1_norm=False):
         self.L, self.D, self.in_w, self.Ts = L, D, in_w, list(Ts)
         self.trans_ctx = trans_ctx
         rng = np.random.RandomState(seed)
         self.frames = [rng.random_sample((T, in_w)).astype(np.float32) for T in Ts]
+        if l1_norm:   # rows L1-normalised like softmax posteriors (SURVEY 8d, config 3/4 inputs)
+            self.frames = [(f / f.sum(1, keepdims=True)).astype(np.float32) for f in self.frames]
         if frame_model:
             self.labels = [rng.randint(0, L, T).astype(np.uint32) for T in Ts]
         else:

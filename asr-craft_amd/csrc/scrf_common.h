@@ -74,6 +74,22 @@ __host__ __device__ inline uint64_t scrf_arc_base(uint32_t t, uint32_t L, uint32
   return (t == 0) ? 0 : (uint64_t)L + (uint64_t)(t - 1) * L * L + (uint64_t)L * (scrf_seg_base(t, D) - 1);
 }
 
+// Posterior-mass self-checks of the reference's computeExpF, per node t:
+//   segmental (nodes/CRF_StdSegStateNode_WithoutDurLab_WithoutSegTransFtr.cpp:917-947): state mass
+//   sum_{l,d} gamma <= 1 + 1e-6 and >= -1e-6, the same for the transition mass, and the two equal
+//   within 1e-6 (the last node compares with 1.0);
+//   frame model (nodes/CRF_StdStateNode.cpp:252-275): both within [0.9, 1.1].
+// The transition mass sum_{c,n} xi[t][c][n] equals sum_c exp(alpha[t][c] + beta[t][c] - Zx) (beta is
+// the log-sum over n of M + sd), which is how the kernels form it -- from arrays they already hold.
+__host__ __device__ inline bool scrf_mass_ok(double state_mass, double trans_mass, bool last, bool frame_model) {
+  if (last) trans_mass = 1.0;   // :902-907 (no following transition)
+  if (frame_model) return state_mass <= 1.1 && state_mass >= 0.9 && trans_mass <= 1.1 && trans_mass >= 0.9;
+  if (!(state_mass <= 1.000001) || !(state_mass >= -0.000001)) return false;
+  if (!(trans_mass <= 1.000001) || !(trans_mass >= -0.000001)) return false;
+  const double d = state_mass - trans_mass;
+  return d <= 0.000001 && d >= -0.000001;
+}
+
 // Device view of a packed batch (all arrays in HBM).
 struct ScrfBatchView {
   uint32_t U;

@@ -254,7 +254,8 @@ __global__ void k_post_state(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint
                              const uint32_t* __restrict__ next_lab, const double* __restrict__ S,
                              const double* __restrict__ M, int m_per_frame, double* __restrict__ AD,
                              const double* __restrict__ beta_g, const double* __restrict__ zx,
-                             double* __restrict__ numer_f, int* __restrict__ status) {
+                             double* __restrict__ numer_f, int* __restrict__ status, double* __restrict__ mass_s) {
+  __shared__ double msum[4];
   const uint32_t L = lay.L, D = lay.D;
   const uint64_t fi = blockIdx.x;  // frame index inside the chunk
   const uint64_t gf = bv.frame_off[u0] + fi;
@@ -276,14 +277,21 @@ __global__ void k_post_state(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint
   }
   const double LN_MAX = 709.782712893384;
   const double* bt = beta_g + fi * L;
+  double gs = 0.0;
   for (uint32_t idx = threadIdx.x; idx < nd * L; idx += blockDim.x) {
     const uint32_t d0 = idx / L, l = idx - d0 * L;
     double a = AD[(row0 + d0) * L + l] + bt[l] - Zx;
     if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
     double y = (l == al && d0 + 1 == ld) ? 1.0 : 0.0;
-    AD[(row0 + d0) * L + l] = y - exp(a);
+    const double g = exp(a);
+    AD[(row0 + d0) * L + l] = y - g;
+    gs += g;
   }
+  gs = wave_sum_f64(gs);
+  if ((threadIdx.x & 63) == 0) msum[threadIdx.x >> 6] = gs;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    mass_s[fi] = (msum[0] + msum[1]) + (msum[2] + msum[3]);
     double nodeLi = 0.0;
     if (lab != SCRF_LAB_BAD && err == 0) {
       if (ld <= nd) nodeLi += S[(row0 + ld - 1) * L + al];
@@ -304,10 +312,10 @@ __global__ void k_post_state(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint
 void launch_post_state(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
                        uint64_t n_frames, const uint32_t* next_lab, const double* S, const double* M,
                        int m_per_frame, double* AD, const double* beta_g, const double* zx, double* numer_f,
-                       int* status) {
+                       int* status, double* mass_s) {
   if (n_frames == 0) return;
   hipLaunchKernelGGL(k_post_state, dim3((uint32_t)n_frames), dim3(256), 0, st, lay, bv, u0, u1, next_lab, S, M,
-                     m_per_frame, AD, beta_g, zx, numer_f, status);
+                     m_per_frame, AD, beta_g, zx, numer_f, status, mass_s);
 }
 
 // numer[u] = sum of the per-frame terms in the reference's order (t = T-1 .. 0, :388-469)

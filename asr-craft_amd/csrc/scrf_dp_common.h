@@ -33,6 +33,25 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// wave-wide sum of doubles on the DPP path (quad permutes, row shifts, the two row broadcasts; lanes
+// outside a shift read 0), total read back from lane 63 as a wave-uniform value: 18 VALU
+// instructions and no LDS crossbar round trips
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+  v = dpp_add_f64<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v = dpp_add_f64<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v = dpp_add_f64<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add_f64<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_add_f64<0x142, 0xa>(v);   // row_bcast:15
+  v = dpp_add_f64<0x143, 0xc>(v);   // row_bcast:31
+  return rdlane(v, 63);
+}
+
 // exp(x) for x <= 0 (including -inf -> 0): the log-sum-exp terms are always max-shifted, so the
 // overflow/NaN handling of the library exp is dead weight in the recursion's inner loop.
 // Cody-Waite reduction by ln2 (hi/lo) + degree-13 Taylor/Horner on |r| <= ln2/2 (truncation

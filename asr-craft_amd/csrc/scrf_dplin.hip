@@ -573,8 +573,9 @@ __global__ __launch_bounds__(256) void k_post_lin(ScrfLayout lay, ScrfBatchView 
                                                   int m_per_frame, double* __restrict__ ES,
                                                   const double* __restrict__ smax, ScrfDpLin o,
                                                   const double* __restrict__ zx, double* __restrict__ numer_f,
-                                                  int* __restrict__ status) {
+                                                  int* __restrict__ status, double* __restrict__ mass_s) {
   __shared__ double fs[64];
+  __shared__ double msum[4];
   const uint32_t L = lay.L, D = lay.D;
   const uint64_t fi = blockIdx.x;  // frame index inside the chunk
   const uint64_t gf = bv.frame_off[u0] + fi;
@@ -601,14 +602,21 @@ __global__ __launch_bounds__(256) void k_post_lin(ScrfLayout lay, ScrfBatchView 
   }
   __syncthreads();
   const double* bt = o.b + fi * L;
+  double gs = 0.0;
   for (uint32_t idx = threadIdx.x; idx < nd * L; idx += blockDim.x) {
     const uint32_t d0 = idx / L, l = idx - d0 * L;
     const double pv = (d0 < np) ? o.p[(fi - 1 - d0) * L + l] : 1.0;
     const double g = (pv * ES[(row0 + d0) * L + l]) * (bt[l] * fs[d0]);
     const double y = (l == al && d0 + 1 == ld) ? 1.0 : 0.0;
     ES[(row0 + d0) * L + l] = y - g;
+    gs += g;
   }
+  // state posterior mass of the node (checked against the transition mass by k_mass_check)
+  gs = wave_sum_f64_dpp(gs);
+  if ((threadIdx.x & 63) == 0) msum[threadIdx.x >> 6] = gs;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    mass_s[fi] = (msum[0] + msum[1]) + (msum[2] + msum[3]);
     double nodeLi = 0.0;
     if (lab != SCRF_LAB_BAD && err == 0) {
       if (ld <= nd) nodeLi += s_true[fi];
@@ -629,10 +637,53 @@ __global__ __launch_bounds__(256) void k_post_lin(ScrfLayout lay, ScrfBatchView 
 void launch_post_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
                      uint64_t n_frames, const uint32_t* next_lab, const double* s_true, const double* M,
                      int m_per_frame, double* ES, const double* smax, const ScrfDpLin& o, const double* zx,
-                     double* numer_f, int* status) {
+                     double* numer_f, int* status, double* mass_s) {
   if (n_frames == 0) return;
   hipLaunchKernelGGL(k_post_lin, dim3((uint32_t)n_frames), dim3(256), 0, st, lay, bv, frame_u, u0, next_lab, s_true, M,
-                     m_per_frame, ES, smax, o, zx, numer_f, status);
+                     m_per_frame, ES, smax, o, zx, numer_f, status, mass_s);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mass_check: the reference's posterior-mass self-checks (scrf_mass_ok, scrf_dp_common.h) per frame:
+// state mass (summed by the posterior kernel while it formed gamma) against the transition mass
+// sum_c exp(alpha[t][c] + beta[t][c] - Zx).  16 lanes per frame.  LIN: alpha/beta are mantissa vectors
+// with per-frame log-scales (ScrfDpLin), else plain log-domain arrays.
+// ------------------------------------------------------------------------------------------
+template <int LIN>
+__global__ __launch_bounds__(256) void k_mass_check(ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0,
+                                                    uint64_t n_frames, uint32_t L, int frame_model,
+                                                    const double* __restrict__ av, const double* __restrict__ ga,
+                                                    const double* __restrict__ bvec, const double* __restrict__ gb,
+                                                    const double* __restrict__ zx, const double* __restrict__ mass_s,
+                                                    int* __restrict__ status) {
+  const uint64_t fi = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const uint32_t sub = threadIdx.x & 15;
+  const bool live = fi < n_frames;
+  const uint64_t fc = live ? fi : 0;
+  const uint64_t gf = bv.frame_off[u0] + fc;
+  const uint32_t u = frame_u[gf];
+  const double Zx = zx[u];
+  double s = 0.0;
+  if (LIN) {
+    for (uint32_t l = sub; l < L; l += 16) s = fma(av[fc * L + l], bvec[fc * L + l], s);
+  } else {
+    for (uint32_t l = sub; l < L; l += 16) s += exp(fmin(av[fc * L + l] + bvec[fc * L + l] - Zx, 700.0));
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) s += shfl_f64(s, (int)((threadIdx.x & 63) ^ o));
+  if (LIN) s *= exp(fmin(ga[fc] + gb[fc] - Zx, 700.0));
+  if (live && sub == 0) {
+    const bool last = (gf + 1 == bv.frame_off[u + 1]);
+    if (!scrf_mass_ok(mass_s[fc], s, last, frame_model != 0)) atomicMax(&status[u], SCRF_ERR_NUMERIC);
+  }
+}
+void launch_mass_check(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                       uint32_t L, int frame_model, int lin, const double* a, const double* ga, const double* b,
+                       const double* gb, const double* zx, const double* mass_s, int* status) {
+  if (n_frames == 0) return;
+  const dim3 grid((uint32_t)((n_frames + 15) / 16));
+  if (lin) hipLaunchKernelGGL(k_mass_check<1>, grid, dim3(256), 0, st, bv, frame_u, u0, n_frames, L, frame_model, a, ga, b, gb, zx, mass_s, status);
+  else hipLaunchKernelGGL(k_mass_check<0>, grid, dim3(256), 0, st, bv, frame_u, u0, n_frames, L, frame_model, a, ga, b, gb, zx, mass_s, status);
 }
 
 // ------------------------------------------------------------------------------------------

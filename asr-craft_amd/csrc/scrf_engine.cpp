@@ -71,6 +71,15 @@ struct scrf_engine_s {
   double* d_msh0 = nullptr;
   bool m0_valid = false;
   double* d_sums = nullptr;   // {numer, zx, n_utts, active}
+  // a batch's gradient and sums are built in a staging buffer and committed to d_grad / d_sums by a kernel
+  // that is a no-op when an utterance of the batch failed (d_latch): a failed scrf_fb_batch leaves the
+  // gradient as it was, and a NUMERIC failure of the linear-domain recursion can be redone in the log domain
+  double* d_stage = nullptr;
+  double* d_sums_stage = nullptr;
+  int* d_latch = nullptr;     // {status code, utterance} of the first failed utterance of the batch in flight
+  int* h_latch = nullptr;     // pinned copy, valid once ev_status has completed
+  hipEvent_t ev_status = nullptr;
+  uint64_t n_lin_fallback = 0;   // batches redone through the log-domain recursion
   char* scratch = nullptr;
   size_t scratch_cap = 0;
   // second lane: alternate chunks of a batch run on a second stream so that the VALU-bound DP
@@ -84,6 +93,10 @@ struct scrf_engine_s {
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
   bool lin_dp = true;
+  // the workgroup-per-utterance log-domain recursion (k_fb: column-wise max-shifted log-sum-exp, the
+  // reference's LogMath) instead of the wavefront kernels, whose transition step works on exp(M - max M):
+  // set for the automatic redo of a batch / hook call that raised SCRF_ERR_NUMERIC there
+  bool force_fb = false;
   // decode from the fused score kernel's float arc weights + reference-order fix-ups (bit-identical
   // to the EXACT path by a rounding-error bound, ScrfDecodeOut); SCRF_FAST_DECODE=0 turns it off
   bool fast_decode = true;
@@ -91,6 +104,10 @@ struct scrf_engine_s {
   double* d_w1 = nullptr;
   uint64_t n_decode_fix = 0, n_decode_fallback = 0;   // entries recomputed / chunks sent back to the EXACT path
   std::string err;
+  // per-kernel HIP-event times of the last timed call (scrf_kernel_timing)
+  struct KTime { std::string name; double ms; uint32_t n; };
+  std::vector<KTime> ktimes;
+  hipEvent_t kev[2] = {nullptr, nullptr};
   bool timing = false;
   hipEvent_t ev[SCRF_N_PHASES + 1][2];
   bool ev_ok = false;
@@ -242,6 +259,14 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_msh0, sizeof(double)));
   CRCHK(hipMalloc((void**)&h->d_sums, sizeof(double) * 4));
+  CRCHK(hipMalloc((void**)&h->d_stage, nb));
+  CRCHK(hipMalloc((void**)&h->d_sums_stage, sizeof(double) * 4));
+  CRCHK(hipMalloc((void**)&h->d_latch, sizeof(int) * 2));
+  CRCHK(hipHostMalloc((void**)&h->h_latch, sizeof(int) * 2, hipHostMallocDefault));
+  h->h_latch[0] = h->h_latch[1] = 0;
+  CRCHK(hipEventCreateWithFlags(&h->ev_status, hipEventDisableTiming));
+  CRCHK(hipEventCreate(&h->kev[0]));
+  CRCHK(hipEventCreate(&h->kev[1]));
   CRCHK(hipMalloc((void**)&h->d_grad2, nb));
   CRCHK(hipMalloc((void**)&h->d_sums2, sizeof(double) * 4));
   CRCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -271,6 +296,11 @@ extern "C" int scrf_destroy(scrf_handle h) {
   hipFree(h->d_lambda); hipFree(h->d_lambda_acc); hipFree(h->d_gsa);
   if (h->own_grad) hipFree(h->d_grad);
   hipFree(h->d_grad2); hipFree(h->d_sums2); hipFree(h->scratch2);
+  hipFree(h->d_stage); hipFree(h->d_sums_stage); hipFree(h->d_latch);
+  if (h->h_latch) hipHostFree(h->h_latch);
+  if (h->ev_status) hipEventDestroy(h->ev_status);
+  if (h->kev[0]) hipEventDestroy(h->kev[0]);
+  if (h->kev[1]) hipEventDestroy(h->kev[1]);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -478,6 +508,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   const uint64_t NF = b->frame_off[n], NS = b->seg_off[n];
   int rc;
 #define BCHK(x) do { rc = (x); if (rc != SCRF_OK) { scrf_batch_destroy(h, b); return rc; } } while (0)
+#define BSYNC() do { hipError_t e_ = hipStreamSynchronize(h->stream); if (e_ != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "scrf_batch_create: %s", hipGetErrorString(e_)); } } while (0)
   BCHK(upload(h, &b->d_T, b->T.data(), n));
   BCHK(upload(h, &b->d_frame_off, b->frame_off.data(), n + 1));
   BCHK(upload(h, &b->d_seg_off, b->seg_off.data(), n + 1));
@@ -486,7 +517,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     std::vector<uint32_t> fu(NF);
     for (uint32_t u = 0; u < n; u++) std::fill(fu.begin() + b->frame_off[u], fu.begin() + b->frame_off[u + 1], u);
     BCHK(upload(h, &b->d_frame_u, fu.data(), NF));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    BSYNC();
   }
   if (have_labels) {
     std::vector<uint32_t> lab(NF);
@@ -508,7 +539,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     }
     BCHK(upload(h, &b->d_next_lab, nxt.data(), NF));
     BCHK(upload(h, &b->d_trans_counts, cnt.data(), cnt.size()));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    BSYNC();
   }
   if (by_windows) {
     BCHK(upload<float>(h, &b->d_windows, nullptr, NS * lay.F + 64));  // tail pad: wide loads may over-read 12 B
@@ -529,7 +560,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
       }
       BCHK(upload(h, &b->d_sframe_off[s], so.data(), n + 1));
       BCHK(upload<float>(h, &b->d_frames[s], nullptr, so[n] * recipes[s].in_width + 64));  // tail pad: wide loads may over-read 12 B
-      HIPCHK(h, hipStreamSynchronize(h->stream));
+      BSYNC();
       for (uint32_t u = 0; u < n; u++) {
         hipError_t e = hipMemcpyAsync(b->d_frames[s] + so[u] * recipes[s].in_width, utts[u].frames[s],
                                       sizeof(float) * (so[u + 1] - so[u]) * recipes[s].in_width, hipMemcpyHostToDevice, h->stream);
@@ -554,7 +585,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
         std::fill(xm.begin() + b->frame_off[u], xm.begin() + b->frame_off[u + 1], m);
       }
       BCHK(upload(h, &b->d_xm_f, xm.data(), NF));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
+      BSYNC();
     }
     // score tiles: the windows of TB whole frames; expected-count tiles: 64 consecutive windows
     const uint32_t D = lay.D, TB = fused_scores_tb(recipes[0].in_width, D);
@@ -590,14 +621,15 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
         b->tile_off[k][u + 1] = td.size();
       }
       BCHK(upload(h, &b->d_tiles[k], td.data(), td.size()));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
+      BSYNC();
     }
   }
   BCHK(upload<double>(h, &b->d_numer, nullptr, n));
   BCHK(upload<double>(h, &b->d_zx, nullptr, n));
   BCHK(upload<int>(h, &b->d_status, nullptr, n));
 #undef BCHK
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  BSYNC();
+#undef BSYNC
   *out = b;
   return SCRF_OK;
 }
@@ -665,6 +697,7 @@ struct ChunkBufs {
   double* fA = nullptr;      // [nfr][L] xi factors
   double* fB = nullptr;
   double* numer_f = nullptr; // [nfr]
+  double* mass_s = nullptr;  // [nfr] state posterior mass per node (reference self-check, computeExpF :917-947)
   // scaled linear-domain recursion (training path of the wavefront DP)
   bool lin = false;
   bool es_ready = false;     // cb.S already holds exp(S - smax) (written by the fused score kernel)
@@ -696,6 +729,7 @@ static uint32_t decode_fix_cap(uint64_t nseg, uint32_t L) {
 // hooks, linear-domain for training); 64 < L <= 256: the multi-wavefront linear-domain kernel,
 // training path only
 static bool wave_path(scrf_handle h, bool post) {
+  if (h->force_fb) return false;
   return dp_wave_supported(h->lay) || (post && h->lin_dp && (dplin_mw_supported(h->lay) || dplin_supported(h->lay)));
 }
 
@@ -739,6 +773,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
       }
     }
     if (nd.post) {
+      tot += pad256(nfr * sizeof(double));                            // mass_s
       if (l.use_tf) {
         tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
         uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
@@ -850,6 +885,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       }
     }
     if (nd.post) {
+      cb->mass_s = a.take<double>(nfr);
       if (l.use_tf) {
         cb->XI = a.take<double>(nfr * LL);
         cb->xrow_next = a.take<uint64_t>(nfr);
@@ -892,6 +928,28 @@ struct PhaseTimer {
   }
 };
 
+// HIP-event time of one kernel launch (or a few belonging together), accumulated by name; only when
+// timing is enabled (the stop waits for the kernel, so it serialises the host with the device)
+struct KernelTimer {
+  scrf_handle h;
+  const char* name;
+  hipStream_t st;
+  KernelTimer(scrf_handle h_, const char* n, hipStream_t s_) : h(h_), name(n), st(s_) {
+    if (h->timing) hipEventRecord(h->kev[0], st);
+  }
+  void stop(uint32_t launches = 1) {
+    if (!h->timing) return;
+    hipEventRecord(h->kev[1], st);
+    hipEventSynchronize(h->kev[1]);
+    float ms = 0;
+    hipEventElapsedTime(&ms, h->kev[0], h->kev[1]);
+    for (auto& k : h->ktimes)
+      if (k.name == name) { k.ms += ms; k.n += launches; return; }
+    h->ktimes.push_back({name, ms, launches});
+  }
+};
+#define KT_RUN(name, st, ...) do { KernelTimer kt_(h, name, st); __VA_ARGS__; kt_.stop(); } while (0)
+
 static ScrfFusedArgs fused_args(scrf_handle h, scrf_batch b, uint32_t u0, int which) {
   ScrfFusedArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -916,10 +974,10 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     ScrfFusedArgs fa = fused_args(h, b, u0, 0);
     // per-frame projections of the five sampled blocks, then the dense part + gather
     if (pframe_supported(W0))
-      launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, 5 * l.L, cb.P);
+      KT_RUN("k_pframe", cb.st, launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, 5 * l.L, cb.P));
     else
-      launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
-                         spec_samples(W0), 5 * l.L, cb.P);
+      KT_RUN("k_scores_mfma(samples)", cb.st, launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
+                         spec_samples(W0), 5 * l.L, cb.P));
     if (cb.Wn) {
       // decode: float arc weights + the rounding screen
       launch_state_l1(cb.st, h->d_lambda, l, h->d_w1);
@@ -933,7 +991,7 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
       // epilogue adds).  1 % covers gamma's denominator and the rounding of the bound itself.
       dz.bound_scale = h->decode_bound_factor * 1.01 * 0x1p-53 * (double)(l.nsfe + 1 + 3 * W0 + 8);
       PhaseTimer tk(h, PH_K_SCORE, cb.st);
-      launch_scores_fused_decode(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], dz);
+      KT_RUN("k_scores_fused(decode)", cb.st, launch_scores_fused_decode(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], dz));
       tk.stop(1);
       tm.stop(3);
       HIPCHK(h, hipGetLastError());
@@ -943,8 +1001,8 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     cb.es_ready = cb.lin && l.L <= 48;
     {
       PhaseTimer tk(h, PH_K_SCORE, cb.st);
-      launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32,
-                          cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels);
+      KT_RUN("k_scores_fused", cb.st, launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32,
+                          cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels));
       tk.stop(1);
     }
     tm.stop(2);
@@ -956,8 +1014,8 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     uint32_t col = 0;
     for (uint32_t s = 0; s < b->n_streams; s++) {
       const scrf_stream_recipe& r = b->recipe[s];
-      launch_windows(cb.st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
-                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col);
+      KT_RUN("k_windows", cb.st, launch_windows(cb.st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
+                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col));
       col += b->width[s];
     }
     tm.stop(b->n_streams);
@@ -966,14 +1024,14 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   uint32_t nl = 1;
   {
     PhaseTimer tk(h, PH_K_SCORE, cb.st);
-    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32);
-    else launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S);
+    if (fast) KT_RUN("k_scores_mfma(state)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32));
+    else KT_RUN("k_scores_exact(state)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S));
     tk.stop(1);
   }
   if (l.use_tf) {
     launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
-    if (fast) launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, f32);
-    else launch_scores_exact(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M);
+    if (fast) KT_RUN("k_scores_mfma(trans)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, f32));
+    else KT_RUN("k_scores_exact(trans)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M));
     nl += 2;
   } else if (!h->m0_valid) {
     // transition scores carry only the bias: one L x L matrix for every frame
@@ -993,6 +1051,7 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
 static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool post, uint32_t* nl_out) {
   const ScrfLayout& l = h->lay;
   const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0];
+  const int frame_model = h->cfg.model_type == SCRF_STDFRAME;
   ScrfBatchView bv = b->view();
   uint32_t nl = 0;
   if (!cb.wave) {
@@ -1000,41 +1059,45 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
       return fail(h, SCRF_ERR_INVALID, "labels x maximum duration = %u x %u is too large for the workgroup-per-utterance recursion "
                   "(its two [D][L] rings must fit 160 KB of LDS; the wavefront kernels cover L <= 256 with D <= 40)", l.L, l.D);
     if (post && cb.xi_acc) HIPCHK(h, hipMemsetAsync(cb.xi_acc, 0, sizeof(double) * nutt * l.L * l.L, cb.st));
-    launch_fb(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, post ? cb.XI : nullptr,
-              post ? cb.xi_acc : nullptr, b->d_numer, b->d_zx, b->d_status, post ? 1 : 0);
+    KT_RUN("k_fb", cb.st, launch_fb(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.alpha, cb.beta, post ? cb.XI : nullptr,
+              post ? cb.xi_acc : nullptr, b->d_numer, b->d_zx, b->d_status, post ? 1 : 0, frame_model));
     nl = 1;
   } else {
-    if (cb.m_per_frame) { launch_exp_m(cb.st, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh); nl++; }
+    if (cb.m_per_frame) { KT_RUN("k_exp_m", cb.st, launch_exp_m(cb.st, cb.M, l.L, nfr, cb.E, cb.ET, cb.msh)); nl++; }
     if (cb.lin) {
       const uint64_t nseg = b->seg_off[u1] - b->seg_off[u0];
       if (!cb.es_ready) {
-        launch_true_scores(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.S, cb.s_true);
-        launch_exp_rows(cb.st, cb.S, nseg, l.L, cb.smax);
+        KT_RUN("k_true_scores", cb.st, launch_true_scores(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.S, cb.s_true));
+        KT_RUN("k_exp_rows", cb.st, launch_exp_rows(cb.st, cb.S, nseg, l.L, cb.smax));
         nl += 2;
       }
       {
         PhaseTimer tk(h, PH_K_DP, cb.st);
-        launch_dp_lin(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.smax, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.dl,
-                      b->d_zx, b->d_status);
+        KT_RUN(l.L > 64 ? "k_dp_lin_mw" : "k_dp_lin", cb.st, launch_dp_lin(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.smax, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.dl,
+                      b->d_zx, b->d_status));
         tk.stop(1);
       }
       if (cb.fused) {
         // posterior pass and the per-frame sums of R in one walk (R is not read back for Z)
-        launch_post_z(cb.st, l, bv, u0, (uint32_t)nutt, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S, cb.smax,
-                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z);
+        if (l.L > 64) HIPCHK(h, hipMemsetAsync(cb.mass_s, 0, sizeof(double) * nfr, cb.st));   // summed over the 64-output groups
+        KT_RUN("k_post_z", cb.st, launch_post_z(cb.st, l, bv, u0, (uint32_t)nutt, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S, cb.smax,
+                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z, cb.mass_s));
         cb.z_ready = true;
       } else {
-        launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
-                        cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status);
+        KT_RUN("k_post_lin", cb.st, launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
+                        cb.smax, cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.mass_s));
       }
-      launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
+      // the reference's posterior-mass self-checks (computeExpF :917-947), before sd / gsd are rescaled below
+      KT_RUN("k_mass_check", cb.st, launch_mass_check(cb.st, bv, b->d_frame_u, u0, nfr, l.L, frame_model, 1, cb.dl.a, cb.dl.ga, cb.dl.b, cb.dl.gb,
+                        b->d_zx, cb.mass_s, b->d_status));
+      KT_RUN("k_numer_reduce", cb.st, launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer));
       // transition posteriors: with transition features the rescaled sd rows are needed as an array; with
       // bias-only transitions only their per-frame factor is, applied inside the A^T B contraction
-      if (l.use_tf) launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
-      else launch_xi_scale(cb.st, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx);
-      nl += 4;
+      if (l.use_tf) KT_RUN("k_xi_lin", cb.st, launch_xi_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx));
+      else KT_RUN("k_xi_scale", cb.st, launch_xi_scale(cb.st, bv, b->d_frame_u, u0, nfr, cb.dl, b->d_zx));
+      nl += 5;
       if (l.use_tf) {
-        launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
+        KT_RUN("k_xi_full", cb.st, launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI));
         nl++;
       }
       if (nl_out) *nl_out = nl;
@@ -1043,19 +1106,21 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
     }
     {
       PhaseTimer tk(h, PH_K_DP, cb.st);
-      launch_dp_wave(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
-                     cb.beta, cb.sd, b->d_zx, b->d_status);
+      KT_RUN("k_dp_wave", cb.st, launch_dp_wave(cb.st, l, bv, u0, (uint32_t)nutt, cb.S, cb.E, cb.ET, cb.msh, cb.m_per_frame, cb.AD, cb.alpha,
+                     cb.beta, cb.sd, b->d_zx, b->d_status));
       tk.stop(1);
     }
     nl++;
     if (post) {
-      launch_post_state(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.beta,
-                        b->d_zx, cb.numer_f, b->d_status);
-      launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer);
-      launch_xi_factors(cb.st, l, bv, u0, u1, nfr, cb.alpha, cb.sd, b->d_zx, cb.fA, cb.fB);
-      nl += 3;
+      KT_RUN("k_post_state", cb.st, launch_post_state(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.S, cb.M, cb.m_per_frame, cb.AD, cb.beta,
+                        b->d_zx, cb.numer_f, b->d_status, cb.mass_s));
+      KT_RUN("k_mass_check", cb.st, launch_mass_check(cb.st, bv, b->d_frame_u, u0, nfr, l.L, frame_model, 0, cb.alpha, nullptr, cb.beta, nullptr,
+                        b->d_zx, cb.mass_s, b->d_status));
+      KT_RUN("k_numer_reduce", cb.st, launch_numer_reduce(cb.st, bv, u0, (uint32_t)nutt, cb.numer_f, b->d_numer));
+      KT_RUN("k_xi_factors", cb.st, launch_xi_factors(cb.st, l, bv, u0, u1, nfr, cb.alpha, cb.sd, b->d_zx, cb.fA, cb.fB));
+      nl += 4;
       if (l.use_tf) {
-        launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI);
+        KT_RUN("k_xi_full", cb.st, launch_xi_full(cb.st, l, bv, u0, u1, nfr, b->d_next_lab, cb.fA, cb.fB, cb.E, cb.msh, cb.XI));
         nl++;
       }
     }
@@ -1065,32 +1130,53 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
   return SCRF_OK;
 }
 
-static int check_status(scrf_handle h, scrf_batch b) {
-  std::vector<int> st(b->U);
-  HIPCHK(h, hipMemcpyAsync(st.data(), b->d_status, sizeof(int) * b->U, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (uint32_t u = 0; u < b->U; u++) {
-    if (st[u] == SCRF_OK) continue;
-    const char* what = st[u] == SCRF_ERR_BAD_LABEL ? "the label is larger than nActualLabs*labMaxDur"
-                       : st[u] == SCRF_ERR_EMPTY   ? "No features read from this sentence."
-                                                   : "overflow / NaN / log of zero in the log-domain recursion";
-    return fail(h, st[u], "utterance %u: %s", u, what);
-  }
+// ---------------------------------------------------------------------------------------------
+// status of a batch: first failed utterance -> {code, utterance} (d_latch), copied to pinned host memory;
+// the commit of the staged gradient is a no-op when the latch is set
+// ---------------------------------------------------------------------------------------------
+__global__ void k_latch_status(const int* __restrict__ status, uint32_t n, int* __restrict__ latch) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const int s = status[u];
+  if (s != 0 && atomicCAS(&latch[0], 0, s) == 0) latch[1] = (int)u;
+}
+__global__ void k_commit(double* __restrict__ grad, const double* __restrict__ stage, uint32_t n,
+                         double* __restrict__ sums, const double* __restrict__ sums_stage,
+                         const int* __restrict__ latch) {
+  if (latch[0] != 0) return;   // a failed batch contributes nothing
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) grad[i] += stage[i];
+  if (i < 3) sums[i] += sums_stage[i];
+}
+
+static const char* status_text(int code) {
+  return code == SCRF_ERR_BAD_LABEL ? "the label is larger than nActualLabs*labMaxDur"
+         : code == SCRF_ERR_EMPTY   ? "No features read from this sentence."
+                                    : "overflow / NaN / log of zero in the recursion, or posterior-mass check failed";
+}
+
+static int queue_status(scrf_handle h, scrf_batch b) {
+  hipLaunchKernelGGL(k_latch_status, dim3((b->U + 255) / 256), dim3(256), 0, h->stream, b->d_status, b->U, h->d_latch);
+  HIPCHK(h, hipMemcpyAsync(h->h_latch, h->d_latch, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_status, h->stream));
   return SCRF_OK;
 }
 
-extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double* zx) {
-  if (!h || !b) return SCRF_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+// One pass of the forward-backward pipeline over the batch into the staging gradient.  latch[2] receives
+// {status code, utterance} of the first failed utterance (0 = clean, gradient committed); *used_lin tells
+// whether any chunk ran the linear-domain recursion.
+static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   const ScrfLayout& l = h->lay;
-  if (!b->d_labels) return fail(h, SCRF_ERR_INVALID, "scrf_fb_batch: the batch carries no labels");
-  if (h->timing) { memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream); }
   HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_latch, 0, sizeof(int) * 2, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_stage, 0, sizeof(double) * l.lambda_len, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_sums_stage, 0, sizeof(double) * 4, h->stream));
   Need nd{true, true, false, false};
   ScrfBatchView bv = b->view();
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
   const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
   nd.fused = fast && b->fused_ok && h->fuse_windows;
+  *used_lin = false;
 
   // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
   // at least four chunks so that both streams always have work
@@ -1126,6 +1212,8 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     ChunkBufs cb;
     int rc = carve(h, b, u0, u1, nd, &cb, lane);
     if (rc != SCRF_OK) return rc;
+    if (!lane) { cb.grad = h->d_stage; cb.sums = h->d_sums_stage; }
+    if (cb.lin) *used_lin = true;
     const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
     rc = run_scores(h, b, u0, u1, cb, fast, f32);
     if (rc != SCRF_OK) return rc;
@@ -1136,6 +1224,12 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
       if (rc != SCRF_OK) return rc;
       tm.stop(nl);
     }
+    // every per-utterance status of the batch is final once the last chunk's posterior kernels are queued:
+    // its copy to the host travels under the expected-count kernels
+    if (!use2 && ci + 1 == n_chunks) {
+      rc = queue_status(h, b);
+      if (rc != SCRF_OK) return rc;
+    }
     {
       PhaseTimer tm(h, PH_EXPF, cb.st);
       uint32_t nl = 1;
@@ -1144,32 +1238,33 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
         ScrfFusedArgs fa = fused_args(h, b, u0, 1);
         {
           PhaseTimer tk(h, PH_K_EXPF, cb.st);
-          launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32);
+          KT_RUN("k_expf_fused", cb.st, launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32));
           tk.stop(1);
         }
-        if (!cb.z_ready) launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z);
+        if (!cb.z_ready) KT_RUN("k_lin_z", cb.st, launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z));
         if (pframe_supported(W0))
-          launch_ztf(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l);
+          KT_RUN("k_ztf", cb.st, launch_ztf(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l));
         else
-          launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
-                           spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l);
+          KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
+                           spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l));
         nl += 2;
       } else {
         PhaseTimer tk(h, PH_K_EXPF, cb.st);
-        if (fast) launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
-        else launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+        if (fast) KT_RUN("k_expf_mfma(state)", cb.st, launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32));
+        else KT_RUN("k_expf_gemm(state)", cb.st, launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s));
         tk.stop(1);
       }
       if (l.use_tf) {
         launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
-        if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32);
-        else launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+        if (fast) KT_RUN("k_expf_mfma(trans)", cb.st, launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32));
+        else KT_RUN("k_expf_gemm(trans)", cb.st, launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t));
         nl += 2;
       }
       tm.stop(nl);
     }
     {
       PhaseTimer tm(h, PH_REDUCE, cb.st);
+      KernelTimer kt(h, "reductions (k_reduce_slabs, k_atb, k_batch_sums)", cb.st);
       if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
         launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
@@ -1180,6 +1275,7 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
                                    cb.lin ? cb.dl.gsd : nullptr);
       else launch_reduce_xiacc(cb.st, cb.xi_acc, (uint32_t)nutt, l, cb.grad);
       launch_batch_sums(cb.st, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, cb.sums);
+      kt.stop(4);
       tm.stop(3);
     }
     HIPCHK(h, hipGetLastError());
@@ -1188,18 +1284,51 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
     // join: lane 1's partial gradient and sums are added once, in a fixed order
     HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    launch_add(h->stream, h->d_grad, h->d_grad2, l.lambda_len);
-    launch_add(h->stream, h->d_sums, h->d_sums2, 3);
+    launch_add(h->stream, h->d_stage, h->d_grad2, l.lambda_len);
+    launch_add(h->stream, h->d_sums_stage, h->d_sums2, 3);
+    int rc = queue_status(h, b);
+    if (rc != SCRF_OK) return rc;
   }
-  if (!l.use_tf && wave_path(h, true)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_grad);
+  if (!l.use_tf && wave_path(h, true)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_stage);
+  hipLaunchKernelGGL(k_commit, dim3((l.lambda_len + 255) / 256), dim3(256), 0, h->stream, h->d_grad, h->d_stage, l.lambda_len,
+                     h->d_sums, h->d_sums_stage, h->d_latch);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventSynchronize(h->ev_status));
+  latch[0] = h->h_latch[0];
+  latch[1] = h->h_latch[1];
+  return SCRF_OK;
+}
+
+extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double* zx) {
+  if (!h || !b) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!b->d_labels) return fail(h, SCRF_ERR_INVALID, "scrf_fb_batch: the batch carries no labels");
+  if (h->timing) {
+    memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); h->ktimes.clear();
+    hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream);
+  }
+  int latch[2] = {0, 0};
+  bool used_lin = false;
+  int rc = fb_run(h, b, latch, &used_lin);
+  if (rc != SCRF_OK) return rc;
+  if (latch[0] == SCRF_ERR_NUMERIC && wave_path(h, true)) {
+    // the wavefront recursions take their transition step on exp(M - max M) (and the linear-domain one
+    // flushes what lies ~700 nats below a frame's maximum); where that empties a whole vector or breaks a
+    // posterior-mass check, the batch is redone with the workgroup kernel, a column-wise max-shifted
+    // log-sum-exp like the reference's LogMath -- the staged gradient of the first pass was dropped
+    h->n_lin_fallback++;
+    h->force_fb = true;
+    rc = fb_run(h, b, latch, &used_lin);
+    h->force_fb = false;
+    if (rc != SCRF_OK) return rc;
+  }
   if (h->timing) {
     hipEventRecord(h->ev[SCRF_N_PHASES][1], h->stream);
     hipEventSynchronize(h->ev[SCRF_N_PHASES][1]);
     hipEventElapsedTime(&h->ms[PH_ALL], h->ev[SCRF_N_PHASES][0], h->ev[SCRF_N_PHASES][1]);
   }
+  if (latch[0] != 0) return fail(h, latch[0], "utterance %d: %s", latch[1], status_text(latch[0]));
   if (numer || zx) {
-    int rc = check_status(h, b);
-    if (rc != SCRF_OK) return rc;
     if (numer) HIPCHK(h, hipMemcpyAsync(numer, b->d_numer, sizeof(double) * b->U, hipMemcpyDeviceToHost, h->stream));
     if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx, sizeof(double) * b->U, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1279,28 +1408,33 @@ extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, ui
                                      double* alpha, double* beta, double* zx) {
   int rc = check_u(h, b, u, "scrf_forward_backward");
   if (rc != SCRF_OK) return rc;
-  (void)prec;
+  if (prec != SCRF_PREC_EXACT) return fail(h, SCRF_ERR_INVALID, "scrf_forward_backward: the node-value hook runs at SCRF_PREC_EXACT only");
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
   Need nd{true, false, true, false};
-  ChunkBufs cb;
-  rc = carve(h, b, u, u + 1, nd, &cb);
-  if (rc != SCRF_OK) return rc;
-  rc = run_scores(h, b, u, u + 1, cb);
-  if (rc != SCRF_OK) return rc;
-  HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
-  rc = run_dp(h, b, u, u + 1, cb, false, nullptr);
-  if (rc != SCRF_OK) return rc;
   uint64_t nseg = b->seg_off[u + 1] - b->seg_off[u];
   uint32_t T = b->T[u];
-  if (alpha_dur) HIPCHK(h, hipMemcpyAsync(alpha_dur, cb.AD, sizeof(double) * nseg * l.L, hipMemcpyDeviceToHost, h->stream));
-  if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, cb.alpha, sizeof(double) * T * l.L, hipMemcpyDeviceToHost, h->stream));
-  if (beta) HIPCHK(h, hipMemcpyAsync(beta, cb.beta, sizeof(double) * T * l.L, hipMemcpyDeviceToHost, h->stream));
-  if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  int st = 0;
-  HIPCHK(h, hipMemcpy(&st, b->d_status + u, sizeof(int), hipMemcpyDeviceToHost));
-  if (st != SCRF_OK && st != SCRF_ERR_BAD_LABEL) return fail(h, st, "utterance %u: numeric failure in forward-backward", u);
+  // second attempt: the workgroup kernel (reference LogMath) when the wavefront recursion gave up
+  for (int attempt = 0; attempt < 2; attempt++) {
+    ChunkBufs cb;
+    rc = carve(h, b, u, u + 1, nd, &cb);
+    if (rc == SCRF_OK) rc = run_scores(h, b, u, u + 1, cb);
+    if (rc == SCRF_OK && hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream) != hipSuccess) rc = fail(h, SCRF_ERR_HIP, "scrf_forward_backward: memset failed");
+    if (rc == SCRF_OK) rc = run_dp(h, b, u, u + 1, cb, false, nullptr);
+    int st = 0;
+    if (rc == SCRF_OK && hipMemcpyAsync(&st, b->d_status + u, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(h, SCRF_ERR_HIP, "scrf_forward_backward: status copy failed");
+    if (rc == SCRF_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, SCRF_ERR_HIP, "scrf_forward_backward: synchronize failed");
+    if (rc != SCRF_OK) { h->force_fb = false; return rc; }
+    if (st == SCRF_ERR_NUMERIC && !h->force_fb && wave_path(h, false)) { h->force_fb = true; continue; }
+    h->force_fb = false;
+    if (st != SCRF_OK && st != SCRF_ERR_BAD_LABEL) return fail(h, st, "utterance %u: numeric failure in forward-backward", u);
+    if (alpha_dur) HIPCHK(h, hipMemcpyAsync(alpha_dur, cb.AD, sizeof(double) * nseg * l.L, hipMemcpyDeviceToHost, h->stream));
+    if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, cb.alpha, sizeof(double) * T * l.L, hipMemcpyDeviceToHost, h->stream));
+    if (beta) HIPCHK(h, hipMemcpyAsync(beta, cb.beta, sizeof(double) * T * l.L, hipMemcpyDeviceToHost, h->stream));
+    if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    break;
+  }
   return SCRF_OK;
 }
 
@@ -1354,7 +1488,7 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
-  if (h->timing) { memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream); }
+  if (h->timing) { memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); h->ktimes.clear(); hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream); }
   const uint64_t NF = b->frame_off[b->U];
   uint32_t *d_lab = nullptr, *d_n = nullptr;
   float* d_cost = nullptr;
@@ -1545,6 +1679,23 @@ extern "C" int scrf_sgd_step(scrf_handle h, double lr_or_eta, int use_adagrad, d
 // ---------------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------------
+extern "C" int scrf_kernel_timing(scrf_handle h, char* buf, size_t cap) {
+  if (!h || !buf || cap == 0) return SCRF_ERR_INVALID;
+  std::string out;
+  char line[256];
+  for (const auto& k : h->ktimes) {
+    snprintf(line, sizeof line, "%s\t%.6f\t%u\n", k.name.c_str(), k.ms, k.n);
+    out += line;
+  }
+  if (out.size() + 1 > cap) return fail(h, SCRF_ERR_INVALID, "scrf_kernel_timing: buffer of %zu bytes too small (%zu needed)", cap, out.size() + 1);
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return SCRF_OK;
+}
+extern "C" int scrf_train_stats(scrf_handle h, uint64_t* n_lin_fallback) {
+  if (!h) return SCRF_ERR_INVALID;
+  if (n_lin_fallback) *n_lin_fallback = h->n_lin_fallback;
+  return SCRF_OK;
+}
 extern "C" int scrf_enable_timing(scrf_handle h, int on) { if (!h) return SCRF_ERR_INVALID; h->timing = on != 0; return SCRF_OK; }
 extern "C" int scrf_last_timing(scrf_handle h, float* ms, uint32_t* n_launch) {
   if (!h) return SCRF_ERR_INVALID;

@@ -22,7 +22,7 @@
 // Kernels: k_pframe (P = F W_k), k_scores_fused (dense part + gather of P + exp epilogue),
 // k_post_z (R = Y - gamma and Z in one walk; k_lin_z is the Z-only form), k_expf_fused (dense part
 // of the expected counts), k_ztf (Z^T F).  DESIGN.md 4.1 has the data flow.
-#include "scrf_kernels.h"
+#include "scrf_dp_common.h"
 
 #include <math.h>
 #include <string.h>
@@ -755,7 +755,8 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
                                                   int m_per_frame, double* __restrict__ ES,
                                                   const double* __restrict__ smax, ScrfDpLin o_,
                                                   const double* __restrict__ zx, double* __restrict__ numer_f,
-                                                  int* __restrict__ status, double* __restrict__ Z) {
+                                                  int* __restrict__ status, double* __restrict__ Z,
+                                                  double* __restrict__ mass_s) {
   __shared__ double pring[DMAX * 64];
   __shared__ double fsb[64];
   const uint32_t D = lay.D, L = lay.L;
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
       al = lab % L;
       ld = lab / L + 1;
     }
+    double gs = 0.0;
 #pragma unroll
     for (int d0 = 0; d0 < DMAX; d0++) {
       int ps = slot - 1 - d0;            // ring slot of p[t-1-d0]
@@ -812,6 +814,14 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
       const double rv = ((uint32_t)d0 < nd) ? y - g : 0.0;
       if (act && (uint32_t)d0 < nd) ESu[(row0 + d0) * L] = rv;
       r[d0] = rv;
+      gs += g;   // r[d0] = 0 and fsb[d0] = 0 past nd
+    }
+    {  // state posterior mass of the node (k_mass_check compares it with the transition mass)
+      const double m = wave_sum_f64_dpp(act ? gs : 0.0);
+      if (lane == 0) {
+        if (gridDim.y == 1) mass_s[f_base + t] = m;
+        else atomicAdd(&mass_s[f_base + t], m);   // L > 64: one partial sum per 64 outputs (buffer zeroed by the caller)
+      }
     }
     w0.add(r); w1.add(r); w2.add(r); w3.add(r); w4.add(r);
     if (act) {
@@ -854,10 +864,11 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
 
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
-                   const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z) {
+                   const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,
+                   double* mass_s) {
   if (n_utts == 0) return;
   dim3 grid(n_utts, (lay.L + 63) / 64);
-#define PZ_GO(N) hipLaunchKernelGGL(k_post_z<N>, grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z)
+#define PZ_GO(N) hipLaunchKernelGGL(k_post_z<N>, grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z, mass_s)
   if (lay.D <= 8) PZ_GO(8);
   else if (lay.D <= 16) PZ_GO(16);
   else if (lay.D <= 25) PZ_GO(25);

@@ -15,7 +15,7 @@ size_t fb_smem_bytes(const ScrfLayout& lay, int NT);
 int fb_block_threads(const ScrfLayout& lay);
 void launch_fb(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                const double* S, const double* M, int m_per_frame, double* AD, double* alpha_g, double* beta_g,
-               double* XI, double* xi_acc, double* numer, double* zx, int* status, int write_post);
+               double* XI, double* xi_acc, double* numer, double* zx, int* status, int write_post, int frame_model = 0);
 void launch_expf_gemm(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, int is_trans,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
@@ -54,7 +54,7 @@ void launch_dp_wave(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uin
 void launch_post_state(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
                        uint64_t n_frames, const uint32_t* next_lab, const double* S, const double* M,
                        int m_per_frame, double* AD, const double* beta_g, const double* zx, double* numer_f,
-                       int* status);
+                       int* status, double* mass_s);
 void launch_numer_reduce(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* numer_f,
                          double* numer);
 void launch_xi_factors(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t u1,
@@ -80,7 +80,12 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
 void launch_post_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
                      uint64_t n_frames, const uint32_t* next_lab, const double* s_true, const double* M,
                      int m_per_frame, double* ES, const double* smax, const ScrfDpLin& o, const double* zx,
-                     double* numer_f, int* status);
+                     double* numer_f, int* status, double* mass_s);
+// posterior-mass self-checks per frame (state mass from the posterior kernel vs sum_c exp(alpha + beta - Zx));
+// lin: a/b are mantissa vectors with log-scales ga/gb, else log-domain arrays (ga, gb unused)
+void launch_mass_check(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                       uint32_t L, int frame_model, int lin, const double* a, const double* ga, const double* b,
+                       const double* gb, const double* zx, const double* mass_s, int* status);
 void launch_xi_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
                    uint64_t n_frames, const ScrfDpLin& o, const double* zx);
 void launch_xi_scale(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
@@ -118,7 +123,8 @@ void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F
                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
-                   const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z);
+                   const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,
+                   double* mass_s);
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                        uint64_t n_tiles, double* slab, int f32);
 

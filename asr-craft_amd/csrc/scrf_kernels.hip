@@ -252,8 +252,9 @@ __global__ void k_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double
                      const double* __restrict__ M, int m_per_frame, double* __restrict__ AD,
                      double* __restrict__ alpha_g, double* __restrict__ beta_g, double* __restrict__ XI,
                      double* __restrict__ xi_acc, double* __restrict__ numer_out, double* __restrict__ zx_out,
-                     int* __restrict__ status, int write_post) {
+                     int* __restrict__ status, int write_post, int frame_model) {
   extern __shared__ double smem[];
+  __shared__ double mass2[2];
   const int L = lay.L, D = lay.D;
   const int NT = blockDim.x, tid = threadIdx.x;
   const uint32_t u = u0 + blockIdx.x;
@@ -370,6 +371,7 @@ __global__ void k_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double
     const int nd = (int)scrf_node_max_dur(t, D);
     const uint64_t base = scrf_seg_base(t, D);
     if (write_post) {
+      double gs = 0.0, xs = 0.0;   // posterior mass of the node: state / transition (computeExpF :917-947)
       for (int idx = tid; idx < nd * L; idx += NT) {
         const int di = idx / L, l = idx - di * L;
         double a = ADu[(base + di) * L + l] + bt[l] - Zx;
@@ -377,6 +379,7 @@ __global__ void k_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double
         double g = exp(a);
         double y = ((uint32_t)l == al && (uint32_t)(di + 1) == ld) ? 1.0 : 0.0;
         ADu[(base + di) * L + l] = y - g;
+        gs += g;
       }
       if (nn > 0) {
         for (int idx = tid; idx < L * L; idx += NT) {
@@ -387,10 +390,17 @@ __global__ void k_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double
           double y = ((uint32_t)ci == al && (uint32_t)n == anl) ? 1.0 : 0.0;
           if (XI) XI[(f_base + t) * LL + idx] = y - x;
           else xi_acc[(size_t)blockIdx.x * LL + idx] += y - x;
+          xs += x;
         }
       } else if (XI) {
         for (int idx = tid; idx < L * L; idx += NT) XI[(f_base + t) * LL + idx] = 0.0;
       }
+      if (tid == 0) { mass2[0] = 0.0; mass2[1] = 0.0; }
+      __syncthreads();
+      for (int o = 32; o >= 1; o >>= 1) { gs += __shfl_xor(gs, o); xs += __shfl_xor(xs, o); }
+      if ((tid & 63) == 0) { atomicAdd(&mass2[0], gs); atomicAdd(&mass2[1], xs); }
+      __syncthreads();
+      if (tid == 0 && !scrf_mass_ok(mass2[0], mass2[1], nn == 0, frame_model != 0)) err = SCRF_ERR_NUMERIC;
     }
     if (tid == 0 && lab != SCRF_LAB_BAD) {
       double nodeLi = 0.0;
@@ -418,13 +428,13 @@ int fb_block_threads(const ScrfLayout& lay) { return lay.L <= 256 ? 256 : 1024; 
 
 void launch_fb(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                const double* S, const double* M, int m_per_frame, double* AD, double* alpha_g, double* beta_g,
-               double* XI, double* xi_acc, double* numer, double* zx, int* status, int write_post) {
+               double* XI, double* xi_acc, double* numer, double* zx, int* status, int write_post, int frame_model) {
   if (n_utts == 0) return;
   int NT = fb_block_threads(lay);
   size_t sm = fb_smem_bytes(lay, NT);
   hipFuncSetAttribute((const void*)k_fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(k_fb, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, S, M, m_per_frame, AD, alpha_g, beta_g,
-                     XI, xi_acc, numer, zx, status, write_post);
+                     XI, xi_acc, numer, zx, status, write_post, frame_model);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -312,6 +312,22 @@ class Engine:
     # ---- measurement
     def enable_timing(self, on=True): self._chk(self.lib.scrf_enable_timing(self.h, C.c_int(int(on))))
 
+    def kernel_timing(self):
+        """[(kernel name, total ms, launches)] of the last timed fb_batch / viterbi_batch, in launch order."""
+        buf = C.create_string_buffer(1 << 16)
+        self._chk(self.lib.scrf_kernel_timing(self.h, buf, C.c_size_t(len(buf))))
+        out = []
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.split("\t")
+            out.append((name, float(ms), int(n)))
+        return out
+
+    def train_stats(self):
+        """batches redone through the log-domain recursion after the linear-domain one raised NUMERIC"""
+        v = C.c_uint64()
+        self._chk(self.lib.scrf_train_stats(self.h, C.byref(v)))
+        return v.value
+
     def last_timing(self):
         ms = (C.c_float * N_PHASES)(); nl = (C.c_uint32 * N_PHASES)()
         self._chk(self.lib.scrf_last_timing(self.h, ms, nl))

@@ -139,77 +139,108 @@ def main():
         dt = float(tmax.item())
 
     out = None
+    gate_err = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: three extra instrumented steps (HIP events on the
-        # engine's stream around every phase and around the three big kernels), kept outside the
-        # timed region because the per-phase event waits would perturb `value`
+        # ---- correctness gate, part 1: the timed steps left a finite model behind
+        if not np.isfinite(eng.get_lambda()).all():
+            gate_err = "lambda is not finite after the timed steps"
+        # ---- roofline: three extra instrumented steps (HIP events on the engine's stream around every
+        # kernel), kept outside the timed region because the per-kernel event waits would perturb `value`
         eng.set_lambda(lam)
         eng.enable_timing(True)
-        acc = {}
+        acc, order = {}, []
         N_INSTR = 3
+        phase = {}
         for _ in range(N_INSTR):
             eng.zero_grad()
             eng.fb_batch(batch, want_scalars=False)
             eng.synchronize()
+            for name, ms_, nl_ in eng.kernel_timing():
+                if name not in acc:
+                    acc[name] = [0.0, 0]; order.append(name)
+                acc[name][0] += ms_; acc[name][1] += nl_
             for k, (ms_, nl_) in eng.last_timing().items():
-                a_ = acc.setdefault(k, [0.0, 0])
-                a_[0] += ms_; a_[1] += nl_
-        tm = {k: (v[0], v[1]) for k, v in acc.items()}
+                phase[k] = phase.get(k, 0.0) + ms_
         eng.enable_timing(False)
         nseg = n_segs(T_FRAMES, D)
-        # algorithmic work per utterance: dense flops of the two state contractions
-        # (2 per MAC, bias excluded); bytes the recursion has to move (S read by the forward and
-        # by the backward sweep, alpha / alpha-plus-trans / beta / sum-over-durations written)
-        flops_gemm = 2.0 * nseg * L * F
-        bytes_dp = 8.0 * (2 * nseg * L + 4 * T_FRAMES * L)
+        nfr = T_FRAMES
         mfma_peak = PEAK["mfma_f32_tflops"] if args.precision == "fast32" else PEAK["mfma_f64_tflops"]
-        kern = {
-            "k_scores": ("k_scores_fused" if args.precision != "exact" else "k_scores_exact", "mfma",
-                         flops_gemm / 1e12, "TFLOP/s", mfma_peak),
-            "k_expf": ("k_expf_fused" if args.precision != "exact" else "k_expf_gemm", "mfma",
-                       flops_gemm / 1e12, "TFLOP/s", mfma_peak),
-            "k_dp": ("k_dp_lin", "hbm", bytes_dp / 1e9, "GB/s", PEAK["hbm_gbs"]),
+        # Work per utterance of every kernel of the step AS EXECUTED: flops the kernel issues
+        # on the matrix pipe (2 per MAC) and the bytes its algorithm has to move (each array once per pass).
+        # The fused kernels contract only the avg|max|min (+ one-hot, bias) column groups densely; the five
+        # sampled blocks are re-associated into the per-frame contractions k_pframe / k_ztf.
+        SL = 8.0 * nseg * L          # one pass over the [N_seg][L] fp64 array
+        VL = 8.0 * nfr * L           # one [T][L] fp64 vector array
+        work = {
+            "k_pframe": (2.0 * nfr * 5 * L * IN_W, 4.0 * nfr * IN_W + 5 * VL),
+            "k_scores_fused": (2.0 * nseg * L * 3 * IN_W, SL + 8.0 * nseg + 5 * VL + 4.0 * nfr * IN_W),
+            "k_windows": (0.0, 4.0 * nseg * F),
+            "k_scores_exact(state)": (0.0, 4.0 * nseg * F + SL),      # fp64 VALU, unfused: priced by bytes only
+            "k_scores_mfma(state)": (2.0 * nseg * L * F, 4.0 * nseg * F + SL),
+            "k_true_scores": (0.0, 8.0 * nfr),
+            "k_exp_rows": (0.0, 2 * SL),
+            "k_dp_lin": (0.0, 2 * SL + 4 * VL),                         # ES read by both sweeps, 4 vectors written
+            "k_dp_wave": (0.0, 3 * SL + 3 * VL),
+            "k_post_z": (0.0, 2 * SL + 5 * VL + 2 * VL),                # ES -> R in place, Z written, p and b read
+            "k_post_lin": (0.0, 2 * SL + 2 * VL),
+            "k_post_state": (0.0, 2 * SL + VL),
+            "k_lin_z": (0.0, SL + 5 * VL),
+            "k_mass_check": (0.0, 2 * VL),
+            "k_expf_fused": (2.0 * nseg * L * (3 * IN_W + D + 1), SL + 4.0 * nfr * IN_W),
+            "k_expf_mfma(state)": (2.0 * nseg * L * F, 4.0 * nseg * F + SL),
+            "k_expf_gemm(state)": (0.0, 4.0 * nseg * F + SL),
+            "k_ztf": (2.0 * nfr * 5 * L * IN_W, 5 * VL + 4.0 * nfr * IN_W),
+            "reductions (k_reduce_slabs, k_atb, k_batch_sums)": (2.0 * nfr * L * L, 2 * VL),
         }
-        dom = max(kern, key=lambda k: tm[k][0])
-        kname, bound, work_per_utt, unit, peak = kern[dom]
-        ms, nl = tm[dom]
-        nl = max(1, int(nl))
-        avg_ms = ms / nl                       # average duration of one launch of that kernel
-        per_step = max(1, nl // N_INSTR)       # launches per step (1 unless the batch had to be chunked)
-        work = work_per_utt * U / per_step     # algorithmic work of one launch
-        achieved = work / (avg_ms / 1e3)
-        # what the fused kernels actually execute on the MFMA: the sampled-frame blocks are
-        # re-associated into per-frame projections, so only 3W (scores) / 3W+D+1 (counts) of the
-        # 8W+D columns go through the dense product (DESIGN.md "roofline accounting")
-        executed = None
-        if bound == "mfma" and args.precision != "exact":
-            cols = 3 * IN_W if dom == "k_scores" else 3 * IN_W + D + 1
-            executed = 2.0 * nseg * L * cols * U / per_step / 1e12
+        kernels = []
+        floors_mfma = floors_hbm = 0.0
+        for name in order:
+            ms_tot, nl = acc[name]
+            ms_step = ms_tot / N_INSTR                          # this kernel's time per step
+            flops_, bytes_ = work.get(name, (0.0, 0.0))
+            t_mfma = flops_ * U / (mfma_peak * 1e12) * 1e3
+            t_hbm = bytes_ * U / (PEAK["hbm_gbs"] * 1e9) * 1e3
+            bound = "mfma" if t_mfma >= t_hbm else "hbm"
+            floor = max(t_mfma, t_hbm)
+            floors_mfma += t_mfma; floors_hbm += t_hbm
+            ent = {"name": name, "ms": round(ms_step, 4), "launches_per_step": max(1, nl // N_INSTR), "bound": bound,
+                   "tflop": round(flops_ * U / 1e12, 5), "gbyte": round(bytes_ * U / 1e9, 4),
+                   "frac": round(floor / ms_step, 4) if ms_step > 0 and floor > 0 else None}
+            kernels.append(ent)
+        dom = max(kernels, key=lambda k: k["ms"])
+        per_step = dom["launches_per_step"]
+        avg_ms = dom["ms"] / per_step
+        if dom["bound"] == "mfma":
+            achieved = dom["tflop"] / per_step / (avg_ms / 1e3); peak = mfma_peak; unit = "TFLOP/s"
+            per_launch = dom["tflop"] / per_step
+        else:
+            achieved = dom["gbyte"] / per_step / (avg_ms / 1e3); peak = PEAK["hbm_gbs"]; unit = "GB/s"
+            per_launch = dom["gbyte"] / per_step
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per utterance from separate rocprofv3 --pmc passes (profiles/README.md)
             with open(tpath) as fh:
                 tj = json.load(fh)
-            ent = tj.get(args.precision, {}).get(kname)
+            ent = tj.get(args.precision, {}).get(dom["name"])
             if ent:
                 traffic = round(ent["bytes_per_utt"] * U / per_step)
-        roofline = {"kernel": kname, "bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 5), "traffic": traffic,
-                    "algorithmic_per_launch": round(work, 6), "launches_per_step": per_step,
-                    "avg_launch_ms": round(avg_ms, 4),
-                    "kernel_ms": {k: round(tm[k][0] / max(1, tm[k][1]), 3) for k in kern},
-                    "phase_ms": {k: round(v[0] / N_INSTR, 3) for k, v in tm.items() if not k.startswith("k_")}}
-        if executed is not None:
-            roofline["executed_per_launch"] = round(executed, 6)
-            roofline["frac_executed"] = round(executed / (avg_ms / 1e3) / peak, 5)
-        # the whole step against SURVEY 8d's per-utterance totals (F_alg = two dense contractions,
-        # B_alg = frames + 3 passes over S + 2 over the recursion arrays): rank-local, timed region
-        step_s = dt / args.steps
-        f_alg = 2.0 * flops_gemm * U
+        frac = achieved / peak
+        assert 0.0 < frac <= 1.0, "roofline fraction %r out of range: the work model of %s is wrong" % (frac, dom["name"])
+        step_ms = 1e3 * dt / args.steps
+        # the whole step against its floors: matrix-pipe time of the flops the design executes, and SURVEY
+        # 8d's algorithmic bytes per utterance (frames + 3 passes over S + 2 over the recursion arrays)
         b_alg = (4.0 * T_FRAMES * IN_W + 3 * 8.0 * (nseg * L + L * L) + 2 * 8.0 * (nseg * L + 2 * T_FRAMES * L)) * U
-        roofline["step"] = {"algorithmic_tflop": round(f_alg / 1e12, 4), "tflops": round(f_alg / 1e12 / step_s, 2),
-                            "frac_mfma": round(f_alg / 1e12 / step_s / mfma_peak, 4),
-                            "algorithmic_gb": round(b_alg / 1e9, 2), "frac_hbm": round(b_alg / 1e9 / step_s / PEAK["hbm_gbs"], 4)}
+        hbm_floor = b_alg / (PEAK["hbm_gbs"] * 1e9) * 1e3
+        roofline = {"kernel": dom["name"], "bound": dom["bound"], "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                    "frac": round(frac, 5), "traffic": traffic,
+                    "work_per_launch": round(per_launch, 6), "work_is": "flops issued on the matrix pipe" if dom["bound"] == "mfma" else "algorithmic bytes",
+                    "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
+                    "kernels": kernels,
+                    "kernels_sum_ms": round(sum(k["ms"] for k in kernels), 3),
+                    "phase_ms": {k: round(v / N_INSTR, 3) for k, v in phase.items() if not k.startswith("k_")},
+                    "step": {"ms": round(step_ms, 3), "mfma_floor_ms": round(floors_mfma, 3),
+                             "hbm_floor_ms": round(hbm_floor, 3), "algorithmic_gb": round(b_alg / 1e9, 2),
+                             "frac_of_larger_floor": round(max(floors_mfma, hbm_floor) / step_ms, 4)}}
         out = {
             "metric": "utterances/sec SCRF forward-backward (TIMIT-shape)",
             "value": round(U * world * args.steps / dt, 2),
@@ -238,9 +269,27 @@ def main():
                          "dtype": "f64 scores (MFMA + reference-order fix-ups), f32 tropical recursion",
                          "arc_weights_recomputed": eng.decode_stats()[0] // 2, "fallback_chunks": eng.decode_stats()[1]}
         if not args.no_cpu_baseline:
-            cb, _ = cpu_baseline(frames, labels, off, lam)
+            cb, (og, on, oz, n_cb) = cpu_baseline(frames, labels, off, lam)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(out["value"] / cb["value"], 1)
+            # ---- correctness gate, part 2 (north_star: log-likelihood and gradients within 1e-4 relative): the
+            # engine's gradient, numerators and log-partitions on the cpu_baseline sample against the oracle's.
+            # The oracle's minibatch gradient is the sum over its worker streams / active streams
+            # (CRF_Minibatch_GradAccumulator.cpp:296-308); every worker of the sample is active.
+            eng.set_lambda(lam)
+            eng.zero_grad()
+            gb = eng.batch_from_frames(fl[:n_cb], ll[:n_cb])
+            gn, gz = eng.fb_batch(gb)
+            gg = eng.get_grad() / cb["cores"]
+            gb.close()
+            e_g = float(np.abs(gg - og).max() / np.abs(og).max())
+            e_n = float(np.abs(gn - on[:n_cb]).max() / max(1.0, np.abs(on[:n_cb]).max()))
+            e_z = float(np.abs(gz - oz[:n_cb]).max() / np.abs(oz[:n_cb]).max())
+            out["parity_gate"] = {"utterances": int(n_cb), "grad_rel": e_g, "numer_rel": e_n, "zx_rel": e_z, "tolerance": 1e-4}
+            if not (e_g <= 1e-4 and e_n <= 1e-4 and e_z <= 1e-4):
+                gate_err = "engine vs oracle on the cpu_baseline sample: grad %.3g numer %.3g zx %.3g (tolerance 1e-4)" % (e_g, e_n, e_z)
+        else:
+            out["parity_gate"] = "skipped (--no-cpu-baseline): finiteness of lambda only"
     batch.close()
     eng.close()
     if dist is not None:
@@ -249,6 +298,9 @@ def main():
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     if rank == 0:
+        if gate_err:
+            sys.stderr.write("bench.py: CORRECTNESS GATE FAILED: %s\n" % gate_err)
+            sys.exit(3)
         print(json.dumps(out))
         sys.stdout.flush()
 

@@ -42,8 +42,10 @@ enum scrf_status {
   SCRF_ERR_INVALID = 1,    /* bad argument / unsupported configuration */
   SCRF_ERR_NO_DEVICE = 2,  /* no HIP device: the product path never falls back to CPU */
   SCRF_ERR_HIP = 3,        /* a HIP runtime call or kernel failed */
-  SCRF_ERR_NUMERIC = 4,    /* overflow/NaN/log(0) as thrown by utils/CRF_LogMath.cpp:192-224,
-                              or posterior-mass check of nodes/...WithoutSegTransFtr.cpp:917-947 */
+  SCRF_ERR_NUMERIC = 4,    /* overflow/NaN/log(0) as thrown by utils/CRF_LogMath.cpp:192-224, or a failed
+                              posterior-mass self-check of computeExpF (nodes/...WithoutSegTransFtr.cpp:917-947:
+                              state mass and transition mass of a node within [-1e-6, 1+1e-6] and equal within
+                              1e-6; frame model nodes/CRF_StdStateNode.cpp:252-275: both within [0.9, 1.1]) */
   SCRF_ERR_BAD_LABEL = 5,  /* label >= nActualLabs*labMaxDur (:627-631) */
   SCRF_ERR_EMPTY = 6,      /* "No features read from this sentence" (gradbuilder :331-335) */
   SCRF_ERR_COMM = 7        /* RCCL failure */
@@ -177,8 +179,20 @@ int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused);
  * utterance of the batch.  The engine's device gradient accumulates (+=) the sum over
  * utterances of (observed - expected) counts; numer[u]/zx[u] (host, may be NULL) receive the
  * per-utterance numerator and log-partition (caller forms logLi = numer - zx,
- * trainers/CRF_SGTrainer.cpp:274).  Asynchronous on the engine stream unless numer/zx given. */
+ * trainers/CRF_SGTrainer.cpp:274).
+ * Errors are reported by THIS call, also without numer/zx: it returns once the batch's recursion and
+ * posterior kernels have finished and their per-utterance status has reached the host (the expected-count
+ * kernels are still in flight then; the call is asynchronous from there on).  SCRF_ERR_BAD_LABEL /
+ * SCRF_ERR_NUMERIC name the first failed utterance in scrf_last_error, as the reference's exceptions do, and
+ * a failed batch contributes NOTHING to the gradient or the batch sums: its gradient is built in a staging
+ * buffer and committed by a kernel that is a no-op when an utterance failed.  The training path runs a
+ * scaled linear-domain recursion; if that raises SCRF_ERR_NUMERIC (a frame vector flushed
+ * to zero: scores spread over more than ~700 nats) the batch is redone automatically with the log-domain
+ * kernels, which follow the reference's LogMath, and only their verdict is reported (scrf_train_stats
+ * counts these batches). */
 int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double* zx);
+/* batches scrf_fb_batch had to redo through the log-domain recursion since scrf_create */
+int scrf_train_stats(scrf_handle h, uint64_t* n_lin_fallback);
 int scrf_zero_grad(scrf_handle h);
 int scrf_get_grad(scrf_handle h, double* grad, uint32_t n);      /* device -> host copy */
 int scrf_add_grad(scrf_handle h, const double* grad, uint32_t n); /* grad += host vector */
@@ -194,7 +208,8 @@ int scrf_get_batch_sums(scrf_handle h, double* sums3);
 int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M);
 /* window synthesis of utterance u: [N_seg][num_feas] (io/CRF_InFtrStream_SeqMultiWindow.cpp) */
 int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* windows);
-/* getAlpha / alphaArray_WithDur / getBeta / computeAlphaSum, with precision `prec`:
+/* getAlpha / alphaArray_WithDur / getBeta / computeAlphaSum from the log-domain recursion over the EXACT
+ * scores (`prec` must be SCRF_PREC_EXACT: the hook exists to compare node values with the reference's):
  * alpha_dur [N_seg][L], alpha [T][L], beta [T][L] (any may be NULL) */
 int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, uint32_t prec,
                           double* alpha_dur, double* alpha, double* beta, double* zx);
@@ -245,6 +260,9 @@ int scrf_sgd_step(scrf_handle h, double lr_or_eta, int use_adagrad, double eps);
  * kernel (the three that dominate a step). */
 #define SCRF_N_PHASES 10
 int scrf_last_timing(scrf_handle h, float* ms, uint32_t* n_launch);
+/* HIP-event time of every kernel of the last timed scrf_fb_batch / scrf_viterbi_batch, one line per kernel
+ * name: "name\tmilliseconds\tlaunches\n" (events recorded on the stream the kernel is launched on) */
+int scrf_kernel_timing(scrf_handle h, char* buf, size_t cap);
 int scrf_enable_timing(scrf_handle h, int on);
 
 #ifdef __cplusplus

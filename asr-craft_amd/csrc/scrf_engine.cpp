@@ -258,7 +258,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_e0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_msh0, sizeof(double)));
-  CRCHK(hipMalloc((void**)&h->d_sums, sizeof(double) * 4));
+  CRCHK(hipMalloc((void**)&h->d_sums, sizeof(double) * 8));
   CRCHK(hipMalloc((void**)&h->d_stage, nb));
   CRCHK(hipMalloc((void**)&h->d_sums_stage, sizeof(double) * 4));
   CRCHK(hipMalloc((void**)&h->d_latch, sizeof(int) * 2));
@@ -276,7 +276,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMemsetAsync(h->d_lambda_acc, 0, nb, h->stream));
   CRCHK(hipMemsetAsync(h->d_gsa, 0, nb, h->stream));
   CRCHK(hipMemsetAsync(h->d_grad, 0, nb, h->stream));
-  CRCHK(hipMemsetAsync(h->d_sums, 0, sizeof(double) * 4, h->stream));
+  CRCHK(hipMemsetAsync(h->d_sums, 0, sizeof(double) * 8, h->stream));
   for (int i = 0; i <= SCRF_N_PHASES; i++) {
     CRCHK(hipEventCreate(&h->ev[i][0]));
     CRCHK(hipEventCreate(&h->ev[i][1]));
@@ -1623,29 +1623,54 @@ extern "C" int scrf_comm_init(scrf_handle h, const void* id128, int rank, int n_
   return SCRF_OK;
 }
 
-__global__ void k_set_active(double* sums4, int active) { sums4[3] = (double)active; }
+__global__ void k_set_tail(double* sums8, int active, double e0, double e1, double e2, double e3) {
+  sums8[3] = (double)active;
+  sums8[4] = e0; sums8[5] = e1; sums8[6] = e2; sums8[7] = e3;
+}
 __global__ void k_div_by_active(double* __restrict__ g, uint32_t n, const double* __restrict__ sums4) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   double a = sums4[3];
   if (i < n && a > 0.0) g[i] = __ddiv_rn(g[i], a);  // grad[i] /= nStreams_active (:306-308)
 }
+__global__ void k_gauss_prior(double* __restrict__ g, uint32_t n, double inv) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] = __dsub_rn(g[i], __dmul_rn(g[i], inv));   // grad[i] -= grad[i] * invSquareVar
+}
 
-extern "C" int scrf_allreduce_grad(scrf_handle h, int active, double* sums4) {
-  if (!h) return SCRF_ERR_INVALID;
+extern "C" int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4,
+                                      double* extra_out) {
+  if (!h || n_extra > 4 || (n_extra && !extra_in)) return SCRF_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t n = h->lay.lambda_len;
-  hipLaunchKernelGGL(k_set_active, dim3(1), dim3(1), 0, h->stream, h->d_sums, active ? 1 : 0);
+  double e[4] = {0, 0, 0, 0};
+  for (uint32_t i = 0; i < n_extra; i++) e[i] = extra_in[i];
+  hipLaunchKernelGGL(k_set_tail, dim3(1), dim3(1), 0, h->stream, h->d_sums, active ? 1 : 0, e[0], e[1], e[2], e[3]);
   if (h->comm) {
     int r = g_rccl.AllReduce(h->d_grad, h->d_grad, n, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
-    if (r == 0) r = g_rccl.AllReduce(h->d_sums, h->d_sums, 4, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
+    if (r == 0) r = g_rccl.AllReduce(h->d_sums, h->d_sums, 8, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
     if (r != 0) return fail(h, SCRF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
   }
   hipLaunchKernelGGL(k_div_by_active, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_grad, n, h->d_sums);
   HIPCHK(h, hipGetLastError());
-  if (sums4) {
-    HIPCHK(h, hipMemcpyAsync(sums4, h->d_sums, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+  if (sums4 || extra_out) {
+    double s8[8];
+    HIPCHK(h, hipMemcpyAsync(s8, h->d_sums, sizeof(double) * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sums4) memcpy(sums4, s8, sizeof(double) * 4);
+    if (extra_out) memcpy(extra_out, s8 + 4, sizeof(double) * n_extra);
   }
+  return SCRF_OK;
+}
+extern "C" int scrf_allreduce_grad(scrf_handle h, int active, double* sums4) {
+  return scrf_allreduce_grad_ex(h, active, nullptr, 0, sums4, nullptr);
+}
+
+extern "C" int scrf_gauss_prior(scrf_handle h, float inv_square_var) {
+  if (!h) return SCRF_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint32_t n = h->lay.lambda_len;
+  hipLaunchKernelGGL(k_gauss_prior, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_grad, n, (double)inv_square_var);
+  HIPCHK(h, hipGetLastError());
   return SCRF_OK;
 }
 

@@ -81,6 +81,7 @@ int main(int argc, char** argv) {
   crf.setLabMaxDur(m.D);
   crf.setNActualLabs(m.fmap.nActualLabs);
   crf.setModelType(m.mtype);
+  crf.setDevice((int)a.num("crf_device", 0));
   std::cout << "LABELS: " << crf.getNLabs() << std::endl;
   std::cout << "LABEL_MAXIMUM_DURATION: " << crf.getLabMaxDur() << std::endl;
   std::cout << "ACTUAL_LABELS: " << crf.getNActualLabs() << std::endl;

@@ -13,6 +13,7 @@ int main(int argc, char** argv) {
   crf.setLabMaxDur(m.D);
   crf.setNActualLabs(m.fmap.nActualLabs);
   crf.setModelType(m.mtype);
+  crf.setDevice((int)a.num("crf_device", 0));
   try {
     crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));
   } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }

@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "crf_amd.h"
-#include "qn_files.h"
+#include "ftr_files.h"
 
 struct Args {
   std::map<std::string, std::string> kv;
@@ -36,69 +36,6 @@ struct Args {
   long num(const std::string& k, long d) const { return has(k) ? atol(kv.at(k).c_str()) : d; }
   double real(const std::string& k, double d) const { return has(k) ? atof(kv.at(k).c_str()) : d; }
 };
-
-// one input stream: sentence u = T x width floats, row-major.  ascii files are held whole; a pfile is
-// read sentence by sentence on demand (a run over `crf_eval_range=0-399` touches those 400 only)
-struct FtrData {
-  size_t width = 0;
-  std::vector<std::vector<float> > utts;      // ascii: everything; pfile: filled by get()
-  std::shared_ptr<qn::PFileReader> pfile;
-  uint32_t ftr_start = 0;
-  size_t size() const { return utts.size(); }
-  const std::vector<float>& get(size_t u) {
-    if (pfile && utts[u].empty() && pfile->num_frames((uint32_t)u) > 0) pfile->read_sent((uint32_t)u, &utts[u], nullptr, ftr_start, (uint32_t)width);
-    return utts[u];
-  }
-  void drop(size_t u) { if (pfile) std::vector<float>().swap(utts[u]); }  // the stream keeps its own copy
-};
-
-inline FtrData read_ascii_ftrs(const std::string& path) {
-  std::ifstream f(path.c_str());
-  if (!f.is_open()) { std::cerr << "cannot open feature file " << path << std::endl; exit(1); }
-  FtrData d;
-  std::string line;
-  while (getline(f, line)) {
-    std::istringstream is(line);
-    long s, t;
-    if (!(is >> s >> t)) continue;
-    if ((size_t)s >= d.utts.size()) d.utts.resize(s + 1);
-    size_t n = 0;
-    float x;
-    while (is >> x) { d.utts[s].push_back(x); n++; }
-    if (d.width == 0) d.width = n;
-    if (n != d.width) { std::cerr << path << ": ragged feature line" << std::endl; exit(1); }
-  }
-  return d;
-}
-
-// pfile stream (QN_build_ftrstream(format="pfile"), io/CRF_FeatureStreamManager.cpp:138), columns
-// ftr_start .. ftr_start+ftr_count (ftr_count 0 = the rest); sentences are read when first asked for
-inline FtrData read_pfile_ftrs(const std::string& path, uint32_t ftr_start, uint32_t ftr_count) {
-  FtrData d;
-  d.pfile.reset(new qn::PFileReader(path));
-  const qn::PFileInfo& info = d.pfile->info();
-  if (ftr_start > info.n_ftrs) qn::fail(path, "ftr_start beyond the file's width");
-  d.width = ftr_count ? ftr_count : info.n_ftrs - ftr_start;
-  if (ftr_start + d.width > info.n_ftrs) qn::fail(path, "ftr_start + ftr_count beyond the file's width");
-  d.ftr_start = ftr_start;
-  d.utts.resize(d.pfile->num_sents());
-  return d;
-}
-
-// hardtarget_file: QuickNet ILAB (QN_InLabStream_ILab, io/CRF_FeatureStreamManager.cpp:285) or the
-// ascii `sent frame label` layout of the bundled fixture -- told apart by the magic
-inline std::vector<std::vector<uint32_t> > read_labs(const std::string& path) {
-  if (qn::is_ilab(path)) return qn::read_ilab(path).labels;
-  std::ifstream f(path.c_str());
-  if (!f.is_open()) { std::cerr << "cannot open label file " << path << std::endl; exit(1); }
-  std::vector<std::vector<uint32_t> > utts;
-  long s, t, l;
-  while (f >> s >> t >> l) {
-    if ((size_t)s >= utts.size()) utts.resize(s + 1);
-    utts[s].push_back((uint32_t)l);
-  }
-  return utts;
-}
 
 struct CliModel {
   CRF_FeatureMap_config fmap;
@@ -137,42 +74,9 @@ inline void refuse_unbuilt_flags(const Args& a, uint32_t D) {
   if (a.has("crf_featuremap_file")) die("crf_featuremap_file: file-defined feature maps are not built");
 }
 
-// streams (ftr1/ftr2/ftr3) + set_fmap_config of CRFTrain/src/Main.cpp:372-430
-inline std::vector<FtrData> load_streams(const Args& a, CliModel* m) {
-  std::vector<FtrData> data;
-  m->D = (uint32_t)a.num("label_maximum_duration", 1);
-  m->L = (uint32_t)a.num("crf_label_size", 0);
-  m->mtype = parse_model_type(a.str("crf_model_type", "stdframe"));
-  if (m->L == 0) { std::cerr << "crf_label_size is required" << std::endl; exit(1); }
-  refuse_unbuilt_flags(a, m->D);
-  m->F = 0;
-  for (int k = 1; k <= 3; k++) {
-    std::string p = "ftr" + std::to_string(k) + "_";
-    if (!a.has(p + "file")) break;
-    const std::string fmt = a.str(p + "format", "pfile");  // the reference's default
-    const uint32_t f0 = (uint32_t)a.num(p + "ftr_start", 0), fc = (uint32_t)a.num(p + "ftr_count", 0);
-    if (fmt == "pfile") {
-      data.push_back(read_pfile_ftrs(a.str(p + "file"), f0, fc));
-    } else if (fmt == "ascii") {
-      if (f0 || fc) { std::cerr << p << "ftr_start/ftr_count need " << p << "format=pfile" << std::endl; exit(1); }
-      data.push_back(read_ascii_ftrs(a.str(p + "file")));
-    } else {
-      std::cerr << p << "format=" << fmt << " is not built (pfile|ascii)" << std::endl;
-      exit(1);
-    }
-    if (data.back().utts.size() != data[0].utts.size()) { std::cerr << p << "file holds " << data.back().utts.size() << " sentences, ftr1_file " << data[0].utts.size() << std::endl; exit(1); }
-    const size_t w = data.back().width;
-    scrf_stream_recipe r;
-    r.in_width = (uint32_t)w;
-    r.left_ctx = (uint32_t)a.num(p + "left_context_len", 0);
-    r.right_ctx = (uint32_t)a.num(p + "right_context_len", 0);
-    r.extract_seg_ftr = (int32_t)a.num(p + "extract_seg_ftr", 0);
-    m->recipes.push_back(r);
-    m->F += (m->D == 1) ? (r.left_ctx + 1 + r.right_ctx) * r.in_width
-            : r.extract_seg_ftr ? 8 * r.in_width + m->D + (r.left_ctx + r.right_ctx) * r.in_width
-                                : (r.left_ctx + 1 + r.right_ctx) * r.in_width;
-  }
-  if (data.empty()) { std::cerr << "ftr1_file is required" << std::endl; exit(1); }
+// set_fmap_config of CRFTrain/src/Main.cpp:372-430: the feature-map configuration from the flags and the
+// joined window width m->F
+inline void set_fmap_config(const Args& a, CliModel* m) {
   CRF_FeatureMap_config& c = m->fmap;
   const std::string fm = a.str("crf_featuremap", "stdstate");
   c.map_type = fm == "stdtrans" ? STDTRANS : STDSTATE;
@@ -195,6 +99,60 @@ inline std::vector<FtrData> load_streams(const Args& a, CliModel* m) {
   c.maxDur = m->D;
   c.durFtrStart = (QNUInt32)a.num("dur_ftr_start", 0);
   c.nActualLabs = (QNUInt32)a.num("num_actual_labs", m->L);
+}
+
+// crf_precision=exact|fast|fast32: arithmetic of the training contractions (scrf_precision, scrf_abi.h).
+// fast (default): fp64 MFMA, sums re-associated (<= 1e-9 relative on gradients; the contract is 1e-4);
+// exact: the reference's operation order everywhere.  Decode entry points are always exact.
+inline uint32_t parse_precision(const Args& a) {
+  const std::string p = a.str("crf_precision", "fast");
+  if (p == "exact") return SCRF_PREC_EXACT;
+  if (p == "fast") return SCRF_PREC_FAST;
+  if (p == "fast32") return SCRF_PREC_FAST32;
+  std::cerr << "crf_precision=" << p << " (exact|fast|fast32)" << std::endl;
+  exit(1);
+}
+inline long env_num(const char* name, long d) { const char* v = getenv(name); return v && *v ? atol(v) : d; }
+
+// streams (ftr1/ftr2/ftr3) + set_fmap_config of CRFTrain/src/Main.cpp:372-430
+inline std::vector<FtrData> load_streams(const Args& a, CliModel* m) {
+  std::vector<FtrData> data;
+  m->D = (uint32_t)a.num("label_maximum_duration", 1);
+  m->L = (uint32_t)a.num("crf_label_size", 0);
+  m->mtype = parse_model_type(a.str("crf_model_type", "stdframe"));
+  if (m->L == 0) { std::cerr << "crf_label_size is required" << std::endl; exit(1); }
+  refuse_unbuilt_flags(a, m->D);
+  m->F = 0;
+  for (int k = 1; k <= 3; k++) {
+    std::string p = "ftr" + std::to_string(k) + "_";
+    if (!a.has(p + "file")) break;
+    const std::string fmt = a.str(p + "format", "pfile");  // the reference's default
+    const uint32_t f0 = (uint32_t)a.num(p + "ftr_start", 0), fc = (uint32_t)a.num(p + "ftr_count", 0);
+    if (fmt == "pfile") {
+      try { data.push_back(read_pfile_ftrs(a.str(p + "file"), f0, fc)); }
+      catch (std::exception& e) { std::cerr << e.what() << std::endl; exit(1); }
+    } else if (fmt == "ascii") {
+      if (f0 || fc) { std::cerr << p << "ftr_start/ftr_count need " << p << "format=pfile" << std::endl; exit(1); }
+      try { data.push_back(read_ascii_ftrs(a.str(p + "file"))); }
+      catch (std::exception& e) { std::cerr << e.what() << std::endl; exit(1); }
+    } else {
+      std::cerr << p << "format=" << fmt << " is not built (pfile|ascii)" << std::endl;
+      exit(1);
+    }
+    if (data.back().utts.size() != data[0].utts.size()) { std::cerr << p << "file holds " << data.back().utts.size() << " sentences, ftr1_file " << data[0].utts.size() << std::endl; exit(1); }
+    const size_t w = data.back().width;
+    scrf_stream_recipe r;
+    r.in_width = (uint32_t)w;
+    r.left_ctx = (uint32_t)a.num(p + "left_context_len", 0);
+    r.right_ctx = (uint32_t)a.num(p + "right_context_len", 0);
+    r.extract_seg_ftr = (int32_t)a.num(p + "extract_seg_ftr", 0);
+    m->recipes.push_back(r);
+    m->F += (m->D == 1) ? (r.left_ctx + 1 + r.right_ctx) * r.in_width
+            : r.extract_seg_ftr ? 8 * r.in_width + m->D + (r.left_ctx + r.right_ctx) * r.in_width
+                                : (r.left_ctx + 1 + r.right_ctx) * r.in_width;
+  }
+  if (data.empty()) { std::cerr << "ftr1_file is required" << std::endl; exit(1); }
+  set_fmap_config(a, m);
   return data;
 }
 

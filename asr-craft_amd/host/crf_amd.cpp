@@ -3,6 +3,9 @@
 
 #include <math.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <iterator>
@@ -11,6 +14,8 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+
+#include "ftr_files.h"
 
 using std::runtime_error;
 using std::string;
@@ -153,8 +158,63 @@ bool CRF_Model::readAverageFromFile(const char* fname, int present) {
 }
 bool CRF_Model::readGradSqrAccFromFile(const char* fname) { return read_vec(fname, gradSqrAcc.data(), gradSqrAcc.size(), 1.0); }
 
-crf_amd::Engine* CRF_Model::engine(int device, uint32_t precision) {
-  if (!eng) eng.reset(new crf_amd::Engine(crf_amd::makeConfig(this, device, precision)));
+// ---- one process per GPU: the RCCL unique id goes from rank 0 to the others through a file ----
+namespace {
+double wall_now() {
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+const double g_launch_time = wall_now();   // the launcher starts all ranks within a fraction of a second
+
+void exchange_comm_id(int rank, const string& path, unsigned char id[128]) {
+  if (rank == 0) {
+    if (scrf_comm_unique_id(id) != SCRF_OK) throw runtime_error(string("scrf_comm_unique_id: ") + scrf_last_error(nullptr));
+    const string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0) throw runtime_error("cannot write the communicator id file " + tmp);
+    if (rename(tmp.c_str(), path.c_str()) != 0) throw runtime_error("cannot publish the communicator id file " + path);
+    return;
+  }
+  // a file older than this launch is the leftover of a run that died: ignored
+  const double deadline = wall_now() + 600.0;
+  while (wall_now() < deadline) {
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && st.st_size == 128 &&
+        (double)st.st_mtim.tv_sec + 1e-9 * (double)st.st_mtim.tv_nsec >= g_launch_time - 2.0) {
+      FILE* f = fopen(path.c_str(), "rb");
+      if (f) {
+        const size_t n = fread(id, 1, 128, f);
+        fclose(f);
+        if (n == 128) return;
+      }
+    }
+    usleep(20000);
+  }
+  throw runtime_error("timed out waiting for rank 0's communicator id file " + path);
+}
+}  // namespace
+
+void CRF_Model::setDistributed(int rank, int world, const string& id_file) {
+  if (world < 1 || rank < 0 || rank >= world) throw runtime_error("CRF_Model::setDistributed: rank outside [0, world)");
+  if (id_file.empty()) throw runtime_error("CRF_Model::setDistributed: a communicator id file is required");
+  if (eng) throw runtime_error("CRF_Model::setDistributed: call it before the engine is first used");
+  dist_on = true;
+  dist_rank = rank;
+  dist_world = world;
+  dist_id_file = id_file;
+}
+
+crf_amd::Engine* CRF_Model::engine() {
+  if (!eng) {
+    eng.reset(new crf_amd::Engine(crf_amd::makeConfig(this, device, precision)));
+    if (dist_on) {
+      unsigned char id[128];
+      exchange_comm_id(dist_rank, dist_id_file, id);
+      eng->check(scrf_comm_init(eng->h, id, dist_rank, dist_world), "scrf_comm_init");   // collective: every rank has the id now
+      if (dist_rank == 0) remove(dist_id_file.c_str());
+    }
+  }
   return eng.get();
 }
 void CRF_Model::pushLambda() {
@@ -184,11 +244,12 @@ static uint32_t recipe_width(const scrf_stream_recipe& r, uint32_t D) {
 CRF_MemoryFeatureStream::CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe> recipes, QNUInt32 max_dur,
                                                  QNUInt32 n_actual_labs)
     : store_(new Store()) {
+  (void)n_actual_labs;   // labels are formed for the model's nActualLabs when a batch is assembled
   store_->recipes = recipes;
   store_->D = max_dur;
-  store_->L = n_actual_labs;
   for (const auto& r : recipes) width_ += recipe_width(r, max_dur);
 }
+CRF_MemoryFeatureStream::~CRF_MemoryFeatureStream() { if (win_eng_) scrf_destroy(win_eng_); }
 
 void CRF_MemoryFeatureStream::addUtterance(const std::vector<std::vector<float> >& frames,
                                            const std::vector<uint32_t>& fl) {
@@ -203,11 +264,12 @@ void CRF_MemoryFeatureStream::addUtterance(const std::vector<std::vector<float> 
   }
   s.T.push_back(T);
   s.frames.push_back(frames);
-  // frame labels -> (label, start) at segment end frames; runs longer than D are split evenly
-  std::vector<uint32_t> lab(T, CRF_LAB_BAD), st(T, CRF_LAB_BAD);
+  // frame labels -> (phone, start) at segment end frames; runs longer than D are split evenly
+  // (io/CRF_InLabStream_SeqMultiWindow.cpp:51-110)
+  std::vector<uint32_t> ph(T, CRF_LAB_BAD), st(T, CRF_LAB_BAD);
   if (!fl.empty()) {
     if (fl.size() != T) throw runtime_error("addUtterance: one label per frame expected");
-    const uint32_t D = s.D, L = s.L;
+    const uint32_t D = s.D;
     for (uint32_t a = 0; a < T;) {
       uint32_t b = a + 1;
       while (b < T && fl[b] == fl[a]) b++;
@@ -218,7 +280,7 @@ void CRF_MemoryFeatureStream::addUtterance(const std::vector<std::vector<float> 
         uint32_t ps = a;
         for (uint32_t p = 0; p < pieces; p++) {
           const uint32_t d = p < rem ? pd + 1 : pd;
-          lab[ps + d - 1] = L * (d - 1) + fl[a];
+          ph[ps + d - 1] = fl[a];
           st[ps + d - 1] = ps;
           ps += d;
         }
@@ -226,18 +288,37 @@ void CRF_MemoryFeatureStream::addUtterance(const std::vector<std::vector<float> 
       a = b;
     }
   }
-  s.seg_labels.push_back(lab);
+  s.seg_phone.push_back(ph);
   s.seg_start.push_back(st);
   end_ = s.T.size();
 }
 
-CRF_MemoryFeatureStream* CRF_MemoryFeatureStream::view(size_t start, size_t count) {
+void CRF_MemoryFeatureStream::join(const CRF_MemoryFeatureStream& other) {
+  Store& s = *store_;
+  const Store& o = *other.store_;
+  if (o.T.size() != s.T.size() || o.D != s.D) throw runtime_error("CRF_FeatureStream::join: the streams hold different utterances");
+  for (size_t u = 0; u < s.T.size(); u++) {
+    if (o.T[u] != s.T[u]) throw runtime_error("CRF_FeatureStream::join: utterance lengths differ between the streams");
+    for (const auto& f : o.frames[u]) s.frames[u].push_back(f);
+  }
+  for (const auto& r : o.recipes) { s.recipes.push_back(r); width_ += recipe_width(r, s.D); }
+  if (s.recipes.size() > SCRF_MAX_STREAMS) throw runtime_error("CRF_FeatureStream::join: more than three input streams");
+}
+
+CRF_MemoryFeatureStream* CRF_MemoryFeatureStream::makeView(size_t start, size_t count) {
   CRF_MemoryFeatureStream* v = new CRF_MemoryFeatureStream(*this);
-  v->begin_ = begin_ + start;
-  v->end_ = std::min(end_, v->begin_ + count);
-  v->cur_ = -1;
-  if (v->mode_ != SEQUENTIAL) { v->epoch_ = 0; v->rewind(); }   // its own order over its own range
+  v->win_eng_ = nullptr;   // the helper engine is not shared
+  v->win_utt_ = -1;
+  v->view(start, count);
   return v;
+}
+
+void CRF_MemoryFeatureStream::view(size_t start, size_t count) {
+  begin_ = begin_ + start;
+  end_ = (count == CRF_UINT32_MAX || count > end_) ? end_ : std::min(end_, begin_ + count);
+  if (begin_ > end_) begin_ = end_;
+  cur_ = -1;
+  if (mode_ != SEQUENTIAL) { epoch_ = 0; rewind(); }   // its own order over its own range
 }
 
 void CRF_MemoryFeatureStream::setPresentation(seqtype type, QNUInt32 seed) {
@@ -286,13 +367,47 @@ bool CRF_MemoryFeatureStream::currentUtterance(Utterance* u) {
   u->frames.clear();
   for (const auto& f : s.frames[cur_]) u->frames.push_back(f.data());
   u->windows = nullptr;
-  u->labels = s.seg_labels[cur_].data();
+  u->labels = nullptr;
+  u->phones = s.seg_phone[cur_].data();
+  u->starts = s.seg_start[cur_].data();
   return true;
 }
 
-// windows ending at the current frame, d = 1..bunch, joined over the streams
-// (what io/CRF_InFtrStream_SeqMultiWindow produces; host-side compatibility path only --
-// the engine synthesises windows on the GPU from currentUtterance())
+// read(): the window vectors of the current utterance come from the engine's window kernel (k_windows, the
+// reference recipe of io/CRF_InFtrStream_SeqMultiWindow.cpp bit for bit) through a private handle whose
+// only job is scrf_windows; the host holds no restatement of the recipe.
+void CRF_MemoryFeatureStream::fetchWindows() {
+  if (win_utt_ == cur_) return;
+  const Store& s = *store_;
+  if (!win_eng_) {
+    scrf_config g;
+    memset(&g, 0, sizeof(g));
+    g.abi_version = SCRF_ABI_VERSION;
+    g.model_type = s.D == 1 ? SCRF_STDFRAME : SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR;
+    g.map_type = SCRF_STDSTATE;
+    g.num_labs = 1; g.num_feas = (uint32_t)width_; g.num_states = 1; g.lab_max_dur = s.D;
+    g.use_state_ftrs = 1; g.state_fidx_start = 0; g.state_fidx_end = (uint32_t)width_ - 1;
+    g.use_state_bias = 1; g.use_trans_bias = 1; g.state_bias_val = 1.0; g.trans_bias_val = 1.0;
+    if (scrf_create(&g, &win_eng_) != SCRF_OK) throw runtime_error(string("CRF_MemoryFeatureStream::read: ") + scrf_last_error(nullptr));
+  }
+  scrf_utt q;
+  memset(&q, 0, sizeof(q));
+  q.T = s.T[cur_];
+  for (size_t k = 0; k < s.frames[cur_].size() && k < SCRF_MAX_STREAMS; k++) q.frames[k] = s.frames[cur_][k].data();
+  scrf_batch b = nullptr;
+  if (scrf_batch_create(win_eng_, &q, 1, (uint32_t)s.recipes.size(), s.recipes.data(), &b) != SCRF_OK)
+    throw runtime_error(string("CRF_MemoryFeatureStream::read: ") + scrf_last_error(win_eng_));
+  uint64_t n_segs = 0;
+  scrf_batch_info(win_eng_, b, nullptr, nullptr, &n_segs, nullptr);
+  win_cache_.resize((size_t)n_segs * width_);
+  const int rc = scrf_windows(win_eng_, b, 0, win_cache_.data());
+  scrf_batch_destroy(win_eng_, b);
+  if (rc != SCRF_OK) throw runtime_error(string("CRF_MemoryFeatureStream::read: ") + scrf_last_error(win_eng_));
+  win_utt_ = cur_;
+}
+
+// windows ending at the current frame, d = 1..bunch, joined over the streams (what
+// io/CRF_InFtrStream_SeqMultiWindow produces) + the 4 label words of the segment ending there
 size_t CRF_MemoryFeatureStream::read(size_t bunch, float* out, QNUInt32* lab_buf) {
   if (cur_ < (long)begin_ || cur_ >= (long)end_) return 0;
   const Store& s = *store_;
@@ -300,44 +415,15 @@ size_t CRF_MemoryFeatureStream::read(size_t bunch, float* out, QNUInt32* lab_buf
   if (t >= T) return 0;
   const uint32_t avail = t + 1 <= D ? t + 1 : D;
   if (bunch != avail) throw runtime_error("CRF_MemoryFeatureStream::read: the number of windows has to be min(t+1, max_dur) at the current frame");
-  size_t col = 0;
-  for (size_t k = 0; k < s.recipes.size(); k++) {
-    const scrf_stream_recipe& r = s.recipes[k];
-    const uint32_t W = r.in_width;
-    const float* fr = s.frames[cur_][k].data();
-    const float* last = fr + (size_t)(r.left_ctx + t) * W;
-    const bool seg = D != 1 && r.extract_seg_ftr;
-    std::vector<float> sum(W, 0.0f), mx(last, last + W), mn(last, last + W);
-    for (uint32_t w = 1; w <= avail; w++) {
-      const float* first = last - (size_t)(w - 1) * W;
-      float* o = out + (size_t)(w - 1) * width_ + col;
-      for (uint32_t c = 0; c < r.left_ctx; c++)
-        for (uint32_t j = 0; j < W; j++) *o++ = first[((long)c - (long)r.left_ctx) * (long)W + j];
-      if (!seg) {
-        for (uint32_t j = 0; j < W; j++) *o++ = first[j];
-      } else {
-        const float ot = (float)(w * 0.1);
-        for (int i = 1; i < 10; i += 2) {
-          const uint32_t step = (uint32_t)ceilf(ot * (float)i) - 1;
-          for (uint32_t j = 0; j < W; j++) *o++ = first[(size_t)step * W + j];
-        }
-        for (uint32_t j = 0; j < W; j++) { sum[j] += first[j]; *o++ = sum[j] / (float)w; }
-        for (uint32_t j = 0; j < W; j++) { if (first[j] > mx[j]) mx[j] = first[j]; *o++ = mx[j]; }
-        for (uint32_t j = 0; j < W; j++) { if (first[j] < mn[j]) mn[j] = first[j]; *o++ = mn[j]; }
-        for (uint32_t kk = 1; kk <= D; kk++) *o++ = kk == w ? 1.0f : 0.0f;
-      }
-      const float* rb = r.extract_seg_ftr ? last : first;
-      for (uint32_t c = 1; c <= r.right_ctx; c++)
-        for (uint32_t j = 0; j < W; j++) *o++ = rb[(size_t)c * W + j];
-    }
-    col += recipe_width(r, D);
-  }
+  fetchWindows();
+  const size_t row0 = t < D ? (size_t)t * (t + 1) / 2 : (size_t)D * (D + 1) / 2 + (size_t)(t - D) * D;
+  memcpy(out, &win_cache_[row0 * width_], sizeof(float) * avail * width_);
   if (lab_buf) {
-    const uint32_t lb = s.seg_labels[cur_][t];
-    if (lb == CRF_LAB_BAD) {
+    const uint32_t ph = s.seg_phone[cur_][t];
+    if (ph == CRF_LAB_BAD) {
       lab_buf[0] = lab_buf[1] = lab_buf[2] = lab_buf[3] = CRF_LAB_BAD;
     } else {
-      lab_buf[0] = lb % s.L;
+      lab_buf[0] = ph;
       lab_buf[1] = s.seg_start[cur_][t];
       lab_buf[2] = t;
       lab_buf[3] = 0;
@@ -345,6 +431,93 @@ size_t CRF_MemoryFeatureStream::read(size_t bunch, float* out, QNUInt32* lab_buf
   }
   frame_++;
   return avail;
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_FeatureStreamManager
+// ------------------------------------------------------------------------------------------
+CRF_FeatureStreamManager::CRF_FeatureStreamManager(int debug, const char* debug_name, char* ftr_fname, const char* ftr_file_fmt,
+                                                   char* ht_fname, size_t ht_offset, size_t ftr_width, size_t first_ftr,
+                                                   size_t num_ftrs, size_t win_ext, size_t win_off, size_t win_len,
+                                                   size_t left_ctx_len, size_t right_ctx_len, bool extract_seg_ftr,
+                                                   bool use_bdy_delta_ftr, int delta_o, int delta_w, char* trn_rng, char* cv_rng,
+                                                   FILE* nfile, int n_mode, double n_am, double n_av, seqtype ts, QNUInt32 rseed,
+                                                   size_t n_threads)
+    : nthreads(n_threads ? n_threads : 1) {
+  (void)debug; (void)n_mode; (void)n_am; (void)n_av;
+  const string who = string("CRF_FeatureStreamManager(") + (debug_name ? debug_name : "") + "): ";
+  if (!ftr_fname || !*ftr_fname) throw runtime_error(who + "no feature file");
+  if (nfile) throw runtime_error(who + "feature normalisation files are not built");
+  if (delta_o != 0) throw runtime_error(who + "delta features are not built");
+  (void)delta_w;
+  if (use_bdy_delta_ftr) throw runtime_error(who + "boundary delta features are not built");
+  if (win_off != 0 || ht_offset != 0) throw runtime_error(who + "window offsets must be 0");
+  if (win_off + win_len > win_ext) throw runtime_error("CRF_FeatureStreamManager::create() caught exception: this->window_offset + this->window_len > this->window_extent.");
+  if (win_len != win_ext) throw runtime_error(who + "window_len must equal window_extent (the label maximum duration)");
+  const string fmt = ftr_file_fmt ? ftr_file_fmt : "pfile";
+  FtrData data;
+  if (fmt == "pfile") data = read_pfile_ftrs(ftr_fname, (uint32_t)first_ftr, (uint32_t)num_ftrs);
+  else if (fmt == "ascii") {
+    if (first_ftr || num_ftrs) throw runtime_error(who + "first_ftr / num_ftrs need format pfile");
+    data = read_ascii_ftrs(ftr_fname);
+  } else throw runtime_error(who + "format " + fmt + " is not built (pfile|ascii)");
+  if (ftr_width != 0 && fmt == "ascii" && ftr_width != data.width) throw runtime_error(who + "ftr_width does not match the file");
+  std::vector<std::vector<uint32_t> > labs;
+  if (ht_fname && *ht_fname) labs = read_labs(ht_fname);
+  scrf_stream_recipe r;
+  r.in_width = (uint32_t)data.width;
+  r.left_ctx = (uint32_t)left_ctx_len;
+  r.right_ctx = (uint32_t)right_ctx_len;
+  r.extract_seg_ftr = extract_seg_ftr ? 1 : 0;
+  const QNUInt32 D = (QNUInt32)win_len;
+  auto fill = [&](const char* rng, std::unique_ptr<CRF_MemoryFeatureStream>* dst) {
+    const std::vector<uint32_t> sents = qn::parse_range(rng ? rng : "all", (uint32_t)data.size());
+    dst->reset(new CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe>(1, r), D));
+    for (uint32_t u : sents) {
+      std::vector<std::vector<float> > fr(1, data.get(u));
+      (*dst)->addUtterance(fr, u < labs.size() ? labs[u] : std::vector<uint32_t>());
+    }
+  };
+  // the training stream reads the train range; the CV stream (built like the reference's, read by no SG
+  // trainer) the CV range
+  fill(trn_rng, &trn);
+  if (cv_rng && *cv_rng && string(cv_rng) != "nil" && string(cv_rng) != "none") fill(cv_rng, &cv);
+  for (size_t u = 0; u < data.size(); u++) data.drop(u);
+  if (ts != SEQUENTIAL) trn->setPresentation(ts, rseed);
+  trn_stream = trn.get();
+  cv_stream = cv.get();
+  if (nthreads > 1) {
+    // child i views [i*floor(n/N), (i+1)*floor(n/N)), the last one to the end (create() :425-464)
+    const size_t nseg = trn->numUtterances(), per = nseg / nthreads;
+    for (size_t i = 0; i < nthreads; i++) {
+      std::unique_ptr<CRF_FeatureStreamManager> c(new CRF_FeatureStreamManager());
+      c->trn.reset(trn->makeView(i * per, i == nthreads - 1 ? CRF_UINT32_MAX : per));
+      c->trn_stream = c->trn.get();
+      children.push_back(std::move(c));
+    }
+  }
+}
+CRF_FeatureStreamManager::~CRF_FeatureStreamManager() {}
+
+void CRF_FeatureStreamManager::join(CRF_FeatureStreamManager* other) {
+  // feature concatenation of the two managers' streams, children pairwise (:108-122)
+  if (!other || !other->trn) throw runtime_error("CRF_FeatureStreamManager::join: nothing to join");
+  old_trn_stream = trn_stream;
+  trn->join(*other->trn);
+  if (cv && other->cv) cv->join(*other->cv);
+  // the children share the parent's storage: they see the joined frames, only their width has to follow
+  if (children.size() != other->children.size()) throw runtime_error("CRF_FeatureStreamManager::join: thread counts differ");
+  for (size_t i = 0; i < children.size(); i++) {
+    const size_t nseg = trn->numUtterances(), per = nseg / nthreads;
+    children[i]->trn.reset(trn->makeView(i * per, i == nthreads - 1 ? CRF_UINT32_MAX : per));
+    children[i]->trn_stream = children[i]->trn.get();
+  }
+}
+size_t CRF_FeatureStreamManager::getNumFtrs() { return trn ? trn->num_ftrs() : 0; }
+void CRF_FeatureStreamManager::rewindAllChildrenTrn() { for (auto& c : children) c->trn_stream->rewind(); }
+void CRF_FeatureStreamManager::display() {
+  std::cout << "feature stream: " << (trn ? trn->numUtterances() : 0) << " utterances, " << getNumFtrs() << " features per window, "
+            << nthreads << " child stream(s)" << std::endl;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -360,7 +533,17 @@ struct HeldUtt {
 
 // pull the stream's current utterance, through the fast path or the read() protocol
 void grab(CRF_FeatureStream* strm, CRF_Model* crf, HeldUtt* h) {
-  if (strm->currentUtterance(&h->u)) return;
+  if (strm->currentUtterance(&h->u)) {
+    if (!h->u.labels && h->u.phones && h->u.starts) {
+      // nActualLabs*(dur-1)+phone of the segment ending at each frame (gradbuilder :216-231)
+      const uint32_t L = crf->getNActualLabs() ? crf->getNActualLabs() : crf->getNLabs();
+      h->labels.assign(h->u.T, CRF_LAB_BAD);
+      for (uint32_t t = 0; t < h->u.T; t++)
+        if (h->u.phones[t] != CRF_LAB_BAD) h->labels[t] = L * (t - h->u.starts[t]) + h->u.phones[t];
+      h->u.labels = h->labels.data();
+    }
+    return;
+  }
   const uint32_t D = crf->getLabMaxDur(), L = crf->getNActualLabs();
   const size_t F = strm->num_ftrs(), LW = strm->num_labs();
   std::vector<float> buf(F * D);
@@ -437,6 +620,29 @@ double CRF_GradBuilder::buildGradient(CRF_FeatureStream* ftr_strm, double* grad,
 CRF_Minibatch_GradAccumulator::CRF_Minibatch_GradAccumulator(CRF_Model* c, std::vector<CRF_FeatureStream*> s)
     : crf(c), ftrStrms(s), segids(s.size(), QN_SEGID_BAD) {}
 
+// stream i = the manager's child i (its trn_stream), or the manager's own stream for one thread
+// (CRF_Minibatch_GradAccumulator.cpp:110-150)
+CRF_Minibatch_GradAccumulator::CRF_Minibatch_GradAccumulator(CRF_Model* myCrf, CRF_FeatureStreamManager* mgr, QNUInt32 myNStreams)
+    : crf(myCrf) {
+  if (!mgr) throw runtime_error("CRF_Minibatch_GradAccumulator: no feature stream manager");
+  if (myNStreams <= 1) {
+    if (!mgr->trn_stream) throw runtime_error("CRF_Minibatch_GradAccumulator() Error: feature stream is NULL for thread 0");
+    ftrStrms.push_back(mgr->trn_stream);
+  } else {
+    for (QNUInt32 i = 0; i < myNStreams; i++) {
+      CRF_FeatureStreamManager* child = mgr->getChild(i);
+      if (!child) throw runtime_error("CRF_Minibatch_GradAccumulator() Error: feature stream manager is NULL for thread " + std::to_string(i));
+      if (!child->trn_stream) throw runtime_error("CRF_Minibatch_GradAccumulator() Error: feature stream is NULL for thread " + std::to_string(i));
+      ftrStrms.push_back(child->trn_stream);
+    }
+  }
+  segids.assign(ftrStrms.size(), QN_SEGID_BAD);
+}
+
+void CRF_Minibatch_GradAccumulator::setObjectiveFunction(objfunctype ofunc) {
+  if (ofunc != EXPF) throw runtime_error("CRF_Minibatch_GradAccumulator: only the EXPF objective is built (the reference disables the others, CRF_GradBuilder.cpp:130-135)");
+}
+
 void CRF_Minibatch_GradAccumulator::setMinibatch(QNUInt32 mb) {
   if (mb != 0 && mb < ftrStrms.size())
     throw runtime_error("CRF_Minibatch_GradAccumulator::setMinibatch() Error: minibatch size is less than the number of threads.");
@@ -457,26 +663,43 @@ double CRF_Minibatch_GradAccumulator::accumulateGradient(double* grad, double* Z
                                                          bool* isEndOfIter) {
   return accumulate(grad, Zx_out, uttCount, isEndOfIter);
 }
-// grad != nullptr: per-stream gradients come to the host and are summed there in stream order, like
-// the reference's join; grad == nullptr: the streams accumulate into the device gradient one after
-// the other (same order, the sums inside one stream's reduction kernels aside) and it is divided there
+
+// stream s of N: its share of a minibatch (CRF_Minibatch_GradAccumulator.cpp:229-241,257) and its
+// contiguous utterance view (io/CRF_FeatureStreamManager.cpp:425-464) -- exported for the CPU tests
+extern "C" uint32_t crf_amd_minibatch_share(uint32_t minibatch, uint32_t n_streams, uint32_t s) {
+  if (minibatch == CRF_UINT32_MAX) return CRF_UINT32_MAX;
+  return minibatch / n_streams + (s < minibatch % n_streams ? 1 : 0);
+}
+extern "C" void crf_amd_view_range(uint32_t n_utts, uint32_t n_streams, uint32_t s, uint32_t* lo, uint32_t* hi) {
+  const uint32_t per = n_utts / n_streams;
+  *lo = s * per;
+  *hi = s == n_streams - 1 ? n_utts : (s + 1) * per;
+}
+
+// One process: grad != nullptr -- per-stream gradients come to the host and are summed there in stream
+// order, like the reference's join; grad == nullptr -- the streams accumulate into the device gradient
+// one after the other (same order) and it is divided there.
+// Distributed (CRF_Model::setDistributed): this process is stream `rank`; the sum over streams and the
+// division by the active ones happen in scrf_allreduce_grad_ex on every rank's device gradient.
 double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter) {
   crf_amd::Engine* e = crf->engine();
   const QNUInt32 n = e->lambda_len, N = (QNUInt32)ftrStrms.size();
   *uttCount = 0;
   *Zx_out = 0.0;
-  if (grad) for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
+  const bool dist = crf->distributed();
+  if (dist && (QNUInt32)crf->distWorld() != N)
+    throw runtime_error("CRF_Minibatch_GradAccumulator: " + std::to_string(N) + " streams but " + std::to_string(crf->distWorld()) + " ranks (threads must equal WORLD_SIZE)");
+  if (grad && !dist) for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
   else e->check(scrf_zero_grad(e->h), "accumulateGradient");
-  const QNUInt32 per = minibatch == CRF_UINT32_MAX ? CRF_UINT32_MAX : minibatch / N;
-  const QNUInt32 rem = minibatch == CRF_UINT32_MAX ? 0 : minibatch % N;
   int nEnd = 0, nActive = 0;
   for (QNUInt32 s = 0; s < N; s++) if (segids[s] == QN_SEGID_BAD) ++nEnd;
   if (nEnd == (int)N) throw runtime_error("All feature streams are at the end! You don't have any utterances or you forget to rewind all the streams.");
   double totNumer = 0.0;
-  std::vector<double> sgrad(grad ? n : 0);
+  std::vector<double> sgrad(grad && !dist ? n : 0);
   for (QNUInt32 s = 0; s < N; s++) {  // stream order == the reference's join/sum order
+    if (dist && (int)s != crf->distRank()) continue;
     if (segids[s] == QN_SEGID_BAD) continue;
-    const QNUInt32 share = per == CRF_UINT32_MAX ? CRF_UINT32_MAX : per + (s < rem ? 1 : 0);
+    const QNUInt32 share = crf_amd_minibatch_share(minibatch, N, s);
     std::vector<HeldUtt> utts;
     do {  // thread run loop: at least one utterance, then until the share is reached or the view ends
       utts.emplace_back();
@@ -485,106 +708,213 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     } while (utts.size() < share && segids[s] != QN_SEGID_BAD);
     BatchGuard g{e};
     make_batch(e, ftrStrms[s], utts, &g);
-    std::vector<double> numer(utts.size()), zx(utts.size());
-    if (grad) e->check(scrf_zero_grad(e->h), "accumulateGradient");
-    e->check(scrf_fb_batch(e->h, g.b, numer.data(), zx.data()), "CRF_Minibatch_GradAccumulator::accumulateGradient()");
-    if (grad) e->check(scrf_get_grad(e->h, sgrad.data(), n), "accumulateGradient");
+    if (grad && !dist) e->check(scrf_zero_grad(e->h), "accumulateGradient");
+    e->check(scrf_fb_batch(e->h, g.b, nullptr, nullptr), "CRF_Minibatch_GradAccumulator::accumulateGradient()");
+    if (grad && !dist) {   // per-stream gradient and sums to the host (they restart with every scrf_zero_grad)
+      double sums[3] = {0, 0, 0};
+      e->check(scrf_get_batch_sums(e->h, sums), "accumulateGradient");
+      e->check(scrf_get_grad(e->h, sgrad.data(), n), "accumulateGradient");
+      totNumer += sums[0];
+      *Zx_out += sums[1];
+    }
     ++nActive;
-    for (size_t i = 0; i < utts.size(); i++) { totNumer += numer[i]; *Zx_out += zx[i]; }
     *uttCount += (QNUInt32)utts.size();
     if (segids[s] == QN_SEGID_BAD) ++nEnd;
-    if (grad) for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
+    if (grad && !dist) for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
   }
-  // averaged over ACTIVE STREAMS (reference quirk)
-  if (grad) for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;
-  else if (nActive > 1) e->check(scrf_div_grad(e->h, (double)nActive), "accumulateGradient");
+  if (dist) {
+    // the other streams' state is only known through the collective: every rank sends "my stream is
+    // exhausted after this step" along with {numerator, Zx, utterances, active}
+    const int r = crf->distRank();
+    const double ended_in = segids[r] == QN_SEGID_BAD ? 1.0 : 0.0;
+    double sums4[4] = {0, 0, 0, 0}, ended_out = 0.0;
+    e->check(scrf_allreduce_grad_ex(e->h, nActive, &ended_in, 1, sums4, &ended_out), "accumulateGradient (all-reduce)");
+    if (grad) e->check(scrf_get_grad(e->h, grad, n), "accumulateGradient");
+    totNumer = sums4[0];
+    *Zx_out = sums4[1];
+    *uttCount = (QNUInt32)(sums4[2] + 0.5);
+    *isEndOfIter = (int)(ended_out + 0.5) == (int)N;
+    // mirror the other streams' end state, so that the all-at-end guard above and rewinds stay meaningful
+    if (*isEndOfIter) for (QNUInt32 s = 0; s < N; s++) segids[s] = QN_SEGID_BAD;
+    return totNumer;
+  }
+  // averaged over ACTIVE STREAMS (reference quirk, :306-308)
+  if (grad) {
+    for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;
+  } else {
+    double sums[3] = {0, 0, 0};
+    e->check(scrf_get_batch_sums(e->h, sums), "accumulateGradient");
+    totNumer = sums[0];
+    *Zx_out = sums[1];
+    if (nActive > 1) e->check(scrf_div_grad(e->h, (double)nActive), "accumulateGradient");
+  }
   *isEndOfIter = nEnd == (int)N;
   return totNumer;
 }
 
 // ------------------------------------------------------------------------------------------
-// CRF_SGTrainer
+// CRF_Trainer / CRF_SGTrainer
 // ------------------------------------------------------------------------------------------
-CRF_SGTrainer::CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> s, const char* wf)
-    : crf_ptr(crf), streams(s), weight_fname(wf) {}
-
 static string dir_of(const string& p) {
   size_t k = p.find_last_of('/');
   return k == string::npos ? string(".") : p.substr(0, k);
 }
-static void touch(const string& f) { std::ofstream o(f.c_str()); if (!o.is_open()) std::cerr << "ERROR: cannot touch the done file " << f << std::endl; }
+static bool touch(const string& f) {
+  std::ofstream o(f.c_str());
+  if (!o.is_open()) { std::cerr << "ERROR: cannot touch the done file " << f << std::endl; return false; }
+  return true;
+}
 
-void CRF_SGTrainer::train() {
+CRF_Trainer::CRF_Trainer(CRF_Model* crf_in, CRF_FeatureStreamManager* ftr_str_mgr, char* wt_fname)
+    : crf_ptr(crf_in), ftr_strm_mgr(ftr_str_mgr), weight_fname(wt_fname ? wt_fname : ""), weight_dir(dir_of(weight_fname)) {}
+void CRF_Trainer::train() { throw runtime_error("CRF_Trainer::train: abstract trainer"); }
+void CRF_Trainer::setObjectiveFunction(objfunctype ofunc) {
+  if (ofunc != EXPF) throw runtime_error("CRF_Trainer::setObjectiveFunction: only the EXPF objective is built (the reference disables the others, CRF_GradBuilder.cpp:130-135)");
+  objective = ofunc;
+}
+bool CRF_Trainer::touchDoneFileIter(int iter) { return touch(weight_dir + "/.done.train.i" + std::to_string(iter)); }
+bool CRF_Trainer::touchDoneFileFinal() { return touch(weight_dir + "/.done.train"); }
+
+CRF_SGTrainer::CRF_SGTrainer(CRF_Model* crf_in, CRF_FeatureStreamManager* mgr, char* wt_fname) : CRF_Trainer(crf_in, mgr, wt_fname) {}
+CRF_SGTrainer::CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> s, const char* wf)
+    : CRF_Trainer(crf, nullptr, const_cast<char*>(wf)), own_streams(s) { nThreads = (int)s.size(); }
+
+void CRF_SGTrainer::train() { sgtrainMinibatch(); }   // both branches of the reference's train() (:58-65)
+
+void CRF_SGTrainer::sgtrainMinibatch() {
   crf_amd::Engine* e = crf_ptr->engine();
   crf_ptr->pushLambda();
   const QNUInt32 n = crf_ptr->getLambdaLen();
-  CRF_Minibatch_GradAccumulator gaccum(crf_ptr, streams);
-  gaccum.setMinibatch(minibatch);
-  gaccum.setUttReport(uttRpt);
+  const bool chief = !crf_ptr->distributed() || crf_ptr->distRank() == 0;   // one writer of files and progress lines
+  std::unique_ptr<CRF_Minibatch_GradAccumulator> gaccum(
+      ftr_strm_mgr ? new CRF_Minibatch_GradAccumulator(crf_ptr, ftr_strm_mgr, (QNUInt32)nThreads)
+                   : new CRF_Minibatch_GradAccumulator(crf_ptr, own_streams));
+  gaccum->setMinibatch((QNUInt32)minibatch);
+  gaccum->setUttReport((int)uttRpt);
   std::vector<double> lambdaAvg(n, 0.0);
   int iCounter = (int)crf_ptr->getInitIter();
   QNUInt32 uCounter = 0;
   int accCnt = (int)crf_ptr->getPresentations();
   double totLogLi = 0.0;
   // a resumed run replays the presentation-order generator (CRF_SGTrainer.cpp:88-93)
-  for (int i = 0; i < iCounter; i++)
-    for (CRF_FeatureStream* st_ : streams) st_->rewind();
-  gaccum.rewindAllAndNextSegs();
+  for (int i = 0; i < iCounter; i++) {
+    if (ftr_strm_mgr) {
+      ftr_strm_mgr->trn_stream->rewind();
+      if (nThreads > 1) ftr_strm_mgr->rewindAllChildrenTrn();
+    } else {
+      for (CRF_FeatureStream* st_ : own_streams) st_->rewind();
+    }
+  }
+  // the reference's prior step scales the gradient by (1 - 1/gvar) (:300-303); kept as written
+  const float invSquareVar = useGvar ? 1 / gvar : 0.0f;
+  gaccum->rewindAllAndNextSegs();
   bool start = true;
   while (iCounter < maxIters) {
-    if (start) {
+    if (start && chief) {
       if (useAdagrad) std::cout << "Iteration: " << iCounter << " starting AdaGrad scaling factor (eta): " << eta << std::endl;
       else std::cout << "Iteration: " << iCounter << " starting LR: " << lr << std::endl;
-      start = false;
     }
+    start = false;
     QNUInt32 inc = 0;
     bool endOfIter = false;
     double Zx = 0.0;
-    const double numer = gaccum.accumulateGradientOnDevice(&Zx, &inc, &endOfIter);
+    const double numer = gaccum->accumulateGradientOnDevice(&Zx, &inc, &endOfIter);
     const double logLi = numer - Zx;
     totLogLi += logLi;
     uCounter += inc;
-    if (uttRpt > 0 && uCounter % uttRpt == 0)
+    if (chief && uttRpt > 0 && uCounter % uttRpt == 0)
       std::cout << " Finished Utt: " << uCounter - 1 << " Batch-Avg Numerator: " << numer / inc << " Batch-Avg Zx: " << Zx / inc
                 << " Batch-Avg LogLi: " << logLi / inc << " Iter-Avg LogLi: " << totLogLi / uCounter << std::endl;
+    if (useGvar) e->check(scrf_gauss_prior(e->h, invSquareVar), "sgtrainMinibatch");
     // update on the device: lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0
     e->check(scrf_sgd_step(e->h, useAdagrad ? eta : (double)lr, useAdagrad, eps), "sgtrainMinibatch");
     accCnt += (int)inc;
     if (endOfIter) {
       crf_ptr->pullLambda();
-      std::stringstream ss;
-      ss << weight_fname << ".i" << iCounter << ".out";
-      std::cout << "Writing Iteration " << iCounter << " weights to file " << ss.str() << std::endl;
-      crf_ptr->writeToFile(ss.str().c_str());
       const double* acc = crf_ptr->getLambdaAcc();
       for (QNUInt32 i = 0; i < n; i++) lambdaAvg[i] = acc[i] / (float)accCnt;
-      std::stringstream sa;
-      sa << weight_fname << ".i" << iCounter << ".avg.out";
-      crf_ptr->writeToFile(sa.str().c_str(), lambdaAvg.data(), n);
-      if (useAdagrad) {
-        std::stringstream sg;
-        sg << weight_fname << ".i" << iCounter << ".gradSqrAcc.out";
-        crf_ptr->writeToFile(sg.str().c_str(), crf_ptr->getGradSqrAcc(), n);
+      if (chief) {
+        std::stringstream ss;
+        ss << weight_fname << ".i" << iCounter << ".out";
+        std::cout << "Writing Iteration " << iCounter << " weights to file " << ss.str() << std::endl;
+        crf_ptr->writeToFile(ss.str().c_str());
+        std::stringstream sa;
+        sa << weight_fname << ".i" << iCounter << ".avg.out";
+        crf_ptr->writeToFile(sa.str().c_str(), lambdaAvg.data(), n);
+        if (useAdagrad) {
+          std::stringstream sg;
+          sg << weight_fname << ".i" << iCounter << ".gradSqrAcc.out";
+          crf_ptr->writeToFile(sg.str().c_str(), crf_ptr->getGradSqrAcc(), n);
+        }
       }
-      gaccum.rewindAllAndNextSegs();
-      std::stringstream sd;
-      sd << dir_of(weight_fname) << "/.done.train.i" << iCounter;
-      touch(sd.str());
+      gaccum->rewindAllAndNextSegs();
+      if (chief) touchDoneFileIter(iCounter);
       iCounter++;
       uCounter = 0;
       totLogLi = 0.0;
       start = true;
       if (!useAdagrad) {
         lr *= lr_decay_rate;
-        std::cout << "Learning rate is decayed by " << lr_decay_rate << " to " << lr << std::endl;
+        if (chief) std::cout << "Learning rate is decayed by " << lr_decay_rate << " to " << lr << std::endl;
       }
     }
   }
   crf_ptr->pullLambda();
-  std::cout << "Writing Final Iteration weights to file " << weight_fname << std::endl;
-  crf_ptr->writeToFile(weight_fname.c_str());
-  crf_ptr->writeToFile((weight_fname + ".avg.out").c_str(), lambdaAvg.data(), n);
-  touch(dir_of(weight_fname) + "/.done.train");
+  if (chief) {
+    std::cout << "Writing Final Iteration weights to file " << weight_fname << std::endl;
+    crf_ptr->writeToFile(weight_fname.c_str());
+    crf_ptr->writeToFile((weight_fname + ".avg.out").c_str(), lambdaAvg.data(), n);
+    touchDoneFileFinal();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_StateVector / CRF_StateNode: node values of one utterance from the engine's hooks
+// ------------------------------------------------------------------------------------------
+CRF_StateVector::CRF_StateVector(CRF_FeatureStream* ftr_strm, CRF_Model* crf) {
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  const uint32_t T = utts[0].u.T, L = crf->getNActualLabs() ? crf->getNActualLabs() : crf->getNLabs(), D = crf->getLabMaxDur();
+  uint64_t n_segs = 0;
+  e->check(scrf_batch_info(e->h, g.b, nullptr, nullptr, &n_segs, nullptr), "CRF_StateVector");
+  S.resize((size_t)n_segs * L); M.resize((size_t)T * L * L);
+  AD.resize((size_t)n_segs * L); AL.resize((size_t)T * L); BE.resize((size_t)T * L);
+  e->check(scrf_scores(e->h, g.b, 0, S.data(), M.data()), "CRF_StateNode::computeTransMatrix");
+  e->check(scrf_forward_backward(e->h, g.b, 0, SCRF_PREC_EXACT, AD.data(), AL.data(), BE.data(), &zx), "CRF_StateNode::computeAlpha");
+  nodes.resize(T);
+  for (uint32_t t = 0; t < T; t++) {
+    CRF_StateNode& nd = nodes[t];
+    const size_t base = t < D ? (size_t)t * (t + 1) / 2 : (size_t)D * (D + 1) / 2 + (size_t)(t - D) * D;
+    nd.alpha = &AL[(size_t)t * L];
+    nd.beta = &BE[(size_t)t * L];
+    nd.alpha_dur = &AD[base * L];
+    nd.S = &S[base * L];
+    nd.M = &M[(size_t)t * L * L];
+    nd.nLabs = L;
+    nd.nodeMaxDur = t + 1 <= D ? t + 1 : D;
+    nd.label = utts[0].u.labels ? utts[0].u.labels[t] : CRF_LAB_BAD;
+    nd.zx = zx;
+    nd.last = t + 1 == T;
+  }
+}
+double CRF_StateNode::computeAlphaSum() {
+  if (!last) throw runtime_error("CRF_StateNode::computeAlphaSum: the node view answers it for the utterance's last node (Zx)");
+  return zx;
+}
+double CRF_StateNode::getStateValue(QNUInt32 lab, QNUInt32 dur) {
+  if (lab >= nLabs || dur < 1 || dur > nodeMaxDur) throw runtime_error("CRF_StateNode::getStateValue: label or duration out of range");
+  return S[(size_t)(dur - 1) * nLabs + lab];
+}
+double CRF_StateNode::getTransValue(QNUInt32 prev_lab, QNUInt32 cur_lab) {
+  if (prev_lab >= nLabs || cur_lab >= nLabs) throw runtime_error("CRF_StateNode::getTransValue: label out of range");
+  return M[(size_t)prev_lab * nLabs + cur_lab];
+}
+double CRF_StateNode::getFullTransValue(QNUInt32 prev_lab, QNUInt32 cur_lab, QNUInt32 dur) {
+  return getTransValue(prev_lab, cur_lab) + getStateValue(cur_lab, dur);
 }
 
 // ------------------------------------------------------------------------------------------

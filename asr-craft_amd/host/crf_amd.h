@@ -8,7 +8,9 @@
 //   CRF_FeatureStream (abstract) + CRF_MemoryFeatureStream       io/CRF_FeatureStream.h:54-66
 //   CRF_GradBuilder::buildGradient                               trainers/gradbuilders/CRF_GradBuilder.h:40
 //   CRF_Minibatch_GradAccumulator::accumulateGradient            trainers/accumulators/...h:66-67
-//   CRF_SGTrainer                                                trainers/CRF_SGTrainer.h:45-48
+//   CRF_FeatureStreamManager                                     io/CRF_FeatureStreamManager.h:60-100
+//   CRF_Trainer / CRF_SGTrainer                                  trainers/CRF_Trainer.h, CRF_SGTrainer.h:45-48
+//   CRF_StateNode / CRF_StateVector (read-only node view)        nodes/CRF_StateNode.h:67-115
 //   CRF_LatticeBuilder_* ::buildLattice<Fst>                     decoders/...WithoutSegTransFtr.h:26
 //
 // QuickNet3 and OpenFST are not dependencies: feature streams are an abstract interface the
@@ -19,6 +21,7 @@
 #define CRF_AMD_H_
 
 #include <stdint.h>
+#include <stdio.h>
 
 #include <memory>
 #include <stdexcept>
@@ -105,8 +108,20 @@ class CRF_Model {
   virtual modeltype getModelType() { return model_type; }
   virtual void setInitIter(QNUInt32 i) { init_iter = i; }
   virtual QNUInt32 getInitIter() { return init_iter; }
-  // the engine bound to this model (created lazily on `device`); lambda is pushed before use
-  crf_amd::Engine* engine(int device = 0, uint32_t precision = SCRF_PREC_EXACT);
+  // the engine bound to this model, created lazily on setDevice()'s GPU with setTrainPrecision()'s
+  // arithmetic policy (crf_device= / crf_precision= of the front-ends); lambda is pushed before use
+  crf_amd::Engine* engine();
+  void setDevice(int d) { device = d; }
+  int getDevice() const { return device; }
+  void setTrainPrecision(uint32_t p) { precision = p; }   // scrf_precision; decode entry points stay EXACT
+  // One process per GPU (RANK / WORLD_SIZE of the launcher): rank r is the reference's stream (thread) r.
+  // The RCCL communicator is created together with the engine; its 128-byte unique id travels from rank 0
+  // to the others through `id_file` (rank 0 writes it, the others poll; removed after the collective
+  // initialisation).  world == 1 with a non-empty id_file exercises the same path on one GPU.
+  void setDistributed(int rank, int world, const std::string& id_file);
+  int distRank() const { return dist_rank; }
+  int distWorld() const { return dist_world; }
+  bool distributed() const { return dist_on; }
   void pushLambda();   // host lambda/lambdaAcc/gradSqrAcc -> device
   void pullLambda();   // device -> host
 
@@ -116,6 +131,11 @@ class CRF_Model {
   CRF_FeatureMap* featureMap = nullptr;
   QNUInt32 init_present = 0, lab_max_dur = 1, nActualLabs = 0, init_iter = 0;
   modeltype model_type = STDFRAME;
+  int device = 0;
+  uint32_t precision = SCRF_PREC_FAST;
+  bool dist_on = false;
+  int dist_rank = 0, dist_world = 1;
+  std::string dist_id_file;
   std::unique_ptr<crf_amd::Engine> eng;
 };
 
@@ -130,13 +150,20 @@ class CRF_FeatureStream {
   virtual int rewind() = 0;
   virtual size_t num_ftrs() = 0;
   virtual size_t num_labs() = 0;
+  // restrict the stream to `count` utterances from `start` (io/CRF_FeatureStream.cpp:345; what
+  // CRF_FeatureStreamManager::create does for child i, :458-460); count == CRF_UINT32_MAX (QN_ALL): to the end
+  virtual void view(size_t start, size_t count) { (void)start; (void)count; throw std::runtime_error("CRF_FeatureStream::view: not supported by this stream"); }
   // Engine fast path: whole utterance at once.  frames[s] = raw frames of stream s incl. context
-  // padding (empty when only windows are available), labels = per-end-frame segment labels.
+  // padding (empty when only windows are available); either labels = per-end-frame segment labels
+  // nActualLabs*(dur-1)+phone, or phones + starts (phone id and first frame of the segment ending at each
+  // frame, CRF_LAB_BAD where none ends) from which the caller forms them for its model.
   struct Utterance {
     uint32_t T = 0;
     std::vector<const float*> frames;
     const float* windows = nullptr;
     const uint32_t* labels = nullptr;
+    const uint32_t* phones = nullptr;
+    const uint32_t* starts = nullptr;
   };
   virtual bool currentUtterance(Utterance* u) { (void)u; return false; }
   virtual const std::vector<scrf_stream_recipe>& recipes() { static std::vector<scrf_stream_recipe> e; return e; }
@@ -146,10 +173,15 @@ class CRF_FeatureStream {
 // per utterance one frame matrix per input stream + frame-level phone labels.
 class CRF_MemoryFeatureStream : public CRF_FeatureStream {
  public:
-  CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe> recipes, QNUInt32 max_dur, QNUInt32 n_actual_labs);
+  CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe> recipes, QNUInt32 max_dur, QNUInt32 n_actual_labs = 0);
+  ~CRF_MemoryFeatureStream() override;
   // frames[s]: (T + lctx_s + rctx_s) x in_width_s, frame_labels: T phone ids (or empty)
   void addUtterance(const std::vector<std::vector<float> >& frames, const std::vector<uint32_t>& frame_labels);
-  CRF_MemoryFeatureStream* view(size_t start, size_t count);  // child stream over a contiguous range
+  CRF_MemoryFeatureStream* makeView(size_t start, size_t count);  // new child stream over a contiguous range
+  void view(size_t start, size_t count) override;                 // the same in place
+  // feature concatenation (CRF_FeatureStream::join, used by CRF_FeatureStreamManager::join): the other
+  // stream's input streams become further streams of this one; same utterances, same lengths
+  void join(const CRF_MemoryFeatureStream& other);
   // presentation order of the utterances (io/CRF_InFtrStream_RandPresent.cpp): a new order at every
   // rewind(), generator seeded with 12345 * epoch + seed as there (:125-128); RANDOM_REPLACE draws
   // numUtterances() utterances with replacement, RANDOM_NO_REPLACE a permutation.  The generator is
@@ -168,12 +200,13 @@ class CRF_MemoryFeatureStream : public CRF_FeatureStream {
  private:
   struct Store {
     std::vector<scrf_stream_recipe> recipes;
-    QNUInt32 D, L;
+    QNUInt32 D;
     std::vector<uint32_t> T;
     std::vector<std::vector<std::vector<float> > > frames;  // [utt][stream]
-    std::vector<std::vector<uint32_t> > seg_labels;         // [utt][T]
-    std::vector<std::vector<uint32_t> > seg_start;          // [utt][T] start frame of the segment ending at t
+    std::vector<std::vector<uint32_t> > seg_phone;          // [utt][T] phone of the segment ending at t (CRF_LAB_BAD: none)
+    std::vector<std::vector<uint32_t> > seg_start;          // [utt][T] its first frame
   };
+  void fetchWindows();   // read(): the current utterance's window vectors, synthesised on the GPU
   std::shared_ptr<Store> store_;
   size_t begin_ = 0, end_ = 0, width_ = 0;
   long cur_ = -1;
@@ -182,6 +215,44 @@ class CRF_MemoryFeatureStream : public CRF_FeatureStream {
   QNUInt32 seed_ = 0, epoch_ = 0;
   std::vector<size_t> order_;   // utterance offsets inside [begin_, end_) in presentation order
   size_t pos_ = 0;
+  // read() protocol: the window vectors come from the engine's k_windows through a private handle
+  // (one utterance at a time); the host never restates the recipe
+  scrf_handle win_eng_ = nullptr;
+  long win_utt_ = -1;
+  std::vector<float> win_cache_;
+};
+
+// The reference's stream factory (io/CRF_FeatureStreamManager.{h,cpp}): one feature file (pfile or ascii)
+// + the hard-target label file -> trn_stream (and cv_stream when a CV range is given), `n_threads` children
+// whose trn_stream views the contiguous utterance range [i*floor(n/N), ...) (the last child takes the
+// remainder, create() :425-464), join() for feature concatenation.  Same constructor arguments as the
+// reference.  Built here: formats pfile / ascii; ftr_width is checked against the file; win_len is the
+// label maximum duration (window_extent == win_len, offsets 0); deltas, norm files and boundary-delta
+// features are refused.  The utterance selection is QN_Range syntax (qn_files.h).
+class CRF_FeatureStreamManager {
+ public:
+  CRF_FeatureStreamManager(int debug, const char* debug_name, char* ftr_fname, const char* ftr_file_fmt, char* ht_fname,
+                           size_t ht_offset, size_t ftr_width, size_t first_ftr, size_t num_ftrs, size_t win_ext,
+                           size_t win_off, size_t win_len, size_t left_ctx_len, size_t right_ctx_len, bool extract_seg_ftr,
+                           bool use_bdy_delta_ftr, int delta_o, int delta_w, char* trn_rng, char* cv_rng, FILE* nfile,
+                           int n_mode, double n_am, double n_av, seqtype ts, QNUInt32 rseed = 0, size_t n_threads = 1);
+  virtual ~CRF_FeatureStreamManager();
+  void join(CRF_FeatureStreamManager* other);
+  size_t getNumFtrs();
+  CRF_FeatureStreamManager* getChild(size_t child) { return child < children.size() ? children[child].get() : nullptr; }
+  size_t getNThreads() { return nthreads; }
+  void rewindAllChildrenTrn();
+  void display();
+
+  CRF_FeatureStream* trn_stream = nullptr;
+  CRF_FeatureStream* cv_stream = nullptr;
+  CRF_FeatureStream* old_trn_stream = nullptr;
+
+ protected:
+  CRF_FeatureStreamManager() {}
+  size_t nthreads = 1;
+  std::unique_ptr<CRF_MemoryFeatureStream> trn, cv;
+  std::vector<std::unique_ptr<CRF_FeatureStreamManager> > children;
 };
 
 namespace crf_amd {
@@ -241,15 +312,24 @@ class CRF_GradBuilder {
   CRF_Model* crf;
 };
 
-// data-parallel layer: N streams (ranks), minibatch split, sum / n_active
+// data-parallel layer: N streams, minibatch split, sum / n_active
+// (trainers/accumulators/CRF_Minibatch_GradAccumulator.{h,cpp}).  In one process the streams run one after
+// the other on the model's GPU (the gradient sum stays on the device).  With CRF_Model::setDistributed
+// every process is ONE of the N streams (rank r == stream r == the manager's child r): it runs its share
+// of the minibatch, then the device gradients and {numerator, Zx, utterances, active, ended} are
+// all-reduced over RCCL (scrf_allreduce_grad_ex) and divided by the number of active streams -- the
+// reference's join / sum / average (:277-312).
 class CRF_Minibatch_GradAccumulator {
  public:
-  CRF_Minibatch_GradAccumulator(CRF_Model* crf, std::vector<CRF_FeatureStream*> streams);
+  CRF_Minibatch_GradAccumulator(CRF_Model* myCrf, CRF_FeatureStreamManager* myFtrStrmMgr, QNUInt32 myNStreams);
+  CRF_Minibatch_GradAccumulator(CRF_Model* crf, std::vector<CRF_FeatureStream*> streams);   // caller-made streams
   virtual ~CRF_Minibatch_GradAccumulator() {}
   void setMinibatch(QNUInt32 mb);
-  void setUttReport(QNUInt32 r) { uttReport = r; }
+  void setUttReport(int r) { uttReport = r; }
+  void setObjectiveFunction(objfunctype ofunc);
+  QNUInt32 getNStreams() { return (QNUInt32)ftrStrms.size(); }
   void rewindAllAndNextSegs();
-  double accumulateGradient(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
+  virtual double accumulateGradient(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
   // the same minibatch, but the summed and averaged gradient STAYS in the engine's device buffer
   // (what CRF_SGTrainer uses: no 2 x lambda_len doubles over PCIe per minibatch)
   double accumulateGradientOnDevice(double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
@@ -259,30 +339,106 @@ class CRF_Minibatch_GradAccumulator {
   CRF_Model* crf;
   std::vector<CRF_FeatureStream*> ftrStrms;
   std::vector<QN_SegID> segids;
-  QNUInt32 minibatch = CRF_UINT32_MAX, uttReport = 0;
+  QNUInt32 minibatch = CRF_UINT32_MAX;
+  int uttReport = 0;
 };
 
-class CRF_SGTrainer {
+// trainers/CRF_Trainer.{h,cpp}
+class CRF_Trainer {
  public:
-  CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> streams, const char* weight_fname);
-  void setMaxIters(int n) { maxIters = n; }
-  void setLR(float v) { lr = v; }
-  void setLRDecayRate(float v) { lr_decay_rate = v; }
-  void setMinibatch(QNUInt32 mb) { minibatch = mb; }
-  void setUseAdagrad(bool b) { useAdagrad = b; }
-  void setEta(double e) { eta = e; }
-  void setUttRpt(QNUInt32 r) { uttRpt = r; }
-  void train();
+  CRF_Trainer(CRF_Model* crf_in, CRF_FeatureStreamManager* ftr_str_mgr, char* wt_fname);
+  virtual ~CRF_Trainer() {}
+  virtual void train();
+  virtual void setMaxIters(int n) { maxIters = n; }
+  virtual void setLR(float v) { lr = v; }
+  virtual void setUttRpt(QNUInt32 r) { uttRpt = r; }
+  virtual void setLogSpace(int v) { useLogspace = v; }
+  virtual void setGaussVar(float gvar_in) { gvar = gvar_in; useGvar = true; }
+  virtual void setLabelMask(bool useMask) { useLabelMask = useMask; }
+  virtual void setObjectiveFunction(objfunctype ofunc);
+  virtual void setLRDecayRate(float v) { lr_decay_rate = v; }
+  virtual std::string getWeightDir() { return weight_dir; }
+  virtual bool touchDoneFileIter(int iter);
+  virtual bool touchDoneFileFinal();
 
  protected:
   CRF_Model* crf_ptr;
-  std::vector<CRF_FeatureStream*> streams;
-  std::string weight_fname;
+  CRF_FeatureStreamManager* ftr_strm_mgr;
+  std::string weight_fname, weight_dir;
   int maxIters = 10;
   float lr = 0.008f, lr_decay_rate = 1.0f;
-  QNUInt32 minibatch = 1, uttRpt = 100;
+  QNUInt32 uttRpt = 100;
+  int useLogspace = 1;
+  float gvar = 0.0f;
+  bool useGvar = false, useLabelMask = false;
+  objfunctype objective = EXPF;
+};
+
+// trainers/CRF_SGTrainer.{h,cpp}: minibatch SGD / AdaGrad, weight averaging, per-iteration files and
+// .done.train markers.  Under CRF_Model::setDistributed only rank 0 writes files and progress lines.
+class CRF_SGTrainer : public CRF_Trainer {
+ public:
+  CRF_SGTrainer(CRF_Model* crf_in, CRF_FeatureStreamManager* ftr_str_mgr, char* wt_fname);
+  CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> streams, const char* weight_fname);   // caller-made streams
+  void train() override;
+  void setNThreads(int n) { nThreads = n; }
+  void setMinibatch(int m) { minibatch = m; }
+  void setEta(double e) { eta = e; }
+  void setUseAdagrad(double b) { useAdagrad = b != 0.0; }
+
+ protected:
+  void sgtrainMinibatch();
+  std::vector<CRF_FeatureStream*> own_streams;   // second constructor
+  int nThreads = 1, minibatch = 1;
   bool useAdagrad = false;
   double eta = 1.0, eps = 1e-12;
+};
+
+// Read-only view of the per-frame DP nodes of ONE utterance (nodes/CRF_StateNode.h:67-115), backed by the
+// engine's parity hooks (scrf_scores, scrf_forward_backward): the values a node of the reference holds
+// after the gradbuilder's forward and backward sweeps.  The compute* virtuals of the reference are steps of
+// a per-node recursion; here the whole utterance is evaluated on the GPU when the vector is loaded, so they
+// are no-ops kept for source compatibility.  Custom CRF_StateNode / CRF_FeatureMap subclasses cannot plug
+// into the device recursion.
+class CRF_StateVector;
+class CRF_StateNode {
+ public:
+  virtual ~CRF_StateNode() {}
+  virtual double computeTransMatrix() { return 0.0; }
+  virtual double computeAlpha() { return 0.0; }
+  virtual double computeFirstAlpha() { return 0.0; }
+  virtual double computeBeta(double scale = 1.0) { (void)scale; return 0.0; }
+  virtual void setTailBeta() {}
+  virtual double computeAlphaSum();                     // Zx on the utterance's last node
+  virtual double* getAlpha() { return alpha; }          // [nActualLabs]
+  virtual double* getBeta() { return beta; }
+  virtual double* getAlphaWithDur() { return alpha_dur; }   // [nodeMaxDur][nActualLabs]: row d-1 = duration d
+  virtual double getStateValue(QNUInt32 lab, QNUInt32 dur = 1);
+  virtual double getTransValue(QNUInt32 prev_lab, QNUInt32 cur_lab);
+  virtual double getFullTransValue(QNUInt32 prev_lab, QNUInt32 cur_lab, QNUInt32 dur = 1);
+  virtual QNUInt32 getLabel() { return label; }
+  virtual QNUInt32 getNodeMaxDur() { return nodeMaxDur; }
+  virtual QNUInt32 getNumAvailLabs() { return nLabs; }
+
+ protected:
+  friend class CRF_StateVector;
+  double *alpha = nullptr, *beta = nullptr, *alpha_dur = nullptr, *S = nullptr, *M = nullptr;
+  QNUInt32 nLabs = 0, nodeMaxDur = 0, label = CRF_LAB_BAD;
+  double zx = 0.0;
+  bool last = false;
+};
+class CRF_StateVector {
+ public:
+  // evaluates the stream's CURRENT utterance under the model's lambda (EXACT scores, log-domain recursion)
+  CRF_StateVector(CRF_FeatureStream* ftr_strm, CRF_Model* crf);
+  size_t getNodeCount() { return nodes.size(); }
+  CRF_StateNode* at(size_t t) { return &nodes.at(t); }
+  double getZx() { return zx; }
+
+ private:
+  std::vector<CRF_StateNode> nodes;
+  std::vector<double> S, M, AD, AL, BE;
+  double zx = 0.0;
 };
 
 // lattice builders: same call as the reference's templates; the arcs come from the engine in
@@ -403,5 +559,11 @@ std::vector<uint32_t> crf_amd_best_path(CRF_FeatureStream* ftr_strm, CRF_Model* 
 // are what crf_amd_best_path returns utterance by utterance.
 size_t crf_amd_best_paths(CRF_FeatureStream* ftr_strm, CRF_Model* crf, size_t max_utts,
                           std::vector<std::vector<uint32_t> >* labels, std::vector<float>* costs, bool* at_end);
+
+// the split arithmetic of the data-parallel layer (exported with C linkage for the CPU tests): share of
+// stream s of a minibatch (CRF_Minibatch_GradAccumulator.cpp:229-241,257), contiguous utterance view of
+// stream s (io/CRF_FeatureStreamManager.cpp:425-464)
+extern "C" uint32_t crf_amd_minibatch_share(uint32_t minibatch, uint32_t n_streams, uint32_t s);
+extern "C" void crf_amd_view_range(uint32_t n_utts, uint32_t n_streams, uint32_t s, uint32_t* lo, uint32_t* hi);
 
 #endif  // CRF_AMD_H_

@@ -242,6 +242,14 @@ int scrf_decode_stats(scrf_handle h, uint64_t* n_recomputed, uint64_t* n_fallbac
 int scrf_comm_unique_id(void* id128);                       /* ncclGetUniqueId, 128 bytes */
 int scrf_comm_init(scrf_handle h, const void* id128, int rank, int n_ranks);
 int scrf_allreduce_grad(scrf_handle h, int active, double* sums4);
+/* the same with up to 4 caller scalars riding in the scalar all-reduce (summed over the ranks): a C++ host
+ * sends its "my stream is exhausted" flag this way, whose sum decides the end of the epoch (:248-250, :312).
+ * extra_out (host, n_extra doubles) and sums4 are read back together; either may be NULL. */
+int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4,
+                           double* extra_out);
+/* the reference's Gaussian-prior step as written (trainers/CRF_SGTrainer.cpp:300-303): grad[i] -= grad[i] *
+ * inv_square_var on the device gradient (it scales the gradient, not lambda -- kept as is) */
+int scrf_gauss_prior(scrf_handle h, float inv_square_var);
 /* grad *= s  (used with an external all-reduce: s = 1/n_active) */
 int scrf_scale_grad(scrf_handle h, double s);
 /* grad[i] /= d on the device: the `/ nStreams_active` of accumulateGradient (:306-308) for a host that

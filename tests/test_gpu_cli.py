@@ -352,13 +352,10 @@ def test_crftrain_resume_and_done_file(tmp_path):
     np.testing.assert_allclose(w2, w1, rtol=2e-4, atol=2e-6)
     a1, a2 = np.loadtxt(str(d1 / "w.out.avg.out")), np.loadtxt(str(d2 / "w.out.avg.out"))
     np.testing.assert_allclose(a2, a1, rtol=2e-4, atol=2e-6)
-    # a missing resume file is an error, and the Gaussian prior is refused rather than ignored
+    # a missing resume file is an error (the Gaussian prior: test_crftrain_precision_flag_and_gaussian_prior)
     r4 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(tmp_path / "x.out"), "init_weight_file=" + str(tmp_path / "nope")],
                         capture_output=True, text=True, timeout=300)
     assert r4.returncode != 0 and "unable to be opened for reading" in r4.stderr
-    r5 = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(tmp_path / "y.out"), "crf_gauss_var=1.0"],
-                        capture_output=True, text=True, timeout=300)
-    assert r5.returncode != 0 and "crf_gauss_var" in r5.stderr
 
 
 @pytest.mark.parametrize("flag,msg", [("ftr1_delta_order=2", "delta"), ("ftr2_norm_file=n.norms", "norm_file"), ("ftr1_window_len=9", "window_len"),
@@ -687,3 +684,132 @@ def test_crfdecode_lm_random_language_models(tmp_path, seed):
         seg_arcs = [x for x in chain if int(x[2]) != 0]
         assert [int(x[2]) - 1 for x in seg_arcs] == [l for (_, _, l) in segs]
         assert [int(x[3]) for x in chain if int(x[3]) != 0] == words
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: the reference's class interfaces, rank / precision / device flags, Gaussian prior
+# ------------------------------------------------------------------------------------------------
+def _train_flags(out, **kw):
+    f = dict(crf_epochs=2, crf_lr=0.1, crf_bunch_size=2, threads=1, crf_utt_rpt=1, crf_train_order="seq")
+    f.update(kw)
+    return _common_flags() + ["hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + out] + \
+        ["%s=%s" % kv for kv in f.items()]
+
+
+def _files(d):
+    return {n: open(os.path.join(d, n), "rb").read() for n in sorted(os.listdir(d)) if n.startswith("w.out")}
+
+
+@pytest.mark.parametrize("threads,bunch", [(1, 1), (2, 3)])
+def test_reference_main_sequence_compiles_links_and_trains(tmp_path, threads, bunch):
+    """tests/host/reference_main_sequence.cpp reproduces the object / call sequence of the reference's
+    CRFTrain main (Main.cpp:508-684) against asr-craft_amd/host/crf_amd.h: it must compile, link against
+    libcrf_amd_host + libscrf_amd, train the bundled fixture, and write the weight files bin/CRFTrain
+    writes for the same flags.  Its CRF_StateNode view of utterance 0 is compared with the oracle."""
+    lib = os.path.join(ROOT, "asr-craft_amd", "lib")
+    exe = str(tmp_path / "refmain")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "asr-craft_amd", "host"),
+                        os.path.join(ROOT, "tests", "host", "reference_main_sequence.cpp"), "-o", exe, "-L" + lib,
+                        "-Wl,-rpath," + lib, "-lcrf_amd_host", "-lscrf_amd"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d1, d2 = tmp_path / "tu", tmp_path / "cli"
+    d1.mkdir(); d2.mkdir()
+    r1 = subprocess.run([exe, G, str(d1 / "w.out"), str(threads), str(bunch), "2"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    r2 = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(str(d2 / "w.out"), threads=threads, crf_bunch_size=bunch),
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    f1, f2 = _files(str(d1)), _files(str(d2))
+    assert sorted(f1) == sorted(f2) and len(f1) == 6 and all(f1[k] == f2[k] for k in f1)
+    assert os.path.exists(str(d1 / ".done.train"))
+    # node view of utterance 0 under the trained (full precision) weights: oracle scores / recursion under the
+    # 6-digit weights differ in the 6th digit, so compare through the weights the run wrote with a loose bound
+    utts = _fixture()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    w = np.loadtxt(str(d1 / "w.out"))
+    X = utts[0][0]; T = X.shape[0]
+    S, M = orc.seg_scores(cfg, lay, w, X, T)
+    rc, ad, al, apt, zx = orc.seg_forward(cfg, S, M, T)
+    rc2, be, sd = orc.seg_backward(cfg, S, M, T)
+    lines = [l.split() for l in r1.stdout.splitlines() if l.startswith("NODE")]
+    assert lines[0][0] == "NODES" and int(lines[0][1]) == T and abs(float(lines[0][3]) - zx) < 1e-4 * abs(zx)
+    for t in range(T):
+        v = dict(zip(lines[1 + t][2::2], lines[1 + t][3::2]))
+        assert int(v["label"]) == int(utts[0][1][t])
+        np.testing.assert_allclose([float(v["state0"]), float(v["state3"]), float(v["trans12"]), float(v["full12"]), float(v["alpha2"]), float(v["beta2"])],
+                                   [S[t, 0], S[t, 3], M[t, 1 * 48 + 2], M[t, 1 * 48 + 2] + S[t, 2], al[t, 2], be[t, 2]], rtol=1e-4, atol=1e-4)
+
+
+def test_crftrain_world_size_one_with_the_communicator_is_byte_identical(tmp_path):
+    """the multi-rank path of CRFTrain (RANK / WORLD_SIZE environment, RCCL communicator initialised through
+    the id file, scrf_allreduce_grad_ex every step) with ONE rank writes the same files as the plain run."""
+    outs = {}
+    for tag, env, extra in [("plain", {}, {}), ("comm", {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, {"crf_force_comm": 1})]:
+        d = tmp_path / tag
+        d.mkdir()
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(str(d / "w.out"), crf_bunch_size=2, **extra),
+                           capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = _files(str(d))
+        assert not os.path.exists(str(d / "w.out.rccl_id"))      # rank 0 removes the id file after the collective init
+    assert sorted(outs["plain"]) == sorted(outs["comm"]) and all(outs["plain"][k] == outs["comm"][k] for k in outs["plain"])
+    # a rank count that does not match `threads` is refused
+    e = dict(os.environ); e.update({"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(str(tmp_path / "x.out"), threads=3), capture_output=True, text=True, timeout=60, env=e)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_crftrain_precision_flag_and_gaussian_prior(tmp_path):
+    """crf_precision=exact|fast agree to the weight file's 6 digits; crf_gauss_var applies the reference's prior
+    step as written (grad -= grad / gvar, CRF_SGTrainer.cpp:300-303), checked against the oracle loop."""
+    ws = {}
+    for prec in ("exact", "fast"):
+        (tmp_path / prec).mkdir()          # one directory per run: the .done.train marker lives next to the weights
+        out = str(tmp_path / prec / "w.out")
+        r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(out, crf_precision=prec, crf_gauss_var=4.0, crf_bunch_size=3),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ws[prec] = np.loadtxt(out)
+    np.testing.assert_allclose(ws["exact"], ws["fast"], rtol=2e-5, atol=1e-12)
+    utts = _fixture()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    lam = np.zeros(lay.lambda_len); acc = np.zeros_like(lam); gsa = np.zeros_like(lam)
+    inv = np.float32(1.0) / np.float32(4.0)
+    for _ in range(2):
+        g = np.zeros(lay.lambda_len)
+        for X, lab in utts:
+            rc, g, _, _ = orc.frame_build_gradient(cfg, lay, lam, X, lab, X.shape[0], grad=g)
+            assert rc == 0
+        g = g - g * float(inv)
+        orc.sgd_step(lam, acc, gsa, g, np.float32(0.1), False, 1e-12)
+    np.testing.assert_allclose(ws["exact"], np.array([float("%g" % v) for v in lam]), rtol=2e-5, atol=1e-12)
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(str(tmp_path / "y.out"), crf_precision="half"), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_precision" in r.stderr
+
+
+def test_memory_stream_read_protocol_serves_device_windows(tmp_path):
+    """CRF_FeatureStream::read (the reference's per-frame protocol) hands out window vectors synthesised by
+    the engine's window kernel -- the host holds no restatement of the recipe; checked through a gradient
+    built from a stream that only offers read() (tests/host/read_protocol.cpp)."""
+    lib = os.path.join(ROOT, "asr-craft_amd", "lib")
+    exe = str(tmp_path / "readproto")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "asr-craft_amd", "host"),
+                        os.path.join(ROOT, "tests", "host", "read_protocol.cpp"), "-o", exe, "-L" + lib,
+                        "-Wl,-rpath," + lib, "-lcrf_amd_host", "-lscrf_amd"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    vals = dict(l.split("=") for l in r.stdout.split())
+    # inputs are generated inside the program from a fixed recipe; restate them here for the oracle
+    L, D, W, T = 4, 3, 2, 7
+    X = np.array([[np.float32(((t * 7 + c * 3) % 11) / 11.0) for c in range(W)] for t in range(T)], dtype=np.float32)
+    fl = np.array([0, 0, 1, 1, 1, 1, 2], dtype=np.uint32)
+    cfg = orc.config(L=L, D=D, F=8 * W + D); lay = orc.Layout(cfg)
+    lam = np.array([((i * 37) % 19 - 9) / 50.0 for i in range(lay.lambda_len)])
+    Xw = orc.windows(X, D)
+    rc, g, numer, zx = orc.seg_build_gradient(cfg, lay, lam, Xw, orc.group_labels(fl, D, L), T)
+    assert rc == 0
+    assert abs(float(vals["zx"]) - zx) < 1e-9 * abs(zx) and abs(float(vals["numer"]) - numer) < 1e-9 * max(1, abs(numer))
+    assert abs(float(vals["gsum"]) - np.abs(g).sum()) < 1e-8 * np.abs(g).sum()
+    assert int(vals["windows_equal"]) == 1

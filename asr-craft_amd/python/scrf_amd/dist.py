@@ -50,12 +50,44 @@ class RankCursor:
         return r
 
 
+class MinibatchReducer:
+    """The reference's join / sum / average (CRF_Minibatch_GradAccumulator.cpp:277-312) for one process per
+    GPU, as ONE collective per SGD step: the gradient and the scalars {numer, zx, n_utts, active} live in one
+    device buffer of lambda_len + 4 doubles that is all-reduced (sum) in place, then grad /= n_active.
+
+    `grad` (a view of the first lambda_len entries) is what the engine accumulates into
+    (Engine.set_grad_buffer(reducer.grad.data_ptr())); `tail` holds the four scalars.  Nothing is allocated
+    and no host value travels to the device per step: the caller flips `set_active` only when its view runs
+    out.  Inactive ranks must contribute a zero gradient.  All ranks call reduce() every step (the
+    reference joins every stream's thread every step)."""
+
+    def __init__(self, lambda_len, device, group=None):
+        self.buf = torch.zeros(lambda_len + 4, dtype=torch.float64, device=device)
+        self.grad = self.buf[:lambda_len]
+        self.tail = self.buf[lambda_len:]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._one = torch.ones((), dtype=torch.float64, device=device)
+        self._active = torch.ones((), dtype=torch.float64, device=device)
+        self._nact = torch.ones((), dtype=torch.float64, device=device)
+
+    def set_active(self, active):
+        self._active.fill_(1.0 if active else 0.0)
+
+    def reduce(self):
+        """in place; returns n_active as a 0-d device tensor (no host synchronisation)"""
+        self.tail[3].copy_(self._active)
+        if self.world > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+        torch.maximum(self.tail[3], self._one, out=self._nact)
+        self.grad.div_(self._nact)
+        return self.tail[3]
+
+
 def reduce_minibatch(grad, scalars, active, group=None):
     """In place: grad <- sum_ranks(grad) / n_active ; scalars = [numer, zx, n_utts] summed.
-    Returns n_active as a 0-d tensor on grad's device (no host synchronisation here: the division
-    happens on the device, callers that need the value call .item()).  Inactive ranks must pass
-    a zero gradient.  All ranks call this every step (the reference joins every stream's thread
-    every step)."""
+    Returns n_active as a 0-d tensor on grad's device.  Convenience form for tests and small tools (it
+    allocates and runs two collectives); training loops use MinibatchReducer."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     extra = torch.zeros(scalars.numel() + 1, dtype=torch.float64, device=grad.device)
     extra[:-1] = scalars

@@ -101,23 +101,23 @@ def main():
     stream = torch.cuda.Stream()  # a real (non-null) HIP stream shared by the engine and torch/RCCL
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
-    grad = torch.zeros(eng.lambda_len, dtype=torch.float64, device="cuda")
-    sums = torch.zeros(4, dtype=torch.float64, device="cuda")
+    from scrf_amd.dist import MinibatchReducer
+    # gradient + {numer, zx, n_utts, active} in one device buffer: one RCCL all-reduce per step
+    red = MinibatchReducer(eng.lambda_len, "cuda") if dist is not None else None
+    grad = red.grad if red is not None else torch.zeros(eng.lambda_len, dtype=torch.float64, device="cuda")
     eng.set_grad_buffer(grad.data_ptr())
     fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
     ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
     batch = eng.batch_from_frames(fl, ll)  # inputs resident in HBM from here on
     lr = 0.1 / U
 
-    from scrf_amd.dist import reduce_minibatch
-
     def step():
         eng.zero_grad()
-        eng.fb_batch(batch, want_scalars=False)  # async on the shared stream
-        if dist is not None:
+        eng.fb_batch(batch, want_scalars=False)  # returns once the recursion's status is known; contractions in flight
+        if red is not None:
             # RCCL all-reduce (sum) of the weight gradient over xGMI, then / active ranks
             # (Minibatch_GradAccumulator.cpp:296-308); every rank is active in this bench
-            reduce_minibatch(grad, sums[:3], True)
+            red.reduce()
         eng.sgd_step(lr, False)
 
     def barrier():

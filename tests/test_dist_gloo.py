@@ -40,12 +40,13 @@ def _utt_grad(orc, cfg, lay, lam, frames, labels, off, D, u, grad):
     return n, z
 
 
-def _worker(rank, world, port, minibatch, out_dir):
+def _worker(rank, world, port, minibatch, out_dir, one_collective=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc, cfg, lay, lam, frames, labels, off, U, D = _problem()
-    from scrf_amd.dist import RankCursor, reduce_minibatch
+    from scrf_amd.dist import MinibatchReducer, RankCursor, reduce_minibatch
     cur = RankCursor(U, world, rank)
+    red = MinibatchReducer(lay.lambda_len, "cpu") if one_collective else None
     steps = []
     while True:
         active = cur.active
@@ -53,8 +54,16 @@ def _worker(rank, world, port, minibatch, out_dir):
         for u in cur.next_step(minibatch):
             a, b = _utt_grad(orc, cfg, lay, lam, frames, labels, off, D, u, g)
             numer += a; zx += b; n += 1
-        gt = torch.from_numpy(g); sc = torch.tensor([numer, zx, float(n)], dtype=torch.float64)
-        n_active = int(reduce_minibatch(gt, sc, active).item())
+        if red is not None:
+            # what bench.py runs: gradient and scalars in one buffer, one all-reduce per step
+            red.grad.copy_(torch.from_numpy(g))
+            red.tail[:3] = torch.tensor([numer, zx, float(n)], dtype=torch.float64)
+            red.set_active(active)
+            n_active = int(red.reduce().item())
+            gt, sc = red.grad.clone(), red.tail[:3].clone()
+        else:
+            gt = torch.from_numpy(g); sc = torch.tensor([numer, zx, float(n)], dtype=torch.float64)
+            n_active = int(reduce_minibatch(gt, sc, active).item())
         if n_active == 0:
             break
         steps.append((gt.numpy().copy(), sc.numpy().copy(), n_active))
@@ -64,10 +73,10 @@ def _worker(rank, world, port, minibatch, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,minibatch", [(2, 3), (3, 4), (2, 2)])
-def test_sharded_minibatches_match_accumulator_semantics(tmp_path, world, minibatch):
+@pytest.mark.parametrize("world,minibatch,one_collective", [(2, 3, False), (3, 4, False), (2, 2, False), (2, 3, True), (3, 5, True)])
+def test_sharded_minibatches_match_accumulator_semantics(tmp_path, world, minibatch, one_collective):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, minibatch, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, minibatch, str(tmp_path), one_collective), nprocs=world, join=True)
     got = np.load(os.path.join(str(tmp_path), "steps.npy"))
     # single-process restatement: streams with contiguous views, sum in stream order / n_active
     orc, cfg, lay, lam, frames, labels, off, U, D = _problem()

@@ -1,14 +1,54 @@
 // CRFFstDecode -- lattice decode front-end (CRFFstDecode/src/Main.cpp): per utterance build the
 // lattice, take the best path (ShortestPath/Project/RmEpsilon/TopSort), write `sent pos label`
 // lines (the ILAB content as ascii); crf_lat_outdir additionally dumps the arc list as text.
-// LM / dictionary composition needs OpenFST and stays host-side future work.
+// crf_output_mlffile (+ crf_olist, crf_osymbols): the MLF path of the reference (Main.cpp:891-1044) -- the
+// utterance's lattice, composed with an LM FST when crf_lm_txt (OpenFST text) or crf_lm_bin is given
+// (Compose + ShortestPath + RmEpsilon + TopSort in one host pass, crf_amd::composeShortestPath; the LM reads
+// the lattice's OUTPUT labels, phone + L*(dur-1) + 1, as the reference's does), best path written as HTK MLF
+// lines (the LM's output symbols; without an LM the lattice's own output labels).  crf_mlf_output_frames adds
+// the first and last frame of each label's segments.  Dictionary / phone-penalty FSTs (crf_dict_fst,
+// crf_phn_fst) and alignment MLFs are refused.
 #include "cli_common.h"
+
+static std::map<long, std::string> read_symbols(const std::string& path) {   // OpenFST text symbol table: `symbol id`
+  std::ifstream f(path.c_str());
+  if (!f.is_open()) { std::cerr << "ERROR: Failed opening file: " << path << std::endl; exit(-1); }
+  std::map<long, std::string> m;
+  std::string sym;
+  long id;
+  while (f >> sym >> id) m[id] = sym;
+  return m;
+}
 
 int main(int argc, char** argv) {
   Args a(argc, argv);
   CliModel m;
   auto data = load_streams(a, &m);
   if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
+  for (const char* k : {"crf_dict_fst", "crf_phn_fst", "crf_align_mlffile", "crf_lm_arpa"})
+    if (a.has(k)) { std::cerr << k << ": not built (the LM goes in as crf_lm_txt / crf_lm_bin over the lattice's output labels)" << std::endl; return 1; }
+  const bool want_mlf = a.has("crf_output_mlffile");
+  crf_amd::ArcListFst lm;
+  const bool have_lm = a.has("crf_lm_txt") || a.has("crf_lm_bin");
+  std::vector<std::string> olist;
+  std::map<long, std::string> osym;
+  std::ofstream mlf;
+  if (want_mlf) {
+    if (!a.has("crf_olist")) { std::cerr << "crf_olist required with crf_output_mlffile." << std::endl; return -1; }
+    std::ifstream f(a.str("crf_olist").c_str());
+    if (!f.is_open()) { std::cerr << "ERROR: Failed opening file: " << a.str("crf_olist") << std::endl; return -1; }
+    std::string ln;
+    while (getline(f, ln)) olist.push_back(ln);
+    if (a.has("crf_osymbols")) osym = read_symbols(a.str("crf_osymbols"));
+    try {
+      if (a.has("crf_lm_txt")) crf_amd::readFstText(a.str("crf_lm_txt").c_str(), &lm);
+      else if (a.has("crf_lm_bin")) crf_amd::readFstBinary(a.str("crf_lm_bin").c_str(), &lm);
+    } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+    if (have_lm) std::cout << "LM: " << lm.n_states << " states, " << lm.arcs.size() << " arcs, " << lm.finals.size() << " final" << std::endl;
+    mlf.open(a.str("crf_output_mlffile").c_str());
+    mlf << "#!MLF!#" << std::endl;
+  } else if (have_lm) { std::cerr << "crf_lm_txt / crf_lm_bin need crf_output_mlffile (the label file holds the lattice's own best path)" << std::endl; return 1; }
+  const bool out_frames = a.num("crf_mlf_output_frames", 0) != 0;
   CRF_Model crf(m.L);
   crf.setLabMaxDur(m.D);
   crf.setNActualLabs(m.fmap.nActualLabs);
@@ -45,7 +85,43 @@ int main(int argc, char** argv) {
     all_labs.push_back(labs);
     u++;
   };
-  if (!a.has("crf_lat_outdir")) {
+  // MLF path (Main.cpp:891-1044) of the lattice `fst` of sentence `sent`
+  auto write_mlf = [&](const crf_amd::ArcListFst& fst, uint32_t sent) {
+    if (sent >= olist.size()) throw std::runtime_error("eval sentence range goes out of the olist size.");
+    crf_amd::ArcListFst best;
+    float total = 0;
+    bool ok;
+    if (have_lm) {
+      ok = crf_amd::composeShortestPath(fst, lm, &best, &total);
+    } else {   // ShortestPath on the lattice alone: an LM that accepts every label and copies it
+      crf_amd::ArcListFst id;
+      id.n_states = 1; id.start = 0; id.SetFinal(0, 0.0f);
+      for (uint32_t l = 1; l <= m.L * m.D; l++) id.arcs.push_back(scrf_arc{0, (int)l, (int)l, 0.0f, 0});
+      ok = crf_amd::composeShortestPath(fst, id, &best, &total);
+    }
+    mlf << "\"" << olist[sent] << "\"" << std::endl;
+    std::cout << "\"" << olist[sent] << "\" : ";
+    if (!ok) std::cerr << "WARNING: no path through lattice and LM for " << olist[sent] << std::endl;
+    uint32_t frame = 0, seg_start = 0;
+    bool open_seg = false;
+    for (const scrf_arc& c : best.arcs) {
+      if (c.ilabel != 0) {   // a segment of the lattice: phone + L*(dur-1) + 1 (frame model: one frame)
+        const uint32_t dur = (uint32_t)(c.ilabel - 1) / m.L + 1;
+        if (!open_seg) { seg_start = frame; open_seg = true; }
+        frame += dur;
+      }
+      if (c.olabel != 0) {
+        if (out_frames) mlf << seg_start << "\t" << (frame ? frame - 1 : 0) << "\t";
+        const std::string w = osym.count(c.olabel) ? osym[c.olabel] : std::to_string(c.olabel);
+        mlf << w << std::endl;
+        std::cout << w << " ";
+        open_seg = false;
+      }
+    }
+    mlf << "." << std::endl;
+    std::cout << ". (weight " << total << ")" << std::endl;
+  };
+  if (!a.has("crf_lat_outdir") && !want_mlf) {
     // best paths only: whole device batches of utterances (crf_bunch_size of them, default 256)
     const size_t bunch = (size_t)std::max(1L, a.num("crf_bunch_size", 256));
     bool at_end = strm.nextseg() == QN_SEGID_BAD;
@@ -66,12 +142,15 @@ int main(int argc, char** argv) {
         crf_amd::ArcListFst fst;
         CRF_LatticeBuilder lb(&strm, &crf);
         lb.buildLattice(&fst, false, (crf_amd::ArcListFst*)nullptr, false);
-        // the reference writes the lattice as an OpenFST binary, fst.<n>.final.fst (:832-837); here that file
-        // (layout unpinned, crf_amd.h) plus the same arcs as text
-        crf_amd::writeFstBinary((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".final.fst").c_str(), fst);
-        std::ofstream lf((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".txt").c_str());
-        for (const scrf_arc& c : fst.arcs) lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << c.w << "\n";
-        lf << fst.final_state << "\n";
+        if (a.has("crf_lat_outdir")) {
+          // the reference writes the lattice as an OpenFST binary, fst.<n>.final.fst (:832-837); here that file
+          // (layout unpinned, crf_amd.h) plus the same arcs as text
+          crf_amd::writeFstBinary((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".final.fst").c_str(), fst);
+          std::ofstream lf((a.str("crf_lat_outdir") + "/fst." + std::to_string(u) + ".txt").c_str());
+          for (const scrf_arc& c : fst.arcs) lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << c.w << "\n";
+          lf << fst.final_state << "\n";
+        }
+        if (want_mlf) write_mlf(fst, sents[u]);
         float cost = 0;
         emit(crf_amd_best_path(&strm, &crf, &cost));
       } catch (std::exception& e) {

@@ -1088,6 +1088,112 @@ void crf_amd::readFstBinary(const char* fname, crf_amd::ArcListFst* fst) {
   if (seen != n_arcs || r.at != r.d.size()) throw runtime_error(r.name + ": the file does not end where its header says" + hint);
 }
 
+bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd::ArcListFst& lm, crf_amd::ArcListFst* best, float* total) {
+  const int S = lat.n_states, Q = lm.n_states;
+  if (S <= 0 || Q <= 0 || lat.start < 0 || lm.start < 0) throw runtime_error("composeShortestPath: a machine has no start state");
+  if ((size_t)S * (size_t)Q > ((size_t)1 << 28)) throw runtime_error("composeShortestPath: lattice x LM too large for the dense product search");
+  const float INF = std::numeric_limits<float>::infinity();
+  // arcs by source state, in insertion order
+  std::vector<std::vector<int> > lout(S), mout(Q);
+  for (size_t i = 0; i < lat.arcs.size(); i++) {
+    const scrf_arc& a = lat.arcs[i];
+    if (a.src < 0 || a.src >= S || a.dst < 0 || a.dst >= S) throw runtime_error("composeShortestPath: lattice arc with a state out of range");
+    if (a.dst <= a.src) throw runtime_error("composeShortestPath: the lattice's state ids are not a topological order");
+    lout[a.src].push_back((int)i);
+  }
+  for (size_t i = 0; i < lm.arcs.size(); i++) {
+    const scrf_arc& a = lm.arcs[i];
+    if (a.src < 0 || a.src >= Q || a.dst < 0 || a.dst >= Q) throw runtime_error("composeShortestPath: LM arc with a state out of range");
+    mout[a.src].push_back((int)i);
+  }
+  std::vector<float> lfin(S, INF), mfin(Q, INF);
+  for (const auto& f : lat.finals) if (f.first >= 0 && f.first < S) lfin[f.first] = std::min(lfin[f.first], f.second);
+  for (const auto& f : lm.finals) if (f.first >= 0 && f.first < Q) mfin[f.first] = std::min(mfin[f.first], f.second);
+  const size_t N = (size_t)S * Q;
+  std::vector<float> dist(N, INF);
+  struct Back { int32_t prev; int32_t la, ma; };   // previous product state, lattice arc (-1: none), LM arc (-1: none)
+  std::vector<Back> back(N, Back{-1, -1, -1});
+  dist[(size_t)lat.start * Q + lm.start] = 0.0f;
+  std::vector<int> work;
+  float best_w = INF;
+  long best_at = -1;
+  for (int s = 0; s < S; s++) {
+    float* ds = &dist[(size_t)s * Q];
+    // epsilon-input closure of the LM at this lattice state
+    work.clear();
+    for (int q = 0; q < Q; q++) if (ds[q] < INF) work.push_back(q);
+    size_t guard = 0;
+    for (size_t k = 0; k < work.size(); k++) {
+      const int q = work[k];
+      for (int ai : mout[q]) {
+        const scrf_arc& m = lm.arcs[ai];
+        if (m.ilabel != 0) continue;
+        const float w = ds[q] + (0.0f + m.w);
+        if (w < ds[m.dst]) {
+          ds[m.dst] = w;
+          back[(size_t)s * Q + m.dst] = Back{(int32_t)((size_t)s * Q + q), -1, ai};
+          work.push_back(m.dst);
+          if (++guard > (size_t)Q * Q + 16) throw runtime_error("composeShortestPath: the LM has an epsilon cycle of negative weight");
+        }
+      }
+    }
+    if (lfin[s] < INF)
+      for (int q = 0; q < Q; q++)
+        if (ds[q] < INF && mfin[q] < INF) {
+          const float w = ds[q] + (lfin[s] + mfin[q]);
+          if (w < best_w) { best_w = w; best_at = (long)((size_t)s * Q + q); }
+        }
+    for (int li : lout[s]) {
+      const scrf_arc& a = lat.arcs[li];
+      float* dd = &dist[(size_t)a.dst * Q];
+      if (a.olabel == 0) {   // the lattice moves alone
+        for (int q = 0; q < Q; q++) {
+          if (ds[q] >= INF) continue;
+          const float w = ds[q] + (a.w + 0.0f);
+          if (w < dd[q]) { dd[q] = w; back[(size_t)a.dst * Q + q] = Back{(int32_t)((size_t)s * Q + q), li, -1}; }
+        }
+        continue;
+      }
+      for (int q = 0; q < Q; q++) {
+        if (ds[q] >= INF) continue;
+        for (int ai : mout[q]) {
+          const scrf_arc& m = lm.arcs[ai];
+          if (m.ilabel != a.olabel) continue;
+          const float w = ds[q] + (a.w + m.w);
+          if (w < dd[m.dst]) { dd[m.dst] = w; back[(size_t)a.dst * Q + m.dst] = Back{(int32_t)((size_t)s * Q + q), li, ai}; }
+        }
+      }
+    }
+  }
+  if (total) *total = best_w;
+  if (best_at < 0) return false;
+  // backtrace, then the chain without label-free arcs
+  struct Step { int il, ol; float w; };
+  std::vector<Step> steps;
+  for (long at = best_at; back[at].prev >= 0; at = back[at].prev) {
+    const Back& b = back[at];
+    const float wl = b.la >= 0 ? lat.arcs[b.la].w : 0.0f, wm = b.ma >= 0 ? lm.arcs[b.ma].w : 0.0f;
+    steps.push_back(Step{b.la >= 0 ? lat.arcs[b.la].ilabel : 0, b.ma >= 0 ? lm.arcs[b.ma].olabel : 0, wl + wm});
+  }
+  std::reverse(steps.begin(), steps.end());
+  if (best) {
+    *best = crf_amd::ArcListFst();
+    int cur = best->AddState();
+    best->SetStart(cur);
+    float carry = 0.0f;
+    for (const Step& st : steps) {
+      if (st.il == 0 && st.ol == 0) { carry += st.w; continue; }
+      const int nxt = best->AddState();
+      best->AddArc(cur, crf_amd::ArcListFst::Arc(st.il, st.ol, carry + st.w, nxt));
+      carry = 0.0f;
+      cur = nxt;
+    }
+    const int sf = (int)(best_at / Q), qf = (int)(best_at % Q);
+    best->SetFinal(cur, carry + (lfin[sf] + mfin[qf]));
+  }
+  return true;
+}
+
 void crf_amd::writeFstBinary(const char* fname, const crf_amd::ArcListFst& fst, const char* arc_type) {
   std::ofstream f(fname, std::ios::binary);
   if (!f.is_open()) throw runtime_error(string("writeFstBinary: cannot open ") + fname);

@@ -294,6 +294,19 @@ void readFstText(const char* fname, ArcListFst* fst);
 // so this layout is UNPINNED: every redundancy is checked (types, counts, exact file length) and anything
 // unexpected is an error that points at `fstprint` + crf_lm_txt.  writeFstBinary emits the same layout.
 void readFstBinary(const char* fname, ArcListFst* fst);
+// ShortestPath(Compose(ArcSort(lat, olabel), lm), 1) + RmEpsilon + TopSort of CRFFstDecode's MLF path
+// (CRFFstDecode/src/Main.cpp:1002-1023) in one pass, for an ACYCLIC `lat` whose state ids are a topological
+// order (the lattices buildLattice emits are) and any `lm` (epsilon-input arcs allowed, no negative epsilon
+// cycles): tropical semiring on float; a composed arc weighs Times(lat arc, lm arc) = w_lat + w_lm and a
+// path accumulates start -> end, d + (w_lat + w_lm); lattice arcs with an epsilon OUTPUT advance the
+// lattice alone, LM arcs with an epsilon INPUT the LM alone; strict-improvement relaxation, lattice states
+// ascending, lattice arcs in insertion order, LM arcs in file order (first relaxed wins ties -- OpenFST is
+// not in the tree, so tie order against its Compose / ShortestPath is UNPINNED).
+// `best` receives the path as a chain (state i -> i+1): one arc per composed arc that carries a label on
+// either side (ilabel = the lattice arc's ilabel, olabel = the LM arc's olabel); the weights of label-free
+// arcs are folded into the next arc (the final weight at the end), as RmEpsilon does on a linear path.
+// Returns false when no path reaches a final state of both machines.
+bool composeShortestPath(const ArcListFst& lat, const ArcListFst& lm, ArcListFst* best, float* total);
 void writeFstBinary(const char* fname, const ArcListFst& fst, const char* arc_type = "standard");
 
 }  // namespace crf_amd

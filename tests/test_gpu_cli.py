@@ -813,3 +813,87 @@ def test_memory_stream_read_protocol_serves_device_windows(tmp_path):
     assert abs(float(vals["zx"]) - zx) < 1e-9 * abs(zx) and abs(float(vals["numer"]) - numer) < 1e-9 * max(1, abs(numer))
     assert abs(float(vals["gsum"]) - np.abs(g).sum()) < 1e-8 * np.abs(g).sum()
     assert int(vals["windows_equal"]) == 1
+
+
+def test_crffstdecode_against_a_language_model_fst(tmp_path):
+    """BASELINE config 4 as stated ("CRFFstDecode lattice decode ... against OpenFST phone LM"): the device
+    lattice of every utterance composed host-side with an LM FST that reads the lattice's output labels
+    (phone + L*(dur-1) + 1) and writes phone symbols, best path written as MLF -- against an exhaustive
+    enumeration over every lattice path x every LM path on the oracle's lattice (CRFFstDecode/src/Main.cpp:
+    1002-1044).  Without an LM the MLF spells the lattice's own best path."""
+    from test_host_compose import brute
+    rng = np.random.RandomState(21)
+    L, D, W = 3, 2, 2
+    Ts = [1, 3, 4]
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    utts = []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdstate",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=2", "crf_lr=1.0",
+                        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # phone "bigram" over phone-duration labels: state = last phone + 1 (0 = start); label l + L*(d-1) + 1 reads as phone l;
+    # a phone may not follow itself at the LM level except through a costly self arc; output = phone symbol 11 + l
+    arcs, finals = [], {}
+    cost = rng.rand(L + 1, L) * 2
+    for q in range(L + 1):
+        for l in range(L):
+            for d in range(D):
+                arcs.append((q, l + 1, l + L * d + 1, 11 + l, float(np.float32(cost[q, l] + (3.0 if q == l + 1 else 0.0) + 0.1 * d))))
+        if q:
+            finals[q] = float(np.float32(rng.rand()))
+    lmf = str(tmp_path / "lm.fst.txt")
+    with open(lmf, "w") as fh:
+        for a in arcs:
+            fh.write("%d %d %d %d %.9g\n" % a)
+        for s_, w_ in finals.items():
+            fh.write("%d %.9g\n" % (s_, w_))
+    olist, osym = str(tmp_path / "olist"), str(tmp_path / "osym.txt")
+    open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
+    open(osym, "w").write("<eps> 0\n" + "".join("p%d %d\n" % (l, 11 + l) for l in range(L)))
+    mlf = str(tmp_path / "out.mlf")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym, "crf_lm_txt=" + lmf,
+                        "crf_output_mlffile=" + mlf, "crf_mlf_output_frames=1", "crf_output_labelfile=" + str(tmp_path / "lab.txt")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "LM: %d states, %d arcs" % (L + 1, len(arcs)) in r.stdout, r.stdout + r.stderr
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+    blocks = open(mlf).read().split('"\n')[1:]
+    totals = [float(x.split("(weight")[1].split(")")[0]) for x in r.stdout.split("\n") if "(weight" in x]
+    assert len(blocks) == len(Ts) and len(totals) == len(Ts)
+    for u, T in enumerate(Ts):
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(cfg, S, M, T)
+        lat = [(int(a["src"]), int(a["dst"]), int(a["ilabel"]), int(a["olabel"]), float(a["w"])) for a in oa]
+        ref = brute(lat, {ofin: 0.0}, 0, arcs, finals, 0, max_eps=0)
+        assert ref and abs(totals[u] - ref[0][0]) < 2e-5 * max(1.0, abs(ref[0][0])), (u, totals[u], ref[0][0])
+        lines = [x.split("\t") for x in blocks[u].split("\n") if x and x != "."]
+        if len(ref) == 1 or ref[1][0] - ref[0][0] > 1e-4:
+            assert [x[2] for x in lines] == ["p%d" % (o - 11) for o in ref[0][2]]
+            # frames: the segments tile the utterance
+            durs = [(il - 1) // L + 1 for il in ref[0][1]]
+            ends = np.cumsum(durs) - 1
+            assert [int(x[1]) for x in lines] == [int(e) for e in ends] and int(lines[0][0]) == 0 and ends[-1] == T - 1
+    # no LM: the MLF spells the lattice's own best path (labels as numbers without a symbol table)
+    mlf2 = str(tmp_path / "out2.mlf")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_output_mlffile=" + mlf2,
+                        "crf_output_labelfile=" + str(tmp_path / "lab2.txt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.loadtxt(str(tmp_path / "lab2.txt")).astype(int).reshape(-1, 3)
+    blocks2 = open(mlf2).read().split('"\n')[1:]
+    for u in range(len(Ts)):
+        labs = [int(x) for x in blocks2[u].split("\n") if x and x != "."]
+        assert labs == [int(v) + 1 for v in got[got[:, 0] == u][:, 2]]
+    # dictionary / phone-penalty FSTs are refused, not ignored
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_dict_fst=d.fst"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_dict_fst" in r.stderr

@@ -576,6 +576,204 @@ int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, 
 
 /* ------------------------------------------------------------------ a15 ---- */
 
+/* ======================================================================================
+ * f3: STDSEG_NO_DUR (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp)
+ * ====================================================================================== */
+void orc_segtrans_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                         const float* segftrs, uint32_t T, double* S, double* M2) {
+  /* computeTransMatrix :69-110: for dur <= numPrevNodes state AND transition values of window dur,
+   * for the remaining (utterance-initial) duration the state value only */
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur, F = cfg->num_feas;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    for (uint32_t dur = 1; dur <= nd; dur++) {
+      const float* x = segftrs + (base + dur - 1) * F;
+      double* Mrow = M2 + (base + dur - 1) * (size_t)L * L;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        S[(base + dur - 1) * L + lab] = orc_state_value(cfg, lay, x, lambda, lab);
+        for (uint32_t plab = 0; plab < L; plab++)
+          Mrow[plab * L + lab] = dur <= np ? orc_trans_value(cfg, lay, x, lambda, plab, lab) : 0.0;
+      }
+    }
+  }
+}
+
+int orc_segtrans_forward(const orc_config* cfg, const double* S, const double* M2, uint32_t T,
+                         double* alpha_dur, double* alpha, double* Zx) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  double* acc = (double*)malloc(sizeof(double) * (L > D ? L : D));
+  double* wd = (double*)malloc(sizeof(double) * D);
+  for (uint32_t l = 0; l < L; l++) { alpha_dur[l] = S[l]; alpha[l] = S[l]; } /* computeFirstAlpha :200-208 */
+  for (uint32_t t = 1; t < T && err == ORC_OK; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    for (uint32_t lab = 0; lab < L; lab++) { /* computeAlpha :132-190 */
+      for (uint32_t dur = 1; dur <= np; dur++) {
+        const double* pa = alpha + (size_t)(t - dur) * L;
+        const double* Mrow = M2 + (base + dur - 1) * (size_t)L * L;
+        acc[0] = pa[0] + Mrow[0 * L + lab];
+        double maxv = acc[0];
+        for (uint32_t plab = 1; plab < L; plab++) {
+          acc[plab] = pa[plab] + Mrow[plab * L + lab];
+          if (acc[plab] > maxv) maxv = acc[plab];
+        }
+        double v = orc_logadd_max_n(acc, maxv, (int)L, &err);
+        v += S[(base + dur - 1) * L + lab];
+        alpha_dur[(base + dur - 1) * L + lab] = v;
+        wd[dur - 1] = v;
+      }
+      for (uint32_t dur = np + 1; dur <= nd; dur++) {
+        alpha_dur[(base + dur - 1) * L + lab] = S[(base + dur - 1) * L + lab];
+        wd[dur - 1] = S[(base + dur - 1) * L + lab];
+      }
+      alpha[(size_t)t * L + lab] = orc_logadd_n(wd, (int)nd, &err);
+    }
+  }
+  if (err == ORC_OK) *Zx = orc_logadd_n(alpha + (size_t)(T - 1) * L, (int)L, &err); /* computeAlphaSum */
+  free(acc); free(wd);
+  return err;
+}
+
+int orc_segtrans_backward(const orc_config* cfg, const double* S, const double* M2, uint32_t T, double* beta) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  double* tb = (double*)malloc(sizeof(double) * (size_t)D * L);
+  double* acc = (double*)malloc(sizeof(double) * (size_t)D * L);
+  for (uint32_t l = 0; l < L; l++) beta[(size_t)(T - 1) * L + l] = 0.0; /* setTailBeta */
+  for (uint32_t t = T - 1; t-- > 0 && err == ORC_OK;) { /* computeBeta :248-310 */
+    const uint32_t nn = (T - 1 - t <= D) ? T - 1 - t : D;
+    for (uint32_t dur = 1; dur <= nn; dur++) {
+      const uint64_t row = orc_seg_base(t + dur, D) + dur - 1;
+      for (uint32_t lab = 0; lab < L; lab++) tb[(dur - 1) * L + lab] = beta[(size_t)(t + dur) * L + lab] + S[row * L + lab];
+    }
+    for (uint32_t clab = 0; clab < L; clab++) {
+      double maxv = M2[(orc_seg_base(t + 1, D) + 0) * (size_t)L * L + clab * L + 0] + tb[0];
+      uint32_t n = 0;
+      for (uint32_t dur = 1; dur <= nn; dur++) {
+        const double* Mrow = M2 + (orc_seg_base(t + dur, D) + dur - 1) * (size_t)L * L;
+        for (uint32_t lab = 0; lab < L; lab++) {
+          acc[n] = Mrow[clab * L + lab] + tb[(dur - 1) * L + lab];
+          if (acc[n] > maxv) maxv = acc[n];
+          n++;
+        }
+      }
+      beta[(size_t)t * L + clab] = orc_logadd_max_n(acc, maxv, (int)n, &err);
+    }
+  }
+  free(tb); free(acc);
+  return err;
+}
+
+int orc_segtrans_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                                const float* segftrs, const uint32_t* labels, uint32_t T,
+                                double* grad, double* numer, double* Zx_out) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur, F = cfg->num_feas;
+  if (T == 0) return ORC_ERR_EMPTY;
+  const uint64_t nseg = orc_num_segs(T, D);
+  int err = ORC_OK;
+  double* ExpF = (double*)calloc(lay->lambda_len, sizeof(double));
+  double* S = (double*)malloc(sizeof(double) * nseg * L);
+  double* M2 = (double*)malloc(sizeof(double) * nseg * L * L);
+  double* ad = (double*)malloc(sizeof(double) * nseg * L);
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double logLi = 0.0, Zx = 0.0;
+  orc_segtrans_scores(cfg, lay, lambda, segftrs, T, S, M2);
+  err = orc_segtrans_forward(cfg, S, M2, T, ad, alpha, &Zx);
+  if (err == ORC_OK) err = orc_segtrans_backward(cfg, S, M2, T, beta);
+  for (uint32_t t = T; t-- > 0 && err == ORC_OK;) {
+    /* CRF_NewGradBuilder_StdSeg.cpp: the nearest EARLIER node that carries a label */
+    uint32_t prev_lab = ORC_LAB_BAD;
+    for (uint32_t u = t; u > 0; u--) {
+      prev_lab = labels[u - 1];
+      if (prev_lab != ORC_LAB_BAD) break;
+    }
+    /* computeExpF :422-560 */
+    uint32_t actualLab = labels[t], labDur = ORC_LAB_BAD, actualPLab = prev_lab;
+    if (actualLab != ORC_LAB_BAD) {
+      if (actualLab >= L * D) { err = ORC_ERR_BAD_LABEL; break; }
+      labDur = labels[t] / L + 1;
+      actualLab = labels[t] % L;
+    }
+    if (actualPLab != ORC_LAB_BAD) {
+      if (actualPLab >= L * D) { err = ORC_ERR_BAD_LABEL; break; }
+      actualPLab = prev_lab % L;
+    }
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    double ab_tot = 0.0, ab_trans_tot = 0.0, nodeLi = 0.0;
+    for (uint32_t dur = 1; dur <= np; dur++) {
+      const float* x = segftrs + (base + dur - 1) * F;
+      const double* pa = alpha + (size_t)(t - dur) * L;
+      const double* Mrow = M2 + (base + dur - 1) * (size_t)L * L;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        double ab = orc_expE(ad[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err);
+        ab_tot += ab;
+        int match = (lab == actualLab && dur == labDur);
+        nodeLi += orc_state_expf(cfg, lay, x, lambda, ExpF, grad, ab, match ? actualLab : ORC_LAB_BAD, lab);
+        for (uint32_t plab = 0; plab < L; plab++) {
+          ab = orc_expE(pa[plab] + Mrow[plab * L + lab] + S[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err);
+          ab_trans_tot += ab;
+          match = (lab == actualLab && dur == labDur && plab == actualPLab);
+          nodeLi += orc_trans_expf(cfg, lay, x, lambda, ExpF, grad, ab, match ? actualPLab : ORC_LAB_BAD,
+                                   match ? actualLab : ORC_LAB_BAD, plab, lab);
+        }
+      }
+    }
+    for (uint32_t dur = np + 1; dur <= nd; dur++) {
+      const float* x = segftrs + (base + dur - 1) * F;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        double ab = orc_expE(ad[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err);
+        ab_tot += ab;
+        int match = (lab == actualLab && dur == labDur);
+        nodeLi += orc_state_expf(cfg, lay, x, lambda, ExpF, grad, ab, match ? actualLab : ORC_LAB_BAD, lab);
+      }
+    }
+    if (np == 0) ab_trans_tot = 1.0;
+    if (ab_tot > 1.000001 || ab_tot < -0.000001 || ab_trans_tot > 1.000001 || ab_trans_tot < -0.000001)
+      set_err(&err, ORC_ERR_PROB_SUM); /* :530-545 (no state == trans check in this node) */
+    logLi += nodeLi;
+  }
+  for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i];
+  *Zx_out = Zx;
+  *numer = logLi;
+  free(ExpF); free(S); free(M2); free(ad); free(alpha); free(beta);
+  return err;
+}
+
+int orc_segtrans_posteriors(const orc_config* cfg, const double* S, const double* M2, uint32_t T,
+                            double* gamma, double* xi, double* Zx_out) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  const uint64_t nseg = orc_num_segs(T, D);
+  int err = ORC_OK;
+  double* ad = (double*)malloc(sizeof(double) * nseg * L);
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double Zx = 0.0;
+  err = orc_segtrans_forward(cfg, S, M2, T, ad, alpha, &Zx);
+  if (err == ORC_OK) err = orc_segtrans_backward(cfg, S, M2, T, beta);
+  for (uint32_t t = 0; t < T && err == ORC_OK; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    for (uint32_t dur = 1; dur <= nd; dur++)
+      for (uint32_t lab = 0; lab < L; lab++) {
+        gamma[(base + dur - 1) * L + lab] = orc_expE(ad[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err);
+        for (uint32_t plab = 0; plab < L; plab++)
+          xi[(base + dur - 1) * (size_t)L * L + plab * L + lab] =
+              dur <= np ? orc_expE(alpha[(size_t)(t - dur) * L + plab] + M2[(base + dur - 1) * (size_t)L * L + plab * L + lab] +
+                                       S[(base + dur - 1) * L + lab] + beta[(size_t)t * L + lab] - Zx, &err)
+                        : 0.0;
+      }
+  }
+  *Zx_out = Zx;
+  free(ad); free(alpha); free(beta);
+  return err;
+}
+
 /* CRF_NewGradBuilder::buildGradient trainers/gradbuilders/CRF_NewGradBuilder.cpp:48-382 with
  * the CRF_StdStateNode methods nodes/CRF_StdStateNode.cpp:58-299 inlined. ftrs: [T][F]. */
 int orc_frame_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,

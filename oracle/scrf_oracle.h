@@ -148,6 +148,27 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
 int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, uint32_t T,
                        double* gamma, double* xi, double* Zx);
 
+/* ---- f3: STDSEG_NO_DUR, segment-dependent transition features ----------------
+ * nodes/CRF_StdSegStateNode_WithoutDurLab.cpp (+ trainers/gradbuilders/CRF_NewGradBuilder_StdSeg.cpp,
+ * which passes the PREVIOUS label).  The transition score of a segment depends on its own window:
+ * M2[(t,d)][p*L+l] = computeTransMatrixValue(window d of node t, p, l) for the durations that have a
+ * predecessor node (d <= numPrevNodes(t)); rows of utterance-initial segments are unused (zero).
+ *   alpha_d[t][l][d] = LSE_p(alpha[t-d][p] + M2[(t,d)][p][l]) + S[(t,d)][l]        (:132-190)
+ *   beta[t][c]       = LSE_{d,l}(M2[(t+d,d)][c][l] + beta[t+d][l] + S[(t+d,d)][l])  (:248-310)
+ *   gamma, xi[(t,d)][p][l] = exp(alpha[t-d][p] + M2 + S + beta[t][l] - Zx)         (:455-500)
+ * S [N_seg][L], M2 [N_seg][L*L], alpha_dur [N_seg][L], alpha / beta [T][L]. */
+void orc_segtrans_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                         const float* segftrs, uint32_t T, double* S, double* M2);
+int orc_segtrans_forward(const orc_config* cfg, const double* S, const double* M2, uint32_t T,
+                         double* alpha_dur, double* alpha, double* Zx);
+int orc_segtrans_backward(const orc_config* cfg, const double* S, const double* M2, uint32_t T, double* beta);
+int orc_segtrans_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                                const float* segftrs, const uint32_t* labels, uint32_t T,
+                                double* grad, double* numer, double* Zx);
+/* posteriors for tests: gamma [N_seg][L], xi [N_seg][L*L] (rows of initial segments zero) */
+int orc_segtrans_posteriors(const orc_config* cfg, const double* S, const double* M2, uint32_t T,
+                            double* gamma, double* xi, double* Zx);
+
 /* ---- a15: frame-level chain ----------------------------------------------- */
 int orc_frame_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
                              const float* ftrs, const uint32_t* labels, uint32_t T,

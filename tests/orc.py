@@ -204,6 +204,87 @@ def seg_build_gradient(cfg, lay, lam, segftrs, labels, T, grad=None):
     return rc, grad, numer.value, zx.value
 
 
+# ---- f3: STDSEG_NO_DUR (segment-dependent transition features) --------------------------- #
+def segtrans_scores(cfg, lay, lam, segftrs, T):
+    L, D = cfg.num_labs, cfg.lab_max_dur
+    segftrs = np.ascontiguousarray(segftrs, dtype=np.float32)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    S = np.zeros((num_segs(T, D), L)); M2 = np.zeros((num_segs(T, D), L * L))
+    lib().orc_segtrans_scores(C.byref(cfg), C.byref(lay.c), _p(lam), _p(segftrs), C.c_uint32(T), _p(S), _p(M2))
+    return S, M2
+
+
+def segtrans_forward(cfg, S, M2, T):
+    L, D = cfg.num_labs, cfg.lab_max_dur
+    ad = np.zeros((num_segs(T, D), L)); al = np.zeros((T, L))
+    zx = C.c_double()
+    rc = lib().orc_segtrans_forward(C.byref(cfg), _p(S), _p(M2), C.c_uint32(T), _p(ad), _p(al), C.byref(zx))
+    return rc, ad, al, zx.value
+
+
+def segtrans_backward(cfg, S, M2, T):
+    beta = np.zeros((T, cfg.num_labs))
+    rc = lib().orc_segtrans_backward(C.byref(cfg), _p(S), _p(M2), C.c_uint32(T), _p(beta))
+    return rc, beta
+
+
+def segtrans_posteriors(cfg, S, M2, T):
+    L, D = cfg.num_labs, cfg.lab_max_dur
+    g = np.zeros((num_segs(T, D), L)); xi = np.zeros((num_segs(T, D), L * L))
+    zx = C.c_double()
+    rc = lib().orc_segtrans_posteriors(C.byref(cfg), _p(S), _p(M2), C.c_uint32(T), _p(g), _p(xi), C.byref(zx))
+    return rc, g, xi, zx.value
+
+
+def segtrans_build_gradient(cfg, lay, lam, segftrs, labels, T, grad=None):
+    segftrs = np.ascontiguousarray(segftrs, dtype=np.float32)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    if grad is None:
+        grad = np.zeros(lay.lambda_len, dtype=np.float64)
+    numer = C.c_double(); zx = C.c_double()
+    rc = lib().orc_segtrans_build_gradient(C.byref(cfg), C.byref(lay.c), _p(lam), _p(segftrs), _p(labels),
+                                           C.c_uint32(T), _p(grad), C.byref(numer), C.byref(zx))
+    return rc, grad, numer.value, zx.value
+
+
+def brute_force_segtrans(S, M2, T, L, D):
+    """every (segmentation, labelling) of the STDSEG_NO_DUR model: a segment (end, d, l) after a segment
+    labelled p scores S[(end,d)][l] + M2[(end,d)][p*L+l] (the first segment of the utterance S alone).
+    Returns Zx, gamma [N_seg, L], xi [N_seg, L*L], the paths and the best one."""
+    paths = []
+
+    def rec(t_next, prev_lab, score, segs):
+        if t_next == T:
+            paths.append((score, tuple(segs)))
+            return
+        for d in range(1, D + 1):
+            end = t_next + d - 1
+            if end >= T:
+                break
+            row = seg_base(end, D) + d - 1
+            for l in range(L):
+                s = score + S[row, l]
+                if prev_lab is not None:
+                    s = s + M2[row, prev_lab * L + l]
+                rec(end + 1, l, s, segs + [(end, d, l)])
+
+    rec(0, None, 0.0, [])
+    scores = np.array([p[0] for p in paths])
+    mx = scores.max()
+    Zx = mx + np.log(np.exp(scores - mx).sum())
+    gamma = np.zeros_like(S); xi = np.zeros_like(M2)
+    for sc, segs in paths:
+        p = np.exp(sc - Zx)
+        for i, (end, d, l) in enumerate(segs):
+            row = seg_base(end, D) + d - 1
+            gamma[row, l] += p
+            if i > 0:
+                xi[row, segs[i - 1][2] * L + l] += p
+    best = max(range(len(paths)), key=lambda i: paths[i][0])
+    return dict(Zx=Zx, gamma=gamma, xi=xi, n_paths=len(paths), paths=paths, best=paths[best])
+
+
 def frame_build_gradient(cfg, lay, lam, ftrs, labels, T, grad=None):
     ftrs = np.ascontiguousarray(ftrs, dtype=np.float32)
     lam = np.ascontiguousarray(lam, dtype=np.float64)

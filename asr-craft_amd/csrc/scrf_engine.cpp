@@ -128,6 +128,7 @@ struct scrf_batch_s {
   uint64_t* d_arc_off = nullptr;
   uint32_t* d_labels = nullptr;
   uint32_t* d_next_lab = nullptr;      // [sum T] label of the next labelled frame (gradbuilder :436-444)
+  uint32_t* d_prev_lab = nullptr;      // [sum T] label of the nearest EARLIER labelled frame (CRF_NewGradBuilder_StdSeg.cpp, STDSEG_NO_DUR)
   uint32_t* d_trans_counts = nullptr;  // [L*L] observed (c -> n) transitions of the whole batch
   uint32_t* d_frame_u = nullptr;       // [sum T] utterance of each frame
   float* d_xm_f = nullptr;             // [sum T] max(|x|, 1, |state bias value|) over the frame's utterance (fused path)
@@ -183,7 +184,7 @@ static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
   if (c.abi_version != SCRF_ABI_VERSION) { *why = "abi_version mismatch"; return SCRF_ERR_INVALID; }
   if (c.num_states != 1) { *why = "only crf_states=1 is built (multi-state nodes are out of scope)"; return SCRF_ERR_INVALID; }
   if (c.num_labs == 0 || c.lab_max_dur == 0 || c.num_feas == 0) { *why = "num_labs, lab_max_dur, num_feas must be > 0"; return SCRF_ERR_INVALID; }
-  if (c.model_type == SCRF_STDSEG || c.model_type == SCRF_STDSEG_NO_DUR) { *why = "model types stdseg / stdseg_no_dur are not built yet"; return SCRF_ERR_INVALID; }
+  if (c.model_type == SCRF_STDSEG) { *why = "model type stdseg (phone x duration labels) is not built"; return SCRF_ERR_INVALID; }
   if (c.model_type > SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR) { *why = "unknown model_type"; return SCRF_ERR_INVALID; }
   if (c.model_type == SCRF_STDFRAME && c.lab_max_dur != 1) { *why = "the maximum duration of labels must be 1 for \"stdframe\" CRF model."; return SCRF_ERR_INVALID; }  // CRFTrain/src/Main.cpp:574-578
   if (c.map_type > SCRF_STDTRANS) { *why = "only dense stdstate/stdtrans feature maps are built"; return SCRF_ERR_INVALID; }
@@ -458,7 +459,7 @@ extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   if (!b) return SCRF_OK;
   if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
   hipFree(b->d_T); hipFree(b->d_frame_off); hipFree(b->d_seg_off); hipFree(b->d_arc_off);
-  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u); hipFree(b->d_xm_f);
+  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_prev_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u); hipFree(b->d_xm_f);
   for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
   hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
   hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]);
@@ -538,6 +539,18 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
       }
     }
     BCHK(upload(h, &b->d_next_lab, nxt.data(), NF));
+    if (h->cfg.model_type == SCRF_STDSEG_NO_DUR) {
+      std::vector<uint32_t> prv(NF);
+      for (uint32_t u = 0; u < n; u++) {
+        uint32_t cur = SCRF_LAB_BAD;
+        for (uint32_t t = 0; t < b->T[u]; t++) {
+          const uint64_t f = b->frame_off[u] + t;
+          prv[f] = cur;
+          if (lab[f] != SCRF_LAB_BAD) cur = lab[f];
+        }
+      }
+      BCHK(upload(h, &b->d_prev_lab, prv.data(), NF));
+    }
     BCHK(upload(h, &b->d_trans_counts, cnt.data(), cnt.size()));
     BSYNC();
   }
@@ -570,7 +583,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   }
   // fused window synthesis: one segment-recipe stream without context whose window is exactly
   // the state feature range, no transition features
-  if (!by_windows && n_streams == 1 && !lay.use_tf && lay.use_sf && recipes[0].extract_seg_ftr &&
+  if (!by_windows && n_streams == 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && !lay.use_tf && lay.use_sf && recipes[0].extract_seg_ftr &&
       !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 && lay.nsfe == 8 * recipes[0].in_width + lay.D &&
       lay.nsfe == lay.F && fused_supported(lay, recipes[0].in_width)) {
     b->fused_ok = true;
@@ -728,8 +741,11 @@ static uint32_t decode_fix_cap(uint64_t nseg, uint32_t L) {
 // does the recursion run on the wavefront kernels?  L <= 64: always (log-domain kernels for the
 // hooks, linear-domain for training); 64 < L <= 256: the multi-wavefront linear-domain kernel,
 // training path only
+// STDSEG_NO_DUR: one transition matrix per window (scrf_segtrans.hip); its own workgroup recursion
+static bool segtrans(scrf_handle h) { return h->cfg.model_type == SCRF_STDSEG_NO_DUR; }
+
 static bool wave_path(scrf_handle h, bool post) {
-  if (h->force_fb) return false;
+  if (h->force_fb || segtrans(h)) return false;
   return dp_wave_supported(h->lay) || (post && h->lin_dp && (dplin_mw_supported(h->lay) || dplin_supported(h->lay)));
 }
 
@@ -751,7 +767,8 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
   if (nd.vitfast) tot += pad256(nseg * l.L * sizeof(float)) + pad256((size_t)decode_fix_cap(nseg, l.L) * 8) + 256;  // Wn, list, count
   else tot += pad256(nseg * l.L * sizeof(double));                  // S
-  if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
+  if (segtrans(h)) tot += pad256(nseg * LL * sizeof(double));               // M2: one matrix per window
+  else if (l.use_tf) tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // M, xrow_cur
   if (nd.fb) {
     const bool wave = wave_path(h, nd.post);
     if (wave && nd.post && h->lin_dp) {
@@ -761,7 +778,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
     } else {
       tot += pad256(nseg * l.L * sizeof(double));                     // AD
       tot += pad256(nfr * l.L * sizeof(double));                      // alpha
-      if (nd.beta || wave) tot += pad256(nfr * l.L * sizeof(double));
+      if (nd.beta || wave || segtrans(h)) tot += pad256(nfr * l.L * sizeof(double));
       if (wave) tot += pad256(nfr * l.L * sizeof(double));            // sd
       if (wave && nd.post) tot += 2 * pad256(nfr * l.L * sizeof(double));  // A, B
     }
@@ -774,7 +791,11 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
     }
     if (nd.post) {
       tot += pad256(nfr * sizeof(double));                            // mass_s
-      if (l.use_tf) {
+      if (segtrans(h)) {
+        tot += pad256(nseg * LL * sizeof(double));                    // XI2
+        uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nseg + 2047) / 2048);
+        tot += pad256((size_t)std::max(1u, nch_t) * LL * l.ntf * sizeof(double));
+      } else if (l.use_tf) {
         tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
         uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
         tot += pad256((size_t)nch_t * LL * l.ntf * sizeof(double));
@@ -835,7 +856,10 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   } else {
     cb->S = a.take<double>(nseg * l.L);
   }
-  if (l.use_tf) {
+  if (segtrans(h)) {
+    cb->M = a.take<double>(nseg * LL);
+    cb->m_per_frame = 2;   // per window
+  } else if (l.use_tf) {
     cb->M = a.take<double>(nfr * LL);
     cb->xrow_cur = a.take<uint64_t>(nfr);
     cb->m_per_frame = 1;
@@ -860,7 +884,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       cb->AD = a.take<double>(nseg * l.L);
       cb->R = cb->AD;
       cb->alpha = a.take<double>(nfr * l.L);
-      if (nd.beta || cb->wave) cb->beta = a.take<double>(nfr * l.L);
+      if (nd.beta || cb->wave || segtrans(h)) cb->beta = a.take<double>(nfr * l.L);
       if (cb->wave) cb->sd = a.take<double>(nfr * l.L);
       if (cb->wave && nd.post) {
         cb->fA = a.take<double>(nfr * l.L);
@@ -886,7 +910,13 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     }
     if (nd.post) {
       cb->mass_s = a.take<double>(nfr);
-      if (l.use_tf) {
+      if (segtrans(h)) {
+        cb->XI = a.take<double>(nseg * LL);
+        cb->nch_t = (uint32_t)std::min<uint64_t>(4, (nseg + 2047) / 2048);
+        if (cb->nch_t == 0) cb->nch_t = 1;
+        cb->rpc_t = (nseg + cb->nch_t - 1) / cb->nch_t;
+        cb->slab_t = a.take<double>((size_t)cb->nch_t * LL * l.ntf);
+      } else if (l.use_tf) {
         cb->XI = a.take<double>(nfr * LL);
         cb->xrow_next = a.take<uint64_t>(nfr);
         cb->nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
@@ -1028,12 +1058,19 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     else KT_RUN("k_scores_exact(state)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S));
     tk.stop(1);
   }
-  if (l.use_tf) {
+  if (segtrans(h)) {
+    // one transition matrix per window: the same contraction over every row of X; the rows of the
+    // utterance-initial segments (no predecessor) are zeroed like the reference leaves them unused
+    if (fast) KT_RUN("k_scores_mfma(trans)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, f32));
+    else KT_RUN("k_scores_exact(trans)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 1, l.L * l.L, cb.M));
+    launch_zero_initial_rows(cb.st, bv, b->d_frame_u, u0, nfr, l.D, l.L, cb.M);
+    nl += 2;
+  } else if (l.use_tf) {
     launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_cur, 0);
     if (fast) KT_RUN("k_scores_mfma(trans)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, scrf_spec_trans(l), l.L * l.L, cb.M, f32));
     else KT_RUN("k_scores_exact(trans)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, cb.xrow_cur, nfr, h->d_lambda, l, 1, l.L * l.L, cb.M));
     nl += 2;
-  } else if (!h->m0_valid) {
+  } else if (!h->m0_valid && !segtrans(h)) {
     // transition scores carry only the bias: one L x L matrix for every frame
     launch_scores_exact(cb.st, cb.X, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
     launch_exp_m(cb.st, h->d_m0, l.L, 1, h->d_e0, h->d_et0, h->d_msh0);
@@ -1054,7 +1091,14 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
   const int frame_model = h->cfg.model_type == SCRF_STDFRAME;
   ScrfBatchView bv = b->view();
   uint32_t nl = 0;
-  if (!cb.wave) {
+  if (segtrans(h)) {
+    if (fb_segtrans_smem_bytes(l, fb_block_threads(l)) > 160 * 1024)
+      return fail(h, SCRF_ERR_INVALID, "labels x maximum duration = %u x %u is too large for the stdseg_no_dur recursion "
+                  "(its three [D][L] rings must fit 160 KB of LDS)", l.L, l.D);
+    KT_RUN("k_fb_segtrans", cb.st, launch_fb_segtrans(cb.st, l, bv, u0, (uint32_t)nutt, b->d_prev_lab, cb.S, cb.M, cb.AD, cb.alpha, cb.beta,
+                       post ? cb.XI : nullptr, b->d_numer, b->d_zx, b->d_status, post ? 1 : 0));
+    nl = 1;
+  } else if (!cb.wave) {
     if (fb_smem_bytes(l, fb_block_threads(l)) > 160 * 1024)
       return fail(h, SCRF_ERR_INVALID, "labels x maximum duration = %u x %u is too large for the workgroup-per-utterance recursion "
                   "(its two [D][L] rings must fit 160 KB of LDS; the wavefront kernels cover L <= 256 with D <= 40)", l.L, l.D);
@@ -1193,7 +1237,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   }
   const size_t n_chunks = cuts.size() - 1;
   const bool use2 = two_lanes && n_chunks >= 2;
-  if (!h->m0_valid && !l.use_tf) {
+  if (!h->m0_valid && !l.use_tf && !segtrans(h)) {
     // transition scores carry only the bias: one L x L matrix (and its exp) for every frame;
     // computed before the lanes fork
     launch_scores_exact(h->stream, nullptr, l.F, nullptr, 1, h->d_lambda, l, 1, l.L * l.L, h->d_m0);
@@ -1254,7 +1298,12 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
         else KT_RUN("k_expf_gemm(state)", cb.st, launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s));
         tk.stop(1);
       }
-      if (l.use_tf) {
+      if (segtrans(h)) {
+        // transition counts of the segment's own window: XI2 rows are windows, no row map
+        if (fast) KT_RUN("k_expf_mfma(trans)", cb.st, launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32));
+        else KT_RUN("k_expf_gemm(trans)", cb.st, launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, nullptr, nseg, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t));
+        nl += 1;
+      } else if (l.use_tf) {
         launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
         if (fast) KT_RUN("k_expf_mfma(trans)", cb.st, launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32));
         else KT_RUN("k_expf_gemm(trans)", cb.st, launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t));
@@ -1270,7 +1319,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
         launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
         launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 5 * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
-      if (l.use_tf) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
+      if (l.use_tf || segtrans(h)) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
       else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad,
                                    cb.lin ? cb.dl.gsd : nullptr);
       else launch_reduce_xiacc(cb.st, cb.xi_acc, (uint32_t)nutt, l, cb.grad);
@@ -1376,7 +1425,10 @@ extern "C" int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* out)
 
 static int copy_M(scrf_handle h, const ChunkBufs& cb, uint32_t T, double* M) {
   const size_t LL = (size_t)h->lay.L * h->lay.L;
-  if (cb.m_per_frame) {
+  if (cb.m_per_frame == 2) {   // STDSEG_NO_DUR: one matrix per window
+    HIPCHK(h, hipMemcpyAsync(M, cb.M, sizeof(double) * scrf_seg_base(T, h->lay.D) * LL, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  } else if (cb.m_per_frame) {
     HIPCHK(h, hipMemcpyAsync(M, cb.M, sizeof(double) * T * LL, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   } else {
@@ -1445,6 +1497,7 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
                                  uint32_t* n_states, int32_t* final_state) {
   int rc = check_u(h, b, u, "scrf_lattice_arcs");
   if (rc != SCRF_OK) return rc;
+  if (segtrans(h)) return fail(h, SCRF_ERR_INVALID, "scrf_lattice_arcs: the stdseg_no_dur lattice (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h) is not built");
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
   const uint32_t T = b->T[u];
@@ -1485,6 +1538,7 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
 extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
                                   uint64_t* lab_off, float* best_cost) {
   if (!h || !b || !seg_labels || !lab_off) return SCRF_ERR_INVALID;
+  if (segtrans(h)) return fail(h, SCRF_ERR_INVALID, "scrf_viterbi_batch: decoding of stdseg_no_dur models is not built");
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;

@@ -35,6 +35,14 @@ void launch_sgd_step(hipStream_t st, double* lambda, double* lambda_acc, double*
 void launch_scale(hipStream_t st, double* v, uint32_t n, double s, int divide);
 void launch_add(hipStream_t st, double* y, const double* x, uint32_t n);
 
+// scrf_segtrans.hip: STDSEG_NO_DUR (one transition matrix per window): workgroup-per-utterance log-domain recursion
+size_t fb_segtrans_smem_bytes(const ScrfLayout& lay, int NT);
+void launch_zero_initial_rows(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                              uint32_t D, uint32_t L, double* M2);
+void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                        const uint32_t* prev_lab, const double* S, const double* M2, double* AD, double* alpha_g,
+                        double* beta_g, double* XI2, double* numer, double* zx, int* status, int write_post);
+
 // scrf_mfma.hip: fp64 MFMA contractions (FAST training precision)
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,

@@ -14,6 +14,7 @@
 // This translation unit is compiled with -ffp-contract=off: the EXACT kernels must not fuse
 // multiply and add (the reference is built without FMA contraction).
 #include "scrf_kernels.h"
+#include "scrf_lse.h"
 
 #include <float.h>
 #include <math.h>
@@ -216,38 +217,6 @@ void launch_scores_exact(hipStream_t st, const float* X, uint32_t F, const uint6
 // Outputs R = Y - gamma (over ad, in place) and Y - xi (per frame, or summed per utterance
 // when transitions carry only a bias): the operands of the expected-count contraction.
 // ------------------------------------------------------------------------------------------
-struct FbLse {
-  int L, G, g, j;
-  bool active;
-  double* red_m;
-  double* red_s;
-};
-
-template <class VAL>
-__device__ __forceinline__ double col_lse(const FbLse& c, int n_i, VAL val, int* err) {
-  // returns LSE_i val(i, j) to the threads of group 0 (others get garbage); 3 barriers
-  double m = -INFINITY;
-  if (c.active)
-    for (int i = c.g; i < n_i; i += c.G) m = fmax(m, val(i, c.j, true));
-  if (c.active) c.red_m[c.g * c.L + c.j] = m;
-  __syncthreads();
-  double mm = -INFINITY, s = 0.0;
-  if (c.active) {
-    for (int gg = 0; gg < c.G; gg++) mm = fmax(mm, c.red_m[gg * c.L + c.j]);
-    for (int i = c.g; i < n_i; i += c.G) s += exp(val(i, c.j, false) - mm);
-    c.red_s[c.g * c.L + c.j] = s;
-  }
-  __syncthreads();
-  double r = 0.0;
-  if (c.active && c.g == 0) {
-    double tot = 0.0;
-    for (int gg = 0; gg < c.G; gg++) tot += c.red_s[gg * c.L + c.j];
-    if (!(tot > 0.0) || isinf(tot) || isnan(tot)) *err = SCRF_ERR_NUMERIC;  // logE(0) / NaN / Inf
-    r = mm + log(tot);
-  }
-  return r;
-}
-
 __global__ void k_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
                      const double* __restrict__ M, int m_per_frame, double* __restrict__ AD,
                      double* __restrict__ alpha_g, double* __restrict__ beta_g, double* __restrict__ XI,

@@ -1,0 +1,244 @@
+// scrf_segtrans.hip -- forward / backward / posteriors of the STDSEG_NO_DUR model: the
+// transition score of a segment comes from the segment's OWN window, so every window (t, d) that has a
+// predecessor carries its own L x L matrix (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp):
+//
+//   M2[(t,d)][p][l]   = computeTransMatrixValue(window d of node t, p, l)             (:69-110)
+//   ad[(t,d)][l]      = LSE_p(alpha[t-d][p] + M2[(t,d)][p][l]) + S[(t,d)][l]  (d <= numPrev) | S   (:132-190)
+//   alpha[t][l]       = LSE_d ad[(t,d)][l] ;  Zx = LSE_l alpha[T-1][l]
+//   beta[t][c]        = LSE_{d,l}(M2[(t+d,d)][c][l] + beta[t+d][l] + S[(t+d,d)][l]) ; beta[T-1] = 0     (:248-310)
+//   gamma[(t,d)][l]   = exp(ad + beta[t][l] - Zx)
+//   xi[(t,d)][p][l]   = exp(alpha[t-d][p] + M2 + S + beta[t][l] - Zx)                  (:455-500)
+//
+// with the gradbuilder of trainers/gradbuilders/CRF_NewGradBuilder_StdSeg.cpp (the PREVIOUS label goes into
+// computeExpF).  One workgroup per utterance, log domain, column-wise max-shifted log-sum-exp (scrf_lse.h)
+// like the reference's LogMath.  Outputs: R = Y - gamma over ad (in place) and XI2 = Y - xi per window
+// ([N_seg][L*L], rows of utterance-initial segments zero) -- the operands of the two expected-count
+// contractions -- plus the numerator, Zx and the node's posterior-mass self-checks (:530-545: state and
+// transition mass each within [-1e-6, 1 + 1e-6]; no state == transition check in this node).
+// The recursion costs L*L*D per frame against L*(L+D) of the TIMIT-demo model: this is the reference's
+// "secondary" model type, served for completeness, not tuned.
+#include "scrf_kernels.h"
+#include "scrf_lse.h"
+
+#include <float.h>
+#include <math.h>
+
+__global__ void k_zero_initial_rows(ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0, uint64_t n_frames,
+                                    uint32_t D, uint32_t LL, double* __restrict__ M2) {
+  // the window of length t+1 ending at frame t < D starts the utterance: no predecessor, no transition matrix
+  const uint64_t fi = blockIdx.x;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  const uint32_t u = frame_u[gf];
+  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  if (t >= D) return;
+  double* row = M2 + ((bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D) + t) * (uint64_t)LL;
+  for (uint32_t i = threadIdx.x; i < LL; i += blockDim.x) row[i] = 0.0;
+}
+void launch_zero_initial_rows(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                              uint32_t D, uint32_t L, double* M2) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_zero_initial_rows, dim3((uint32_t)n_frames), dim3(256), 0, st, bv, frame_u, u0, n_frames, D, L * L, M2);
+}
+
+__global__ void k_fb_segtrans(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const uint32_t* __restrict__ prev_lab,
+                              const double* __restrict__ S, const double* __restrict__ M2, double* __restrict__ AD,
+                              double* __restrict__ alpha_g, double* __restrict__ beta_g, double* __restrict__ XI2,
+                              double* __restrict__ numer_out, double* __restrict__ zx_out, int* __restrict__ status,
+                              int write_post) {
+  extern __shared__ double smem[];
+  __shared__ double zx_s;
+  __shared__ double mass2[2];
+  const int L = lay.L, D = lay.D;
+  const int NT = blockDim.x, tid = threadIdx.x;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const size_t LL = (size_t)L * L;
+  const double* Su = S + s_base * L;
+  const double* Mu = M2 + s_base * LL;
+  double* ADu = AD + s_base * L;
+  double* alu = alpha_g + f_base * L;
+  double* beu = beta_g + f_base * L;
+  const uint32_t* labs = bv.labels ? bv.labels + bv.frame_off[u] : nullptr;
+  const uint32_t* plabs = prev_lab ? prev_lab + bv.frame_off[u] : nullptr;
+
+  FbLse c;
+  c.L = L;
+  c.G = NT / L;
+  if (c.G < 1) c.G = 1;
+  c.g = tid / L;
+  c.j = tid - c.g * L;
+  c.active = c.g < c.G && tid < c.G * L;
+  double* aring = smem;                        // [D][L] alpha of the last D nodes
+  double* bring = aring + (size_t)D * L;       // [D][L] beta of the next D nodes
+  double* tb = bring + (size_t)D * L;          // [D][L] beta[t+d] + S[(t+d,d)]
+  c.red_m = tb + (size_t)D * L;                // [G][L]
+  c.red_s = c.red_m + (size_t)c.G * L;         // [G][L]
+  int err = 0;
+  if (T == 0) {
+    if (tid == 0) { status[u] = SCRF_ERR_EMPTY; numer_out[u] = 0.0; zx_out[u] = 0.0; }
+    return;
+  }
+
+  // ---- forward -----------------------------------------------------------------------------
+  for (int l = tid; l < L; l += NT) {   // computeFirstAlpha :200-208
+    const double a = Su[l];
+    ADu[l] = a;
+    alu[l] = a;
+    aring[l] = a;
+  }
+  __syncthreads();
+  for (int t = 1; t < T; t++) {
+    const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+    const uint64_t base = scrf_seg_base(t, D);
+    double run_m = -INFINITY, run_s = 0.0, a_new = 0.0;   // group 0, thread j = l: log-sum over the durations
+    for (int d = 1; d <= nd; d++) {
+      double v;
+      if (d <= np) {
+        const double* pa = aring + (size_t)((t - d) % D) * L;
+        const double* Mrow = Mu + (base + d - 1) * LL;
+        const double r = col_lse(c, L, [&](int p, int l, bool) { return pa[p] + Mrow[(size_t)p * L + l]; }, &err);
+        v = r + ((c.active && c.g == 0) ? Su[(base + d - 1) * L + c.j] : 0.0);
+      } else {
+        v = (c.active && c.g == 0) ? Su[(base + d - 1) * L + c.j] : 0.0;
+      }
+      if (c.active && c.g == 0) {
+        ADu[(base + d - 1) * L + c.j] = v;
+        if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }   // (exp(-inf) = 0 on the first value)
+        else run_s += exp(v - run_m);
+      }
+    }
+    if (c.active && c.g == 0) {
+      if (!(run_s > 0.0) || isinf(run_s) || isnan(run_s)) err = SCRF_ERR_NUMERIC;
+      a_new = run_m + log(run_s);
+      alu[(size_t)t * L + c.j] = a_new;
+    }
+    __syncthreads();                       // every read of the slot that node t overwrites (node t - D) is done
+    if (c.active && c.g == 0) aring[(size_t)(t % D) * L + c.j] = a_new;
+    __syncthreads();
+  }
+  if (tid == 0) {  // computeAlphaSum: logAdd(alphaArray, L) in index order
+    const double* al = aring + (size_t)((T - 1) % D) * L;
+    double mx = al[0];
+    for (int l = 1; l < L; l++) if (al[l] > mx) mx = al[l];
+    double sum = 0.0;
+    for (int l = 0; l < L; l++) sum += exp(al[l] - mx);
+    zx_s = mx + log(sum);
+  }
+  __threadfence();   // alpha of every node is read back from memory by the posterior pass below
+  __syncthreads();
+  const double Zx = zx_s;
+  if (isnan(Zx) || isinf(Zx)) err = SCRF_ERR_NUMERIC;
+
+  // ---- backward + posteriors -----------------------------------------------------------------
+  const double LN_MAX = 709.782712893384;  // log(DBL_MAX): expE overflow guard (CRF_LogMath.cpp:213)
+  double numer = 0.0;
+  for (int t = T - 1; t >= 0; t--) {
+    const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+    double* bt = bring + (size_t)(t % D) * L;
+    if (nn == 0) {
+      for (int l = tid; l < L; l += NT) bt[l] = 0.0;   // setTailBeta
+      __syncthreads();
+    } else {
+      for (int idx = tid; idx < nn * L; idx += NT) {   // tempBeta :262-271
+        const int di = idx / L, l = idx - di * L;
+        tb[idx] = bring[(size_t)((t + di + 1) % D) * L + l] + Su[(scrf_seg_base(t + di + 1, D) + di) * L + l];
+      }
+      __syncthreads();
+      const double r = col_lse(c, nn * L,
+                               [&](int i, int cl, bool) {
+                                 const int di = i / L, l = i - di * L;
+                                 return Mu[(scrf_seg_base(t + di + 1, D) + di) * LL + (size_t)cl * L + l] + tb[i];
+                               },
+                               &err);
+      // bt is the ring slot of node t + D, whose last reader was the tempBeta fill above
+      if (c.active && c.g == 0) bt[c.j] = r;
+      __syncthreads();
+    }
+    for (int l = tid; l < L; l += NT) beu[(size_t)t * L + l] = bt[l];
+    if (write_post) {
+      // true labels of this node and of the nearest earlier labelled node (computeExpF :430-450)
+      const uint32_t lab = labs ? labs[t] : SCRF_LAB_BAD;
+      const uint32_t pl = plabs ? plabs[t] : SCRF_LAB_BAD;
+      uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD, apl = SCRF_LAB_BAD;
+      if (lab != SCRF_LAB_BAD) {
+        if (lab >= (uint32_t)L * D) err = SCRF_ERR_BAD_LABEL;
+        al = lab % L;
+        ld = lab / L + 1;
+      }
+      if (pl != SCRF_LAB_BAD) {
+        if (pl >= (uint32_t)L * D) err = SCRF_ERR_BAD_LABEL;
+        apl = pl % L;
+      }
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      const uint64_t base = scrf_seg_base(t, D);
+      double gs = 0.0, xs = 0.0;
+      // transition posteriors first: they read ad-free quantities; then gamma overwrites ad in place
+      for (int d = 1; d <= nd; d++) {
+        double* Xrow = XI2 + (s_base + base + d - 1) * LL;
+        if (d <= np) {
+          const double* pa = alu + (size_t)(t - d) * L;
+          const double* Mrow = Mu + (base + d - 1) * LL;
+          for (int idx = tid; idx < L * L; idx += NT) {
+            const int p = idx / L, l = idx - p * L;
+            const double a = pa[p] + Mrow[idx] + Su[(base + d - 1) * L + l] + bt[l] - Zx;
+            if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+            const double x = exp(a);
+            const double y = ((uint32_t)l == al && (uint32_t)d == ld && (uint32_t)p == apl) ? 1.0 : 0.0;
+            Xrow[idx] = y - x;
+            xs += x;
+          }
+        } else {
+          for (int idx = tid; idx < L * L; idx += NT) Xrow[idx] = 0.0;
+        }
+      }
+      for (int idx = tid; idx < nd * L; idx += NT) {
+        const int di = idx / L, l = idx - di * L;
+        const double a = ADu[(base + di) * L + l] + bt[l] - Zx;
+        if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+        const double g = exp(a);
+        const double y = ((uint32_t)l == al && (uint32_t)(di + 1) == ld) ? 1.0 : 0.0;
+        ADu[(base + di) * L + l] = y - g;
+        gs += g;
+      }
+      if (tid == 0) { mass2[0] = 0.0; mass2[1] = 0.0; }
+      __syncthreads();
+      for (int o = 32; o >= 1; o >>= 1) { gs += __shfl_xor(gs, o); xs += __shfl_xor(xs, o); }
+      if ((tid & 63) == 0) { atomicAdd(&mass2[0], gs); atomicAdd(&mass2[1], xs); }
+      __syncthreads();
+      if (tid == 0) {
+        const double sm = mass2[0], tm = np == 0 ? 1.0 : mass2[1];
+        if (!(sm <= 1.000001) || !(sm >= -0.000001) || !(tm <= 1.000001) || !(tm >= -0.000001)) err = SCRF_ERR_NUMERIC;
+        if (lab != SCRF_LAB_BAD && err == 0 && ld <= (uint32_t)nd) {
+          double nodeLi = Su[(base + ld - 1) * L + al];
+          if ((int)ld <= np && apl != SCRF_LAB_BAD) nodeLi += Mu[(base + ld - 1) * LL + (size_t)apl * L + al];
+          numer += nodeLi;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    numer_out[u] = numer;
+    zx_out[u] = Zx;
+  }
+  if (err) atomicMax(&status[u], err);
+}
+
+size_t fb_segtrans_smem_bytes(const ScrfLayout& lay, int NT) {
+  int G = NT / (int)lay.L;
+  if (G < 1) G = 1;
+  return sizeof(double) * ((size_t)3 * lay.D * lay.L + (size_t)2 * G * lay.L);
+}
+
+void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                        const uint32_t* prev_lab, const double* S, const double* M2, double* AD, double* alpha_g,
+                        double* beta_g, double* XI2, double* numer, double* zx, int* status, int write_post) {
+  if (n_utts == 0) return;
+  const int NT = fb_block_threads(lay);
+  const size_t sm = fb_segtrans_smem_bytes(lay, NT);
+  hipFuncSetAttribute((const void*)k_fb_segtrans, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(k_fb_segtrans, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, prev_lab, S, M2, AD, alpha_g, beta_g, XI2,
+                     numer, zx, status, write_post);
+}

@@ -246,7 +246,9 @@ class Engine:
         return T * (T + 1) // 2 if T < D else D * (D + 1) // 2 + (T - D) * D
 
     def scores(self, batch, u, T):
-        S = np.zeros((self.num_segs(T), self.L)); M = np.zeros((T, self.L * self.L))
+        """S [N_seg, L]; M [T, L*L] -- for STDSEG_NO_DUR one transition matrix per window: [N_seg, L*L]"""
+        S = np.zeros((self.num_segs(T), self.L))
+        M = np.zeros((self.num_segs(T) if self.cfg.model_type == STDSEG_NO_DUR else T, self.L * self.L))
         self._chk(self.lib.scrf_scores(self.h, batch.handle, C.c_uint32(u), _p(S), _p(M)))
         return S, M
 

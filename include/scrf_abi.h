@@ -55,7 +55,8 @@ enum scrf_status {
 enum scrf_model_type {
   SCRF_STDFRAME = 0,
   SCRF_STDSEG = 1,                       /* not built */
-  SCRF_STDSEG_NO_DUR = 2,                /* not built */
+  SCRF_STDSEG_NO_DUR = 2,                /* transition features from the segment's own window: training path built
+                                            (scrf_fb_batch, parity hooks; scrf_segtrans.hip); decode entry points refuse it */
   SCRF_STDSEG_NO_DUR_NO_TRANSFTR = 3,    /* served by the same engine (bias-only transitions) */
   SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR = 4  /* the TIMIT-demo model */
 };
@@ -204,7 +205,9 @@ int scrf_set_grad_buffer(scrf_handle h, void* dptr);
 int scrf_get_batch_sums(scrf_handle h, double* sums3);
 
 /* ---- parity hooks: the node accessors of nodes/CRF_StateNode.h:67-115 ---------------------- */
-/* getStateValue(lab,dur) / getTransValue(p,c): S[N_seg][L], M[T][L*L] of utterance u (EXACT) */
+/* getStateValue(lab,dur) / getTransValue(p,c): S[N_seg][L], M[T][L*L] of utterance u (EXACT).  For
+ * SCRF_STDSEG_NO_DUR M is [N_seg][L*L]: getTransValue(p,c,dur) of every window, the rows of utterance-initial
+ * windows (no predecessor) zero (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp:69-110, :570-580) */
 int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M);
 /* window synthesis of utterance u: [N_seg][num_feas] (io/CRF_InFtrStream_SeqMultiWindow.cpp) */
 int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* windows);

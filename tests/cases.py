@@ -13,7 +13,7 @@ class Case:
     TIMIT demo's ftr2 stream (demo/segmental-timit-demo.cfg.in:21-24)."""
 
     def __init__(self, L, D, in_w, Ts, trans_ctx=None, seed=0, lam_scale=0.3, frame_model=False,
-                 scratch_bytes=0, precision=0, l1_norm=False):
+                 scratch_bytes=0, precision=0, l1_norm=False, model_type=None, trans_share=None):
         self.L, self.D, self.in_w, self.Ts = L, D, in_w, list(Ts)
         self.trans_ctx = trans_ctx
         rng = np.random.RandomState(seed)
@@ -28,7 +28,13 @@ class Case:
         self.recipes = [scrf_amd.StreamRecipe(in_w, 0, 0, 1)]
         self.frames2 = None
         mt = orc.STDFRAME if frame_model else orc.STDSEG_NO_DUR_NO_SEGTRANSFTR
-        if trans_ctx is None:
+        if model_type is not None:
+            mt = model_type
+        if trans_ctx is None and trans_share is not None:
+            # transition features = columns [lo, hi] of the segment's own window vector (single stream)
+            self.F = Fs
+            kw = dict(model_type=mt, L=L, D=D, F=Fs, use_trans_ftrs=True, tfs=trans_share[0], tfe=trans_share[1])
+        elif trans_ctx is None:
             self.F = Fs
             kw = dict(model_type=mt, L=L, D=D, F=Fs)
         else:
@@ -70,6 +76,8 @@ class Case:
         for u, T in enumerate(self.Ts):
             if self.ocfg.model_type == orc.STDFRAME:
                 rc, g, n, z = orc.frame_build_gradient(self.ocfg, self.olay, self.lam, self.windows(u), self.labels[u], T, grad=g)
+            elif self.ocfg.model_type == orc.STDSEG_NO_DUR:
+                rc, g, n, z = orc.segtrans_build_gradient(self.ocfg, self.olay, self.lam, self.windows(u), self.labels[u], T, grad=g)
             else:
                 rc, g, n, z = orc.seg_build_gradient(self.ocfg, self.olay, self.lam, self.windows(u), self.labels[u], T, grad=g)
             assert rc == 0, rc

@@ -503,7 +503,8 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     b->seg_off[u + 1] = b->seg_off[u] + scrf_seg_base(q.T, lay.D);
     uint64_t na = (lay.D == 1 && h->cfg.model_type == SCRF_STDFRAME)
                       ? (uint64_t)lay.L + (uint64_t)(q.T - 1) * lay.L * lay.L + lay.L
-                      : scrf_arc_base(q.T, lay.L, lay.D) + lay.L;
+                      : h->cfg.model_type == SCRF_STDSEG_NO_DUR ? segtrans_num_arcs(q.T, lay.L, lay.D)
+                                                                : scrf_arc_base(q.T, lay.L, lay.D) + lay.L;
     b->arc_off[u + 1] = b->arc_off[u] + na;
   }
   const uint64_t NF = b->frame_off[n], NS = b->seg_off[n];
@@ -1497,15 +1498,15 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
                                  uint32_t* n_states, int32_t* final_state) {
   int rc = check_u(h, b, u, "scrf_lattice_arcs");
   if (rc != SCRF_OK) return rc;
-  if (segtrans(h)) return fail(h, SCRF_ERR_INVALID, "scrf_lattice_arcs: the stdseg_no_dur lattice (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h) is not built");
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
   const uint32_t T = b->T[u];
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
   const uint64_t na = b->arc_off[u + 1] - b->arc_off[u];
   if (n_arcs) *n_arcs = na;
-  if (n_states) *n_states = frame_model ? l.L * T + 2 : (uint32_t)scrf_node_start_state(T, l.L) + 1;
-  if (final_state) *final_state = frame_model ? (int32_t)(l.L * T + 1) : scrf_node_start_state(T, l.L);
+  // STDSEG_NO_DUR: one state per (node, label) like the frame lattice (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h)
+  if (n_states) *n_states = (frame_model || segtrans(h)) ? l.L * T + 2 : (uint32_t)scrf_node_start_state(T, l.L) + 1;
+  if (final_state) *final_state = (frame_model || segtrans(h)) ? (int32_t)(l.L * T + 1) : scrf_node_start_state(T, l.L);
   if (!arcs) return SCRF_OK;
   Need nd{norm != 0, false, false, false};
   ChunkBufs cb;
@@ -1527,7 +1528,8 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
   }
   scrf_arc* d_arcs = nullptr;
   HIPCHK(h, hipMalloc((void**)&d_arcs, sizeof(scrf_arc) * na));
-  launch_arcs(h->stream, l, T, frame_model, cb.S, cb.M, cb.m_per_frame, final_w, d_arcs);
+  if (segtrans(h)) launch_arcs_segtrans(h->stream, l, T, cb.S, cb.M, final_w, d_arcs);
+  else launch_arcs(h->stream, l, T, frame_model, cb.S, cb.M, cb.m_per_frame, final_w, d_arcs);
   hipError_t e = hipMemcpyAsync(arcs, d_arcs, sizeof(scrf_arc) * na, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   hipFree(d_arcs);
@@ -1538,7 +1540,6 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
 extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
                                   uint64_t* lab_off, float* best_cost) {
   if (!h || !b || !seg_labels || !lab_off) return SCRF_ERR_INVALID;
-  if (segtrans(h)) return fail(h, SCRF_ERR_INVALID, "scrf_viterbi_batch: decoding of stdseg_no_dur models is not built");
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
@@ -1604,8 +1605,9 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
       rc = run_scores(h, b, u0, u1, cb);
       if (rc != SCRF_OK) break;
       PhaseTimer tm(h, PH_VIT);
-      launch_viterbi(h->stream, l, b->view(), u0, u1 - u0, cb.S, cb.M, cb.m_per_frame, frame_model, cb.bp_b, cb.bp_e,
-                     d_lab, d_n, d_cost);
+      if (segtrans(h)) launch_viterbi_segtrans(h->stream, l, b->view(), u0, u1 - u0, cb.S, cb.M, cb.bp_b, cb.bp_e, d_lab, d_n, d_cost);
+      else launch_viterbi(h->stream, l, b->view(), u0, u1 - u0, cb.S, cb.M, cb.m_per_frame, frame_model, cb.bp_b, cb.bp_e,
+                          d_lab, d_n, d_cost);
       tm.stop(1);
       u0 = u1;
     } while (fast && u0 < u_end && rc == SCRF_OK);

@@ -43,6 +43,13 @@ void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv,
                         const uint32_t* prev_lab, const double* S, const double* M2, double* AD, double* alpha_g,
                         double* beta_g, double* XI2, double* numer, double* zx, int* status, int write_post);
 
+uint64_t segtrans_num_arcs(uint32_t T, uint32_t L, uint32_t D);
+void launch_arcs_segtrans(hipStream_t st, const ScrfLayout& lay, uint32_t T, const double* S, const double* M2, float final_w,
+                          scrf_arc* arcs);
+void launch_viterbi_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                             const double* S, const double* M2, uint16_t* bp_p, uint16_t* bp_d, uint32_t* out_labels,
+                             uint32_t* out_n, float* out_cost);
+
 // scrf_mfma.hip: fp64 MFMA contractions (FAST training precision)
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,

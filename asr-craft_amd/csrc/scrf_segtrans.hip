@@ -242,3 +242,149 @@ void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv,
   hipLaunchKernelGGL(k_fb_segtrans, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, prev_lab, S, M2, AD, alpha_g, beta_g, XI2,
                      numer, zx, status, write_post);
 }
+
+// ------------------------------------------------------------------------------------------
+// Lattice of the STDSEG_NO_DUR model (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h): state 0 =
+// start, node t owns the L states 1 + t*L + l; arcs in AddArc order -- node by node, per label, per
+// duration with a predecessor every previous label p (state(t-dur, p) -> state(t, l), labels
+// l + L*(dur-1) + 1, weight float(-1 * (M2 + S)) = float(-getFullTransValue)), then the utterance-initial
+// duration from the start state (float(-S)); last the L epsilon arcs of weight final_w into the final state.
+// One workgroup per node; the arc index inside the node is closed form.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t segtrans_arc_base(uint32_t t, uint32_t L, uint32_t D) {
+  // arcs emitted before node t: node tau < D has tau predecessors and one initial duration
+  if (t <= D) return (uint64_t)L * ((uint64_t)L * t * (t - (t ? 1 : 0)) / 2 + t);
+  return (uint64_t)L * ((uint64_t)L * D * (D - 1) / 2 + D) + (uint64_t)(t - D) * L * D * L;
+}
+uint64_t segtrans_num_arcs(uint32_t T, uint32_t L, uint32_t D) { return T ? segtrans_arc_base(T, L, D) + L : 0; }
+
+__global__ void k_arcs_segtrans(ScrfLayout lay, uint32_t T, const double* __restrict__ S, const double* __restrict__ M2,
+                                float final_w, scrf_arc* __restrict__ arcs) {
+  const uint32_t L = lay.L, D = lay.D, t = blockIdx.x;
+  const size_t LL = (size_t)L * L;
+  if (t == T) {   // final arcs
+    for (uint32_t l = threadIdx.x; l < L; l += blockDim.x)
+      arcs[segtrans_arc_base(T, L, D) + l] = scrf_arc{(int32_t)(1 + (T - 1) * L + l), 0, 0, final_w, (int32_t)(1 + T * L)};
+    return;
+  }
+  const uint32_t np = scrf_num_prev(t, D), nd = scrf_node_max_dur(t, D);
+  const uint64_t base = scrf_seg_base(t, D), a0 = segtrans_arc_base(t, L, D);
+  const uint32_t per_lab = np * L + (nd - np);
+  for (uint32_t i = threadIdx.x; i < L * per_lab; i += blockDim.x) {
+    const uint32_t l = i / per_lab, k = i - l * per_lab;
+    scrf_arc a;
+    a.dst = (int32_t)(1 + t * L + l);
+    if (k < np * L) {
+      const uint32_t dur = k / L + 1, p = k - (dur - 1) * L;
+      a.src = (int32_t)(1 + (t - dur) * L + p);
+      a.ilabel = a.olabel = (int32_t)(l + L * (dur - 1) + 1);
+      a.w = (float)(-1 * (M2[(base + dur - 1) * LL + (size_t)p * L + l] + S[(base + dur - 1) * L + l]));
+    } else {
+      const uint32_t dur = np + 1 + (k - np * L);
+      a.src = 0;
+      a.ilabel = a.olabel = (int32_t)(l + L * (dur - 1) + 1);
+      a.w = (float)(-1 * S[(base + dur - 1) * L + l]);
+    }
+    arcs[a0 + i] = a;
+  }
+}
+void launch_arcs_segtrans(hipStream_t st, const ScrfLayout& lay, uint32_t T, const double* S, const double* M2, float final_w,
+                          scrf_arc* arcs) {
+  if (T == 0) return;
+  hipLaunchKernelGGL(k_arcs_segtrans, dim3(T + 1), dim3(256), 0, st, lay, T, S, M2, final_w, arcs);
+}
+
+// ------------------------------------------------------------------------------------------
+// Best path over that lattice without materialising it: ShortestPath's relaxation in state order with
+// strict improvement (first relaxed wins): state(t, l) is reached from the start state first (the
+// utterance-initial duration), then from state(t-dur, p) with dur DEscending (lower state ids first) and
+// p ascending; the final state from state(T-1, l), l ascending.  Path cost = left-to-right float sum.
+// One workgroup per utterance, thread = label; costs of the last D nodes in an LDS ring.
+// ------------------------------------------------------------------------------------------
+__global__ void k_viterbi_segtrans(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
+                                   const double* __restrict__ M2, uint16_t* __restrict__ bp_p, uint16_t* __restrict__ bp_d,
+                                   uint32_t* __restrict__ out_labels, uint32_t* __restrict__ out_n,
+                                   float* __restrict__ out_cost) {
+  extern __shared__ float vring[];   // [D][L]
+  const int L = lay.L, D = lay.D;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const size_t LL = (size_t)L * L;
+  const double* Su = S + s_base * L;
+  const double* Mu = M2 + s_base * LL;
+  uint16_t* bpp = bp_p + f_base * L;
+  uint16_t* bpd = bp_d + f_base * L;
+  uint32_t* outl = out_labels + bv.frame_off[u];
+  for (int t = 0; t < T; t++) {
+    const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+    const uint64_t base = scrf_seg_base(t, D);
+    for (int l = tid; l < L; l += NT) {
+      float best = INFINITY;
+      int bd = 0, bpv = 0xffff;
+      if (nd > np) {   // from the start state: distance 0 + float(-S)
+        best = 0.0f + (float)(-1 * Su[(base + nd - 1) * L + l]);
+        bd = nd;
+      }
+      for (int dur = np; dur >= 1; dur--) {
+        const float* cp = vring + (size_t)((t - dur) % D) * L;
+        const double* Mrow = Mu + (base + dur - 1) * LL;
+        const double sv = Su[(base + dur - 1) * L + l];
+        for (int p = 0; p < L; p++) {
+          const float c = cp[p] + (float)(-1 * (Mrow[(size_t)p * L + l] + sv));
+          if (c < best) { best = c; bd = dur; bpv = p; }
+        }
+      }
+      bpd[(size_t)t * L + l] = (uint16_t)bd;
+      bpp[(size_t)t * L + l] = (uint16_t)bpv;
+      // the ring slot of node t is node t - D's, which this step still reads (dur = D): the new costs wait
+      // in a staging row until every thread has finished reading
+      vring[(size_t)D * L + l] = best;
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += NT) vring[(size_t)(t % D) * L + l] = vring[(size_t)D * L + l];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float best = INFINITY;
+    int bl = -1;
+    const float* cl = vring + (size_t)((T - 1) % D) * L;
+    for (int l = 0; l < L; l++) {
+      const float cst = cl[l] + -0.0f;
+      if (cst < best) { best = cst; bl = l; }
+    }
+    uint32_t n = 0;
+    if (bl >= 0) {
+      int t = T - 1, l = bl;
+      while (true) {
+        const int d = bpd[(size_t)t * L + l];
+        outl[n++] = (uint32_t)(l + L * (d - 1));
+        const int p = bpp[(size_t)t * L + l];
+        if (p == 0xffff) break;
+        t -= d;
+        l = p;
+      }
+      for (uint32_t i = 0; i < n / 2; i++) {
+        const uint32_t tmp = outl[i];
+        outl[i] = outl[n - 1 - i];
+        outl[n - 1 - i] = tmp;
+      }
+      best = best + 0.0f;  // Times(distance, Final = One)
+    }
+    out_n[u] = n;
+    out_cost[u] = best;
+  }
+}
+void launch_viterbi_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                             const double* S, const double* M2, uint16_t* bp_p, uint16_t* bp_d, uint32_t* out_labels,
+                             uint32_t* out_n, float* out_cost) {
+  if (n_utts == 0) return;
+  int NT = ((int)lay.L + 63) / 64 * 64;
+  if (NT > 1024) NT = 1024;
+  const size_t sm = sizeof(float) * (size_t)(lay.D + 1) * lay.L;
+  hipFuncSetAttribute((const void*)k_viterbi_segtrans, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(k_viterbi_segtrans, dim3(n_utts), dim3(NT), sm, st, lay, bv, u0, S, M2, bp_p, bp_d, out_labels, out_n,
+                     out_cost);
+}

@@ -55,8 +55,8 @@ enum scrf_status {
 enum scrf_model_type {
   SCRF_STDFRAME = 0,
   SCRF_STDSEG = 1,                       /* not built */
-  SCRF_STDSEG_NO_DUR = 2,                /* transition features from the segment's own window: training path built
-                                            (scrf_fb_batch, parity hooks; scrf_segtrans.hip); decode entry points refuse it */
+  SCRF_STDSEG_NO_DUR = 2,                /* transition features from the segment's own window (one L x L matrix per
+                                            window): training, parity hooks, lattice arcs and best path (scrf_segtrans.hip) */
   SCRF_STDSEG_NO_DUR_NO_TRANSFTR = 3,    /* served by the same engine (bias-only transitions) */
   SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR = 4  /* the TIMIT-demo model */
 };

@@ -975,6 +975,63 @@ uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const doub
   return na;
 }
 
+/* decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h: node t owns L states (one per label) from 1 + t*L;
+ * per label, for dur = 1..numPrev and every previous label an arc from state(t-dur, p) with
+ * float(-1 * getFullTransValue(p, lab, dur)) = float(-(M2 + S)), then the utterance-initial duration from
+ * the start state with float(-S); labels lab + L*(dur-1) + 1 on both tapes; L epsilon arcs of weight -Zx
+ * (= -0.0 without norm) into the final state. */
+uint64_t orc_segtrans_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D) {
+  uint64_t n = 0;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
+    n += (uint64_t)L * ((uint64_t)np * L + (nd - np));
+  }
+  return T ? n + L : 0;
+}
+uint64_t orc_segtrans_lattice_arcs(const orc_config* cfg, const double* S, const double* M2, uint32_t T,
+                                   int norm, double alpha_sum, orc_arc* arcs, uint32_t* n_states,
+                                   int32_t* final_state) {
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  uint64_t na = 0;
+  int next_state = 1;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
+    for (uint32_t lab = 0; lab < L; lab++) {
+      const int cur_state = next_state++;
+      int cur_lab = (int)lab;
+      for (uint32_t dur = 1; dur <= np; dur++) {
+        for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+          float value = -1 * (M2[(base + dur - 1) * (size_t)L * L + prev_lab * L + lab] + S[(base + dur - 1) * L + lab]);
+          orc_arc a = {1 + (int)((t - dur) * L + prev_lab), cur_lab + 1, cur_lab + 1, value, cur_state};
+          arcs[na++] = a;
+        }
+        cur_lab += (int)L;
+      }
+      for (uint32_t dur = np + 1; dur <= nd; dur++) {
+        float value = -1 * S[(base + dur - 1) * L + lab];
+        orc_arc a = {0, cur_lab + 1, cur_lab + 1, value, cur_state};
+        arcs[na++] = a;
+        cur_lab += (int)L;
+      }
+    }
+  }
+  int fin = -1;
+  if (T > 0) {
+    double Zx = 0;
+    if (norm) Zx = -1 * alpha_sum;
+    fin = next_state++;
+    for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+      float w = -Zx;
+      orc_arc a = {1 + (int)((T - 1) * L + prev_lab), 0, 0, w, fin};
+      arcs[na++] = a;
+    }
+  }
+  *n_states = (uint32_t)next_state;
+  *final_state = fin;
+  return na;
+}
+
 uint64_t orc_frame_lattice_num_arcs(uint32_t T, uint32_t L) {
   if (T == 0) return L;
   return (uint64_t)L + (uint64_t)(T - 1) * L * L + L;

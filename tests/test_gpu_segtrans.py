@@ -88,10 +88,6 @@ def test_chunking_sgd_and_errors():
     with pytest.raises(scrf_amd.ScrfError) as ei:
         e2.fb_batch(bad, want_scalars=False)
     assert ei.value.code == 5 and np.array_equal(e2.get_grad(), g0)
-    # decode entry points refuse this model type with a message
-    with pytest.raises(scrf_amd.ScrfError) as ei:
-        e2.viterbi_batch(b2)
-    assert "stdseg_no_dur" in str(ei.value)
     for x in (b1, b2, bad): x.close()
     e1.close(); e2.close()
 
@@ -110,3 +106,26 @@ def test_bias_only_transitions_equal_the_timit_demo_model():
     assert np.abs(g1 - g2).max() <= 1e-10 * np.abs(g2).max()
     for x in (b1, b2): x.close()
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_lattice_arcs_and_best_path(ci):
+    """decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h: arcs byte for byte in AddArc order (also with the
+    normaliser on the final arcs), and the batched best path == ShortestPath on the oracle's lattice."""
+    c = Case(seed=700 + ci, model_type=NO_DUR, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng, with_labels=False)
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.segtrans_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.segtrans_lattice_arcs(c.ocfg, So, Mo, T)
+        ga, gns, gfin = eng.lattice_arcs(b, u)
+        assert (gns, gfin) == (ons, ofin) and ga.tobytes() == oa.tobytes()
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol) and np.float32(cost[u]).tobytes() == np.float32(oc).tobytes()
+        if u == 0:
+            rc, ad, al, zx = orc.segtrans_forward(c.ocfg, So, Mo, T)
+            oan, _, _ = orc.segtrans_lattice_arcs(c.ocfg, So, Mo, T, norm=True, alpha_sum=zx)
+            gan, _, _ = eng.lattice_arcs(b, u, norm=True)
+            assert gan[:-c.L].tobytes() == oan[:-c.L].tobytes()
+            np.testing.assert_allclose(gan["w"][-c.L:], oan["w"][-c.L:], rtol=1e-6)
+    b.close(); eng.close()

@@ -107,3 +107,23 @@ def test_without_transition_features_it_is_the_no_segtransftr_model():
     _, g2, n2, z2 = orc.seg_build_gradient(c2, l2, lam, X, labels, T)
     assert abs(z1 - z2) < 1e-12 * abs(z2) and abs(n1 - n2) < 1e-12 * max(1, abs(n2))
     np.testing.assert_allclose(g1, g2, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("L,D,T", [(2, 2, 4), (3, 3, 6), (2, 3, 5), (3, 2, 1), (2, 4, 7)])
+def test_lattice_structure_and_best_path(L, D, T):
+    """decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h: one state per (node, label); the shortest path's
+    cost is -(best path score) of the enumeration and its labels spell the best segmentation; with norm the
+    final arcs carry Zx."""
+    cfg, lay, lam, X, _ = _case(L, D, T, 2, seed=40 + L * 10 + T)
+    S, M2 = orc.segtrans_scores(cfg, lay, lam, X, T)
+    arcs, ns, fin = orc.segtrans_lattice_arcs(cfg, S, M2, T)
+    assert ns == 1 + T * L + 1 and fin == ns - 1
+    assert np.all(arcs["dst"] > arcs["src"])                      # state ids are a topological order
+    bf = orc.brute_force_segtrans(S, M2, T, L, D)
+    labs, cost = orc.best_path(arcs, ns, fin)
+    sc, segs = bf["best"]
+    assert [int(x) for x in labs] == [l + L * (d - 1) for (_, d, l) in segs]
+    assert abs(-cost - sc) < 1e-5 * max(1, abs(sc))
+    rc, ad, al, zx = orc.segtrans_forward(cfg, S, M2, T)
+    arcs_n, _, _ = orc.segtrans_lattice_arcs(cfg, S, M2, T, norm=True, alpha_sum=zx)
+    assert np.array_equal(arcs_n[:-L], arcs[:-L]) and np.all(arcs_n["w"][-L:] == np.float32(zx))

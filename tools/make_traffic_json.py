@@ -1,11 +1,11 @@
-"""profiles/r01_traffic.json from the per-kernel FETCH_SIZE / WRITE_SIZE passes (tools/pmc_kernels.sh output):
+"""profiles/<tag>_traffic.json from the per-kernel FETCH_SIZE / WRITE_SIZE passes (tools/pmc_kernels.sh output):
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB -- gfx950 tallies 128-byte read requests at 64 bytes
 (MI355X_MICROARCH.md, "HBM").  usage: python tools/make_traffic_json.py <round tag, e.g. r01> [utterances per launch]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 U = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-KEEP = ("k_scores_fused", "k_dp_lin", "k_post_z", "k_expf_fused")
+KEEP = ("k_scores_fused", "k_dp_lin", "k_post_z", "k_expf_fused", "k_pframe", "k_ztf", "k_mass_check")
 
 
 def parse(path):
@@ -25,10 +25,16 @@ def parse(path):
 
 res = {}
 for prec in ("fast", "fast32"):
-    f = parse(os.path.join(ROOT, "profiles", "%s_%s_pmc_fetch.txt" % (tag, prec)))
-    w = parse(os.path.join(ROOT, "profiles", "%s_%s_pmc_write.txt" % (tag, prec)))
+    pf = os.path.join(ROOT, "profiles", "%s_%s_pmc_fetch.txt" % (tag, prec))
+    pw = os.path.join(ROOT, "profiles", "%s_%s_pmc_write.txt" % (tag, prec))
+    if not (os.path.exists(pf) and os.path.exists(pw)):
+        continue
+    f = parse(pf)
+    w = parse(pw)
     res[prec] = {}
     for k in KEEP:
+        if k not in f or k not in w:
+            continue
         fr, wr = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
         b = int((2 * fr + wr) * 1024)
         res[prec][k] = {"fetch_size_kb_raw": fr, "write_size_kb": wr, "bytes_per_launch": b, "bytes_per_utt": b / U}

@@ -13,7 +13,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collectio
 for r in csv.DictReader(open(sys.argv[1])):
     k=r['Kernel_Name'][:40]; acc[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k].add(r['Dispatch_Id'])
 for k in acc:
-    if not any(x in k for x in ('fused','k_lin_z','k_dp','k_post','k_exp_rows','k_atb','mfma','k_xi','k_reduce')): continue
+    if not any(x in k for x in ('fused','k_lin_z','k_dp','k_post','k_exp_rows','k_atb','mfma','k_xi','k_reduce','k_pframe','k_ztf','k_mass')): continue
     print(k, 'launches', len(n[k]))
     for c,v in sorted(acc[k].items()): print('   %-32s %.4g' % (c, v/len(n[k])))
 PY

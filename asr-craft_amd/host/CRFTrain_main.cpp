@@ -23,7 +23,8 @@ int main(int argc, char** argv) {
     if (!a.has("ftr1_file")) { std::cerr << "ftr1_file is required" << std::endl; return 1; }
     if (!a.has("hardtarget_file")) { std::cerr << "hardtarget_file is required" << std::endl; return 1; }
     if (!a.has("out_weight_file")) { std::cerr << "out_weight_file is required" << std::endl; return 1; }
-    if (a.str("crf_train_method", "sg") != "sg") { std::cerr << "only crf_train_method=sg is built" << std::endl; return 1; }
+    const std::string method = a.str("crf_train_method", "sg");
+    if (method != "sg" && method != "lbfgs") { std::cerr << "crf_train_method=" << method << " is not built (sg|lbfgs)" << std::endl; return 1; }
     CliModel m;
     m.D = (uint32_t)a.num("label_maximum_duration", 1);
     m.L = (uint32_t)a.num("crf_label_size", 0);
@@ -92,12 +93,18 @@ int main(int argc, char** argv) {
 
     // ---- Main.cpp:632-684: the trainer
     std::string wf = a.str("out_weight_file");
-    CRF_Trainer* my_trainer = new CRF_SGTrainer(&my_crf, &str1, &wf[0]);
-    ((CRF_SGTrainer*)my_trainer)->setObjectiveFunction(EXPF);
-    ((CRF_SGTrainer*)my_trainer)->setUseAdagrad((double)a.num("crf_use_adagrad", 0));
-    ((CRF_SGTrainer*)my_trainer)->setEta(a.real("crf_adagrad_eta", 1.0));
-    ((CRF_SGTrainer*)my_trainer)->setNThreads((int)threads);
-    ((CRF_SGTrainer*)my_trainer)->setMinibatch((int)a.num("crf_bunch_size", 1));
+    CRF_Trainer* my_trainer;
+    if (method == "lbfgs") {
+      my_trainer = new CRF_LBFGSTrainer(&my_crf, &str1, &wf[0]);
+      ((CRF_LBFGSTrainer*)my_trainer)->setObjectiveFunction(EXPF);
+    } else {
+      my_trainer = new CRF_SGTrainer(&my_crf, &str1, &wf[0]);
+      ((CRF_SGTrainer*)my_trainer)->setObjectiveFunction(EXPF);
+      ((CRF_SGTrainer*)my_trainer)->setUseAdagrad((double)a.num("crf_use_adagrad", 0));
+      ((CRF_SGTrainer*)my_trainer)->setEta(a.real("crf_adagrad_eta", 1.0));
+      ((CRF_SGTrainer*)my_trainer)->setNThreads((int)threads);
+      ((CRF_SGTrainer*)my_trainer)->setMinibatch((int)a.num("crf_bunch_size", 1));
+    }
     if (rank == 0) {
       std::cout << "MINIBATCH SIZE: " << a.num("crf_bunch_size", 1) << std::endl;
       std::cout << "NUMBER OF THREADS: " << threads << std::endl;

@@ -16,6 +16,7 @@
 #include <sstream>
 
 #include "ftr_files.h"
+#include "lbfgs.h"
 
 using std::runtime_error;
 using std::string;
@@ -864,6 +865,115 @@ void CRF_SGTrainer::sgtrainMinibatch() {
     std::cout << "Writing Final Iteration weights to file " << weight_fname << std::endl;
     crf_ptr->writeToFile(weight_fname.c_str());
     crf_ptr->writeToFile((weight_fname + ".avg.out").c_str(), lambdaAvg.data(), n);
+    touchDoneFileFinal();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_GradAccumulator (full batch) / CRF_LBFGSTrainer
+// ------------------------------------------------------------------------------------------
+void CRF_GradAccumulator::setObjectiveFunction(objfunctype ofunc) {
+  if (ofunc != EXPF) throw runtime_error("CRF_GradAccumulator: only the EXPF objective is built");
+}
+
+double CRF_GradAccumulator::accumulateGradient(CRF_FeatureStreamManager* mgr, int nStreams, double* grad, QNUInt32* uttCount) {
+  crf_amd::Engine* e = crf->engine();
+  const QNUInt32 n = e->lambda_len;
+  const bool dist = crf->distributed();
+  if (dist && crf->distWorld() != nStreams)
+    throw runtime_error("CRF_GradAccumulator: " + std::to_string(nStreams) + " streams but " + std::to_string(crf->distWorld()) + " ranks");
+  crf->pushLambda();
+  e->check(scrf_zero_grad(e->h), "accumulateGradient");
+  for (int s = 0; s < nStreams; s++) {
+    if (dist && s != crf->distRank()) continue;
+    CRF_FeatureStream* strm = nStreams == 1 ? mgr->trn_stream : mgr->getChild((size_t)s)->trn_stream;
+    strm->rewind();
+    QN_SegID segid = strm->nextseg();
+    if (segid == QN_SEGID_BAD) throw runtime_error("Feature stream contains no utterances!");
+    while (segid != QN_SEGID_BAD) {   // the stream's whole view, in device batches
+      std::vector<HeldUtt> utts;
+      do {
+        utts.emplace_back();
+        grab(strm, crf, &utts.back());
+        segid = strm->nextseg();
+      } while (utts.size() < deviceBatch && segid != QN_SEGID_BAD);
+      BatchGuard g{e};
+      make_batch(e, strm, utts, &g);
+      e->check(scrf_fb_batch(e->h, g.b, nullptr, nullptr), "CRF_GradAccumulator::accumulateGradient()");
+    }
+  }
+  double sums[4] = {0, 0, 0, 0};
+  if (dist) {
+    // sum over the ranks; the collective divides by the active ranks (all of them here): undone
+    e->check(scrf_allreduce_grad_ex(e->h, 1, nullptr, 0, sums, nullptr), "accumulateGradient (all-reduce)");
+    e->check(scrf_scale_grad(e->h, sums[3]), "accumulateGradient");
+  } else {
+    e->check(scrf_get_batch_sums(e->h, sums), "accumulateGradient");
+  }
+  e->check(scrf_get_grad(e->h, grad, n), "accumulateGradient");
+  *uttCount = (QNUInt32)(sums[2] + 0.5);
+  return sums[0] - sums[1];
+}
+
+CRF_LBFGSTrainer::CRF_LBFGSTrainer(CRF_Model* crf_in, CRF_FeatureStreamManager* mgr, char* wt_fname) : CRF_Trainer(crf_in, mgr, wt_fname) {
+  iCounter = (int)crf_ptr->getInitIter();
+  for (int i = 0; i < iCounter; ++i) ftr_strm_mgr->trn_stream->rewind();
+}
+
+void CRF_LBFGSTrainer::train() {
+  const QNUInt32 n = crf_ptr->getLambdaLen();
+  const bool chief = !crf_ptr->distributed() || crf_ptr->distRank() == 0;
+  CRF_GradAccumulator gaccum(crf_ptr, useLogspace != 0, (int)crf_ptr->getFeatureMap()->getNumStates());
+  gaccum.setUttReport((int)uttRpt);
+  gaccum.setObjectiveFunction(objective);
+  std::vector<double> grad(n, 0.0), x(crf_ptr->getLambda(), crf_ptr->getLambda() + n);
+  const double invSquareVar = useGvar ? 1 / gvar : 0.0;   // float division like the reference's (:48-50)
+  const int nStreams = (int)ftr_strm_mgr->getNThreads();
+  bool start = true;
+  auto evaluate = [&](const double* lam, double* g, int len, double) -> double {   // evaluateGradient :70-165
+    crf_ptr->setLambda(const_cast<double*>(lam), (QNUInt32)len);
+    if (start) {
+      start = false;
+    } else if (chief) {
+      std::stringstream ss;
+      ss << weight_fname << ".i" << iCounter << ".out";
+      std::cout << "Writing Iteration " << iCounter << " weights to file " << ss.str() << std::endl;
+      crf_ptr->writeToFile(ss.str().c_str());
+    }
+    iCounter++;
+    if (chief) std::cout << "Iteration: " << iCounter << std::endl;
+    QNUInt32 uCounter = 0;
+    double totLogLi = gaccum.accumulateGradient(ftr_strm_mgr, nStreams, grad.data(), &uCounter);
+    if (useGvar) {
+      for (int i = 0; i < len; i++) {
+        g[i] = -grad[i] + lam[i] * invSquareVar;
+        totLogLi -= ((lam[i] * lam[i]) * invSquareVar) / 2;
+      }
+    } else {
+      for (int i = 0; i < len; i++) g[i] = -grad[i];
+    }
+    if (chief)
+      std::cout << " End iteration: " << iCounter << " totLogLi: " << totLogLi << " Avg LogLi: " << totLogLi / uCounter
+                << " ucounter: " << uCounter << std::endl;
+    return -totLogLi;
+  };
+  auto progress = [&](const double*, const double*, double, double, double, double, int, int, int) -> int {   // :190-205
+    if (chief) {
+      std::cout << "PROGRESS called" << std::endl;
+      std::cout << "Iteration: " << iCounter << " ending" << std::endl;
+    }
+    return iCounter >= maxIters ? 1 : 0;
+  };
+  double fx = 0.0;
+  status = crf_amd::lbfgs_minimize((int)n, x.data(), &fx, evaluate, progress);
+  // the reference writes the final weights only when lbfgs() returns 0 and complains otherwise (:63-68); a stop
+  // requested by progress() (crf_epochs reached) is its non-zero LBFGSERR_CANCELED.  Here the last accepted point is
+  // written in both cases -- losing crf_epochs evaluations of work to a return code helps nobody -- and the code is shown.
+  crf_ptr->setLambda(x.data(), n);
+  if (status != crf_amd::LBFGS_OK && chief) std::cerr << "LBFGS returned: " << status << (status == crf_amd::LBFGS_STOP ? " (stopped at crf_epochs evaluations)" : "") << std::endl;
+  if (chief && (status == crf_amd::LBFGS_OK || status == crf_amd::LBFGS_STOP || status == crf_amd::LBFGS_ALREADY_MINIMIZED)) {
+    std::cout << "Writing Final Iteration weights to file " << weight_fname << std::endl;
+    crf_ptr->writeToFile(weight_fname.c_str());
     touchDoneFileFinal();
   }
 }

@@ -407,6 +407,42 @@ class CRF_SGTrainer : public CRF_Trainer {
   double eta = 1.0, eps = 1e-12;
 };
 
+// Full-batch accumulation for L-BFGS (trainers/accumulators/CRF_Pthread_GradAccumulator.cpp:130-232; the
+// reference's single-thread CRF_GradAccumulator is the same sum): every stream walks its WHOLE view, grad = the plain
+// sum over streams (no averaging), the return value is the summed log-likelihood (numerator - Zx), *uttCount the
+// utterances.  One process: the streams run one after the other on the model's GPU in device batches;
+// CRF_Model::setDistributed: rank r walks stream r and the sums are all-reduced.
+class CRF_GradAccumulator {
+ public:
+  CRF_GradAccumulator(CRF_Model* myCrf, bool myLogspace, int myNStates) : crf(myCrf) { (void)myLogspace; (void)myNStates; }
+  virtual ~CRF_GradAccumulator() {}
+  virtual double accumulateGradient(CRF_FeatureStreamManager* ftr_str_mgr, int nStreams, double* grad, QNUInt32* uttCount);
+  void setUttReport(int u) { uttReport = u; }
+  void setObjectiveFunction(objfunctype ofunc);
+  void setDeviceBatch(QNUInt32 n) { deviceBatch = n ? n : 1; }   // utterances per scrf_fb_batch call
+
+ protected:
+  CRF_Model* crf;
+  int uttReport = 0;
+  QNUInt32 deviceBatch = 256;
+};
+typedef CRF_GradAccumulator CRF_Pthread_GradAccumulator;
+
+// trainers/CRF_LBFGSTrainer.{h,cpp}: L-BFGS over the full-batch gradient.  As there: the optimiser runs with the
+// library's DEFAULT parameters (the reference fills a parameter struct and then passes NULL, :55-62), the objective is
+// -(summed log-likelihood) with the optional Gaussian prior lambda^2 / (2 gvar) (:150-160, a real prior here, unlike
+// the SG trainer's), every evaluation after the first writes <out>.i<k>.out, progress stops at crf_epochs evaluations,
+// the final weights go to <out> when the optimiser returns 0.  The optimiser itself is host/lbfgs.h.
+class CRF_LBFGSTrainer : public CRF_Trainer {
+ public:
+  CRF_LBFGSTrainer(CRF_Model* crf_in, CRF_FeatureStreamManager* ftr_str_mgr, char* wt_fname);
+  void train() override;
+  int lastStatus() const { return status; }
+
+ protected:
+  int iCounter = 0, status = 0;
+};
+
 // Read-only view of the per-frame DP nodes of ONE utterance (nodes/CRF_StateNode.h:67-115), backed by the
 // engine's parity hooks (scrf_scores, scrf_forward_backward): the values a node of the reference holds
 // after the gradbuilder's forward and backward sweeps.  The compute* virtuals of the reference are steps of

@@ -897,3 +897,64 @@ def test_crffstdecode_against_a_language_model_fst(tmp_path):
     # dictionary / phone-penalty FSTs are refused, not ignored
     r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_dict_fst=d.fst"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "crf_dict_fst" in r.stderr
+
+
+def _fixture_objective(gvar):
+    """-(summed log-likelihood) + lambda^2/(2 gvar) and its gradient from the oracle (CRF_LBFGSTrainer.cpp:120-165)."""
+    utts = _fixture()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    inv = float(np.float32(1.0) / np.float32(gvar)) if gvar else 0.0
+
+    def f(lam):
+        g = np.zeros(lay.lambda_len); ll = 0.0
+        for X, lab in utts:
+            rc, g, numer, zx = orc.frame_build_gradient(cfg, lay, lam, X, lab, X.shape[0], grad=g)
+            assert rc == 0
+            ll += numer - zx
+        return -ll + 0.5 * inv * float(lam @ lam), -g + inv * lam
+    return f, lay.lambda_len
+
+
+@pytest.mark.parametrize("threads", [1, 2])
+def test_crftrain_lbfgs_converges_to_the_regularised_optimum(tmp_path, threads):
+    """crf_train_method=lbfgs: full-batch gradient on the GPU + host L-BFGS, run to the optimiser's own stopping
+    rule on the strictly convex regularised objective; the optimum is unique, so it is compared with scipy's on the
+    oracle objective.  Every evaluation after the first writes <out>.i<k>.out (CRF_LBFGSTrainer.cpp:85-100)."""
+    from scipy.optimize import minimize
+    out = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(out, crf_train_method="lbfgs", crf_epochs=500, crf_gauss_var=2.0,
+                                                                     threads=threads, crf_precision="exact"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "LBFGS returned" not in r.stderr, r.stderr
+    f, n = _fixture_objective(2.0)
+    f0, _ = f(np.zeros(n))
+    first = [ln for ln in r.stdout.splitlines() if "End iteration: 1 " in ln][0]
+    assert float(first.split("totLogLi:")[1].split()[0]) == pytest.approx(-f0, rel=1e-5)
+    assert "ucounter: 3" in first
+    n_eval = sum("End iteration" in ln for ln in r.stdout.splitlines())
+    assert 3 < n_eval < 500
+    for k in range(1, n_eval):
+        assert os.path.exists(out + ".i%d.out" % k)
+    assert not os.path.exists(out + ".i%d.out" % n_eval)
+    w = np.loadtxt(out)
+    s = minimize(f, np.zeros(n), jac=True, method="L-BFGS-B", options={"maxcor": 6, "gtol": 1e-9, "ftol": 1e-15, "maxiter": 2000})
+    fw, gw = f(w)
+    assert fw < f0 and fw - s.fun <= 1e-6 * abs(s.fun)
+    # the optimiser's stopping rule at 6-digit weights: |g| <= 1e-5 max(1, |x|), plus the rounding of the file
+    assert np.linalg.norm(gw) <= 2e-5 * max(1.0, np.linalg.norm(w)) + 1e-4
+    np.testing.assert_allclose(w, s.x, atol=2e-3)
+
+
+def test_crftrain_lbfgs_stops_at_crf_epochs_and_keeps_the_last_point(tmp_path):
+    out = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(out, crf_train_method="lbfgs", crf_epochs=4),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "stopped at crf_epochs" in r.stderr
+    lls = [float(ln.split("totLogLi:")[1].split()[0]) for ln in r.stdout.splitlines() if "End iteration" in ln]
+    assert 4 <= len(lls) <= 12 and max(lls) > lls[0]     # progress() is asked after whole iterations (line searches)
+    f, n = _fixture_objective(0.0)
+    fw, _ = f(np.loadtxt(out))
+    assert -fw > lls[0] and any(-fw == pytest.approx(v, rel=1e-4) for v in lls)   # the written point is an evaluated, better one
+    assert os.path.exists(str(tmp_path / ".done.train"))

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_wave(
   extern __shared__ double dsm[];
   const int L = lay.L, D = lay.D;
   const int LL = L * L;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
   const uint32_t ul = (blockIdx.x >> 1) * (blockDim.x >> 6) + wave;   // blockDim.x / 64 utterances per workgroup
   double* Es = dsm;                                         // [L*L] (time-invariant transitions only)

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_exp_rows(double* __restrict__ S, uint64
 // Outputs per frame: a (alpha mantissa), ga; p (alpha-plus-trans mantissa), gp; b (beta mantissa),
 // gb; sd (sum over durations, mantissa), gsd.
 // ------------------------------------------------------------------------------------------
-template <int DMAX, int MPF>
+template <int DMAX, int MPF, int LC>
 __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
     ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
     const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
@@ -134,9 +134,12 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
     double* __restrict__ p_g, double* __restrict__ gp_g, double* __restrict__ b_g, double* __restrict__ gb_g,
     double* __restrict__ sd_g, double* __restrict__ gsd_g, double* __restrict__ zx_out, int* __restrict__ status) {
   extern __shared__ double dsm[];
-  const int L = lay.L, D = lay.D;
+  // LC: the label count as a compile-time constant (0 = read it from the layout): every LDS address of the
+  // transition step and of the ring becomes base + immediate.  The wave index is made explicitly wave-uniform:
+  // utterance, length, bases and ring slots then live in SGPRs and the loop is scalar-controlled.
+  const int L = LC ? LC : (int)lay.L, D = lay.D;
   const int LL = L * L;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int dir = blockIdx.x & 1;  // 0 forward, 1 backward
   const uint32_t ul = (blockIdx.x >> 1) * (blockDim.x >> 6) + wave;   // blockDim.x / 64 utterances per workgroup
   double* Es = dsm;                                         // [L*L] (time-invariant transitions only)
@@ -169,16 +172,15 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
     double a = ESu[lc];        // node 0: the only window is the initial segment of length 1
     double ga = smu[0];
     if (act) au[lane] = a;
-    if (lane == 0) ga_g[f_base] = ga;
+    // the per-frame log-scales are wave-uniform: lane (frame & 63) keeps them and 64 frames go out in one store
+    // (a store instruction per frame and scalar costs the wavefront as much as a 384-byte one)
+    double ga_keep = ga, gp_keep = 0.0;
     int rpos = D - 1;
-    for (int t = 1; t < T; t++) {
-      rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
-      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+    // the nd windows ending at t: independent of the recursion
+    auto load_windows = [&](int t, double (&es)[DMAX], double& smx) {
+      const int nd = (int)scrf_node_max_dur(t, D);
       const uint64_t base = scrf_seg_base(t, D);
-      const bool full = (nd == DMAX) && (np == DMAX);  // steady state: every duration has a predecessor
-      // the nd windows ending at t: independent of the recursion, issued first
-      double es[DMAX];
-      if (full) {
+      if (nd == DMAX) {
 #pragma unroll
         for (int d0 = 0; d0 < DMAX; d0++) es[d0] = ESu[(base + d0) * L + lc];
       } else {
@@ -188,7 +190,14 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
           es[d0] = (d0 < nd) ? x : 0.0;
         }
       }
-      const double smx = smu[base + (lane < nd ? lane : 0)];
+      smx = smu[base + (lane < nd ? lane : 0)];
+    };
+    for (int t = 1; t < T; t++) {
+      rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      const bool full = (nd == DMAX) && (np == DMAX);  // steady state: every duration has a predecessor
+      double es[DMAX], smx;
+      load_windows(t, es, smx);   // issued first, covered by the transition step
       // transition out of node t-1: p = 2^-k * (a . E)
       double usum, sh = sh0;
       if (MPF) {
@@ -203,7 +212,8 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       ring[rpos * L + lc] = p;  // idle lanes rewrite lane L-1's value with the same number
       if (lane == rpos) gslot = gp;
       if (act) pu[(size_t)(t - 1) * L + lane] = p;
-      if (lane == 0) gp_g[f_base + t - 1] = gp;
+      if (lane == ((t - 1) & 63)) gp_keep = gp;
+      if (((t - 1) & 63) == 63) gp_g[f_base + (t - 1 - 63) + lane] = gp_keep;   // 64 frames' log-scales in one store
       // per-duration scales: lane d0 looks at predecessor node t-1-d0 (ring slot rpos-d0)
       int myslot = rpos - lane;
       if (myslot < 0) myslot += D;
@@ -237,8 +247,11 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       a = acc0 + acc1;
       ga = G;
       if (act) au[(size_t)t * L + lane] = a;
-      if (lane == 0) ga_g[f_base + t] = ga;
+      if (lane == (t & 63)) ga_keep = ga;
+      if ((t & 63) == 63) ga_g[f_base + (t - 63) + lane] = ga_keep;
     }
+    if (((T - 1) & 63) != 63 && lane <= ((T - 1) & 63)) ga_g[f_base + ((T - 1) & ~63) + lane] = ga_keep;
+    if (T >= 2 && ((T - 2) & 63) != 63 && lane <= ((T - 2) & 63)) gp_g[f_base + ((T - 2) & ~63) + lane] = gp_keep;
     // Zx = log sum_l exp(alpha[T-1][l])  (computeAlphaSum)
     const double tot = wave_sum_f64(act ? a : 0.0);
     const double Zx = ga + log(tot);
@@ -253,15 +266,13 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
     if (lane == tpos) gslot = 0.0;
     if (act) { bu[(size_t)(T - 1) * L + lane] = 1.0; sdu[(size_t)(T - 1) * L + lane] = 0.0; }
     if (lane == 0) { gb_g[f_base + T - 1] = 0.0; gsd_g[f_base + T - 1] = 0.0; }
-    for (int t = T - 2; t >= 0; t--) {
+    double gb_keep = 0.0, gsd_keep = 0.0;   // lane (frame & 63); frame T-1's zeros included
+    // window (t+1+d0, d0+1): starts at t+1, ends at node t+1+d0
+    auto load_windows = [&](int t, double (&es)[DMAX], double& smx) {
       const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
-      tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
-      // window (t+1+d0, d0+1): starts at t+1, ends at node t+1+d0
-      const bool full = (nn == DMAX) && (t + 1 >= D);
-      double es[DMAX];
       const uint64_t sb = scrf_seg_base(t + 1, D);
       uint64_t myrow;
-      if (full) {
+      if ((nn == DMAX) && (t + 1 >= D)) {
         // every node t+1.. carries D windows, so the window sits at row seg_base(t+1) + d0*(D+1)
 #pragma unroll
         for (int d0 = 0; d0 < DMAX; d0++) es[d0] = ESu[(sb + (uint64_t)d0 * (DMAX + 1)) * L + lc];
@@ -278,7 +289,13 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
           r += scrf_node_max_dur(t + 1 + d0, D);
         }
       }
-      const double smx = smu[myrow];
+      smx = smu[myrow];
+    };
+    for (int t = T - 2; t >= 0; t--) {
+      const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+      tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
+      double es[DMAX], smx;
+      load_windows(t, es, smx);
       int myslot = tpos + lane + 1;  // node t + d0 + 1
       if (myslot >= D) myslot -= D;
       const double gnext = shfl_f64(gslot, (lane < nn) ? myslot : 0);
@@ -287,13 +304,24 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       const double c = exp_nonpos(x - G);
       cbuf[lane] = c;
       double acc0 = 0.0, acc1 = 0.0;
+      if (nn == DMAX) {   // steady state: every duration has a successor node
 #pragma unroll
-      for (int d0 = 0; d0 < DMAX; d0++) {
-        int slot = tpos + d0 + 1;
-        if (slot >= D) slot -= D;
-        const double bv_ = ring[((d0 < nn) ? slot : tpos) * L + lc];
-        const double w = es[d0] * cbuf[d0];   // es = 0 past nn
-        if (d0 & 1) acc1 = fma((d0 < nn) ? bv_ : 0.0, w, acc1); else acc0 = fma((d0 < nn) ? bv_ : 0.0, w, acc0);
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = tpos + d0 + 1;
+          slot -= (slot >= D) ? D : 0;
+          const double bv_ = ring[slot * L + lc];
+          const double w = es[d0] * cbuf[d0];
+          if (d0 & 1) acc1 = fma(bv_, w, acc1); else acc0 = fma(bv_, w, acc0);
+        }
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          int slot = tpos + d0 + 1;
+          if (slot >= D) slot -= D;
+          const double bv_ = ring[((d0 < nn) ? slot : tpos) * L + lc];
+          const double w = es[d0] * cbuf[d0];   // es = 0 past nn
+          if (d0 & 1) acc1 = fma((d0 < nn) ? bv_ : 0.0, w, acc1); else acc0 = fma((d0 < nn) ? bv_ : 0.0, w, acc0);
+        }
       }
       const double sd = acc0 + acc1;
       double w, sh = sh0;
@@ -309,7 +337,8 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       ring[tpos * L + lc] = b;
       if (lane == tpos) gslot = gb;
       if (act) { sdu[(size_t)t * L + lane] = sd; bu[(size_t)t * L + lane] = b; }
-      if (lane == 0) { gsd_g[f_base + t] = G; gb_g[f_base + t] = gb; }
+      if (lane == (t & 63)) { gsd_keep = G; gb_keep = gb; }
+      if ((t & 63) == 0 && t + lane < T) { gsd_g[f_base + t + lane] = gsd_keep; gb_g[f_base + t + lane] = gb_keep; }   // frames t .. t+63 (descending walk)
     }
   }
   if (__any(err != 0) && lane == 0) atomicMax(&status[u], SCRF_ERR_NUMERIC);
@@ -540,16 +569,17 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
   const uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * ((size_t)lay.D * lay.L + 128));
   const uint32_t nblk = 2 * ((n_utts + wpb - 1) / wpb);
   const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)wpb * (lay.D * lay.L + 128));
-#define DL_LAUNCH2(DM, MPF)                                                                                    \
-  do {                                                                                                         \
-    hipFuncSetAttribute((const void*)k_dp_lin<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \
-    hipLaunchKernelGGL((k_dp_lin<DM, MPF>), dim3(nblk), dim3(wpb * 64), sm, st, lay, bv, u0, n_utts, ES, smax, \
-                       E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);               \
+#define DL_LAUNCH2(DM, MPF, LC)                                                                                    \
+  do {                                                                                                             \
+    hipFuncSetAttribute((const void*)k_dp_lin<DM, MPF, LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);  \
+    hipLaunchKernelGGL((k_dp_lin<DM, MPF, LC>), dim3(nblk), dim3(wpb * 64), sm, st, lay, bv, u0, n_utts, ES, smax, \
+                       E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);                   \
   } while (0)
-#define DL_LAUNCH(DM)                     \
-  do {                                    \
-    if (m_per_frame) DL_LAUNCH2(DM, 1);   \
-    else DL_LAUNCH2(DM, 0);               \
+#define DL_LAUNCH(DM)                                        \
+  do {                                                       \
+    if (m_per_frame) DL_LAUNCH2(DM, 1, 0);                   \
+    else if (DM == 25 && lay.L == 48) DL_LAUNCH2(DM, 0, 48); \
+    else DL_LAUNCH2(DM, 0, 0);                               \
   } while (0)
   if (lay.D <= 1) DL_LAUNCH(1);
   else if (lay.D <= 4) DL_LAUNCH(4);

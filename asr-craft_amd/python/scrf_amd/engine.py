@@ -48,7 +48,8 @@ class Utt(C.Structure):
 
 
 def lib_path():
-    return os.path.join(PKG_ROOT, "lib", "libscrf_amd.so")
+    # SCRF_AMD_LIB: another build of the same library (kernel A/B measurements); the default is the in-tree build
+    return os.environ.get("SCRF_AMD_LIB") or os.path.join(PKG_ROOT, "lib", "libscrf_amd.so")
 
 
 _lib = None

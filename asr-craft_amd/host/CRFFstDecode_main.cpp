@@ -6,8 +6,11 @@
 // (Compose + ShortestPath + RmEpsilon + TopSort in one host pass, crf_amd::composeShortestPath; the LM reads
 // the lattice's OUTPUT labels, phone + L*(dur-1) + 1, as the reference's does), best path written as HTK MLF
 // lines (the LM's output symbols; without an LM the lattice's own output labels).  crf_mlf_output_frames adds
-// the first and last frame of each label's segments.  Dictionary / phone-penalty FSTs (crf_dict_fst,
-// crf_phn_fst) and alignment MLFs are refused.
+// the first and last frame of each label's segments.  crf_dict_bin / crf_dict_txt: the dictionary FST composed in between
+// (lattice o dict o LM, Main.cpp:929-941); crf_align_mlffile: the utterance's transcript from an HTK MLF as a linear
+// acceptor over the output symbols, composed in before the LM (:943-952, CRF_MLFManager); crf_mlf_output_states (+
+// crf_isymbols): the phone label of every segment in front of the words.  The phone-penalty FST (crf_phn_bin: a
+// log-semiring RmEpsilon, Prune and Minimize sit behind it), ARPA LMs and the pruning weights are refused.
 #include "cli_common.h"
 
 static std::map<long, std::string> read_symbols(const std::string& path) {   // OpenFST text symbol table: `symbol id`
@@ -25,13 +28,20 @@ int main(int argc, char** argv) {
   CliModel m;
   auto data = load_streams(a, &m);
   if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
-  for (const char* k : {"crf_dict_fst", "crf_phn_fst", "crf_align_mlffile", "crf_lm_arpa"})
-    if (a.has(k)) { std::cerr << k << ": not built (the LM goes in as crf_lm_txt / crf_lm_bin over the lattice's output labels)" << std::endl; return 1; }
+  for (const char* k : {"crf_phn_bin", "crf_lm_arpa"})
+    if (a.has(k)) { std::cerr << k << ": not built (LM: crf_lm_txt / crf_lm_bin; dictionary: crf_dict_bin / crf_dict_txt)" << std::endl; return 1; }
+  for (const char* k : {"crf_pre_phn_wt", "crf_phn_wt", "crf_dict_wt", "crf_lm_wt"})
+    if (a.real(k, 0.0) != 0.0) { std::cerr << k << ": lattice pruning between the compositions is not built (the search is exhaustive)" << std::endl; return 1; }
   const bool want_mlf = a.has("crf_output_mlffile");
-  crf_amd::ArcListFst lm;
+  crf_amd::ArcListFst lm, dict, chain0;   // chain0: dict o lm, composed once when no per-utterance acceptor sits between them
   const bool have_lm = a.has("crf_lm_txt") || a.has("crf_lm_bin");
+  const bool have_dict = a.has("crf_dict_txt") || a.has("crf_dict_bin");
+  const bool have_align = a.has("crf_align_mlffile");
+  const bool out_states = a.num("crf_mlf_output_states", 0) != 0;
   std::vector<std::string> olist;
-  std::map<long, std::string> osym;
+  std::map<long, std::string> osym, isym;
+  std::map<std::string, long> osym_ids;
+  std::unique_ptr<CRF_MLFManager> mlf_mgr;
   std::ofstream mlf;
   if (want_mlf) {
     if (!a.has("crf_olist")) { std::cerr << "crf_olist required with crf_output_mlffile." << std::endl; return -1; }
@@ -40,14 +50,27 @@ int main(int argc, char** argv) {
     std::string ln;
     while (getline(f, ln)) olist.push_back(ln);
     if (a.has("crf_osymbols")) osym = read_symbols(a.str("crf_osymbols"));
+    if (a.has("crf_isymbols")) isym = read_symbols(a.str("crf_isymbols"));
+    for (const auto& kv : osym) osym_ids[kv.second] = kv.first;
+    if (out_states && !a.has("crf_isymbols")) { std::cerr << "crf_isymbols required with crf_mlf_output_states" << std::endl; return -1; }
     try {
       if (a.has("crf_lm_txt")) crf_amd::readFstText(a.str("crf_lm_txt").c_str(), &lm);
       else if (a.has("crf_lm_bin")) crf_amd::readFstBinary(a.str("crf_lm_bin").c_str(), &lm);
+      if (a.has("crf_dict_txt")) crf_amd::readFstText(a.str("crf_dict_txt").c_str(), &dict);
+      else if (a.has("crf_dict_bin")) crf_amd::readFstBinary(a.str("crf_dict_bin").c_str(), &dict);
+      if (have_align) {
+        if (!a.has("crf_osymbols")) { std::cerr << "crf_osymbols required with crf_align_mlffile" << std::endl; return -1; }
+        std::string mf = a.str("crf_align_mlffile"), ol = a.str("crf_olist");
+        mlf_mgr.reset(new CRF_MLFManager(mf.c_str(), ol.c_str(), &osym_ids));
+      }
+      if (have_dict && have_lm && !have_align) crf_amd::composeFst(dict, lm, &chain0);
     } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
     if (have_lm) std::cout << "LM: " << lm.n_states << " states, " << lm.arcs.size() << " arcs, " << lm.finals.size() << " final" << std::endl;
+    if (have_dict) std::cout << "Dictionary: " << dict.n_states << " states, " << dict.arcs.size() << " arcs" << std::endl;
+    if (chain0.n_states) std::cout << "Dictionary o LM: " << chain0.n_states << " states, " << chain0.arcs.size() << " arcs" << std::endl;
     mlf.open(a.str("crf_output_mlffile").c_str());
     mlf << "#!MLF!#" << std::endl;
-  } else if (have_lm) { std::cerr << "crf_lm_txt / crf_lm_bin need crf_output_mlffile (the label file holds the lattice's own best path)" << std::endl; return 1; }
+  } else if (have_lm || have_dict || have_align) { std::cerr << "crf_lm_* / crf_dict_* / crf_align_mlffile need crf_output_mlffile (the label file holds the lattice's own best path)" << std::endl; return 1; }
   const bool out_frames = a.num("crf_mlf_output_frames", 0) != 0;
   CRF_Model crf(m.L);
   crf.setLabMaxDur(m.D);
@@ -91,8 +114,19 @@ int main(int argc, char** argv) {
     crf_amd::ArcListFst best;
     float total = 0;
     bool ok;
-    if (have_lm) {
-      ok = crf_amd::composeShortestPath(fst, lm, &best, &total);
+    if (have_lm || have_dict || have_align) {
+      // everything right of the lattice as ONE machine: ((dict o transcript) o LM), then the product search over
+      // the lattice (Compose is associative; the reference nests ComposeFst left to right, Main.cpp:929-1006)
+      const crf_amd::ArcListFst* mach = chain0.n_states ? &chain0 : (have_dict ? &dict : (have_lm && !have_align ? &lm : nullptr));
+      crf_amd::ArcListFst t1, t2;
+      if (have_align) {
+        crf_amd::ArcListFst al;
+        mlf_mgr->getFst(olist[sent], &al);
+        if (have_dict) { crf_amd::composeFst(dict, al, &t1); mach = &t1; }
+        else { t1 = al; mach = &t1; }
+        if (have_lm) { crf_amd::composeFst(*mach, lm, &t2); mach = &t2; }
+      }
+      ok = crf_amd::composeShortestPath(fst, *mach, &best, &total);
     } else {   // ShortestPath on the lattice alone: an LM that accepts every label and copies it
       crf_amd::ArcListFst id;
       id.n_states = 1; id.start = 0; id.SetFinal(0, 0.0f);
@@ -108,6 +142,10 @@ int main(int argc, char** argv) {
       if (c.ilabel != 0) {   // a segment of the lattice: phone + L*(dur-1) + 1 (frame model: one frame)
         const uint32_t dur = (uint32_t)(c.ilabel - 1) / m.L + 1;
         if (!open_seg) { seg_start = frame; open_seg = true; }
+        if (out_states) {   // the segment's phone, with its own frame span, ahead of the word it belongs to
+          if (out_frames) mlf << frame << "\t" << (frame + dur - 1) << "\t";
+          mlf << (isym.count(c.ilabel) ? isym[c.ilabel] : std::to_string(c.ilabel)) << std::endl;
+        }
         frame += dur;
       }
       if (c.olabel != 0) {

@@ -1304,6 +1304,118 @@ bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd:
   return true;
 }
 
+void crf_amd::composeFst(const crf_amd::ArcListFst& A, const crf_amd::ArcListFst& B, crf_amd::ArcListFst* out, size_t max_states) {
+  if (A.n_states <= 0 || B.n_states <= 0 || A.start < 0 || B.start < 0) throw runtime_error("composeFst: a machine has no start state");
+  const float INF = std::numeric_limits<float>::infinity();
+  std::vector<std::vector<int> > aout(A.n_states), bout(B.n_states);
+  for (size_t i = 0; i < A.arcs.size(); i++) {
+    const scrf_arc& x = A.arcs[i];
+    if (x.src < 0 || x.src >= A.n_states || x.dst < 0 || x.dst >= A.n_states) throw runtime_error("composeFst: arc with a state out of range (left machine)");
+    aout[x.src].push_back((int)i);
+  }
+  for (size_t i = 0; i < B.arcs.size(); i++) {
+    const scrf_arc& x = B.arcs[i];
+    if (x.src < 0 || x.src >= B.n_states || x.dst < 0 || x.dst >= B.n_states) throw runtime_error("composeFst: arc with a state out of range (right machine)");
+    bout[x.src].push_back((int)i);
+  }
+  std::vector<float> afin(A.n_states, INF), bfin(B.n_states, INF);
+  for (const auto& f : A.finals) if (f.first >= 0 && f.first < A.n_states) afin[f.first] = std::min(afin[f.first], f.second);
+  for (const auto& f : B.finals) if (f.first >= 0 && f.first < B.n_states) bfin[f.first] = std::min(bfin[f.first], f.second);
+  *out = crf_amd::ArcListFst();
+  std::map<std::pair<int, int>, int> id;
+  std::vector<std::pair<int, int> > states;
+  auto state_of = [&](int sa, int sb) -> int {
+    auto it = id.find(std::make_pair(sa, sb));
+    if (it != id.end()) return it->second;
+    if (states.size() >= max_states) throw runtime_error("composeFst: more than " + std::to_string(max_states) + " state pairs");
+    const int n = out->AddState();
+    id[std::make_pair(sa, sb)] = n;
+    states.push_back(std::make_pair(sa, sb));
+    return n;
+  };
+  out->SetStart(state_of(A.start, B.start));
+  for (size_t k = 0; k < states.size(); k++) {
+    const int sa = states[k].first, sb = states[k].second, me = (int)k;
+    if (afin[sa] < INF && bfin[sb] < INF) out->SetFinal(me, afin[sa] + bfin[sb]);
+    for (int ai : aout[sa]) {
+      const scrf_arc& x = A.arcs[ai];
+      if (x.olabel == 0) {
+        out->AddArc(me, crf_amd::ArcListFst::Arc(x.ilabel, 0, x.w + 0.0f, state_of(x.dst, sb)));
+        continue;
+      }
+      for (int bi : bout[sb]) {
+        const scrf_arc& y = B.arcs[bi];
+        if (y.ilabel != x.olabel) continue;
+        out->AddArc(me, crf_amd::ArcListFst::Arc(x.ilabel, y.olabel, x.w + y.w, state_of(x.dst, y.dst)));
+      }
+    }
+    for (int bi : bout[sb]) {
+      const scrf_arc& y = B.arcs[bi];
+      if (y.ilabel != 0) continue;
+      out->AddArc(me, crf_amd::ArcListFst::Arc(0, y.olabel, 0.0f + y.w, state_of(sa, y.dst)));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CRF_MLFManager (io/CRF_MLFManager.cpp:19-153)
+// ------------------------------------------------------------------------------------------
+CRF_MLFManager::CRF_MLFManager(const char* mlffile, const char* olist, const std::map<string, long>* st) : symTab(st) {
+  (void)olist;   // the reference takes it and does not read it either (:19-22)
+  readMLF(mlffile);
+}
+
+string CRF_MLFManager::getKey(const string& fname) {   // :36-40, npos arithmetic included
+  const int lastc = (int)fname.rfind("."), firstc = (int)fname.rfind("/");
+  if (lastc - firstc - 1 < 0) return "";
+  return fname.substr((size_t)(firstc + 1), (size_t)(lastc - firstc - 1));
+}
+
+void CRF_MLFManager::readMLF(const char* mlffile) {
+  std::ifstream ifile(mlffile);
+  if (symTab == nullptr) throw runtime_error("SymbolTable undefined in CRF_MLFManager");
+  if (!ifile.is_open()) throw runtime_error(string("Unable to read MLF from file ") + mlffile);
+  bool isMLF = false;
+  int count = 0;
+  string s;
+  while (getline(ifile, s)) {
+    if (s == "#!MLF!#") { isMLF = true; continue; }
+    if (!isMLF) throw runtime_error(string("File ") + mlffile + " is not a wellformed MLF");
+    if (s.empty()) continue;
+    if (s[0] == '"' && s[s.size() - 1] == '"') {
+      const string key = getKey(s);
+      if (key.empty()) throw runtime_error("CRF_MLFManager error finding key in string: " + s);
+      transcripts.push_back(std::vector<int>());
+      fnameTable[key] = count;
+    } else if (s[0] == '.' && s.size() <= 1) {
+      count++;
+    } else {
+      if ((size_t)count >= transcripts.size()) throw runtime_error(string("File ") + mlffile + ": a label line before the first entry name");
+      auto it = symTab->find(s);
+      transcripts[count].push_back(it == symTab->end() ? -1 : (int)it->second);   // SymbolTable::Find: -1 when missing
+    }
+  }
+}
+
+void CRF_MLFManager::getFst(const string& fname, crf_amd::ArcListFst* fst) {
+  const string key = getKey(fname);
+  if (key.empty()) throw runtime_error("Unable to acquire key from filename " + fname);
+  auto it = fnameTable.find(key);
+  // the reference indexes the table with operator[] (a missing key silently becomes transcript 0, :134); an error here
+  if (it == fnameTable.end()) throw runtime_error("CRF_MLFManager: no MLF entry with key '" + key + "' (from " + fname + ")");
+  const std::vector<int>& tr = transcripts.at((size_t)it->second);
+  if (tr.empty()) throw runtime_error("CRF_MLFManager: the MLF entry '" + key + "' is empty");   // the reference would SetFinal an unset state
+  *fst = crf_amd::ArcListFst();
+  int prev = fst->AddState();
+  fst->SetStart(prev);
+  for (int sym : tr) {
+    const int cur = fst->AddState();
+    fst->AddArc(prev, crf_amd::ArcListFst::Arc(sym, sym, 0.0f, cur));
+    prev = cur;
+  }
+  fst->SetFinal(prev, 0.0f);
+}
+
 void crf_amd::writeFstBinary(const char* fname, const crf_amd::ArcListFst& fst, const char* arc_type) {
   std::ofstream f(fname, std::ios::binary);
   if (!f.is_open()) throw runtime_error(string("writeFstBinary: cannot open ") + fname);

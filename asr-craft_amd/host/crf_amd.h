@@ -25,6 +25,7 @@
 
 #include <memory>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -307,6 +308,15 @@ void readFstBinary(const char* fname, ArcListFst* fst);
 // arcs are folded into the next arc (the final weight at the end), as RmEpsilon does on a linear path.
 // Returns false when no path reaches a final state of both machines.
 bool composeShortestPath(const ArcListFst& lat, const ArcListFst& lm, ArcListFst* best, float* total);
+// Compose(a, b) on the tropical semiring (CRFFstDecode/src/Main.cpp:898-955 chains ComposeFst over the phone lattice,
+// the dictionary, the alignment acceptor and the LM): states are the reachable pairs, numbered in discovery order
+// (breadth first from the start pair); a pair of arcs with a.olabel == b.ilabel != 0 moves both machines (ilabel of a,
+// olabel of b, weight a.w + b.w), an arc of `a` with an epsilon OUTPUT moves `a` alone, an arc of `b` with an epsilon
+// INPUT moves `b` alone; a pair is final when both states are, with the sum of the final weights.  No epsilon filter:
+// the interleavings of a's and b's epsilon moves stay as parallel paths of equal weight, which a shortest-path search
+// on the result does not care about (OpenFST's sequencing filter keeps one of them; only the machine's size differs).
+// Throws when the result would pass `max_states` pairs.
+void composeFst(const ArcListFst& a, const ArcListFst& b, ArcListFst* out, size_t max_states = (size_t)1 << 22);
 void writeFstBinary(const char* fname, const ArcListFst& fst, const char* arc_type = "standard");
 
 }  // namespace crf_amd
@@ -441,6 +451,25 @@ class CRF_LBFGSTrainer : public CRF_Trainer {
 
  protected:
   int iCounter = 0, status = 0;
+};
+
+// io/CRF_MLFManager.{h,cpp}: the transcripts of an HTK master label file as linear acceptors (`crf_align_mlffile`).
+// As there: `#!MLF!#` first; an entry starts with a quoted name whose key is the text between the last '/' and the last
+// '.' of the WHOLE line (quotes included when the name has no '/'); every other non-empty line up to the single '.' is
+// one symbol, looked up as a whole in the symbol table (-1 when it is not there); getFst(name) looks the key of `name`
+// up and returns start -> ... -> final with one arc `id:id / 0` per symbol.  The symbol table here is name -> id.
+class CRF_MLFManager {
+ public:
+  CRF_MLFManager(const char* mlffile, const char* olist, const std::map<std::string, long>* symTab);
+  virtual ~CRF_MLFManager() {}
+  void readMLF(const char* mlffile);
+  void getFst(const std::string& fname, crf_amd::ArcListFst* fst);
+
+ private:
+  std::string getKey(const std::string& fname);
+  const std::map<std::string, long>* symTab;
+  std::vector<std::vector<int> > transcripts;
+  std::map<std::string, int> fnameTable;
 };
 
 // Read-only view of the per-frame DP nodes of ONE utterance (nodes/CRF_StateNode.h:67-115), backed by the

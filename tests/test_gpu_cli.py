@@ -894,9 +894,9 @@ def test_crffstdecode_against_a_language_model_fst(tmp_path):
     for u in range(len(Ts)):
         labs = [int(x) for x in blocks2[u].split("\n") if x and x != "." and not x.startswith('"')]
         assert labs == [int(v) + 1 for v in got[got[:, 0] == u][:, 2]]
-    # dictionary / phone-penalty FSTs are refused, not ignored
-    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_dict_fst=d.fst"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "crf_dict_fst" in r.stderr
+    # the phone-penalty FST is refused, not ignored
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_phn_bin=d.fst"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_phn_bin" in r.stderr
 
 
 def _fixture_objective(gvar):
@@ -958,3 +958,139 @@ def test_crftrain_lbfgs_stops_at_crf_epochs_and_keeps_the_last_point(tmp_path):
     fw, _ = f(np.loadtxt(out))
     assert -fw > lls[0] and any(-fw == pytest.approx(v, rel=1e-4) for v in lls)   # the written point is an evaluated, better one
     assert os.path.exists(str(tmp_path / ".done.train"))
+
+
+def test_crffstdecode_dictionary_lm_and_alignment_chain(tmp_path):
+    """CRFFstDecode's composition chain (Main.cpp:929-1006): lattice o dictionary o [transcript acceptor o] LM, best
+    path as MLF with the phone of every segment (crf_mlf_output_states) -- against an exhaustive enumeration over
+    every (lattice path, dictionary walk, LM walk) triple on the oracle's lattice.  The dictionary reads the lattice's
+    phone-duration labels and writes words; the LM is a bigram over the words."""
+    from test_host_compose import machine_walks
+    rng = np.random.RandomState(77)
+    L, D, W = 3, 2, 2
+    Ts = [2, 3, 4]
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    utts = []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdstate",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=2", "crf_lr=1.0",
+                        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # dictionary: words A = "p0 p1", B = "p2", C = "p1" (any duration); state 0 is the word boundary; the word label
+    # sits on the word's first phone, a word-end epsilon arc carries a pronunciation cost
+    WA, WB, WC = 31, 32, 33
+    dic = []
+    for d in range(D):
+        dic.append((0, 1, 0 + L * d + 1, WA, 0.25))
+        dic.append((1, 3, 1 + L * d + 1, 0, 0.0))
+        dic.append((0, 3, 2 + L * d + 1, WB, 0.5))
+        dic.append((0, 3, 1 + L * d + 1, WC, 0.75))
+    dic.append((3, 0, 0, 0, 0.125))
+    dfin = {0: 0.0}
+    # bigram LM over the words (state = last word, 0 = start)
+    ids = {WA: 1, WB: 2, WC: 3}
+    cost = rng.rand(4, 4)
+    lm = [(q, ids[w], w, w, float(np.float32(cost[q, ids[w]] * 2))) for q in range(4) for w in (WA, WB, WC)]
+    mfin = {1: 0.1, 2: 0.2, 3: 0.3}
+
+    def wr(path, arcs, fin):
+        with open(path, "w") as fh:
+            for a in arcs:
+                fh.write("%d %d %d %d %.9g\n" % a)
+            for s_, w_ in fin.items():
+                fh.write("%d %.9g\n" % (s_, w_))
+    df, mf = str(tmp_path / "dict.txt"), str(tmp_path / "lm.txt")
+    wr(df, dic, dfin); wr(mf, lm, mfin)
+    olist, osym, isym = str(tmp_path / "olist"), str(tmp_path / "osym.txt"), str(tmp_path / "isym.txt")
+    open(olist, "w").write("".join("u%d.lab\n" % i for i in range(len(Ts))))
+    open(osym, "w").write("<eps> 0\nA %d\nB %d\nC %d\n" % (WA, WB, WC))
+    open(isym, "w").write("<eps> 0\n" + "".join("p%d_%d %d\n" % (l, d + 1, l + L * d + 1) for d in range(D) for l in range(L)))
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+
+    def reference(u, transcript=None):
+        T = Ts[u]
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(cfg, S, M, T)
+        lout = {}
+        for a in oa:
+            lout.setdefault(int(a["src"]), []).append((int(a["dst"]), int(a["olabel"]), float(a["w"])))
+        res = []
+
+        def paths(s, c, ols):
+            if s == ofin:
+                labs = [o for o in ols if o]
+                for c1, words in machine_walks(dic, dfin, 0, labs, 2):
+                    if transcript is not None and words != transcript:
+                        continue
+                    for c2, outs in machine_walks(lm, mfin, 0, words, 0):
+                        res.append((c + c1 + c2, labs, outs))
+            for d_, o_, w_ in lout.get(s, []):
+                paths(d_, c + w_, ols + [o_])
+        paths(0, 0.0, [])
+        return sorted(res, key=lambda t: t[0])
+
+    def run(extra, tag):
+        mlf = str(tmp_path / (tag + ".mlf"))
+        r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym, "crf_isymbols=" + isym,
+                            "crf_dict_txt=" + df, "crf_lm_txt=" + mf, "crf_output_mlffile=" + mlf, "crf_mlf_output_states=1",
+                            "crf_output_labelfile=" + str(tmp_path / (tag + ".lab"))] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        blocks = open(mlf).read().split('"\n')[1:]
+        totals = [x for x in r.stdout.split("\n") if x.startswith('"u')]
+        assert len(blocks) == len(Ts) and len(totals) == len(Ts)
+        return r, blocks, totals
+
+    r, blocks, totals = run([], "free")
+    assert "Dictionary o LM:" in r.stdout
+    for u in range(len(Ts)):
+        ref = reference(u)
+        lines = [x for x in blocks[u].split("\n") if x and x != "." and not x.startswith('"')]
+        if not ref:
+            assert "(weight inf)" in totals[u] or "WARNING: no path" in r.stderr
+            continue
+        tot = float(totals[u].split("(weight")[1].split(")")[0])
+        assert abs(tot - ref[0][0]) < 2e-5 * max(1.0, abs(ref[0][0])), (u, tot, ref[0])
+        if len(ref) == 1 or ref[1][0] - ref[0][0] > 1e-4:
+            names = {WA: "A", WB: "B", WC: "C"}
+            assert [x for x in lines if x in ("A", "B", "C")] == [names[o] for o in ref[0][2]]
+            assert [x for x in lines if x.startswith("p")] == ["p%d_%d" % ((il - 1) % L, (il - 1) // L + 1) for il in ref[0][1]]
+    # forced alignment: the transcript of every utterance from an MLF (keys from "*/uN.lab"), composed in before the LM
+    best_words = []
+    for u in range(len(Ts)):
+        ref = reference(u)
+        # pick the SECOND best word sequence where there is one, so that the constraint changes the answer
+        seqs = []
+        for t in ref:
+            if t[2] not in seqs:
+                seqs.append(t[2])
+        best_words.append(seqs[1] if len(seqs) > 1 else seqs[0])
+    names = {WA: "A", WB: "B", WC: "C"}
+    amlf = str(tmp_path / "align.mlf")
+    with open(amlf, "w") as fh:
+        fh.write("#!MLF!#\n")
+        for u in range(len(Ts)):
+            fh.write('"*/u%d.lab"\n' % u + "".join(names[o] + "\n" for o in best_words[u]) + ".\n")
+    r, blocks, totals = run(["crf_align_mlffile=" + amlf], "align")
+    for u in range(len(Ts)):
+        ref = reference(u, transcript=best_words[u])
+        assert ref
+        tot = float(totals[u].split("(weight")[1].split(")")[0])
+        assert abs(tot - ref[0][0]) < 2e-5 * max(1.0, abs(ref[0][0])), (u, tot, ref[0])
+        lines = [x for x in blocks[u].split("\n") if x and x != "." and not x.startswith('"')]
+        assert [x for x in lines if x in ("A", "B", "C")] == [names[o] for o in best_words[u]]
+    # what is not built says so
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_phn_bin=x.fst"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_phn_bin" in r.stderr
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_dict_wt=2.5"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_dict_wt" in r.stderr

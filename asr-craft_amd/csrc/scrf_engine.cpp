@@ -184,7 +184,7 @@ static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
   if (c.abi_version != SCRF_ABI_VERSION) { *why = "abi_version mismatch"; return SCRF_ERR_INVALID; }
   if (c.num_states != 1) { *why = "only crf_states=1 is built (multi-state nodes are out of scope)"; return SCRF_ERR_INVALID; }
   if (c.num_labs == 0 || c.lab_max_dur == 0 || c.num_feas == 0) { *why = "num_labs, lab_max_dur, num_feas must be > 0"; return SCRF_ERR_INVALID; }
-  if (c.model_type == SCRF_STDSEG) { *why = "model type stdseg (phone x duration labels) is not built"; return SCRF_ERR_INVALID; }
+  if (c.model_type == SCRF_STDSEG && c.num_labs % c.lab_max_dur != 0) { *why = "stdseg: the number of all labels and the maximum duration of labels do not correspond (nLabs = nActualLabs * labMaxDur)"; return SCRF_ERR_INVALID; }
   if (c.model_type > SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR) { *why = "unknown model_type"; return SCRF_ERR_INVALID; }
   if (c.model_type == SCRF_STDFRAME && c.lab_max_dur != 1) { *why = "the maximum duration of labels must be 1 for \"stdframe\" CRF model."; return SCRF_ERR_INVALID; }  // CRFTrain/src/Main.cpp:574-578
   if (c.map_type > SCRF_STDTRANS) { *why = "only dense stdstate/stdtrans feature maps are built"; return SCRF_ERR_INVALID; }
@@ -503,6 +503,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     b->seg_off[u + 1] = b->seg_off[u] + scrf_seg_base(q.T, lay.D);
     uint64_t na = (lay.D == 1 && h->cfg.model_type == SCRF_STDFRAME)
                       ? (uint64_t)lay.L + (uint64_t)(q.T - 1) * lay.L * lay.L + lay.L
+                      : h->cfg.model_type == SCRF_STDSEG ? 0   // no lattice for this model type
                       : h->cfg.model_type == SCRF_STDSEG_NO_DUR ? segtrans_num_arcs(q.T, lay.L, lay.D)
                                                                 : scrf_arc_base(q.T, lay.L, lay.D) + lay.L;
     b->arc_off[u + 1] = b->arc_off[u] + na;
@@ -533,14 +534,14 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
         nxt[f] = cur;
         const uint32_t lb = lab[f];
         if (lb != SCRF_LAB_BAD) {
-          if (t + 1 < b->T[u] && cur != SCRF_LAB_BAD && lb < lay.L * lay.D && cur < lay.L * lay.D)
+          if (t + 1 < b->T[u] && cur != SCRF_LAB_BAD && lb < lay.L * lay.D && cur < lay.L * lay.D && h->cfg.model_type != SCRF_STDSEG)
             cnt[(size_t)(lb % lay.L) * lay.L + cur % lay.L]++;
           cur = lb;
         }
       }
     }
     BCHK(upload(h, &b->d_next_lab, nxt.data(), NF));
-    if (h->cfg.model_type == SCRF_STDSEG_NO_DUR) {
+    if (h->cfg.model_type == SCRF_STDSEG_NO_DUR || h->cfg.model_type == SCRF_STDSEG) {
       std::vector<uint32_t> prv(NF);
       for (uint32_t u = 0; u < n; u++) {
         uint32_t cur = SCRF_LAB_BAD;
@@ -584,7 +585,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   }
   // fused window synthesis: one segment-recipe stream without context whose window is exactly
   // the state feature range, no transition features
-  if (!by_windows && n_streams == 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && !lay.use_tf && lay.use_sf && recipes[0].extract_seg_ftr &&
+  if (!by_windows && n_streams == 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && !lay.use_tf && lay.use_sf && recipes[0].extract_seg_ftr &&
       !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 && lay.nsfe == 8 * recipes[0].in_width + lay.D &&
       lay.nsfe == lay.F && fused_supported(lay, recipes[0].in_width)) {
     b->fused_ok = true;
@@ -1207,6 +1208,78 @@ static int queue_status(scrf_handle h, scrf_batch b) {
   return SCRF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// STDSEG (duration-labelled, scrf_stdseg.hip): its own small pipeline -- windows, scores, workgroup recursion,
+// posteriors, per-weight gradient -- in chunks of utterances that fit the scratch budget.  h->lay is the layout over
+// the FULL labels (lay.L = nLabs); La = nActualLabs.
+// ---------------------------------------------------------------------------------------------
+static bool stdseg(scrf_handle h) { return h->cfg.model_type == SCRF_STDSEG; }
+static uint32_t stdseg_La(scrf_handle h) { return h->lay.L / h->lay.D; }
+
+struct StdsegBufs {
+  float* X; uint32_t *row_t, *row_d, *row_u;
+  double *S, *MX, *alpha, *beta, *G, *XI, *mass_s, *mass_t;
+};
+static size_t stdseg_chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nfr, uint64_t nseg, bool post) {
+  const ScrfLayout& l = h->lay;
+  const uint32_t La = stdseg_La(h);
+  size_t tot = 0;
+  if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
+  tot += 3 * pad256(nseg * sizeof(uint32_t));
+  tot += 3 * pad256(nseg * La * sizeof(double)) + pad256(nseg * (size_t)l.L * La * sizeof(double));   // S, alpha, beta, MX
+  if (post) tot += pad256(nseg * La * sizeof(double)) + pad256(nseg * (size_t)l.L * La * sizeof(double)) + 2 * pad256(nfr * sizeof(double));
+  return tot;
+}
+// chunk [u0, u1): scores and recursion (and, with post, posteriors, numerators, the gradient into `grad`)
+static int stdseg_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, bool post, double* grad, StdsegBufs* out) {
+  const ScrfLayout& l = h->lay;
+  const uint32_t La = stdseg_La(h);
+  const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
+  const size_t need = stdseg_chunk_bytes(h, b, nfr, nseg, post);
+  int rc = ensure_scratch(h, need);
+  if (rc != SCRF_OK) return rc;
+  Arena a{h->scratch, h->scratch_cap, 0};
+  StdsegBufs sb;
+  memset(&sb, 0, sizeof(sb));
+  ScrfBatchView bv = b->view();
+  hipStream_t st = h->stream;
+  if (b->mode == 1) {
+    sb.X = a.take<float>(nseg * l.F);
+    uint32_t col = 0;
+    for (uint32_t s = 0; s < b->n_streams; s++) {
+      const scrf_stream_recipe& r = b->recipe[s];
+      launch_windows(st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx, r.right_ctx, r.extract_seg_ftr,
+                     sb.X, l.F, col);
+      col += b->width[s];
+    }
+  } else {
+    sb.X = b->d_windows + b->seg_off[u0] * l.F;
+  }
+  sb.row_t = a.take<uint32_t>(nseg); sb.row_d = a.take<uint32_t>(nseg); sb.row_u = a.take<uint32_t>(nseg);
+  sb.S = a.take<double>(nseg * La); sb.alpha = a.take<double>(nseg * La); sb.beta = a.take<double>(nseg * La);
+  sb.MX = a.take<double>(nseg * (size_t)l.L * La);
+  launch_stdseg_rowinfo(st, bv, b->d_frame_u, u0, nfr, l.D, sb.row_t, sb.row_d, sb.row_u);
+  launch_stdseg_scores(st, l, La, sb.X, nseg, sb.row_t, sb.row_d, h->d_lambda, sb.S, sb.MX);
+  launch_stdseg_fb(st, l, La, bv, u0, u1 - u0, sb.S, sb.MX, sb.alpha, sb.beta, b->d_zx, b->d_status);
+  if (post) {
+    sb.G = a.take<double>(nseg * La); sb.XI = a.take<double>(nseg * (size_t)l.L * La);
+    sb.mass_s = a.take<double>(nfr); sb.mass_t = a.take<double>(nfr);
+    HIPCHK(h, hipMemsetAsync(sb.mass_s, 0, sizeof(double) * nfr, st));
+    HIPCHK(h, hipMemsetAsync(sb.mass_t, 0, sizeof(double) * nfr, st));
+    launch_stdseg_post(st, l, La, bv, u0, u1 - u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.S, sb.MX, sb.alpha, sb.beta,
+                       b->d_zx, sb.G, sb.XI, sb.mass_s, sb.mass_t, b->d_numer, b->d_status);
+    launch_stdseg_expf(st, l, La, bv, u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.X, sb.G, sb.XI, grad);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (out) *out = sb;
+  return SCRF_OK;
+}
+static uint32_t stdseg_plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, bool post) {
+  uint32_t u1 = u0 + 1;
+  while (u1 < b->U && stdseg_chunk_bytes(h, b, b->frame_off[u1 + 1] - b->frame_off[u0], b->seg_off[u1 + 1] - b->seg_off[u0], post) <= h->cfg.scratch_bytes) u1++;
+  return u1;
+}
+
 // One pass of the forward-backward pipeline over the batch into the staging gradient.  latch[2] receives
 // {status code, utterance} of the first failed utterance (0 = clean, gradient committed); *used_lin tells
 // whether any chunk ran the linear-domain recursion.
@@ -1216,12 +1289,30 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   HIPCHK(h, hipMemsetAsync(h->d_latch, 0, sizeof(int) * 2, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_stage, 0, sizeof(double) * l.lambda_len, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_sums_stage, 0, sizeof(double) * 4, h->stream));
+  *used_lin = false;
+  if (stdseg(h)) {
+    for (uint32_t u0 = 0; u0 < b->U;) {
+      const uint32_t u1 = stdseg_plan_chunk(h, b, u0, true);
+      int rc = stdseg_run_chunk(h, b, u0, u1, true, h->d_stage, nullptr);
+      if (rc != SCRF_OK) return rc;
+      launch_stdseg_sums(h->stream, b->d_numer, b->d_zx, u0, u1 - u0, h->d_sums_stage);
+      u0 = u1;
+    }
+    int rc = queue_status(h, b);
+    if (rc != SCRF_OK) return rc;
+    hipLaunchKernelGGL(k_commit, dim3((l.lambda_len + 255) / 256), dim3(256), 0, h->stream, h->d_grad, h->d_stage, l.lambda_len,
+                       h->d_sums, h->d_sums_stage, h->d_latch);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventSynchronize(h->ev_status));
+    latch[0] = h->h_latch[0];
+    latch[1] = h->h_latch[1];
+    return SCRF_OK;
+  }
   Need nd{true, true, false, false};
   ScrfBatchView bv = b->view();
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
   const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
   nd.fused = fast && b->fused_ok && h->fuse_windows;
-  *used_lin = false;
 
   // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
   // at least four chunks so that both streams always have work
@@ -1444,6 +1535,30 @@ extern "C" int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, d
   int rc = check_u(h, b, u, "scrf_scores");
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipSetDevice(h->device));
+  if (stdseg(h)) {   // S [N_seg][nActualLabs], M [N_seg][nLabs][nActualLabs]
+    StdsegBufs sb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = stdseg_run_chunk(h, b, u, u + 1, false, nullptr, &sb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t ns = b->seg_off[u + 1] - b->seg_off[u];
+    const uint32_t La = stdseg_La(h);
+    if (S) HIPCHK(h, hipMemcpyAsync(S, sb.S, sizeof(double) * ns * La, hipMemcpyDeviceToHost, h->stream));
+    if (M) HIPCHK(h, hipMemcpyAsync(M, sb.MX, sizeof(double) * ns * h->lay.L * La, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SCRF_OK;
+  }
+  if (stdseg(h)) {   // S [N_seg][nActualLabs], M [N_seg][nLabs][nActualLabs]
+    StdsegBufs sb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = stdseg_run_chunk(h, b, u, u + 1, false, nullptr, &sb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t ns = b->seg_off[u + 1] - b->seg_off[u];
+    const uint32_t La = stdseg_La(h);
+    if (S) HIPCHK(h, hipMemcpyAsync(S, sb.S, sizeof(double) * ns * La, hipMemcpyDeviceToHost, h->stream));
+    if (M) HIPCHK(h, hipMemcpyAsync(M, sb.MX, sizeof(double) * ns * h->lay.L * La, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SCRF_OK;
+  }
   Need nd{false, false, false, false};
   ChunkBufs cb;
   rc = carve(h, b, u, u + 1, nd, &cb);
@@ -1463,6 +1578,22 @@ extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, ui
   if (rc != SCRF_OK) return rc;
   if (prec != SCRF_PREC_EXACT) return fail(h, SCRF_ERR_INVALID, "scrf_forward_backward: the node-value hook runs at SCRF_PREC_EXACT only");
   HIPCHK(h, hipSetDevice(h->device));
+  if (stdseg(h)) {   // alpha_dur and beta: the nodes' alpha / beta over full labels, [N_seg][nActualLabs]; `alpha` is not written
+    StdsegBufs sb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = stdseg_run_chunk(h, b, u, u + 1, false, nullptr, &sb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t ns = b->seg_off[u + 1] - b->seg_off[u];
+    const uint32_t La = stdseg_La(h);
+    int st = 0;
+    if (alpha_dur) HIPCHK(h, hipMemcpyAsync(alpha_dur, sb.alpha, sizeof(double) * ns * La, hipMemcpyDeviceToHost, h->stream));
+    if (beta) HIPCHK(h, hipMemcpyAsync(beta, sb.beta, sizeof(double) * ns * La, hipMemcpyDeviceToHost, h->stream));
+    if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&st, b->d_status + u, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (st != SCRF_OK) return fail(h, st, "utterance %u: numeric failure in forward-backward", u);
+    return SCRF_OK;
+  }
   const ScrfLayout& l = h->lay;
   Need nd{true, false, true, false};
   uint64_t nseg = b->seg_off[u + 1] - b->seg_off[u];
@@ -1496,6 +1627,7 @@ extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, ui
 // ---------------------------------------------------------------------------------------------
 extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int norm, scrf_arc* arcs, uint64_t* n_arcs,
                                  uint32_t* n_states, int32_t* final_state) {
+  if (h && stdseg(h)) return fail(h, SCRF_ERR_INVALID, "scrf_lattice_arcs: decoding is not built for the stdseg model type (training and node values only)");
   int rc = check_u(h, b, u, "scrf_lattice_arcs");
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipSetDevice(h->device));
@@ -1539,6 +1671,7 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
 
 extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
                                   uint64_t* lab_off, float* best_cost) {
+  if (h && stdseg(h)) return fail(h, SCRF_ERR_INVALID, "scrf_viterbi_batch: decoding is not built for the stdseg model type (training and node values only)");
   if (!h || !b || !seg_labels || !lab_off) return SCRF_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;

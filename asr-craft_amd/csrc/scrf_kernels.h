@@ -143,4 +143,20 @@ void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                        uint64_t n_tiles, double* slab, int f32);
 
+// ---- STDSEG (scrf_stdseg.hip): lay is the layout over FULL labels (lay.L = nLabs), La = nActualLabs
+void launch_stdseg_rowinfo(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                           uint32_t D, uint32_t* row_t, uint32_t* row_d, uint32_t* row_u);
+void launch_stdseg_scores(hipStream_t st, const ScrfLayout& lay, uint32_t La, const float* X, uint64_t n_rows,
+                          const uint32_t* row_t, const uint32_t* row_d, const double* lambda, double* S, double* MX);
+void launch_stdseg_fb(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                      const double* S, const double* MX, double* alpha, double* beta, double* zx, int* status);
+void launch_stdseg_post(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                        uint64_t n_rows, const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u,
+                        const uint32_t* prev_lab, const double* S, const double* MX, const double* alpha, const double* beta,
+                        const double* zx, double* G, double* XI, double* mass_s, double* mass_t, double* numer, int* status);
+void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint64_t n_rows,
+                        const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u, const uint32_t* prev_lab,
+                        const float* X, const double* G, const double* XI, double* grad);
+void launch_stdseg_sums(hipStream_t st, const double* numer, const double* zx, uint32_t u0, uint32_t n, double* sums);
+
 #endif  // SCRF_KERNELS_H_

@@ -247,7 +247,13 @@ class Engine:
         return T * (T + 1) // 2 if T < D else D * (D + 1) // 2 + (T - D) * D
 
     def scores(self, batch, u, T):
-        """S [N_seg, L]; M [T, L*L] -- for STDSEG_NO_DUR one transition matrix per window: [N_seg, L*L]"""
+        """S [N_seg, L]; M [T, L*L] -- for STDSEG_NO_DUR one transition matrix per window: [N_seg, L*L]; for STDSEG
+        (L = all labels, La = L / D phones) S [N_seg, La] and M [N_seg, L, La] (previous FULL label x phone)"""
+        if self.cfg.model_type == STDSEG:
+            La = self.L // self.D
+            S = np.zeros((self.num_segs(T), La)); M = np.zeros((self.num_segs(T), self.L, La))
+            self._chk(self.lib.scrf_scores(self.h, batch.handle, C.c_uint32(u), _p(S), _p(M)))
+            return S, M
         S = np.zeros((self.num_segs(T), self.L))
         M = np.zeros((self.num_segs(T) if self.cfg.model_type == STDSEG_NO_DUR else T, self.L * self.L))
         self._chk(self.lib.scrf_scores(self.h, batch.handle, C.c_uint32(u), _p(S), _p(M)))
@@ -259,6 +265,12 @@ class Engine:
         return X
 
     def forward_backward(self, batch, u, T, prec=PREC_EXACT):
+        if self.cfg.model_type == STDSEG:   # the nodes' alpha / beta over full labels: [N_seg, La] each
+            La = self.L // self.D
+            al = np.zeros((self.num_segs(T), La)); be = np.zeros((self.num_segs(T), La))
+            zx = C.c_double()
+            self._chk(self.lib.scrf_forward_backward(self.h, batch.handle, C.c_uint32(u), C.c_uint32(prec), _p(al), None, _p(be), C.byref(zx)))
+            return al, None, be, zx.value
         ad = np.zeros((self.num_segs(T), self.L)); al = np.zeros((T, self.L)); be = np.zeros((T, self.L))
         zx = C.c_double()
         self._chk(self.lib.scrf_forward_backward(self.h, batch.handle, C.c_uint32(u), C.c_uint32(prec), _p(ad), _p(al),

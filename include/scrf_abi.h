@@ -54,7 +54,7 @@ enum scrf_status {
 /* modeltype, CRF.h:50 */
 enum scrf_model_type {
   SCRF_STDFRAME = 0,
-  SCRF_STDSEG = 1,                       /* not built */
+  SCRF_STDSEG = 1,                       /* duration-labelled: num_labs = nActualLabs * lab_max_dur; training + node values, no decoding */
   SCRF_STDSEG_NO_DUR = 2,                /* transition features from the segment's own window (one L x L matrix per
                                             window): training, parity hooks, lattice arcs and best path (scrf_segtrans.hip) */
   SCRF_STDSEG_NO_DUR_NO_TRANSFTR = 3,    /* served by the same engine (bias-only transitions) */
@@ -207,13 +207,16 @@ int scrf_get_batch_sums(scrf_handle h, double* sums3);
 /* ---- parity hooks: the node accessors of nodes/CRF_StateNode.h:67-115 ---------------------- */
 /* getStateValue(lab,dur) / getTransValue(p,c): S[N_seg][L], M[T][L*L] of utterance u (EXACT).  For
  * SCRF_STDSEG_NO_DUR M is [N_seg][L*L]: getTransValue(p,c,dur) of every window, the rows of utterance-initial
- * windows (no predecessor) zero (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp:69-110, :570-580) */
+ * windows (no predecessor) zero (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp:69-110, :570-580).  For SCRF_STDSEG
+ * (La = num_labs / lab_max_dur) S is [N_seg][La] -- row (t,dur), phone = the node's stateArray[(dur-1)*La + phone] -- and
+ * M is [N_seg][num_labs][La] = transMatrix[plab*num_labs + clab] (nodes/CRF_StdSegStateNode.cpp:83-127) */
 int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M);
 /* window synthesis of utterance u: [N_seg][num_feas] (io/CRF_InFtrStream_SeqMultiWindow.cpp) */
 int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* windows);
 /* getAlpha / alphaArray_WithDur / getBeta / computeAlphaSum from the log-domain recursion over the EXACT
  * scores (`prec` must be SCRF_PREC_EXACT: the hook exists to compare node values with the reference's):
- * alpha_dur [N_seg][L], alpha [T][L], beta [T][L] (any may be NULL) */
+ * alpha_dur [N_seg][L], alpha [T][L], beta [T][L] (any may be NULL).  SCRF_STDSEG: alpha_dur and beta receive the nodes'
+ * alpha / beta over full labels as [N_seg][La]; `alpha` is not written */
 int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, uint32_t prec,
                           double* alpha_dur, double* alpha, double* beta, double* zx);
 

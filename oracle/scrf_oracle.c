@@ -577,6 +577,167 @@ int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, 
 /* ------------------------------------------------------------------ a15 ---- */
 
 /* ======================================================================================
+ * f3: STDSEG (nodes/CRF_StdSegStateNode.cpp): labels carry the duration, clab = (dur-1)*nActualLabs + phone;
+ * cfg->num_labs is the FULL label count nLabs (the feature map and the weight layout are over full labels),
+ * nActualLabs = nLabs / labMaxDur (:40).  Node values are kept per window row: alpha / beta / S at
+ * [row(t,dur)][phone] is the node's entry clab; MX[row(t,dur)][plab][phone] is transMatrix[plab*nLabs + clab] with
+ * plab a full label of node t-dur (entries with plab >= that node's numAvailLabs are never read).
+ * ====================================================================================== */
+static uint32_t stdseg_actual_labs(const orc_config* cfg) { return cfg->num_labs / cfg->lab_max_dur; }
+
+void orc_stdseg_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* segftrs,
+                       uint32_t T, double* S, double* MX) {
+  /* computeTransMatrix :83-127 */
+  const uint32_t NL = cfg->num_labs, D = cfg->lab_max_dur, L = stdseg_actual_labs(cfg), F = cfg->num_feas;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    for (uint32_t dur = 1; dur <= nd; dur++) {
+      const float* x = segftrs + (base + dur - 1) * F;
+      double* Mrow = MX + (base + dur - 1) * (size_t)NL * L;
+      const uint32_t pavail = dur <= np ? L * orc_node_max_dur(t - dur, D) : 0;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        const uint32_t clab = (dur - 1) * L + lab;
+        S[(base + dur - 1) * L + lab] = orc_state_value(cfg, lay, x, lambda, clab);
+        for (uint32_t plab = 0; plab < NL; plab++)
+          Mrow[(size_t)plab * L + lab] = plab < pavail ? orc_trans_value(cfg, lay, x, lambda, plab, clab) : 0.0;
+      }
+    }
+  }
+}
+
+int orc_stdseg_forward(const orc_config* cfg, const double* S, const double* MX, uint32_t T, double* alpha, double* Zx) {
+  /* computeFirstAlpha :189-198, computeAlpha :136-180, computeAlphaSum :436-447 */
+  const uint32_t NL = cfg->num_labs, D = cfg->lab_max_dur, L = stdseg_actual_labs(cfg);
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  double* acc = (double*)malloc(sizeof(double) * NL);
+  for (uint32_t t = 0; t < T && err == ORC_OK; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    for (uint32_t dur = 1; dur <= np; dur++) {
+      const uint64_t pbase = orc_seg_base(t - dur, D);
+      const uint32_t pavail = L * orc_node_max_dur(t - dur, D);
+      const double* pa = alpha + pbase * L;   /* the previous node's alpha over its full labels: rows are contiguous */
+      const double* Mrow = MX + (base + dur - 1) * (size_t)NL * L;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        acc[0] = pa[0] + Mrow[lab];
+        double maxv = acc[0];
+        for (uint32_t plab = 1; plab < pavail; plab++) {
+          acc[plab] = pa[plab] + Mrow[(size_t)plab * L + lab];
+          if (acc[plab] > maxv) maxv = acc[plab];
+        }
+        double v = orc_logadd_max_n(acc, maxv, (int)pavail, &err);
+        v += S[(base + dur - 1) * L + lab];
+        alpha[(base + dur - 1) * L + lab] = v;
+      }
+    }
+    for (uint32_t dur = np + 1; dur <= nd; dur++)
+      for (uint32_t lab = 0; lab < L; lab++) alpha[(base + dur - 1) * L + lab] = S[(base + dur - 1) * L + lab];
+  }
+  if (err == ORC_OK)
+    *Zx = orc_logadd_n(alpha + orc_seg_base(T - 1, D) * L, (int)(L * orc_node_max_dur(T - 1, D)), &err);
+  free(acc);
+  return err;
+}
+
+int orc_stdseg_backward(const orc_config* cfg, const double* S, const double* MX, uint32_t T, double* beta) {
+  /* computeBeta :211-260; setTailBeta nodes/CRF_StdStateNode.cpp:198-204 */
+  const uint32_t NL = cfg->num_labs, D = cfg->lab_max_dur, L = stdseg_actual_labs(cfg);
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  double* tb = (double*)malloc(sizeof(double) * NL);
+  double* acc = (double*)malloc(sizeof(double) * NL);
+  {
+    const uint64_t base = orc_seg_base(T - 1, D);
+    for (uint32_t i = 0; i < L * orc_node_max_dur(T - 1, D); i++) beta[base * L + i] = 0.0;
+  }
+  for (uint32_t t = T - 1; t-- > 0 && err == ORC_OK;) {
+    const uint32_t nn = (T - 1 - t <= D) ? T - 1 - t : D;
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t avail = L * orc_node_max_dur(t, D);
+    for (uint32_t dur = 1; dur <= nn; dur++) {
+      const uint64_t row = orc_seg_base(t + dur, D) + dur - 1;
+      for (uint32_t lab = 0; lab < L; lab++) tb[(dur - 1) * L + lab] = beta[row * L + lab] + S[row * L + lab];
+    }
+    for (uint32_t clab = 0; clab < avail; clab++) {
+      double maxv = MX[(orc_seg_base(t + 1, D) + 0) * (size_t)NL * L + (size_t)clab * L + 0] + tb[0];
+      uint32_t n = 0;
+      for (uint32_t dur = 1; dur <= nn; dur++) {
+        const double* Mrow = MX + (orc_seg_base(t + dur, D) + dur - 1) * (size_t)NL * L;
+        for (uint32_t lab = 0; lab < L; lab++) {
+          acc[n] = Mrow[(size_t)clab * L + lab] + tb[n];
+          if (acc[n] > maxv) maxv = acc[n];
+          n++;
+        }
+      }
+      beta[base * L + clab] = orc_logadd_max_n(acc, maxv, (int)n, &err);
+    }
+  }
+  free(tb); free(acc);
+  return err;
+}
+
+int orc_stdseg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* segftrs,
+                              const uint32_t* labels, uint32_t T, double* grad, double* numer, double* Zx_out) {
+  /* trainers/gradbuilders/CRF_NewGradBuilder_StdSeg.cpp (shared with STDSEG_NO_DUR) + computeExpF :345-424 */
+  const uint32_t NL = cfg->num_labs, D = cfg->lab_max_dur, L = stdseg_actual_labs(cfg), F = cfg->num_feas;
+  if (T == 0) return ORC_ERR_EMPTY;
+  const uint64_t nseg = orc_num_segs(T, D);
+  int err = ORC_OK;
+  double* ExpF = (double*)calloc(lay->lambda_len, sizeof(double));
+  double* S = (double*)malloc(sizeof(double) * nseg * L);
+  double* MX = (double*)malloc(sizeof(double) * nseg * (size_t)NL * L);
+  double* alpha = (double*)malloc(sizeof(double) * nseg * L);
+  double* beta = (double*)malloc(sizeof(double) * nseg * L);
+  double logLi = 0.0, Zx = 0.0;
+  orc_stdseg_scores(cfg, lay, lambda, segftrs, T, S, MX);
+  err = orc_stdseg_forward(cfg, S, MX, T, alpha, &Zx);
+  if (err == ORC_OK) err = orc_stdseg_backward(cfg, S, MX, T, beta);
+  for (uint32_t t = T; t-- > 0 && err == ORC_OK;) {
+    uint32_t prev_lab = ORC_LAB_BAD;   /* the nearest EARLIER node that carries a label */
+    for (uint32_t u = t; u > 0; u--) {
+      prev_lab = labels[u - 1];
+      if (prev_lab != ORC_LAB_BAD) break;
+    }
+    const uint32_t label = labels[t];
+    if (label != ORC_LAB_BAD && label >= NL) { err = ORC_ERR_BAD_LABEL; break; }
+    if (prev_lab != ORC_LAB_BAD && prev_lab >= NL) { err = ORC_ERR_BAD_LABEL; break; }
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t nd = orc_node_max_dur(t, D), np = num_prev(t, D);
+    double ab_tot = 0.0, ab_trans_tot = 0.0, nodeLi = 0.0;
+    for (uint32_t dur = 1; dur <= nd; dur++) {
+      const float* x = segftrs + (base + dur - 1) * F;
+      const double* Mrow = MX + (base + dur - 1) * (size_t)NL * L;
+      for (uint32_t lab = 0; lab < L; lab++) {
+        const uint32_t clab = (dur - 1) * L + lab;
+        const size_t at = (base + dur - 1) * L + lab;
+        double ab = orc_expE(alpha[at] + beta[at] - Zx, &err);
+        ab_tot += ab;
+        nodeLi += orc_state_expf(cfg, lay, x, lambda, ExpF, grad, ab, label, clab);
+        if (dur > np) continue;
+        const double* pa = alpha + orc_seg_base(t - dur, D) * L;
+        const uint32_t pavail = L * orc_node_max_dur(t - dur, D);
+        for (uint32_t plab = 0; plab < pavail; plab++) {
+          ab = orc_expE(pa[plab] + Mrow[(size_t)plab * L + lab] + S[at] + beta[at] - Zx, &err);
+          ab_trans_tot += ab;
+          nodeLi += orc_trans_expf(cfg, lay, x, lambda, ExpF, grad, ab, prev_lab, label, plab, clab);
+        }
+      }
+    }
+    if (np == 0) ab_trans_tot = 1.0;
+    if (ab_tot > 1.000001 || ab_tot < -0.000001 || ab_trans_tot > 1.000001 || ab_trans_tot < -0.000001)
+      set_err(&err, ORC_ERR_PROB_SUM); /* :402-421 */
+    logLi += nodeLi;
+  }
+  for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i];
+  *Zx_out = Zx;
+  *numer = logLi;
+  free(ExpF); free(S); free(MX); free(alpha); free(beta);
+  return err;
+}
+
+/* ======================================================================================
  * f3: STDSEG_NO_DUR (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp)
  * ====================================================================================== */
 void orc_segtrans_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda,

@@ -148,6 +148,15 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
 int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, uint32_t T,
                        double* gamma, double* xi, double* Zx);
 
+/* ---- f3: STDSEG (duration-labelled; cfg->num_labs = nLabs = nActualLabs * lab_max_dur) ------------------------
+ * S, alpha, beta: [N_seg][nActualLabs] (row (t,dur), phone = the node's entry (dur-1)*nActualLabs + phone);
+ * MX: [N_seg][nLabs][nActualLabs] = transMatrix[plab*nLabs + clab] of the window's node */
+void orc_stdseg_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* segftrs,
+                       uint32_t T, double* S, double* MX);
+int orc_stdseg_forward(const orc_config* cfg, const double* S, const double* MX, uint32_t T, double* alpha, double* Zx);
+int orc_stdseg_backward(const orc_config* cfg, const double* S, const double* MX, uint32_t T, double* beta);
+int orc_stdseg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* segftrs,
+                              const uint32_t* labels, uint32_t T, double* grad, double* numer, double* Zx_out);
 /* ---- f3: STDSEG_NO_DUR, segment-dependent transition features ----------------
  * nodes/CRF_StdSegStateNode_WithoutDurLab.cpp (+ trainers/gradbuilders/CRF_NewGradBuilder_StdSeg.cpp,
  * which passes the PREVIOUS label).  The transition score of a segment depends on its own window:

@@ -45,6 +45,8 @@ class Case:
             self.recipes.append(scrf_amd.StreamRecipe(in_w, c, c, 0))
             kw = dict(model_type=mt, L=L, D=D, F=self.F, sfe=Fs - 1, use_trans_ftrs=True, tfs=Fs)
         self.Fs = Fs
+        if mt == orc.STDSEG:   # the feature map and the weight layout run over all labels: nLabs = nActualLabs * D
+            kw["L"] = L * D
         self.ocfg = orc.config(**kw)
         self.olay = orc.Layout(self.ocfg)
         self.gcfg = scrf_amd.make_config(scratch_bytes=scratch_bytes, precision=precision, **kw)
@@ -76,6 +78,8 @@ class Case:
         for u, T in enumerate(self.Ts):
             if self.ocfg.model_type == orc.STDFRAME:
                 rc, g, n, z = orc.frame_build_gradient(self.ocfg, self.olay, self.lam, self.windows(u), self.labels[u], T, grad=g)
+            elif self.ocfg.model_type == orc.STDSEG:
+                rc, g, n, z = orc.stdseg_build_gradient(self.ocfg, self.olay, self.lam, self.windows(u), self.labels[u], T, grad=g)
             elif self.ocfg.model_type == orc.STDSEG_NO_DUR:
                 rc, g, n, z = orc.segtrans_build_gradient(self.ocfg, self.olay, self.lam, self.windows(u), self.labels[u], T, grad=g)
             else:

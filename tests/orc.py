@@ -250,6 +250,78 @@ def segtrans_build_gradient(cfg, lay, lam, segftrs, labels, T, grad=None):
     return rc, grad, numer.value, zx.value
 
 
+def stdseg_scores(cfg, lay, lam, segftrs, T):
+    NL, D = cfg.num_labs, cfg.lab_max_dur
+    L = NL // D
+    segftrs = np.ascontiguousarray(segftrs, dtype=np.float32)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    S = np.zeros((num_segs(T, D), L)); MX = np.zeros((num_segs(T, D), NL, L))
+    lib().orc_stdseg_scores(C.byref(cfg), C.byref(lay.c), _p(lam), _p(segftrs), C.c_uint32(T), _p(S), _p(MX))
+    return S, MX
+
+
+def stdseg_forward(cfg, S, MX, T):
+    al = np.zeros_like(S)
+    zx = C.c_double()
+    rc = lib().orc_stdseg_forward(C.byref(cfg), _p(S), _p(MX), C.c_uint32(T), _p(al), C.byref(zx))
+    return rc, al, zx.value
+
+
+def stdseg_backward(cfg, S, MX, T):
+    beta = np.zeros_like(S)
+    rc = lib().orc_stdseg_backward(C.byref(cfg), _p(S), _p(MX), C.c_uint32(T), _p(beta))
+    return rc, beta
+
+
+def stdseg_build_gradient(cfg, lay, lam, segftrs, labels, T, grad=None):
+    segftrs = np.ascontiguousarray(segftrs, dtype=np.float32)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    if grad is None:
+        grad = np.zeros(lay.lambda_len, dtype=np.float64)
+    numer = C.c_double(); zx = C.c_double()
+    rc = lib().orc_stdseg_build_gradient(C.byref(cfg), C.byref(lay.c), _p(lam), _p(segftrs), _p(labels),
+                                         C.c_uint32(T), _p(grad), C.byref(numer), C.byref(zx))
+    return rc, grad, numer.value, zx.value
+
+
+def brute_force_stdseg(S, MX, T, L, D):
+    """every (segmentation, labelling) of the STDSEG model: a segment (end, d, l) after a segment (., dp, p) scores
+    S[(end,d)][l] + MX[(end,d)][(dp-1)*L + p][l] (the first segment of the utterance S alone).
+    Returns Zx, gamma [N_seg, L], xi [N_seg, L*D, L], the paths and the best one."""
+    paths = []
+
+    def rec(t_next, prev, score, segs):
+        if t_next == T:
+            paths.append((score, tuple(segs)))
+            return
+        for d in range(1, D + 1):
+            end = t_next + d - 1
+            if end >= T:
+                break
+            row = seg_base(end, D) + d - 1
+            for l in range(L):
+                s = score + S[row, l]
+                if prev is not None:
+                    s = s + MX[row, prev, l]
+                rec(end + 1, (d - 1) * L + l, s, segs + [(end, d, l)])
+
+    rec(0, None, 0.0, [])
+    scores = np.array([p[0] for p in paths])
+    mx = scores.max()
+    Zx = mx + np.log(np.exp(scores - mx).sum())
+    gamma = np.zeros_like(S); xi = np.zeros_like(MX)
+    for sc, segs in paths:
+        p = np.exp(sc - Zx)
+        for i, (end, d, l) in enumerate(segs):
+            row = seg_base(end, D) + d - 1
+            gamma[row, l] += p
+            if i > 0:
+                xi[row, (segs[i - 1][1] - 1) * L + segs[i - 1][2], l] += p
+    best = max(range(len(paths)), key=lambda i: paths[i][0])
+    return dict(Zx=Zx, gamma=gamma, xi=xi, n_paths=len(paths), paths=paths, best=paths[best])
+
+
 def brute_force_segtrans(S, M2, T, L, D):
     """every (segmentation, labelling) of the STDSEG_NO_DUR model: a segment (end, d, l) after a segment
     labelled p scores S[(end,d)][l] + M2[(end,d)][p*L+l] (the first segment of the utterance S alone).

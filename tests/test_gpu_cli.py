@@ -1094,3 +1094,49 @@ def test_crffstdecode_dictionary_lm_and_alignment_chain(tmp_path):
     assert r.returncode != 0 and "crf_phn_bin" in r.stderr
     r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_dict_wt=2.5"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "crf_dict_wt" in r.stderr
+
+
+def test_crftrain_stdseg_model_type(tmp_path):
+    """crf_model_type=stdseg (duration-labelled: crf_label_size = num_actual_labs * label_maximum_duration) trains
+    through the same front-end; weights against the oracle's SGD loop over orc.stdseg_build_gradient.  The decoders
+    refuse the model type."""
+    from scrf_amd import synth
+    rng = np.random.RandomState(31)
+    L, D, W = 3, 2, 2
+    Ts = [3, 5, 4]
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    utts, phones = [], []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            ph = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X); phones.append(ph)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, ph[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % (L * D), "num_actual_labs=%d" % L,
+             "crf_featuremap=stdstate", "crf_model_type=stdseg", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    epochs, lr = 2, 0.5
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=%d" % epochs,
+                        "crf_lr=%g" % lr, "crf_bunch_size=1", "threads=1", "crf_train_order=seq"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    F = 8 * W + D
+    cfg = orc.config(model_type=orc.STDSEG, L=L * D, D=D, F=F); lay = orc.Layout(cfg)
+    assert "FEATURES: %d" % lay.lambda_len in r.stdout
+    lam = np.zeros(lay.lambda_len); acc = np.zeros_like(lam); gsa = np.zeros_like(lam)
+    for _ in range(epochs):
+        for u, T in enumerate(Ts):
+            labs = synth.group_labels(phones[u].astype(np.uint32), D, L)
+            rc, g, _, _ = orc.stdseg_build_gradient(cfg, lay, lam, orc.windows(utts[u], D), labs, T)
+            assert rc == 0
+            orc.sgd_step(lam, acc, gsa, g, np.float32(lr), False, 1e-12)
+    w = np.loadtxt(wf)
+    assert np.abs(w).max() > 0
+    np.testing.assert_allclose(w, np.array([float("%g" % v) for v in lam]), rtol=2e-5, atol=1e-12)
+    olist = str(tmp_path / "olist")
+    open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
+    for exe in ("CRFFstDecode", "CRFDecode"):
+        r = subprocess.run([os.path.join(BIN, exe)] + model + ["weight_file=" + wf, "crf_output_labelfile=" + str(tmp_path / "dec.txt"), "crf_olist=" + olist],
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "stdseg" in (r.stderr + r.stdout)

@@ -1,0 +1,103 @@
+"""-m gpu: SURVEY row f3, second step -- the STDSEG model (labels carry the duration: own state weights per
+(phone, duration), transitions over full labels from the segment's own window, nodes/CRF_StdSegStateNode.cpp, with
+trainers/gradbuilders/CRF_NewGradBuilder_StdSeg.cpp) through the same engine and C ABI, training side and node values,
+against the oracle's restatement (tests/test_oracle_stdseg.py pins that one by brute force).  Decoding is refused for
+this model type.  Bars: scores bit-exact; node values 1e-11; gradient, numerator, Zx 1e-10."""
+import numpy as np
+import pytest
+
+import orc
+import scrf_amd
+from cases import Case
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+CASES = [
+    dict(L=3, D=3, in_w=2, Ts=[1, 2, 3, 4, 7], trans_share=(0, 1)),          # transition features: two window columns
+    dict(L=2, D=4, in_w=3, Ts=[3, 4, 5, 12], trans_ctx=1),                    # second stream: boundary context
+    dict(L=5, D=2, in_w=4, Ts=[1, 6, 9], trans_share=(4, 9)),
+    dict(L=4, D=5, in_w=3, Ts=[4, 5, 6, 15]),                                 # T = D-1, D, D+1, 3D; bias-only transitions
+    dict(L=12, D=4, in_w=4, Ts=[20, 9], lam_scale=0.1),                       # 48 full labels
+]
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_scores_and_node_values(ci):
+    c = Case(seed=900 + ci, model_type=orc.STDSEG, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng)
+    assert eng.lambda_len == c.olay.lambda_len
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.stdseg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        S, M = eng.scores(b, u, T)
+        assert np.array_equal(bits(S), bits(So)) and np.array_equal(bits(M), bits(Mo))
+        rc, al, zx = orc.stdseg_forward(c.ocfg, So, Mo, T)
+        rc2, be = orc.stdseg_backward(c.ocfg, So, Mo, T)
+        assert rc == 0 and rc2 == 0
+        gal, _, gbe, gzx = eng.forward_backward(b, u, T)
+        assert abs(gzx - zx) <= 1e-11 * max(1, abs(zx))
+        np.testing.assert_allclose(gal, al, rtol=1e-11, atol=1e-11)
+        # beta is defined on the labels a node can carry: rows of the node; all of them here
+        np.testing.assert_allclose(gbe, be, rtol=1e-11, atol=1e-11)
+    b.close(); eng.close()
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_fb_batch_gradient(ci):
+    c = Case(seed=900 + ci, model_type=orc.STDSEG, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, on, oz = c.oracle_gradient()
+    tol = 1e-10
+    assert np.abs(numer - on).max() <= tol * max(1, np.abs(on).max())
+    assert np.abs(zx - oz).max() <= tol * np.abs(oz).max()
+    assert np.abs(g - og).max() <= tol * max(1.0, np.abs(og).max())
+    # a second batch accumulates; sums follow
+    numer2, zx2 = eng.fb_batch(b)
+    np.testing.assert_allclose(eng.get_grad(), 2 * g, rtol=1e-12, atol=1e-13)
+    s = eng.batch_sums()
+    assert abs(s[0] - 2 * on.sum()) <= 1e-9 * max(1, abs(on.sum())) and s[2] == 2 * len(c.Ts)
+    b.close(); eng.close()
+
+
+def test_chunked_batches_equal_one_chunk():
+    kw = dict(L=3, D=3, in_w=2, Ts=[5, 7, 3, 9, 4, 8], trans_share=(0, 1))
+    c1 = Case(seed=77, model_type=orc.STDSEG, **kw)
+    c2 = Case(seed=77, model_type=orc.STDSEG, scratch_bytes=1 << 16, **kw)     # a few utterances per chunk
+    out = []
+    for c in (c1, c2):
+        eng = c.engine(); b = c.batch(eng)
+        numer, zx = eng.fb_batch(b)
+        out.append((numer.copy(), zx.copy(), eng.get_grad().copy()))
+        b.close(); eng.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12, atol=1e-13)
+
+
+def test_errors_and_refusals():
+    c = Case(seed=5, model_type=orc.STDSEG, L=3, D=3, in_w=2, Ts=[6, 5])
+    eng = c.engine()
+    # a label outside nLabs
+    bad = [l.copy() for l in c.labels]
+    bad[1][-1] = 3 * 3 + 2
+    b = eng.batch_from_frames(c.frames, bad, c.recipes, None)
+    with pytest.raises(scrf_amd.ScrfError) as ei:
+        eng.fb_batch(b)
+    assert "label" in str(ei.value).lower()
+    assert np.all(eng.get_grad() == 0.0)          # a failed batch contributes nothing
+    b.close()
+    b = c.batch(eng)
+    with pytest.raises(scrf_amd.ScrfError):
+        eng.lattice_arcs(b, 0)
+    with pytest.raises(scrf_amd.ScrfError):
+        eng.viterbi_batch(b)
+    b.close(); eng.close()
+    # nLabs must be a multiple of the maximum duration (nodes/CRF_StdSegStateNode.cpp:34-40)
+    with pytest.raises(scrf_amd.ScrfError):
+        scrf_amd.Engine(scrf_amd.make_config(model_type=orc.STDSEG, L=10, D=3, F=19))

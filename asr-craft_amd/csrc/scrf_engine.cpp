@@ -503,7 +503,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     b->seg_off[u + 1] = b->seg_off[u] + scrf_seg_base(q.T, lay.D);
     uint64_t na = (lay.D == 1 && h->cfg.model_type == SCRF_STDFRAME)
                       ? (uint64_t)lay.L + (uint64_t)(q.T - 1) * lay.L * lay.L + lay.L
-                      : h->cfg.model_type == SCRF_STDSEG ? 0   // no lattice for this model type
+                      : h->cfg.model_type == SCRF_STDSEG ? stdseg_num_arcs(q.T, lay.L / lay.D, lay.D)
                       : h->cfg.model_type == SCRF_STDSEG_NO_DUR ? segtrans_num_arcs(q.T, lay.L, lay.D)
                                                                 : scrf_arc_base(q.T, lay.L, lay.D) + lay.L;
     b->arc_off[u + 1] = b->arc_off[u] + na;
@@ -1627,10 +1627,44 @@ extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, ui
 // ---------------------------------------------------------------------------------------------
 extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int norm, scrf_arc* arcs, uint64_t* n_arcs,
                                  uint32_t* n_states, int32_t* final_state) {
-  if (h && stdseg(h)) return fail(h, SCRF_ERR_INVALID, "scrf_lattice_arcs: decoding is not built for the stdseg model type (training and node values only)");
   int rc = check_u(h, b, u, "scrf_lattice_arcs");
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipSetDevice(h->device));
+  if (stdseg(h)) {   // decoders/CRF_LatticeBuilder_StdSeg.h: one state per (node, available full label)
+    const uint32_t La = stdseg_La(h), T = b->T[u];
+    const uint64_t ns = b->seg_off[u + 1] - b->seg_off[u], na = b->arc_off[u + 1] - b->arc_off[u];
+    if (n_arcs) *n_arcs = na;
+    if (n_states) *n_states = (uint32_t)(2 + ns * La);
+    if (final_state) *final_state = (int32_t)(1 + ns * La);
+    if (!arcs) return SCRF_OK;
+    StdsegBufs sb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = stdseg_run_chunk(h, b, u, u + 1, false, nullptr, &sb);
+    if (rc != SCRF_OK) return rc;
+    float final_w = -0.0f;
+    if (norm) {
+      double asum = 0;
+      HIPCHK(h, hipMemcpyAsync(&asum, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      const double Zx = -1 * asum;
+      final_w = (float)(-Zx);
+    }
+    std::vector<uint64_t> off;
+    stdseg_row_arc_offsets(T, La, h->lay.D, &off);
+    uint64_t* d_off = nullptr;
+    scrf_arc* d_arcs = nullptr;
+    hipError_t e = hipMalloc((void**)&d_off, sizeof(uint64_t) * off.size());
+    if (e == hipSuccess) e = hipMalloc((void**)&d_arcs, sizeof(scrf_arc) * na);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), sizeof(uint64_t) * off.size(), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+      launch_stdseg_arcs(h->stream, h->lay, La, T, ns, d_off, sb.S, sb.MX, final_w, d_arcs);
+      e = hipMemcpyAsync(arcs, d_arcs, sizeof(scrf_arc) * na, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_off); hipFree(d_arcs);
+    if (e != hipSuccess) return fail(h, SCRF_ERR_HIP, "scrf_lattice_arcs: %s", hipGetErrorString(e));
+    return SCRF_OK;
+  }
   const ScrfLayout& l = h->lay;
   const uint32_t T = b->T[u];
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
@@ -1671,7 +1705,6 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
 
 extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64_t max_labels,
                                   uint64_t* lab_off, float* best_cost) {
-  if (h && stdseg(h)) return fail(h, SCRF_ERR_INVALID, "scrf_viterbi_batch: decoding is not built for the stdseg model type (training and node values only)");
   if (!h || !b || !seg_labels || !lab_off) return SCRF_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& l = h->lay;
@@ -1696,7 +1729,30 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   ndf.fused = ndf.vitfast = true;
   const bool fast = h->fast_decode && b->fused_ok && h->fuse_windows && !frame_model && l.L <= 0xffff;
   int rc = SCRF_OK;
-  for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK;) {
+  if (stdseg(h)) {
+    const uint32_t La = stdseg_La(h);
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK;) {
+      // the chunk's scores in the scratch arena, path costs and back pointers behind them
+      uint32_t u1 = stdseg_plan_chunk(h, b, u0, true);   // `post` sizing leaves room for the two decode arrays
+      StdsegBufs sb;
+      rc = stdseg_run_chunk(h, b, u0, u1, false, nullptr, &sb);
+      if (rc != SCRF_OK) break;
+      const uint64_t nseg = b->seg_off[u1] - b->seg_off[u0];
+      float* vc = nullptr;
+      uint16_t* bp = nullptr;
+      hipError_t e = hipMalloc((void**)&vc, sizeof(float) * nseg * La);
+      if (e == hipSuccess) e = hipMalloc((void**)&bp, sizeof(uint16_t) * nseg * La);
+      if (e == hipSuccess) {
+        launch_stdseg_viterbi(h->stream, h->lay, La, b->view(), u0, u1 - u0, sb.S, sb.MX, vc, bp, d_lab, d_n, d_cost);
+        e = hipStreamSynchronize(h->stream);
+      }
+      hipFree(vc); hipFree(bp);
+      if (e != hipSuccess) { rc = fail(h, SCRF_ERR_HIP, "scrf_viterbi_batch: %s", hipGetErrorString(e)); break; }
+      u0 = u1;
+    }
+  }
+  for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK && !stdseg(h);) {
     uint32_t u_end = u0;
     if (fast) {
       const uint32_t u1 = plan_chunk(h, b, u0, ndf);

@@ -4,6 +4,8 @@
 
 #include "scrf_common.h"
 
+#include <vector>
+
 void launch_windows(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
                     uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, uint32_t lctx,
                     uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col);
@@ -158,5 +160,12 @@ void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, Scrf
                         const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u, const uint32_t* prev_lab,
                         const float* X, const double* G, const double* XI, double* grad);
 void launch_stdseg_sums(hipStream_t st, const double* numer, const double* zx, uint32_t u0, uint32_t n, double* sums);
+uint64_t stdseg_num_arcs(uint32_t T, uint32_t La, uint32_t D);
+void stdseg_row_arc_offsets(uint32_t T, uint32_t La, uint32_t D, std::vector<uint64_t>* off);
+void launch_stdseg_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t La, uint32_t T, uint64_t n_rows, const uint64_t* row_arc,
+                        const double* S, const double* MX, float final_w, scrf_arc* arcs);
+void launch_stdseg_viterbi(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                           const double* S, const double* MX, float* vc, uint16_t* bp, uint32_t* out_labels, uint32_t* out_n,
+                           float* out_cost);
 
 #endif  // SCRF_KERNELS_H_

@@ -15,6 +15,8 @@
 
 #include <math.h>
 
+#include <vector>
+
 // ------------------------------------------------------------------------------------------
 // row -> (utterance, frame, duration)
 // ------------------------------------------------------------------------------------------
@@ -290,6 +292,140 @@ __global__ void k_stdseg_sums(const double* __restrict__ numer, const double* __
 }
 
 // ------------------------------------------------------------------------------------------
+// lattice (decoders/CRF_LatticeBuilder_StdSeg.h:40-590): state 0 = start; state of (t, clab) = 1 + row(t,dur)*La + phone;
+// arcs per node dur ascending, phone ascending, previous full label ascending, weight float(-1*(transMatrix + stateArray)),
+// utterance-initial durations one arc from the start with float(-1*stateArray); labels clab + 1; then the final state's
+// epsilon arcs.  row_arc[row] = index of the row's first arc (host prefix sums); one thread per (row, phone).
+// ------------------------------------------------------------------------------------------
+__global__ void k_stdseg_arcs(ScrfLayout lay, uint32_t La, uint32_t T, uint64_t n_rows, const uint64_t* __restrict__ row_arc,
+                              const double* __restrict__ S, const double* __restrict__ MX, float final_w,
+                              scrf_arc* __restrict__ arcs) {
+  const uint32_t NL = lay.L, D = lay.D;
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_last = La * scrf_node_max_dur(T - 1, D);
+  if (e >= n_rows * La + n_last) return;
+  const int fin = 1 + (int)(n_rows * La);
+  if (e >= n_rows * La) {   // final arcs
+    const uint32_t pl = (uint32_t)(e - n_rows * La);
+    scrf_arc a;
+    a.src = 1 + (int)(scrf_seg_base(T - 1, D) * La + pl); a.ilabel = 0; a.olabel = 0; a.w = final_w; a.dst = fin;
+    arcs[row_arc[n_rows] + pl] = a;
+    return;
+  }
+  const uint64_t row = e / La;
+  const uint32_t lab = (uint32_t)(e % La);
+  // (t, dur) of the row
+  uint32_t t, dur;
+  {
+    const uint64_t tri = (uint64_t)D * (D + 1) / 2;
+    if (row < tri) {
+      t = 0;
+      while (scrf_seg_base(t + 1, D) <= row) t++;
+    } else {
+      t = D + (uint32_t)((row - tri) / D);
+    }
+    dur = (uint32_t)(row - scrf_seg_base(t, D)) + 1;
+  }
+  const uint32_t clab = (dur - 1) * La + lab;
+  const int cur_state = 1 + (int)(row * La + lab);
+  const double sv = S[row * La + lab];
+  if (dur <= scrf_num_prev(t, D)) {
+    const uint32_t pavail = La * scrf_node_max_dur(t - dur, D);
+    const int pstart = 1 + (int)(scrf_seg_base(t - dur, D) * La);
+    scrf_arc* out = arcs + row_arc[row] + (uint64_t)lab * pavail;
+    for (uint32_t pl = 0; pl < pavail; pl++) {
+      scrf_arc a;
+      a.src = pstart + (int)pl; a.ilabel = (int)clab + 1; a.olabel = (int)clab + 1;
+      a.w = (float)(-1 * (MX[(row * NL + pl) * La + lab] + sv));
+      a.dst = cur_state;
+      out[pl] = a;
+    }
+  } else {
+    scrf_arc a;
+    a.src = 0; a.ilabel = (int)clab + 1; a.olabel = (int)clab + 1; a.w = (float)(-1 * sv); a.dst = cur_state;
+    arcs[row_arc[row] + lab] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// best path = ShortestPath on that lattice (tropical semiring on float, states relaxed in id order, strict
+// improvement: a state keeps the first of equal candidates): a state (t, clab) is entered from node t-dur only, previous
+// full label ascending, or from the start; the final state from the last node's labels ascending.
+// One workgroup per utterance; vc: [N_seg][La] float path costs, bp: previous full label (0xffff = start).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stdseg_viterbi(ScrfLayout lay, uint32_t La, ScrfBatchView bv, uint32_t u0,
+                                                        const double* __restrict__ S, const double* __restrict__ MX,
+                                                        float* __restrict__ vc, uint16_t* __restrict__ bp,
+                                                        uint32_t* __restrict__ out_labels, uint32_t* __restrict__ out_n,
+                                                        float* __restrict__ out_cost) {
+  const uint32_t NL = lay.L, D = lay.D;
+  const uint32_t u = u0 + blockIdx.x;
+  const uint32_t T = bv.T[u];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* Su = S + s_base * La;
+  const double* Mu = MX + s_base * (uint64_t)NL * La;
+  float* vu = vc + s_base * La;
+  uint16_t* bu = bp + s_base * La;
+  uint32_t* outl = out_labels + bv.frame_off[u];
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = scrf_seg_base(t, D);
+    const uint32_t nd = scrf_node_max_dur(t, D), np = scrf_num_prev(t, D);
+    for (uint32_t e = threadIdx.x; e < nd * La; e += blockDim.x) {
+      const uint32_t dur = e / La + 1, lab = e % La;
+      const uint64_t at = (base + dur - 1) * La + lab;
+      const double sv = Su[at];
+      float best = INFINITY;
+      uint32_t bpv = 0xffff;
+      if (dur <= np) {
+        const float* pc = vu + scrf_seg_base(t - dur, D) * La;
+        const uint32_t pavail = La * scrf_node_max_dur(t - dur, D);
+        const double* Mrow = Mu + (base + dur - 1) * (uint64_t)NL * La + lab;
+        for (uint32_t pl = 0; pl < pavail; pl++) {
+          const float c = pc[pl] + (float)(-1 * (Mrow[(uint64_t)pl * La] + sv));
+          if (c < best) { best = c; bpv = pl; }
+        }
+      } else {
+        best = 0.0f + (float)(-1 * sv);
+      }
+      vu[at] = best;
+      bu[at] = (uint16_t)bpv;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float best = INFINITY;
+    int bl = -1;
+    const uint64_t lbase = scrf_seg_base(T - 1, D);
+    const uint32_t n_last = La * scrf_node_max_dur(T - 1, D);
+    for (uint32_t cl = 0; cl < n_last; cl++) {
+      const float c = vu[lbase * La + cl] + -0.0f;
+      if (c < best) { best = c; bl = (int)cl; }
+    }
+    uint32_t n = 0;
+    if (bl >= 0) {
+      int t = (int)T - 1;
+      uint32_t cl = (uint32_t)bl;
+      while (true) {
+        outl[n++] = cl;
+        const uint32_t dur = cl / La + 1;
+        const uint32_t p = bu[scrf_seg_base((uint32_t)t, D) * La + cl];
+        if (p == 0xffff) break;
+        t -= (int)dur;
+        cl = p;
+      }
+      for (uint32_t i = 0; i < n / 2; i++) {
+        const uint32_t tmp = outl[i];
+        outl[i] = outl[n - 1 - i];
+        outl[n - 1 - i] = tmp;
+      }
+      best = best + 0.0f;  // Times(distance, Final = One)
+    }
+    out_n[u] = n;
+    out_cost[u] = best;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_stdseg_rowinfo(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
@@ -330,4 +466,39 @@ void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, Scrf
 }
 void launch_stdseg_sums(hipStream_t st, const double* numer, const double* zx, uint32_t u0, uint32_t n, double* sums) {
   hipLaunchKernelGGL(k_stdseg_sums, dim3(1), dim3(1), 0, st, numer, zx, u0, n, sums);
+}
+uint64_t stdseg_num_arcs(uint32_t T, uint32_t La, uint32_t D) {
+  uint64_t na = 0;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint32_t np = scrf_num_prev(t, D), nd = scrf_node_max_dur(t, D);
+    for (uint32_t dur = 1; dur <= np; dur++) na += (uint64_t)La * La * scrf_node_max_dur(t - dur, D);
+    na += (uint64_t)(nd - np) * La;
+  }
+  if (T > 0) na += (uint64_t)La * scrf_node_max_dur(T - 1, D);
+  return na;
+}
+// first arc of every window row of one utterance (n_rows + 1 entries; the last = first final arc)
+void stdseg_row_arc_offsets(uint32_t T, uint32_t La, uint32_t D, std::vector<uint64_t>* off) {
+  off->clear();
+  uint64_t na = 0;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint32_t np = scrf_num_prev(t, D), nd = scrf_node_max_dur(t, D);
+    for (uint32_t dur = 1; dur <= nd; dur++) {
+      off->push_back(na);
+      na += dur <= np ? (uint64_t)La * La * scrf_node_max_dur(t - dur, D) : La;
+    }
+  }
+  off->push_back(na);
+}
+void launch_stdseg_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t La, uint32_t T, uint64_t n_rows, const uint64_t* row_arc,
+                        const double* S, const double* MX, float final_w, scrf_arc* arcs) {
+  if (T == 0) return;
+  const uint64_t n = n_rows * La + (uint64_t)La * scrf_node_max_dur(T - 1, lay.D);
+  hipLaunchKernelGGL(k_stdseg_arcs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, lay, La, T, n_rows, row_arc, S, MX, final_w, arcs);
+}
+void launch_stdseg_viterbi(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
+                           const double* S, const double* MX, float* vc, uint16_t* bp, uint32_t* out_labels, uint32_t* out_n,
+                           float* out_cost) {
+  if (n_utts == 0) return;
+  hipLaunchKernelGGL(k_stdseg_viterbi, dim3(n_utts), dim3(256), 0, st, lay, La, bv, u0, S, MX, vc, bp, out_labels, out_n, out_cost);
 }

@@ -54,7 +54,7 @@ enum scrf_status {
 /* modeltype, CRF.h:50 */
 enum scrf_model_type {
   SCRF_STDFRAME = 0,
-  SCRF_STDSEG = 1,                       /* duration-labelled: num_labs = nActualLabs * lab_max_dur; training + node values, no decoding */
+  SCRF_STDSEG = 1,                       /* duration-labelled: num_labs = nActualLabs * lab_max_dur */
   SCRF_STDSEG_NO_DUR = 2,                /* transition features from the segment's own window (one L x L matrix per
                                             window): training, parity hooks, lattice arcs and best path (scrf_segtrans.hip) */
   SCRF_STDSEG_NO_DUR_NO_TRANSFTR = 3,    /* served by the same engine (bias-only transitions) */

@@ -1193,6 +1193,71 @@ uint64_t orc_segtrans_lattice_arcs(const orc_config* cfg, const double* S, const
   return na;
 }
 
+/* decoders/CRF_LatticeBuilder_StdSeg.h:40-590 (STDSEG).  State 0 = start; node t owns one state per available full
+ * label, numbered from nodeStartStates[t] = 1 + La * seg_base(t) (:300-305, :425-427, :452-454), i.e. state of
+ * (t, clab) = 1 + row(t,dur)*La + phone; arcs per node: dur ascending, phone ascending, then previous full label
+ * ascending with weight float(-1 * getFullTransValue(plab, clab)) = float(-(transMatrix + stateArray)), the
+ * utterance-initial durations one arc from the start state with float(-1 * stateArray[clab]); labels clab + 1;
+ * final state last, reached from every available label of the last node by an epsilon arc of weight -Zx
+ * (Zx = -alpha sum with norm, else 0). */
+uint64_t orc_stdseg_lattice_num_arcs(uint32_t T, uint32_t La, uint32_t D) {
+  uint64_t na = 0;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
+    for (uint32_t dur = 1; dur <= np; dur++) na += (uint64_t)La * La * orc_node_max_dur(t - dur, D);
+    na += (uint64_t)(nd - np) * La;
+  }
+  if (T > 0) na += (uint64_t)La * orc_node_max_dur(T - 1, D);
+  return na;
+}
+
+uint64_t orc_stdseg_lattice_arcs(const orc_config* cfg, const double* S, const double* MX, uint32_t T, int norm,
+                                 double alpha_sum, orc_arc* arcs, uint32_t* n_states, int32_t* final_state) {
+  const uint32_t NL = cfg->num_labs, D = cfg->lab_max_dur, La = NL / D;
+  uint64_t na = 0;
+  int next_state = 1;
+  for (uint32_t t = 0; t < T; t++) {
+    const uint64_t base = orc_seg_base(t, D);
+    const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
+    int cur_lab = 0;
+    for (uint32_t dur = 1; dur <= nd; dur++) {
+      for (uint32_t lab = 0; lab < La; lab++) {
+        const int cur_state = next_state++;
+        const size_t at = (base + dur - 1) * La + lab;
+        if (dur <= np) {
+          const uint32_t pavail = La * orc_node_max_dur(t - dur, D);
+          const int pstart = 1 + (int)(orc_seg_base(t - dur, D) * La);
+          for (uint32_t prev_lab = 0; prev_lab < pavail; prev_lab++) {
+            float value = -1 * (MX[((base + dur - 1) * (size_t)NL + prev_lab) * La + lab] + S[at]);
+            orc_arc a = {pstart + (int)prev_lab, cur_lab + 1, cur_lab + 1, value, cur_state};
+            arcs[na++] = a;
+          }
+        } else {
+          float value = -1 * S[at];
+          orc_arc a = {0, cur_lab + 1, cur_lab + 1, value, cur_state};
+          arcs[na++] = a;
+        }
+        cur_lab++;
+      }
+    }
+  }
+  int fin = -1;
+  if (T > 0) {
+    double Zx = 0;
+    if (norm) Zx = -1 * alpha_sum;
+    fin = next_state++;
+    const int pstart = 1 + (int)(orc_seg_base(T - 1, D) * La);
+    for (uint32_t prev_lab = 0; prev_lab < La * orc_node_max_dur(T - 1, D); prev_lab++) {
+      float w = -Zx;
+      orc_arc a = {pstart + (int)prev_lab, 0, 0, w, fin};
+      arcs[na++] = a;
+    }
+  }
+  *n_states = (uint32_t)next_state;
+  *final_state = fin;
+  return na;
+}
+
 uint64_t orc_frame_lattice_num_arcs(uint32_t T, uint32_t L) {
   if (T == 0) return L;
   return (uint64_t)L + (uint64_t)(T - 1) * L * L + L;

@@ -206,6 +206,9 @@ uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const doub
                               uint32_t* n_states, int32_t* final_state);
 /* STDSEG_NO_DUR: decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h (S [N_seg][L], M2 [N_seg][L*L]) */
 uint64_t orc_segtrans_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D);
+uint64_t orc_stdseg_lattice_num_arcs(uint32_t T, uint32_t La, uint32_t D);
+uint64_t orc_stdseg_lattice_arcs(const orc_config* cfg, const double* S, const double* MX, uint32_t T, int norm,
+                                 double alpha_sum, orc_arc* arcs, uint32_t* n_states, int32_t* final_state);
 uint64_t orc_segtrans_lattice_arcs(const orc_config* cfg, const double* S, const double* M2, uint32_t T,
                                    int norm, double alpha_sum, orc_arc* arcs, uint32_t* n_states,
                                    int32_t* final_state);

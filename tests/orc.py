@@ -84,6 +84,8 @@ def lib():
         _lib.orc_seg_lattice_arcs.restype = C.c_uint64
         _lib.orc_segtrans_lattice_num_arcs.restype = C.c_uint64
         _lib.orc_segtrans_lattice_arcs.restype = C.c_uint64
+        _lib.orc_stdseg_lattice_num_arcs.restype = C.c_uint64
+        _lib.orc_stdseg_lattice_arcs.restype = C.c_uint64
         _lib.orc_frame_lattice_num_arcs.restype = C.c_uint64
         _lib.orc_frame_lattice_arcs.restype = C.c_uint64
         _lib.orc_best_path.restype = C.c_int64
@@ -403,6 +405,17 @@ def segtrans_lattice_arcs(cfg, S, M2, T, norm=False, alpha_sum=0.0):
     ns = C.c_uint32(); fin = C.c_int32()
     na = lib().orc_segtrans_lattice_arcs(C.byref(cfg), _p(S), _p(M2), C.c_uint32(T), C.c_int(int(norm)),
                                          C.c_double(alpha_sum), _p(arcs), C.byref(ns), C.byref(fin))
+    assert na == n, (na, n)
+    return arcs, ns.value, fin.value
+
+
+def stdseg_lattice_arcs(cfg, S, MX, T, norm=False, alpha_sum=0.0):
+    NL, D = cfg.num_labs, cfg.lab_max_dur
+    n = int(lib().orc_stdseg_lattice_num_arcs(C.c_uint32(T), C.c_uint32(NL // D), C.c_uint32(D)))
+    arcs = np.zeros(n, dtype=ARC_DTYPE)
+    ns = C.c_uint32(); fin = C.c_int32()
+    na = lib().orc_stdseg_lattice_arcs(C.byref(cfg), _p(S), _p(MX), C.c_uint32(T), C.c_int(int(norm)),
+                                       C.c_double(alpha_sum), _p(arcs), C.byref(ns), C.byref(fin))
     assert na == n, (na, n)
     return arcs, ns.value, fin.value
 

@@ -1098,8 +1098,7 @@ def test_crffstdecode_dictionary_lm_and_alignment_chain(tmp_path):
 
 def test_crftrain_stdseg_model_type(tmp_path):
     """crf_model_type=stdseg (duration-labelled: crf_label_size = num_actual_labs * label_maximum_duration) trains
-    through the same front-end; weights against the oracle's SGD loop over orc.stdseg_build_gradient.  The decoders
-    refuse the model type."""
+    through the same front-end; weights against the oracle's SGD loop over orc.stdseg_build_gradient."""
     from scrf_amd import synth
     rng = np.random.RandomState(31)
     L, D, W = 3, 2, 2
@@ -1134,9 +1133,19 @@ def test_crftrain_stdseg_model_type(tmp_path):
     w = np.loadtxt(wf)
     assert np.abs(w).max() > 0
     np.testing.assert_allclose(w, np.array([float("%g" % v) for v in lam]), rtol=2e-5, atol=1e-12)
+    # CRFFstDecode: lattice + best path of the trained model == the oracle's shortest path; CRFDecode (the LM decoder)
+    # exists for stdframe and stdseg_no_dur_no_segtransftr only, as in the reference (CRFDecode/src/Main.cpp:1059-1077)
+    dec = str(tmp_path / "dec.txt")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_output_labelfile=" + dec], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.loadtxt(dec).astype(int).reshape(-1, 3)
+    for u, T in enumerate(Ts):
+        S, MX = orc.stdseg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        oa, ons, ofin = orc.stdseg_lattice_arcs(cfg, S, MX, T)
+        ol, _ = orc.best_path(oa, ons, ofin)
+        assert list(got[got[:, 0] == u][:, 2]) == list(ol)
     olist = str(tmp_path / "olist")
     open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
-    for exe in ("CRFFstDecode", "CRFDecode"):
-        r = subprocess.run([os.path.join(BIN, exe)] + model + ["weight_file=" + wf, "crf_output_labelfile=" + str(tmp_path / "dec.txt"), "crf_olist=" + olist],
-                           capture_output=True, text=True, timeout=60)
-        assert r.returncode != 0 and "stdseg" in (r.stderr + r.stdout)
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_output_labelfile=" + str(tmp_path / "dec2.txt"), "crf_olist=" + olist],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "stdseg" in (r.stderr + r.stdout)

@@ -1,8 +1,9 @@
 """-m gpu: SURVEY row f3, second step -- the STDSEG model (labels carry the duration: own state weights per
 (phone, duration), transitions over full labels from the segment's own window, nodes/CRF_StdSegStateNode.cpp, with
 trainers/gradbuilders/CRF_NewGradBuilder_StdSeg.cpp) through the same engine and C ABI, training side and node values,
-against the oracle's restatement (tests/test_oracle_stdseg.py pins that one by brute force).  Decoding is refused for
-this model type.  Bars: scores bit-exact; node values 1e-11; gradient, numerator, Zx 1e-10."""
+against the oracle's restatement (tests/test_oracle_stdseg.py pins that one by brute force), plus its lattice
+(decoders/CRF_LatticeBuilder_StdSeg.h) and best path.  Bars: scores and lattice arcs bit-exact; node values 1e-11;
+gradient, numerator, Zx 1e-10; Viterbi labels and float cost identical to the oracle's shortest path."""
 import numpy as np
 import pytest
 
@@ -92,12 +93,30 @@ def test_errors_and_refusals():
     assert "label" in str(ei.value).lower()
     assert np.all(eng.get_grad() == 0.0)          # a failed batch contributes nothing
     b.close()
-    b = c.batch(eng)
-    with pytest.raises(scrf_amd.ScrfError):
-        eng.lattice_arcs(b, 0)
-    with pytest.raises(scrf_amd.ScrfError):
-        eng.viterbi_batch(b)
-    b.close(); eng.close()
+    eng.close()
     # nLabs must be a multiple of the maximum duration (nodes/CRF_StdSegStateNode.cpp:34-40)
     with pytest.raises(scrf_amd.ScrfError):
         scrf_amd.Engine(scrf_amd.make_config(model_type=orc.STDSEG, L=10, D=3, F=19))
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_lattice_arcs_and_best_path(ci):
+    c = Case(seed=900 + ci, model_type=orc.STDSEG, **CASES[ci])
+    eng = c.engine(); b = c.batch(eng, with_labels=False)
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.stdseg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.stdseg_lattice_arcs(c.ocfg, So, Mo, T)
+        ga, gns, gfin = eng.lattice_arcs(b, u)
+        assert gns == ons and gfin == ofin and ga.tobytes() == oa.tobytes()
+        rc, al, zx = orc.stdseg_forward(c.ocfg, So, Mo, T)
+        oa2, _, _ = orc.stdseg_lattice_arcs(c.ocfg, So, Mo, T, norm=True, alpha_sum=zx)
+        ga2, _, _ = eng.lattice_arcs(b, u, norm=True)
+        nlast = c.L * min(T, c.D)
+        assert ga2[:-nlast].tobytes() == oa2[:-nlast].tobytes()
+        np.testing.assert_allclose(ga2["w"][-nlast:], oa2["w"][-nlast:], rtol=1e-6)
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol) and np.float32(cost[u]) == np.float32(oc)
+        # the labels tile the utterance
+        assert sum(int(x) // c.L + 1 for x in labs[u]) == T
+    b.close(); eng.close()

@@ -112,3 +112,27 @@ def test_duration_specific_state_weights_matter_and_collapse():
     _, _, zx = orc.stdseg_forward(cfg, S, MX, T)
     _, _, _, zx2 = orc.segtrans_forward(cfg2, S2, M2, T)
     assert abs(zx - zx2) < 1e-12 * max(1, abs(zx))
+
+
+@pytest.mark.parametrize("L,D,T", [(2, 2, 4), (3, 3, 6), (2, 3, 5), (3, 3, 1), (2, 4, 7)])
+def test_lattice_paths_are_the_labelled_segmentations(L, D, T):
+    """decoders/CRF_LatticeBuilder_StdSeg.h: the lattice's paths are exactly the labelled segmentations, each with
+    (float sums of) the negated model score; its best path is the enumeration's best segmentation."""
+    cfg, lay, lam, X, _ = _case(L, D, T, 2, seed=40 + L * 100 + D * 10 + T)
+    S, MX = orc.stdseg_scores(cfg, lay, lam, X, T)
+    bf = orc.brute_force_stdseg(S, MX, T, L, D)
+    arcs, ns, fin = orc.stdseg_lattice_arcs(cfg, S, MX, T)
+    assert ns == 2 + L * orc.num_segs(T, D) and fin == ns - 1
+    # arcs leave states in ascending target order and every target is above its source (topological)
+    assert np.all(arcs["dst"] > arcs["src"])
+    # path count by dynamic programming over the states == number of enumerated segmentations
+    cnt = np.zeros(ns); cnt[0] = 1
+    for a in arcs:
+        cnt[a["dst"]] += cnt[a["src"]]
+    assert cnt[fin] == bf["n_paths"]
+    ol, cost = orc.best_path(arcs, ns, fin)
+    best_sc, best_segs = bf["best"]
+    assert abs(-cost - best_sc) < 1e-4 * max(1.0, abs(best_sc))
+    scores = sorted(p[0] for p in bf["paths"])
+    if len(scores) == 1 or scores[-1] - scores[-2] > 1e-4:
+        assert list(ol) == [(d - 1) * L + l for (_, d, l) in best_segs]

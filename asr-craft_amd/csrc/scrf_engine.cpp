@@ -182,7 +182,9 @@ static uint32_t window_width(const scrf_stream_recipe& r, uint32_t D) {
 
 static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
   if (c.abi_version != SCRF_ABI_VERSION) { *why = "abi_version mismatch"; return SCRF_ERR_INVALID; }
-  if (c.num_states != 1) { *why = "only crf_states=1 is built (multi-state nodes are out of scope)"; return SCRF_ERR_INVALID; }
+  if (c.num_states == 0) { *why = "num_states must be >= 1"; return SCRF_ERR_INVALID; }
+  if (c.num_states > 1 && (c.model_type != SCRF_STDFRAME || c.lab_max_dur != 1)) { *why = "crf_states > 1 is built for the frame-level model only (the reference's segmental n-state node exists for stdseg_no_dur_no_segtransftr alone and is not built)"; return SCRF_ERR_INVALID; }
+  if (c.num_states > 1 && c.num_labs % c.num_states != 0) { *why = "Invalid state/label combination while computing transitions"; return SCRF_ERR_INVALID; }  // CRF_StdFeatureMap.cpp:476-479
   if (c.num_labs == 0 || c.lab_max_dur == 0 || c.num_feas == 0) { *why = "num_labs, lab_max_dur, num_feas must be > 0"; return SCRF_ERR_INVALID; }
   if (c.model_type == SCRF_STDSEG && c.num_labs % c.lab_max_dur != 0) { *why = "stdseg: the number of all labels and the maximum duration of labels do not correspond (nLabs = nActualLabs * labMaxDur)"; return SCRF_ERR_INVALID; }
   if (c.model_type > SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR) { *why = "unknown model_type"; return SCRF_ERR_INVALID; }
@@ -202,7 +204,12 @@ static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
   l->nsf = l->nsfe + (l->use_sb ? 1 : 0);
   l->ntf = l->ntfe + (l->use_tb ? 1 : 0);
   l->stride = l->nsf + l->L * l->ntf;
+  l->K = c.num_states;
   uint64_t ll = (uint64_t)l->L * l->stride;
+  if (l->K > 1) {   // :480-485: end->start + self + next-state transitions
+    const uint64_t P = l->L / l->K;
+    ll = (uint64_t)l->L * l->nsf + (P * P + 2 * (uint64_t)l->L - P) * l->ntf;
+  }
   if (ll == 0 || ll > 0xfffffff0ull) { *why = "lambda_len out of range"; return SCRF_ERR_INVALID; }
   l->lambda_len = (uint32_t)ll;
   return SCRF_OK;
@@ -501,7 +508,8 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     b->T[u] = q.T;
     b->frame_off[u + 1] = b->frame_off[u] + q.T;
     b->seg_off[u + 1] = b->seg_off[u] + scrf_seg_base(q.T, lay.D);
-    uint64_t na = (lay.D == 1 && h->cfg.model_type == SCRF_STDFRAME)
+    uint64_t na = lay.K > 1 ? ns_num_arcs(q.T, lay.L, lay.K)
+                  : (lay.D == 1 && h->cfg.model_type == SCRF_STDFRAME)
                       ? (uint64_t)lay.L + (uint64_t)(q.T - 1) * lay.L * lay.L + lay.L
                       : h->cfg.model_type == SCRF_STDSEG ? stdseg_num_arcs(q.T, lay.L / lay.D, lay.D)
                       : h->cfg.model_type == SCRF_STDSEG_NO_DUR ? segtrans_num_arcs(q.T, lay.L, lay.D)
@@ -1280,6 +1288,71 @@ static uint32_t stdseg_plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, bool
   return u1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// n-state frame model (crf_states > 1, scrf_nstate.hip): the same small pipeline shape as STDSEG
+// ---------------------------------------------------------------------------------------------
+static bool nstate(scrf_handle h) { return h->lay.K > 1; }
+struct NstateBufs {
+  float* X;
+  double *S, *TD, *TO, *TE, *alpha, *beta, *G, *XD, *XO, *XE, *mass_s, *mass_t;
+};
+static size_t nstate_chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nfr, bool post) {
+  const ScrfLayout& l = h->lay;
+  const uint64_t P = l.L / l.K;
+  size_t tot = 0;
+  if (b->mode == 1) tot += pad256(nfr * l.F * sizeof(float));
+  tot += 5 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * P * P * sizeof(double));              // S, TD, TO, alpha, beta, TE
+  if (post) tot += 3 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * P * P * sizeof(double)) + 2 * pad256(nfr * sizeof(double));
+  return tot;
+}
+static int nstate_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, bool post, double* grad, NstateBufs* out) {
+  const ScrfLayout& l = h->lay;
+  const uint64_t P = l.L / l.K;
+  const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0];
+  int rc = ensure_scratch(h, nstate_chunk_bytes(h, b, nfr, post));
+  if (rc != SCRF_OK) return rc;
+  Arena a{h->scratch, h->scratch_cap, 0};
+  NstateBufs nb;
+  memset(&nb, 0, sizeof(nb));
+  ScrfBatchView bv = b->view();
+  hipStream_t st = h->stream;
+  if (b->mode == 1) {
+    nb.X = a.take<float>(nfr * l.F);
+    uint32_t col = 0;
+    for (uint32_t s = 0; s < b->n_streams; s++) {
+      const scrf_stream_recipe& r = b->recipe[s];
+      launch_windows(st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx, r.right_ctx, r.extract_seg_ftr,
+                     nb.X, l.F, col);
+      col += b->width[s];
+    }
+  } else {
+    nb.X = b->d_windows + b->seg_off[u0] * l.F;
+  }
+  nb.S = a.take<double>(nfr * l.L); nb.TD = a.take<double>(nfr * l.L); nb.TO = a.take<double>(nfr * l.L);
+  nb.alpha = a.take<double>(nfr * l.L); nb.beta = a.take<double>(nfr * l.L);
+  nb.TE = a.take<double>(nfr * P * P);
+  launch_ns_scores(st, l, nb.X, nfr, h->d_lambda, nb.S, nb.TD, nb.TO, nb.TE);
+  launch_ns_fb(st, l, bv, u0, u1 - u0, nb.S, nb.TD, nb.TO, nb.TE, nb.alpha, nb.beta, b->d_zx, b->d_status);
+  if (post) {
+    nb.G = a.take<double>(nfr * l.L); nb.XD = a.take<double>(nfr * l.L); nb.XO = a.take<double>(nfr * l.L);
+    nb.XE = a.take<double>(nfr * P * P);
+    nb.mass_s = a.take<double>(nfr); nb.mass_t = a.take<double>(nfr);
+    HIPCHK(h, hipMemsetAsync(nb.mass_s, 0, sizeof(double) * nfr, st));
+    HIPCHK(h, hipMemsetAsync(nb.mass_t, 0, sizeof(double) * nfr, st));
+    launch_ns_post(st, l, bv, b->d_frame_u, u0, u1 - u0, nfr, nb.S, nb.TD, nb.TO, nb.TE, nb.alpha, nb.beta, b->d_zx, nb.G, nb.XD, nb.XO,
+                   nb.XE, nb.mass_s, nb.mass_t, b->d_numer, b->d_status);
+    launch_ns_expf(st, l, bv, b->d_frame_u, u0, nfr, nb.X, nb.G, nb.XD, nb.XO, nb.XE, grad);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (out) *out = nb;
+  return SCRF_OK;
+}
+static uint32_t nstate_plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, bool post) {
+  uint32_t u1 = u0 + 1;
+  while (u1 < b->U && nstate_chunk_bytes(h, b, b->frame_off[u1 + 1] - b->frame_off[u0], post) <= h->cfg.scratch_bytes) u1++;
+  return u1;
+}
+
 // One pass of the forward-backward pipeline over the batch into the staging gradient.  latch[2] receives
 // {status code, utterance} of the first failed utterance (0 = clean, gradient committed); *used_lin tells
 // whether any chunk ran the linear-domain recursion.
@@ -1290,10 +1363,10 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   HIPCHK(h, hipMemsetAsync(h->d_stage, 0, sizeof(double) * l.lambda_len, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_sums_stage, 0, sizeof(double) * 4, h->stream));
   *used_lin = false;
-  if (stdseg(h)) {
+  if (stdseg(h) || nstate(h)) {
     for (uint32_t u0 = 0; u0 < b->U;) {
-      const uint32_t u1 = stdseg_plan_chunk(h, b, u0, true);
-      int rc = stdseg_run_chunk(h, b, u0, u1, true, h->d_stage, nullptr);
+      const uint32_t u1 = nstate(h) ? nstate_plan_chunk(h, b, u0, true) : stdseg_plan_chunk(h, b, u0, true);
+      int rc = nstate(h) ? nstate_run_chunk(h, b, u0, u1, true, h->d_stage, nullptr) : stdseg_run_chunk(h, b, u0, u1, true, h->d_stage, nullptr);
       if (rc != SCRF_OK) return rc;
       launch_stdseg_sums(h->stream, b->d_numer, b->d_zx, u0, u1 - u0, h->d_sums_stage);
       u0 = u1;
@@ -1535,6 +1608,21 @@ extern "C" int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, d
   int rc = check_u(h, b, u, "scrf_scores");
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipSetDevice(h->device));
+  if (nstate(h)) {   // S [T][nLabs]; M [T][2*nLabs + P*P]: self transitions | c -> c+1 | end state of p -> start state of q
+    NstateBufs nb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = nstate_run_chunk(h, b, u, u + 1, false, nullptr, &nb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t T = b->T[u], L = h->lay.L, P = L / h->lay.K, w = 2 * L + P * P;
+    if (S) HIPCHK(h, hipMemcpyAsync(S, nb.S, sizeof(double) * T * L, hipMemcpyDeviceToHost, h->stream));
+    if (M) {
+      HIPCHK(h, hipMemcpy2DAsync(M, sizeof(double) * w, nb.TD, sizeof(double) * L, sizeof(double) * L, T, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpy2DAsync(M + L, sizeof(double) * w, nb.TO, sizeof(double) * L, sizeof(double) * L, T, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpy2DAsync(M + 2 * L, sizeof(double) * w, nb.TE, sizeof(double) * P * P, sizeof(double) * P * P, T, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SCRF_OK;
+  }
   if (stdseg(h)) {   // S [N_seg][nActualLabs], M [N_seg][nLabs][nActualLabs]
     StdsegBufs sb;
     HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
@@ -1544,6 +1632,21 @@ extern "C" int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, d
     const uint32_t La = stdseg_La(h);
     if (S) HIPCHK(h, hipMemcpyAsync(S, sb.S, sizeof(double) * ns * La, hipMemcpyDeviceToHost, h->stream));
     if (M) HIPCHK(h, hipMemcpyAsync(M, sb.MX, sizeof(double) * ns * h->lay.L * La, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SCRF_OK;
+  }
+  if (nstate(h)) {   // S [T][nLabs]; M [T][2*nLabs + P*P]: self transitions | c -> c+1 | end state of p -> start state of q
+    NstateBufs nb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = nstate_run_chunk(h, b, u, u + 1, false, nullptr, &nb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t T = b->T[u], L = h->lay.L, P = L / h->lay.K, w = 2 * L + P * P;
+    if (S) HIPCHK(h, hipMemcpyAsync(S, nb.S, sizeof(double) * T * L, hipMemcpyDeviceToHost, h->stream));
+    if (M) {
+      HIPCHK(h, hipMemcpy2DAsync(M, sizeof(double) * w, nb.TD, sizeof(double) * L, sizeof(double) * L, T, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpy2DAsync(M + L, sizeof(double) * w, nb.TO, sizeof(double) * L, sizeof(double) * L, T, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpy2DAsync(M + 2 * L, sizeof(double) * w, nb.TE, sizeof(double) * P * P, sizeof(double) * P * P, T, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SCRF_OK;
   }
@@ -1578,6 +1681,21 @@ extern "C" int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, ui
   if (rc != SCRF_OK) return rc;
   if (prec != SCRF_PREC_EXACT) return fail(h, SCRF_ERR_INVALID, "scrf_forward_backward: the node-value hook runs at SCRF_PREC_EXACT only");
   HIPCHK(h, hipSetDevice(h->device));
+  if (nstate(h)) {   // alpha, beta: [T][nLabs]; alpha_dur is not written
+    NstateBufs nb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = nstate_run_chunk(h, b, u, u + 1, false, nullptr, &nb);
+    if (rc != SCRF_OK) return rc;
+    const uint64_t n = (uint64_t)b->T[u] * h->lay.L;
+    int st = 0;
+    if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, nb.alpha, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    if (beta) HIPCHK(h, hipMemcpyAsync(beta, nb.beta, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    if (zx) HIPCHK(h, hipMemcpyAsync(zx, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&st, b->d_status + u, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (st != SCRF_OK) return fail(h, st, "utterance %u: numeric failure in forward-backward", u);
+    return SCRF_OK;
+  }
   if (stdseg(h)) {   // alpha_dur and beta: the nodes' alpha / beta over full labels, [N_seg][nActualLabs]; `alpha` is not written
     StdsegBufs sb;
     HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
@@ -1630,6 +1748,33 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
   int rc = check_u(h, b, u, "scrf_lattice_arcs");
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipSetDevice(h->device));
+  if (nstate(h)) {   // decoders/CRF_LatticeBuilder.h nStateBuildLattice
+    const uint32_t T = b->T[u], L = h->lay.L;
+    const uint64_t na = b->arc_off[u + 1] - b->arc_off[u];
+    if (n_arcs) *n_arcs = na;
+    if (n_states) *n_states = L * T + 2;
+    if (final_state) *final_state = (int32_t)(L * T + 1);
+    if (!arcs) return SCRF_OK;
+    NstateBufs nb;
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    rc = nstate_run_chunk(h, b, u, u + 1, false, nullptr, &nb);
+    if (rc != SCRF_OK) return rc;
+    float final_w = 0.0f;
+    if (norm) {
+      double asum = 0;
+      HIPCHK(h, hipMemcpyAsync(&asum, b->d_zx + u, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      final_w = (float)(-1 * asum);
+    }
+    scrf_arc* d_arcs = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_arcs, sizeof(scrf_arc) * na));
+    launch_ns_arcs(h->stream, h->lay, T, nb.S, nb.TD, nb.TO, nb.TE, final_w, d_arcs);
+    hipError_t e = hipMemcpyAsync(arcs, d_arcs, sizeof(scrf_arc) * na, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_arcs);
+    if (e != hipSuccess) return fail(h, SCRF_ERR_HIP, "scrf_lattice_arcs: %s", hipGetErrorString(e));
+    return SCRF_OK;
+  }
   if (stdseg(h)) {   // decoders/CRF_LatticeBuilder_StdSeg.h: one state per (node, available full label)
     const uint32_t La = stdseg_La(h), T = b->T[u];
     const uint64_t ns = b->seg_off[u + 1] - b->seg_off[u], na = b->arc_off[u + 1] - b->arc_off[u];
@@ -1729,6 +1874,27 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   ndf.fused = ndf.vitfast = true;
   const bool fast = h->fast_decode && b->fused_ok && h->fuse_windows && !frame_model && l.L <= 0xffff;
   int rc = SCRF_OK;
+  if (nstate(h)) {
+    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
+    for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK;) {
+      const uint32_t u1 = nstate_plan_chunk(h, b, u0, true);
+      NstateBufs nb;
+      rc = nstate_run_chunk(h, b, u0, u1, false, nullptr, &nb);
+      if (rc != SCRF_OK) break;
+      const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0];
+      float* vc = nullptr;
+      uint16_t* bp = nullptr;
+      hipError_t e = hipMalloc((void**)&vc, sizeof(float) * nfr * l.L);
+      if (e == hipSuccess) e = hipMalloc((void**)&bp, sizeof(uint16_t) * nfr * l.L);
+      if (e == hipSuccess) {
+        launch_ns_viterbi(h->stream, l, b->view(), u0, u1 - u0, nb.S, nb.TD, nb.TO, nb.TE, vc, bp, d_lab, d_n, d_cost);
+        e = hipStreamSynchronize(h->stream);
+      }
+      hipFree(vc); hipFree(bp);
+      if (e != hipSuccess) { rc = fail(h, SCRF_ERR_HIP, "scrf_viterbi_batch: %s", hipGetErrorString(e)); break; }
+      u0 = u1;
+    }
+  }
   if (stdseg(h)) {
     const uint32_t La = stdseg_La(h);
     HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
@@ -1752,7 +1918,7 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
       u0 = u1;
     }
   }
-  for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK && !stdseg(h);) {
+  for (uint32_t u0 = 0; u0 < b->U && rc == SCRF_OK && !stdseg(h) && !nstate(h);) {
     uint32_t u_end = u0;
     if (fast) {
       const uint32_t u1 = plan_chunk(h, b, u0, ndf);

@@ -168,4 +168,22 @@ void launch_stdseg_viterbi(hipStream_t st, const ScrfLayout& lay, uint32_t La, S
                            const double* S, const double* MX, float* vc, uint16_t* bp, uint32_t* out_labels, uint32_t* out_n,
                            float* out_cost);
 
+// ---- n-state frame model (scrf_nstate.hip): lay.K > 1
+void launch_ns_scores(hipStream_t st, const ScrfLayout& lay, const float* X, uint64_t n_frames, const double* lambda, double* S,
+                      double* TD, double* TO, double* TE);
+void launch_ns_fb(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* S,
+                  const double* TD, const double* TO, const double* TE, double* alpha, double* beta, double* zx, int* status);
+void launch_ns_post(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint32_t n_utts,
+                    uint64_t n_frames, const double* S, const double* TD, const double* TO, const double* TE, const double* alpha,
+                    const double* beta, const double* zx, double* G, double* XD, double* XO, double* XE, double* mass_s,
+                    double* mass_t, double* numer, int* status);
+void launch_ns_expf(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                    const float* X, const double* G, const double* XD, const double* XO, const double* XE, double* grad);
+uint64_t ns_num_arcs(uint32_t T, uint32_t L, uint32_t K);
+void launch_ns_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t T, const double* S, const double* TD, const double* TO,
+                    const double* TE, float final_w, scrf_arc* arcs);
+void launch_ns_viterbi(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* S,
+                       const double* TD, const double* TO, const double* TE, float* vc, uint16_t* bp, uint32_t* out_labels,
+                       uint32_t* out_n, float* out_cost);
+
 #endif  // SCRF_KERNELS_H_

@@ -22,7 +22,7 @@ using std::runtime_error;
 using std::string;
 
 // ------------------------------------------------------------------------------------------
-// CRF_FeatureMap: lambda layout of the dense maps, numStates == 1
+// CRF_FeatureMap: lambda layout of the dense maps, one state or n states per label
 // (same closed form as ScrfLayout; ftrmaps/CRF_StdFeatureMap.cpp:280-320,355-410,472-517)
 // ------------------------------------------------------------------------------------------
 CRF_FeatureMap::CRF_FeatureMap(CRF_FeatureMap_config* cnf) : config(cnf) { recalc(); }
@@ -34,24 +34,42 @@ CRF_FeatureMap* CRF_FeatureMap::createFeatureMap(CRF_FeatureMap_config* cnf) {
 }
 
 QNUInt32 CRF_FeatureMap::recalc() {
-  if (config->numStates != 1)
-    throw runtime_error("CRF_StdFeatureMap created exception: only single-state models are built");
-  const QNUInt32 L = config->numLabs;
+  const QNUInt32 L = config->numLabs, K = config->numStates;
+  if (K == 0) throw runtime_error("CRF_StdFeatureMap created exception: numStates is 0");
+  numActualLabels = L / K;
+  if (numActualLabels * K != L) throw runtime_error("CRF_StdFeatureMap created exception: Invalid state/label combination while computing transitions");
   numStateFuncs = numTransFuncs = 0;
   if (config->useStateFtrs) numStateFuncs += config->stateFidxEnd - config->stateFidxStart + 1;
   if (config->useStateBias) numStateFuncs += 1;
   if (config->useTransFtrs) numTransFuncs += config->transFidxEnd - config->transFidxStart + 1;
   if (config->useTransBias) numTransFuncs += 1;
-  numFtrFuncs = L * (numStateFuncs + L * numTransFuncs);
+  // end->start transitions + diagonal self transitions + off-diagonal transitions (CRF_StdFeatureMap.cpp:480-485)
+  const QNUInt32 transMult = K == 1 ? L * L : numActualLabels * numActualLabels + L + L - numActualLabels;
+  numFtrFuncs = L * numStateFuncs + transMult * numTransFuncs;
   return numFtrFuncs;
 }
 
 QNUInt32 CRF_FeatureMap::getStateFeatureIdx(QNUInt32 clab, QNUInt32 fno) {
-  return clab * (numStateFuncs + config->numLabs * numTransFuncs) + fno;
+  const QNUInt32 K = config->numStates;
+  if (K == 1) return clab * (numStateFuncs + config->numLabs * numTransFuncs) + fno;
+  const QNUInt32 ns = (clab + K - 1) / K;   // start states among the labels before clab (:293-312)
+  return clab * numStateFuncs + numTransFuncs * (ns * (numActualLabels + 1) + (clab - ns) * 2) + fno;
 }
 
 QNUInt32 CRF_FeatureMap::getTransFeatureIdx(QNUInt32 clab, QNUInt32 plab, QNUInt32 fno) {
-  return clab * (numStateFuncs + config->numLabs * numTransFuncs) + numStateFuncs + plab * numTransFuncs + fno;
+  const QNUInt32 K = config->numStates;
+  if (K == 1) return clab * (numStateFuncs + config->numLabs * numTransFuncs) + numStateFuncs + plab * numTransFuncs + fno;
+  QNUInt32 v = getStateFeatureIdx(clab) + numStateFuncs;   // :367-407; (QNUInt32)-1 = no such transition
+  if (plab != clab) {
+    v += numTransFuncs;
+    if (clab % K == 0) {
+      if ((plab + 1) % K != 0) return (QNUInt32)-1;
+      v += (plab / K) * numTransFuncs;
+    } else if (plab != clab - 1) {
+      return (QNUInt32)-1;
+    }
+  }
+  return v + fno;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -74,7 +74,7 @@ class CRF_FeatureMap {
 
  protected:
   CRF_FeatureMap_config* config;
-  QNUInt32 numFtrFuncs = 0, numStateFuncs = 0, numTransFuncs = 0;
+  QNUInt32 numFtrFuncs = 0, numStateFuncs = 0, numTransFuncs = 0, numActualLabels = 0;
 };
 typedef CRF_FeatureMap CRF_StdFeatureMap;
 

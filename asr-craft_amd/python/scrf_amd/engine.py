@@ -79,13 +79,13 @@ def window_width(in_width, D, lctx=0, rctx=0, extract_seg=True):
 
 def make_config(model_type=STDSEG_NO_DUR_NO_SEGTRANSFTR, L=48, D=25, F=337, sfs=0, sfe=-1, use_trans_ftrs=False,
                 tfs=0, tfe=-1, use_state_ftrs=True, use_state_bias=True, use_trans_bias=True,
-                state_bias_val=1.0, trans_bias_val=1.0, device_id=0, precision=PREC_EXACT, scratch_bytes=0):
+                state_bias_val=1.0, trans_bias_val=1.0, device_id=0, precision=PREC_EXACT, scratch_bytes=0, num_states=1):
     """Same meaning as CRFTrain's set_fmap_config (CRFTrain/src/Main.cpp:372-430)."""
     if sfe is None or sfe < 0:
         sfe = F - 1
     if tfe is None or tfe < 0:
         tfe = F - 1
-    return Config(ABI_VERSION, model_type, STDTRANS if use_trans_ftrs else STDSTATE, L, F, 1, D,
+    return Config(ABI_VERSION, model_type, STDTRANS if use_trans_ftrs else STDSTATE, L, F, num_states, D,
                   int(use_state_ftrs), sfs, sfe, int(use_trans_ftrs), tfs, tfe, int(use_state_bias),
                   int(use_trans_bias), state_bias_val, trans_bias_val, device_id, precision, scratch_bytes)
 
@@ -249,6 +249,11 @@ class Engine:
     def scores(self, batch, u, T):
         """S [N_seg, L]; M [T, L*L] -- for STDSEG_NO_DUR one transition matrix per window: [N_seg, L*L]; for STDSEG
         (L = all labels, La = L / D phones) S [N_seg, La] and M [N_seg, L, La] (previous FULL label x phone)"""
+        if self.cfg.num_states > 1:   # n-state frame model: M [T, 2 L + P*P] = self | c -> c+1 | end of p -> start of q
+            P = self.L // self.cfg.num_states
+            S = np.zeros((T, self.L)); M = np.zeros((T, 2 * self.L + P * P))
+            self._chk(self.lib.scrf_scores(self.h, batch.handle, C.c_uint32(u), _p(S), _p(M)))
+            return S, M
         if self.cfg.model_type == STDSEG:
             La = self.L // self.D
             S = np.zeros((self.num_segs(T), La)); M = np.zeros((self.num_segs(T), self.L, La))
@@ -265,6 +270,11 @@ class Engine:
         return X
 
     def forward_backward(self, batch, u, T, prec=PREC_EXACT):
+        if self.cfg.num_states > 1:
+            al = np.zeros((T, self.L)); be = np.zeros((T, self.L))
+            zx = C.c_double()
+            self._chk(self.lib.scrf_forward_backward(self.h, batch.handle, C.c_uint32(u), C.c_uint32(prec), None, _p(al), _p(be), C.byref(zx)))
+            return None, al, be, zx.value
         if self.cfg.model_type == STDSEG:   # the nodes' alpha / beta over full labels: [N_seg, La] each
             La = self.L // self.D
             al = np.zeros((self.num_segs(T), La)); be = np.zeros((self.num_segs(T), La))

@@ -87,9 +87,13 @@ double orc_logadd_n(const double* R, int n, int* err) {
 /* ftrmaps/CRF_StdFeatureMap.cpp:472-517 (recalc), :280-320, :355-410 with numStates==1 */
 int orc_layout_init(const orc_config* cfg, orc_layout* lay) {
   const uint32_t L = cfg->num_labs;
+  const uint32_t K = cfg->num_states > 1 ? cfg->num_states : 1;
   memset(lay, 0, sizeof(*lay));
   if (L == 0) return ORC_ERR_CONFIG;
-  uint32_t trans_mult = L * L; /* :481 */
+  const uint32_t P = L / K; /* numActualLabels :474 */
+  if (P * K != L) return ORC_ERR_CONFIG; /* "Invalid state/label combination" :476-479 */
+  /* :480-485: end->start transitions + diagonal self transitions + off-diagonal transitions */
+  uint32_t trans_mult = K == 1 ? L * L : P * P + L + L - P;
   uint32_t nff = 0, nsf = 0, ntf = 0;
   if (cfg->use_state_ftrs) {
     if (cfg->state_fidx_end < cfg->state_fidx_start) return ORC_ERR_CONFIG;
@@ -115,14 +119,38 @@ int orc_layout_init(const orc_config* cfg, orc_layout* lay) {
   lay->state_idx = (uint32_t*)malloc(sizeof(uint32_t) * L);
   lay->trans_idx = (uint32_t*)malloc(sizeof(uint32_t) * L * L);
   if (!lay->state_idx || !lay->trans_idx) return ORC_ERR_CONFIG;
-  for (uint32_t clab = 0; clab < L; clab++) {
-    /* computeStateFeatureIdx :280-320 */
-    lay->state_idx[clab] = (clab == 0) ? 0 : clab * (nsf + L * ntf);
-    for (uint32_t plab = 0; plab < L; plab++) {
-      /* computeTransFeatureIdx :365 */
-      lay->trans_idx[plab * L + clab] = clab * (nsf + L * ntf) + nsf + plab * ntf;
+  if (K == 1) {
+    for (uint32_t clab = 0; clab < L; clab++) {
+      /* computeStateFeatureIdx :280-320 */
+      lay->state_idx[clab] = (clab == 0) ? 0 : clab * (nsf + L * ntf);
+      for (uint32_t plab = 0; plab < L; plab++) {
+        /* computeTransFeatureIdx :365 */
+        lay->trans_idx[plab * L + clab] = clab * (nsf + L * ntf) + nsf + plab * ntf;
+      }
     }
+    return ORC_OK;
   }
+  /* n-state blocks (:293-312): a label's state functions, its self transition, then for a phone's start state the
+   * transitions from every phone's end state, for the other states the one from the state before */
+  uint32_t at = 0;
+  for (uint32_t clab = 0; clab < L; clab++) {
+    lay->state_idx[clab] = at;
+    at += nsf + ((clab % K == 0) ? (P + 1) * ntf : 2 * ntf);
+  }
+  for (uint32_t clab = 0; clab < L; clab++)
+    for (uint32_t plab = 0; plab < L; plab++) { /* computeTransFeatureIdx :367-407 */
+      uint32_t v = lay->state_idx[clab] + nsf;
+      if (plab != clab) {
+        v += ntf;
+        if (clab % K == 0) {
+          if ((plab + 1) % K != 0) v = 0xffffffffu;
+          else v += (plab / K) * ntf;
+        } else if (plab != clab - 1) {
+          v = 0xffffffffu;
+        }
+      }
+      lay->trans_idx[plab * L + clab] = v;
+    }
   return ORC_OK;
 }
 
@@ -1185,6 +1213,219 @@ uint64_t orc_segtrans_lattice_arcs(const orc_config* cfg, const double* S, const
     for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
       float w = -Zx;
       orc_arc a = {1 + (int)((T - 1) * L + prev_lab), 0, 0, w, fin};
+      arcs[na++] = a;
+    }
+  }
+  *n_states = (uint32_t)next_state;
+  *final_state = fin;
+  return na;
+}
+
+/* ======================================================================================
+ * f3: n-state frame model (nodes/CRF_StdNStateNode.cpp + trainers/gradbuilders/CRF_NewGradBuilder.cpp)
+ * ====================================================================================== */
+void orc_nstate_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* ftrs, uint32_t T,
+                       double* S, double* TD, double* TO, double* TE) {
+  /* computeTransMatrix :68-90 */
+  const uint32_t L = cfg->num_labs, K = cfg->num_states, P = L / K, F = cfg->num_feas;
+  for (uint32_t t = 0; t < T; t++) {
+    const float* x = ftrs + (size_t)t * F;
+    for (uint32_t clab = 0; clab < L; clab++) {
+      S[(size_t)t * L + clab] = orc_state_value(cfg, lay, x, lambda, clab);
+      TD[(size_t)t * L + clab] = orc_trans_value(cfg, lay, x, lambda, clab, clab);
+      if (clab % K == 0) {
+        for (uint32_t plab = 0; plab < P; plab++)
+          TE[(size_t)t * P * P + plab * P + clab / K] = orc_trans_value(cfg, lay, x, lambda, plab * K + K - 1, clab);
+      } else {
+        TO[(size_t)t * L + clab - 1] = orc_trans_value(cfg, lay, x, lambda, clab - 1, clab);
+      }
+    }
+    for (uint32_t e = K - 1; e < L; e += K) TO[(size_t)t * L + e] = 0.0; /* end states have no next state */
+  }
+}
+
+int orc_nstate_forward(const orc_config* cfg, const double* S, const double* TD, const double* TO, const double* TE,
+                       uint32_t T, double* alpha, double* Zx) {
+  /* computeFirstAlpha :148-157, computeAlpha :100-137, computeAlphaSum :376-383 */
+  const uint32_t L = cfg->num_labs, K = cfg->num_states, P = L / K;
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  double* acc = (double*)malloc(sizeof(double) * P);
+  for (uint32_t c = 0; c < L; c++) alpha[c] = S[c];
+  for (uint32_t t = 1; t < T && err == ORC_OK; t++) {
+    const double* pa = alpha + (size_t)(t - 1) * L;
+    double* a = alpha + (size_t)t * L;
+    for (uint32_t clab = 0; clab < L; clab++) {
+      double v = pa[clab] + TD[(size_t)t * L + clab];
+      if (clab % K == 0) {
+        const uint32_t q = clab / K;
+        acc[0] = pa[K - 1] + TE[(size_t)t * P * P + q];
+        double maxv = acc[0];
+        for (uint32_t plab = 1; plab < P; plab++) {
+          acc[plab] = pa[plab * K + K - 1] + TE[(size_t)t * P * P + plab * P + q];
+          if (acc[plab] > maxv) maxv = acc[plab];
+        }
+        const double ls = orc_logadd_max_n(acc, maxv, (int)P, &err);
+        v = orc_logadd2(v, ls, &err);
+      } else {
+        v = orc_logadd2(v, pa[clab - 1] + TO[(size_t)t * L + clab - 1], &err);
+      }
+      a[clab] = v + S[(size_t)t * L + clab];
+    }
+  }
+  if (err == ORC_OK) *Zx = orc_logadd_n(alpha + (size_t)(T - 1) * L, (int)L, &err);
+  free(acc);
+  return err;
+}
+
+int orc_nstate_backward(const orc_config* cfg, const double* S, const double* TD, const double* TO, const double* TE,
+                        uint32_t T, double* beta) {
+  /* setTailBeta :262-267; node t+1's computeBeta(beta of node t) :170-207 */
+  const uint32_t L = cfg->num_labs, K = cfg->num_states, P = L / K;
+  int err = ORC_OK;
+  if (T == 0) return ORC_ERR_EMPTY;
+  double* acc = (double*)malloc(sizeof(double) * P);
+  double* tb = (double*)malloc(sizeof(double) * L);
+  for (uint32_t c = 0; c < L; c++) beta[(size_t)(T - 1) * L + c] = 0.0;
+  for (uint32_t t = T - 1; t-- > 0 && err == ORC_OK;) {
+    const uint32_t n = t + 1;
+    for (uint32_t c = 0; c < L; c++) tb[c] = beta[(size_t)n * L + c] + S[(size_t)n * L + c];
+    for (uint32_t plab = 0; plab < L; plab++) {
+      double v = tb[plab] + TD[(size_t)n * L + plab];
+      if ((plab + 1) % K == 0) {
+        const uint32_t ip = (plab + 1) / K - 1;
+        acc[0] = TE[(size_t)n * P * P + ip * P] + tb[0];
+        double maxv = acc[0];
+        for (uint32_t q = 1; q < P; q++) {
+          acc[q] = TE[(size_t)n * P * P + ip * P + q] + tb[q * K];
+          if (acc[q] > maxv) maxv = acc[q];
+        }
+        const double ls = orc_logadd_max_n(acc, maxv, (int)P, &err);
+        v = orc_logadd2(v, ls, &err);
+      } else {
+        v = orc_logadd2(v, TO[(size_t)n * L + plab] + tb[plab + 1], &err);
+      }
+      beta[(size_t)t * L + plab] = v;
+    }
+  }
+  free(acc); free(tb);
+  return err;
+}
+
+int orc_nstate_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* ftrs,
+                              const uint32_t* labels, uint32_t T, double* grad, double* numer, double* Zx_out) {
+  /* CRF_NewGradBuilder::buildGradient (frame level) with computeExpF :273-331 */
+  const uint32_t L = cfg->num_labs, K = cfg->num_states, P = L / K, F = cfg->num_feas;
+  if (T == 0) return ORC_ERR_EMPTY;
+  int err = ORC_OK;
+  double* ExpF = (double*)calloc(lay->lambda_len, sizeof(double));
+  double* S = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* TD = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* TO = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* TE = (double*)malloc(sizeof(double) * (size_t)T * P * P);
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
+  double logLi = 0.0, Zx = 0.0;
+  orc_nstate_scores(cfg, lay, lambda, ftrs, T, S, TD, TO, TE);
+  err = orc_nstate_forward(cfg, S, TD, TO, TE, T, alpha, &Zx);
+  if (err == ORC_OK) err = orc_nstate_backward(cfg, S, TD, TO, TE, T, beta);
+  for (uint32_t t = T; t-- > 0 && err == ORC_OK;) {
+    const float* x = ftrs + (size_t)t * F;
+    const double* pa = (t > 0) ? alpha + (size_t)(t - 1) * L : NULL;
+    const uint32_t prev_lab = (t > 0) ? labels[t - 1] : L + 1;
+    const uint32_t label = labels[t];
+    const double* a = alpha + (size_t)t * L;
+    const double* b = beta + (size_t)t * L;
+    const double* St = S + (size_t)t * L;
+    double ab_tot = 0.0, ab_trans_tot = 0.0, nodeLi = 0.0;
+    for (uint32_t clab = 0; clab < L; clab++) {
+      double ab = orc_expE(a[clab] + b[clab] - Zx, &err);
+      ab_tot += ab;
+      nodeLi += orc_state_expf(cfg, lay, x, lambda, ExpF, grad, ab, label, clab);
+      if (prev_lab > L) {
+        ab_trans_tot = 1.0;
+        continue;
+      }
+      ab = orc_expE(pa[clab] + TD[(size_t)t * L + clab] + St[clab] + b[clab] - Zx, &err);
+      ab_trans_tot += ab;
+      nodeLi += orc_trans_expf(cfg, lay, x, lambda, ExpF, grad, ab, prev_lab, label, clab, clab);
+      if (clab % K == 0) {
+        const uint32_t q = clab / K;
+        for (uint32_t plab = 0; plab < P; plab++) {
+          const uint32_t rp = plab * K + K - 1;
+          ab = orc_expE(pa[rp] + TE[(size_t)t * P * P + plab * P + q] + St[clab] + b[clab] - Zx, &err);
+          ab_trans_tot += ab;
+          nodeLi += orc_trans_expf(cfg, lay, x, lambda, ExpF, grad, ab, prev_lab, label, rp, clab);
+        }
+      } else {
+        ab = orc_expE(pa[clab - 1] + TO[(size_t)t * L + clab - 1] + St[clab] + b[clab] - Zx, &err);
+        ab_trans_tot += ab;
+        nodeLi += orc_trans_expf(cfg, lay, x, lambda, ExpF, grad, ab, prev_lab, label, clab - 1, clab);
+      }
+    }
+    if (ab_tot > 1.1 || ab_tot < 0.9 || ab_trans_tot > 1.1 || ab_trans_tot < 0.9) set_err(&err, ORC_ERR_PROB_SUM); /* :333-349 */
+    logLi += nodeLi;
+  }
+  for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i];
+  *Zx_out = Zx;
+  *numer = logLi;
+  free(ExpF); free(S); free(TD); free(TO); free(TE); free(alpha); free(beta);
+  return err;
+}
+
+/* decoders/CRF_LatticeBuilder.h:715-840 nStateBuildLattice: state 0 = start, state of (t, c) = 1 + t*nLabs + c; node 0 from
+ * the start with float(-1*stateArray); node t: a phone's start state from every phone's END state (ascending) and then
+ * from itself, the other states from the state before and then from themselves, weight float(-1*getFullTransValue);
+ * the final state from EVERY label of the last node with weight Zx (= -alpha sum with norm, else 0). */
+uint64_t orc_nstate_lattice_num_arcs(uint32_t T, uint32_t nLabs, uint32_t K) {
+  if (T == 0) return 0;
+  const uint32_t P = nLabs / K;
+  return (uint64_t)nLabs + (uint64_t)(T - 1) * ((uint64_t)P * (P + 1) + (uint64_t)(nLabs - P) * 2) + nLabs;
+}
+
+uint64_t orc_nstate_lattice_arcs(const orc_config* cfg, const double* S, const double* TD, const double* TO, const double* TE,
+                                 uint32_t T, int norm, double alpha_sum, orc_arc* arcs, uint32_t* n_states, int32_t* final_state) {
+  const uint32_t L = cfg->num_labs, K = cfg->num_states, P = L / K;
+  uint64_t na = 0;
+  int next_state = 1;
+  for (uint32_t t = 0; t < T; t++) {
+    for (uint32_t c = 0; c < L; c++) {
+      const int cur_state = next_state++;
+      const double sv = S[(size_t)t * L + c];
+      if (t == 0) {
+        float value = -1 * sv;
+        orc_arc a = {0, (int)c + 1, (int)c + 1, value, cur_state};
+        arcs[na++] = a;
+        continue;
+      }
+      const int pbase = 1 + (int)((t - 1) * L);
+      if (c % K == 0) {
+        for (uint32_t pl = K - 1; pl < L; pl += K) {
+          float value = -1 * (TE[(size_t)t * P * P + (pl / K) * P + c / K] + sv);
+          orc_arc a = {pbase + (int)pl, (int)c + 1, (int)c + 1, value, cur_state};
+          arcs[na++] = a;
+        }
+        float value = -1 * (TD[(size_t)t * L + c] + sv);
+        orc_arc a = {pbase + (int)c, (int)c + 1, (int)c + 1, value, cur_state};
+        arcs[na++] = a;
+      } else {
+        float value = -1 * (TO[(size_t)t * L + c - 1] + sv);
+        orc_arc a = {pbase + (int)c - 1, (int)c + 1, (int)c + 1, value, cur_state};
+        arcs[na++] = a;
+        value = -1 * (TD[(size_t)t * L + c] + sv);
+        orc_arc a2 = {pbase + (int)c, (int)c + 1, (int)c + 1, value, cur_state};
+        arcs[na++] = a2;
+      }
+    }
+  }
+  int fin = -1;
+  if (T > 0) {
+    double Zx = 0;
+    if (norm) Zx = -1 * alpha_sum;
+    fin = next_state++;
+    for (uint32_t pl = 0; pl < L; pl++) {
+      float w = Zx;
+      orc_arc a = {1 + (int)((T - 1) * L + pl), 0, 0, w, fin};
       arcs[na++] = a;
     }
   }

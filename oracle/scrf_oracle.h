@@ -57,7 +57,7 @@ enum {
 };
 
 /* Mirror of CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) + model fields
- * of CRF_Model (CRF_Model.h). numStates is fixed to 1 (SURVEY #11 out of scope). */
+ * of CRF_Model (CRF_Model.h). */
 typedef struct {
   uint32_t model_type;
   uint32_t num_labs;      /* numLabs == nActualLabs for the NO_DUR models and STDFRAME */
@@ -69,6 +69,8 @@ typedef struct {
   uint32_t trans_fidx_start, trans_fidx_end; /* inclusive */
   int32_t use_state_bias, use_trans_bias;
   double state_bias_val, trans_bias_val;
+  uint32_t num_states;    /* numStates (0 and 1 both mean one state per label); > 1: the n-state topology of
+                             nodes/CRF_StdNStateNode.cpp over num_labs = phones * num_states labels, STDFRAME only */
 } orc_config;
 
 /* lambda index layout (ftrmaps/CRF_StdFeatureMap.cpp:280-320,355-410,472-517) */
@@ -148,6 +150,20 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
 int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, uint32_t T,
                        double* gamma, double* xi, double* Zx);
 
+/* ---- f3: n-state frame model (nodes/CRF_StdNStateNode.cpp, decoders/CRF_LatticeBuilder.h nStateBuildLattice):
+ * cfg->num_states = K > 1, P = num_labs / K phones; label c is state c % K of phone c / K.  Transitions allowed: self
+ * (c -> c), next state inside a phone (c-1 -> c), end state of any phone -> start state of any phone.
+ * S [T][nLabs]; TD [T][nLabs] self transitions; TO [T][nLabs] entry c = transition c -> c+1 (unused for end states);
+ * TE [T][P*P] entry p*P + q = end state of phone p -> start state of phone q.  The layout (orc_layout_init with
+ * num_states > 1) marks transitions outside the topology with trans_idx = 0xffffffff. */
+void orc_nstate_scores(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* ftrs, uint32_t T,
+                       double* S, double* TD, double* TO, double* TE);
+int orc_nstate_forward(const orc_config* cfg, const double* S, const double* TD, const double* TO, const double* TE,
+                       uint32_t T, double* alpha, double* Zx);
+int orc_nstate_backward(const orc_config* cfg, const double* S, const double* TD, const double* TO, const double* TE,
+                        uint32_t T, double* beta);
+int orc_nstate_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda, const float* ftrs,
+                              const uint32_t* labels, uint32_t T, double* grad, double* numer, double* Zx_out);
 /* ---- f3: STDSEG (duration-labelled; cfg->num_labs = nLabs = nActualLabs * lab_max_dur) ------------------------
  * S, alpha, beta: [N_seg][nActualLabs] (row (t,dur), phone = the node's entry (dur-1)*nActualLabs + phone);
  * MX: [N_seg][nLabs][nActualLabs] = transMatrix[plab*nLabs + clab] of the window's node */
@@ -206,6 +222,9 @@ uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const doub
                               uint32_t* n_states, int32_t* final_state);
 /* STDSEG_NO_DUR: decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h (S [N_seg][L], M2 [N_seg][L*L]) */
 uint64_t orc_segtrans_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D);
+uint64_t orc_nstate_lattice_num_arcs(uint32_t T, uint32_t nLabs, uint32_t K);
+uint64_t orc_nstate_lattice_arcs(const orc_config* cfg, const double* S, const double* TD, const double* TO, const double* TE,
+                                 uint32_t T, int norm, double alpha_sum, orc_arc* arcs, uint32_t* n_states, int32_t* final_state);
 uint64_t orc_stdseg_lattice_num_arcs(uint32_t T, uint32_t La, uint32_t D);
 uint64_t orc_stdseg_lattice_arcs(const orc_config* cfg, const double* S, const double* MX, uint32_t T, int norm,
                                  double alpha_sum, orc_arc* arcs, uint32_t* n_states, int32_t* final_state);

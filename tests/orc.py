@@ -34,6 +34,7 @@ class OrcConfig(C.Structure):
         ("use_trans_bias", C.c_int32),
         ("state_bias_val", C.c_double),
         ("trans_bias_val", C.c_double),
+        ("num_states", C.c_uint32),
     ]
 
 
@@ -84,6 +85,8 @@ def lib():
         _lib.orc_seg_lattice_arcs.restype = C.c_uint64
         _lib.orc_segtrans_lattice_num_arcs.restype = C.c_uint64
         _lib.orc_segtrans_lattice_arcs.restype = C.c_uint64
+        _lib.orc_nstate_lattice_num_arcs.restype = C.c_uint64
+        _lib.orc_nstate_lattice_arcs.restype = C.c_uint64
         _lib.orc_stdseg_lattice_num_arcs.restype = C.c_uint64
         _lib.orc_stdseg_lattice_arcs.restype = C.c_uint64
         _lib.orc_frame_lattice_num_arcs.restype = C.c_uint64
@@ -98,14 +101,14 @@ def _p(a):
 
 def config(model_type=STDSEG_NO_DUR_NO_SEGTRANSFTR, L=3, D=3, F=4, sfs=0, sfe=None,
            use_trans_ftrs=False, tfs=0, tfe=None, use_state_ftrs=True, use_state_bias=True,
-           use_trans_bias=True, state_bias_val=1.0, trans_bias_val=1.0):
+           use_trans_bias=True, state_bias_val=1.0, trans_bias_val=1.0, num_states=1):
     """Mirror of CRFTrain's set_fmap_config (CRFTrain/src/Main.cpp:372-430)."""
     if sfe is None or sfe < 0:
         sfe = F - 1
     if tfe is None or tfe < 0:
         tfe = F - 1
     return OrcConfig(model_type, L, D, F, int(use_state_ftrs), sfs, sfe, int(use_trans_ftrs), tfs,
-                     tfe, int(use_state_bias), int(use_trans_bias), state_bias_val, trans_bias_val)
+                     tfe, int(use_state_bias), int(use_trans_bias), state_bias_val, trans_bias_val, num_states)
 
 
 class Layout:
@@ -250,6 +253,94 @@ def segtrans_build_gradient(cfg, lay, lam, segftrs, labels, T, grad=None):
     rc = lib().orc_segtrans_build_gradient(C.byref(cfg), C.byref(lay.c), _p(lam), _p(segftrs), _p(labels),
                                            C.c_uint32(T), _p(grad), C.byref(numer), C.byref(zx))
     return rc, grad, numer.value, zx.value
+
+
+def nstate_scores(cfg, lay, lam, ftrs, T):
+    L, K = cfg.num_labs, cfg.num_states
+    P = L // K
+    ftrs = np.ascontiguousarray(ftrs, dtype=np.float32)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    S = np.zeros((T, L)); TD = np.zeros((T, L)); TO = np.zeros((T, L)); TE = np.zeros((T, P * P))
+    lib().orc_nstate_scores(C.byref(cfg), C.byref(lay.c), _p(lam), _p(ftrs), C.c_uint32(T), _p(S), _p(TD), _p(TO), _p(TE))
+    return S, TD, TO, TE
+
+
+def nstate_forward(cfg, S, TD, TO, TE, T):
+    al = np.zeros_like(S)
+    zx = C.c_double()
+    rc = lib().orc_nstate_forward(C.byref(cfg), _p(S), _p(TD), _p(TO), _p(TE), C.c_uint32(T), _p(al), C.byref(zx))
+    return rc, al, zx.value
+
+
+def nstate_backward(cfg, S, TD, TO, TE, T):
+    be = np.zeros_like(S)
+    rc = lib().orc_nstate_backward(C.byref(cfg), _p(S), _p(TD), _p(TO), _p(TE), C.c_uint32(T), _p(be))
+    return rc, be
+
+
+def nstate_build_gradient(cfg, lay, lam, ftrs, labels, T, grad=None):
+    ftrs = np.ascontiguousarray(ftrs, dtype=np.float32)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    if grad is None:
+        grad = np.zeros(lay.lambda_len, dtype=np.float64)
+    numer = C.c_double(); zx = C.c_double()
+    rc = lib().orc_nstate_build_gradient(C.byref(cfg), C.byref(lay.c), _p(lam), _p(ftrs), _p(labels), C.c_uint32(T), _p(grad),
+                                         C.byref(numer), C.byref(zx))
+    return rc, grad, numer.value, zx.value
+
+
+def nstate_lattice_arcs(cfg, S, TD, TO, TE, T, norm=False, alpha_sum=0.0):
+    n = int(lib().orc_nstate_lattice_num_arcs(C.c_uint32(T), C.c_uint32(cfg.num_labs), C.c_uint32(cfg.num_states)))
+    arcs = np.zeros(n, dtype=ARC_DTYPE)
+    ns = C.c_uint32(); fin = C.c_int32()
+    na = lib().orc_nstate_lattice_arcs(C.byref(cfg), _p(S), _p(TD), _p(TO), _p(TE), C.c_uint32(T), C.c_int(int(norm)),
+                                       C.c_double(alpha_sum), _p(arcs), C.byref(ns), C.byref(fin))
+    assert na == n, (na, n)
+    return arcs, ns.value, fin.value
+
+
+def nstate_trans(cfg, TD, TO, TE, t, p, c):
+    """transition score p -> c at frame t under the n-state topology, None when it is not allowed"""
+    L, K = cfg.num_labs, cfg.num_states
+    P = L // K
+    if p == c:
+        return TD[t, c]
+    if c % K == 0:
+        return TE[t, (p // K) * P + c // K] if (p + 1) % K == 0 else None
+    return TO[t, c - 1] if p == c - 1 else None
+
+
+def brute_force_nstate(cfg, S, TD, TO, TE, T):
+    """every label sequence the n-state topology allows (any state may start and end an utterance, as
+    computeFirstAlpha / computeAlphaSum have it): Zx, per-frame posteriors, the best sequence"""
+    L = cfg.num_labs
+    paths = []
+
+    def rec(t, prev, score, seq):
+        if t == T:
+            paths.append((score, tuple(seq)))
+            return
+        for c in range(L):
+            s = score + S[t, c]
+            if prev is not None:
+                tr = nstate_trans(cfg, TD, TO, TE, t, prev, c)
+                if tr is None:
+                    continue
+                s = s + tr
+            rec(t + 1, c, s, seq + [c])
+
+    rec(0, None, 0.0, [])
+    scores = np.array([p[0] for p in paths])
+    mx = scores.max()
+    Zx = mx + np.log(np.exp(scores - mx).sum())
+    gamma = np.zeros((T, L))
+    for sc, seq in paths:
+        p = np.exp(sc - Zx)
+        for t, c in enumerate(seq):
+            gamma[t, c] += p
+    best = max(range(len(paths)), key=lambda i: paths[i][0])
+    return dict(Zx=Zx, gamma=gamma, n_paths=len(paths), paths=paths, best=paths[best])
 
 
 def stdseg_scores(cfg, lay, lam, segftrs, T):

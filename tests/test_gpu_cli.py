@@ -1149,3 +1149,38 @@ def test_crftrain_stdseg_model_type(tmp_path):
     r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_output_labelfile=" + str(tmp_path / "dec2.txt"), "crf_olist=" + olist],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "stdseg" in (r.stderr + r.stdout)
+
+
+def test_crftrain_and_fstdecode_with_three_states_per_label(tmp_path):
+    """crf_states=3 on the reference's bundled fixture (48 labels = 16 phones x 3 states): CRFTrain against the oracle's
+    SGD loop over orc.nstate_build_gradient (nodes/CRF_StdNStateNode.cpp), CRFFstDecode against the shortest path of the
+    oracle's n-state lattice (decoders/CRF_LatticeBuilder.h nStateBuildLattice)."""
+    out = str(tmp_path / "w.out")
+    lr, epochs, K = 0.1, 2, 3
+    flags = _common_flags() + ["crf_states=%d" % K]
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + flags + ["hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + out,
+                        "crf_epochs=%d" % epochs, "crf_lr=%g" % lr, "crf_bunch_size=1", "threads=1", "crf_train_order=seq"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    utts = _fixture()
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6, num_states=K); lay = orc.Layout(cfg)
+    assert "FEATURES: %d" % lay.lambda_len in r.stdout
+    lam = np.zeros(lay.lambda_len); acc = np.zeros_like(lam); gsa = np.zeros_like(lam)
+    for _ in range(epochs):
+        for X, lab in utts:
+            rc, g, _, _ = orc.nstate_build_gradient(cfg, lay, lam, X, lab, X.shape[0])
+            assert rc == 0
+            orc.sgd_step(lam, acc, gsa, g, np.float32(lr), False, 1e-12)
+    w = np.loadtxt(out)
+    assert np.abs(w).max() > 0
+    np.testing.assert_allclose(w, np.array([float("%g" % v) for v in lam]), rtol=2e-5, atol=1e-12)
+    dec = str(tmp_path / "labels.txt")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + flags + ["weight_file=" + out, "crf_output_labelfile=" + dec], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.loadtxt(dec).astype(int)
+    for u, (X, _) in enumerate(utts):
+        T = X.shape[0]
+        S, TD, TO, TE = orc.nstate_scores(cfg, lay, w, X, T)
+        arcs, ns, fin = orc.nstate_lattice_arcs(cfg, S, TD, TO, TE, T)
+        ol, _ = orc.best_path(arcs, ns, fin)
+        assert list(got[got[:, 0] == u][:, 2]) == list(ol)

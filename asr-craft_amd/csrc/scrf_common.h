@@ -25,17 +25,21 @@ struct ScrfLayout {
   uint32_t lambda_len;
   uint32_t K;          // states per label (numStates); 1 except for the n-state frame model (scrf_nstate.hip)
 
-  // K > 1 (ftrmaps/CRF_StdFeatureMap.cpp:293-312, :367-407): a label's block is its state functions, its self
-  // transition, then for a phone's start state the transitions from every phone's end state, for the other states
-  // the one from the state before; transitions outside that topology have no weights (0xffffffff)
-  __host__ __device__ inline uint32_t state_idx(uint32_t c) const {
+  // one state per label: the closed form every kernel of the dense models uses
+  __host__ __device__ inline uint32_t state_idx(uint32_t c) const { return c * stride; }
+  __host__ __device__ inline uint32_t trans_idx(uint32_t p, uint32_t c) const { return c * stride + nsf + p * ntf; }
+  // any K (scrf_nstate.hip and the layout hooks).  K > 1 (ftrmaps/CRF_StdFeatureMap.cpp:293-312, :367-407): a label's
+  // block is its state functions, its self transition, then for a phone's start state the transitions from every
+  // phone's end state, for the other states the one from the state before; transitions outside that topology have no
+  // weights (0xffffffff)
+  __host__ __device__ inline uint32_t state_idx_k(uint32_t c) const {
     if (K <= 1) return c * stride;
     const uint32_t ns = (c + K - 1) / K;   // start states among the labels before c
     return c * nsf + ntf * (ns * (L / K + 1) + (c - ns) * 2);
   }
-  __host__ __device__ inline uint32_t trans_idx(uint32_t p, uint32_t c) const {
+  __host__ __device__ inline uint32_t trans_idx_k(uint32_t p, uint32_t c) const {
     if (K <= 1) return c * stride + nsf + p * ntf;
-    uint32_t v = state_idx(c) + nsf;
+    uint32_t v = state_idx_k(c) + nsf;
     if (p == c) return v;
     v += ntf;
     if (c % K == 0) return ((p + 1) % K == 0) ? v + (p / K) * ntf : 0xffffffffu;

@@ -353,13 +353,16 @@ extern "C" int scrf_num_trans_funcs(scrf_handle h, uint32_t* n) { if (!h || !n) 
 extern "C" int scrf_state_idx(scrf_handle h, uint32_t clab, uint32_t fno, uint32_t* idx) {
   if (!h || !idx) return SCRF_ERR_INVALID;
   if (clab >= h->lay.L) return fail(h, SCRF_ERR_INVALID, "scrf_state_idx: label %u >= %u", clab, h->lay.L);
-  *idx = h->lay.state_idx(clab) + fno;  // getStateFeatureIdx :421-423
+  *idx = h->lay.state_idx_k(clab) + fno;  // getStateFeatureIdx :421-423
   return SCRF_OK;
 }
 extern "C" int scrf_trans_idx(scrf_handle h, uint32_t plab, uint32_t clab, uint32_t fno, uint32_t* idx) {
   if (!h || !idx) return SCRF_ERR_INVALID;
   if (clab >= h->lay.L || plab >= h->lay.L) return fail(h, SCRF_ERR_INVALID, "scrf_trans_idx: label out of range");
-  *idx = h->lay.trans_idx(plab, clab) + fno;  // getTransFeatureIdx :435-437
+  {
+    const uint32_t v = h->lay.trans_idx_k(plab, clab);   // getTransFeatureIdx :435-437; 0xffffffff: no such transition (n-state topology)
+    *idx = v == 0xffffffffu ? v : v + fno;
+  }
   return SCRF_OK;
 }
 

@@ -1,7 +1,7 @@
 // scrf_nstate.hip -- the n-state frame model (crf_states = K > 1; nodes/CRF_StdNStateNode.cpp): label c is state c % K
 // of phone c / K (P = nLabs / K phones).  Allowed transitions: self (c -> c), next state inside a phone (c-1 -> c), end
 // state of any phone -> start state of any phone; the weight layout holds exactly those
-// (ftrmaps/CRF_StdFeatureMap.cpp:280-407, ScrfLayout::state_idx / trans_idx with K > 1).
+// (ftrmaps/CRF_StdFeatureMap.cpp:280-407, ScrfLayout::state_idx_k / trans_idx_k).
 //
 // Per frame: S[c] state values, TD[c] self transitions, TO[c] = transition c -> c+1 (unused for end states),
 // TE[p*P + q] = end state of phone p -> start state of phone q (diagTransMatrix / offDiagTransMatrix /
@@ -49,12 +49,12 @@ __global__ __launch_bounds__(256) void k_ns_scores(ScrfLayout lay, const float* 
   const uint64_t fr = e / L;
   const uint32_t c = (uint32_t)(e % L);
   const float* x = X + fr * lay.F;
-  S[fr * L + c] = ns_dot(lay, x, lambda, lay.state_idx(c), true);
-  TD[fr * L + c] = ns_dot(lay, x, lambda, lay.trans_idx(c, c), false);
+  S[fr * L + c] = ns_dot(lay, x, lambda, lay.state_idx_k(c), true);
+  TD[fr * L + c] = ns_dot(lay, x, lambda, lay.trans_idx_k(c, c), false);
   if (c % K == 0) {
-    for (uint32_t p = 0; p < P; p++) TE[fr * P * P + p * P + c / K] = ns_dot(lay, x, lambda, lay.trans_idx(p * K + K - 1, c), false);
+    for (uint32_t p = 0; p < P; p++) TE[fr * P * P + p * P + c / K] = ns_dot(lay, x, lambda, lay.trans_idx_k(p * K + K - 1, c), false);
   } else {
-    TO[fr * L + c - 1] = ns_dot(lay, x, lambda, lay.trans_idx(c - 1, c), false);
+    TO[fr * L + c - 1] = ns_dot(lay, x, lambda, lay.trans_idx_k(c - 1, c), false);
   }
   if ((c + 1) % K == 0) TO[fr * L + c] = 0.0;
 }
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(256) void k_ns_expf(ScrfLayout lay, ScrfBatchView b
   uint32_t lo = 0, hi = L - 1;
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) / 2;
-    if (lay.state_idx(mid) <= i) lo = mid; else hi = mid - 1;
+    if (lay.state_idx_k(mid) <= i) lo = mid; else hi = mid - 1;
   }
-  const uint32_t c = lo, r = i - lay.state_idx(c);
+  const uint32_t c = lo, r = i - lay.state_idx_k(c);
   const bool is_state = r < lay.nsf;
   uint32_t k = r, j = 0, plab = c;
   if (!is_state) { j = (r - lay.nsf) / lay.ntf; k = (r - lay.nsf) % lay.ntf; if (j > 0) plab = (c % K == 0) ? (j - 1) * K + K - 1 : c - 1; }

@@ -32,6 +32,17 @@ int main(int argc, char** argv) {
     if (a.has(k)) { std::cerr << k << ": not built (LM: crf_lm_txt / crf_lm_bin; dictionary: crf_dict_bin / crf_dict_txt)" << std::endl; return 1; }
   for (const char* k : {"crf_pre_phn_wt", "crf_phn_wt", "crf_dict_wt", "crf_lm_wt"})
     if (a.real(k, 0.0) != 0.0) { std::cerr << k << ": lattice pruning between the compositions is not built (the search is exhaustive)" << std::endl; return 1; }
+  // crf_decode_mode=align (Main.cpp:464-471, :841-848): the best path of lattice o label acceptor -- the labels of
+  // hardtarget_file in their order, every run of equal node labels stretched or shrunk to fit -- written to the label file
+  const std::string mode = a.str("crf_decode_mode", "decode");
+  if (mode != "decode" && mode != "align") { std::cerr << "crf_decode_mode=" << mode << " (decode|align)" << std::endl; return 1; }
+  const bool align_mode = mode == "align";
+  if (align_mode && !a.has("hardtarget_file")) { std::cerr << "hardtarget_file required when crf_decode_mode=align" << std::endl; return -1; }
+  std::vector<std::vector<uint32_t> > hard_labs;
+  if (align_mode) {
+    try { hard_labs = read_labs(a.str("hardtarget_file")); }
+    catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
+  }
   const bool want_mlf = a.has("crf_output_mlffile");
   crf_amd::ArcListFst lm, dict, chain0;   // chain0: dict o lm, composed once when no per-utterance acceptor sits between them
   const bool have_lm = a.has("crf_lm_txt") || a.has("crf_lm_bin");
@@ -89,7 +100,15 @@ int main(int argc, char** argv) {
   for (uint32_t u : sents) {
     std::vector<std::vector<float> > fr(data.size());
     for (size_t s = 0; s < data.size(); s++) { fr[s] = data[s].get(u); data[s].drop(u); }
-    strm.addUtterance(fr, std::vector<uint32_t>());
+    if (align_mode) {
+      if (u >= hard_labs.size() || hard_labs[u].size() != fr[0].size() / m.recipes[0].in_width) {
+        std::cerr << "hardtarget_file: sentence " << u << ": one label per frame expected" << std::endl;
+        return -1;
+      }
+      strm.addUtterance(fr, hard_labs[u]);
+    } else {
+      strm.addUtterance(fr, std::vector<uint32_t>());
+    }
   }
   // crf_output_format=ilab writes QuickNet ILAB (CRFFstDecode/src/Main.cpp:203); the default here
   // is the same content as ascii `sent pos label` lines
@@ -159,7 +178,7 @@ int main(int argc, char** argv) {
     mlf << "." << std::endl;
     std::cout << ". (weight " << total << ")" << std::endl;
   };
-  if (!a.has("crf_lat_outdir") && !want_mlf) {
+  if (!a.has("crf_lat_outdir") && !want_mlf && !align_mode) {
     // best paths only: whole device batches of utterances (crf_bunch_size of them, default 256)
     const size_t bunch = (size_t)std::max(1L, a.num("crf_bunch_size", 256));
     bool at_end = strm.nextseg() == QN_SEGID_BAD;
@@ -177,9 +196,9 @@ int main(int argc, char** argv) {
   } else {
     while (strm.nextseg() != QN_SEGID_BAD) {
       try {  // the reference prints the exception and continues with the next utterance (:1052-1054)
-        crf_amd::ArcListFst fst;
+        crf_amd::ArcListFst fst, lab_fst;
         CRF_LatticeBuilder lb(&strm, &crf);
-        lb.buildLattice(&fst, false, (crf_amd::ArcListFst*)nullptr, false);
+        lb.buildLattice(&fst, align_mode, align_mode ? &lab_fst : (crf_amd::ArcListFst*)nullptr, false);
         if (a.has("crf_lat_outdir")) {
           // the reference writes the lattice as an OpenFST binary, fst.<n>.final.fst (:832-837); here that file
           // (layout unpinned, crf_amd.h) plus the same arcs as text
@@ -189,6 +208,18 @@ int main(int argc, char** argv) {
           lf << fst.final_state << "\n";
         }
         if (want_mlf) write_mlf(fst, sents[u]);
+        if (align_mode) {   // ShortestPath(Compose(lattice, labels)), Project(output), RmEpsilon: olabel - 1 per arc
+          crf_amd::ArcListFst best;
+          float total = 0;
+          std::vector<uint32_t> labs;
+          if (crf_amd::composeShortestPath(fst, lab_fst, &best, &total)) {
+            for (const scrf_arc& c : best.arcs) { if (c.olabel != 0) labs.push_back((uint32_t)(c.olabel - 1)); }
+          } else {
+            std::cerr << "WARNING: the labels of sentence " << sents[u] << " do not fit its lattice" << std::endl;
+          }
+          emit(labs);
+          continue;
+        }
         float cost = 0;
         emit(crf_amd_best_path(&strm, &crf, &cost));
       } catch (std::exception& e) {

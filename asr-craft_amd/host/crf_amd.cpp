@@ -1048,11 +1048,15 @@ double CRF_StateNode::getFullTransValue(QNUInt32 prev_lab, QNUInt32 cur_lab, QNU
 // ------------------------------------------------------------------------------------------
 // lattice / best path
 // ------------------------------------------------------------------------------------------
-int CRF_LatticeBuilder::latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint32_t* n_states, int32_t* fin) {
+int CRF_LatticeBuilder::latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint32_t* n_states, int32_t* fin, std::vector<QNUInt32>* node_labels) {
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();
   std::vector<HeldUtt> utts(1);
   grab(ftr_strm, crf, &utts[0]);
+  if (node_labels) {   // the nodes' labels (frame labels, or phone-duration labels at segment ends, CRF_LAB_BAD elsewhere)
+    node_labels->clear();
+    if (utts[0].u.labels) node_labels->assign(utts[0].u.labels, utts[0].u.labels + utts[0].u.T);
+  }
   BatchGuard g{e};
   make_batch(e, ftr_strm, utts, &g);
   uint64_t na = 0;

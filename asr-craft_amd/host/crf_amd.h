@@ -527,12 +527,35 @@ class CRF_LatticeBuilder {
   virtual ~CRF_LatticeBuilder() {}
   template <class Fst>
   int buildLattice(Fst* fst, bool align = false, Fst* alignFst = nullptr, bool norm = true) {
-    (void)alignFst;
-    if (align) throw std::runtime_error("buildLattice: alignment lattices are outside the built hot path");
     std::vector<scrf_arc> arcs;
     uint32_t n_states = 0;
     int32_t fin = -1;
-    int seq_len = latticeArcs(norm, &arcs, &n_states, &fin);
+    std::vector<QNUInt32> node_labels;
+    int seq_len = latticeArcs(norm, &arcs, &n_states, &fin, align ? &node_labels : nullptr);
+    if (align) {
+      // the label acceptor of decoders/CRF_LatticeBuilder.h:172-184 (every builder has the same block): one state per
+      // run of equal node labels, entered by lab:lab / 0 and carrying a self loop lab:lab / 0, lab = node label + 1
+      // (an unlabelled node is CRF_LAB_BAD + 1 == 0 there: an epsilon run)
+      if (!alignFst) throw std::runtime_error("buildLattice: align mode needs the label FST");
+      if (node_labels.empty()) throw std::runtime_error("CRF_LatticeBuilder::buildLattice() caught exception: The label stream is found NULL or the label width is found 0 under the align mode.");
+      typedef typename Fst::Arc LArc;
+      int cur = alignFst->AddState();
+      alignFst->SetStart(cur);
+      bool first = true;
+      QNUInt32 cur_lab = 0;
+      for (QNUInt32 nl : node_labels) {
+        const QNUInt32 lab = nl + 1;   // unsigned wrap for CRF_LAB_BAD, as there
+        if (first || lab != cur_lab) {
+          const int prev = cur;
+          cur = alignFst->AddState();
+          alignFst->AddArc(prev, LArc((int)lab, (int)lab, 0, cur));
+          alignFst->AddArc(cur, LArc((int)lab, (int)lab, 0, cur));
+          first = false;
+          cur_lab = lab;
+        }
+      }
+      alignFst->SetFinal(cur, 0);
+    }
     for (uint32_t s = 0; s < n_states; s++) fst->AddState();
     fst->SetStart(0);
     typedef typename Fst::Arc Arc;
@@ -542,7 +565,7 @@ class CRF_LatticeBuilder {
   }
 
  protected:
-  int latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint32_t* n_states, int32_t* final_state);
+  int latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint32_t* n_states, int32_t* final_state, std::vector<QNUInt32>* node_labels = nullptr);
   CRF_FeatureStream* ftr_strm;
   CRF_Model* crf;
 };

@@ -1184,3 +1184,63 @@ def test_crftrain_and_fstdecode_with_three_states_per_label(tmp_path):
         arcs, ns, fin = orc.nstate_lattice_arcs(cfg, S, TD, TO, TE, T)
         ol, _ = orc.best_path(arcs, ns, fin)
         assert list(got[got[:, 0] == u][:, 2]) == list(ol)
+
+
+def test_crffstdecode_align_mode_on_bundled_fixture(tmp_path):
+    """crf_decode_mode=align (CRFFstDecode/src/Main.cpp:464-471, :841-848): best path of lattice o label acceptor -- the
+    label RUNS of hardtarget_file in their order, boundaries free -- against a dynamic program over the oracle's frame
+    scores constrained to that run sequence."""
+    out = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _train_flags(out, crf_epochs=3, crf_lr=0.3), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    utts = _fixture()
+    # labels to align to: the fixture's runs in reversed order, so that the constraint is not the free best path
+    alt = str(tmp_path / "alt.lab")
+    runs_all = []
+    with open(alt, "w") as f:
+        for u, (X, lab) in enumerate(utts):
+            T = X.shape[0]
+            seq = [int(lab[0])] + [int(lab[t]) for t in range(1, T) if lab[t] != lab[t - 1]]
+            seq = seq[::-1] if len(seq) > 1 else seq
+            frames = []
+            for i, s_ in enumerate(seq):
+                frames += [s_] * (T // len(seq) + (1 if i < T % len(seq) else 0))
+            runs_all.append(seq)
+            for t in range(T):
+                f.write("%d %d %d\n" % (u, t, frames[t]))
+    dec = str(tmp_path / "align.txt")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + _common_flags() + ["weight_file=" + out, "crf_output_labelfile=" + dec, "crf_decode_mode=align",
+                        "hardtarget_file=" + alt], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.loadtxt(dec).astype(int).reshape(-1, 3)
+    cfg = orc.config(model_type=orc.STDFRAME, L=48, D=1, F=6); lay = orc.Layout(cfg)
+    w = np.loadtxt(out)
+    checked = 0
+    for u, (X, _) in enumerate(utts):
+        T = X.shape[0]
+        S, M = orc.seg_scores(cfg, lay, w, X, T)
+        seq = runs_all[u]
+        R = len(seq)
+        INF = np.float32(np.inf)
+        cost = np.full((T, R), INF, dtype=np.float32)
+        cost[0, 0] = np.float32(0.0) + np.float32(-S[0, seq[0]])
+        for t in range(1, T):
+            for r_ in range(R):
+                for pr in (r_, r_ - 1):
+                    if pr < 0 or cost[t - 1, pr] == INF:
+                        continue
+                    c_ = cost[t - 1, pr] + np.float32(-(M[t, seq[pr] * 48 + seq[r_]] + S[t, seq[r_]]))
+                    if c_ < cost[t, r_]:
+                        cost[t, r_] = c_
+        lab_u = list(got[got[:, 0] == u][:, 2])
+        assert len(lab_u) == T
+        collapsed = [lab_u[0]] + [lab_u[t] for t in range(1, T) if lab_u[t] != lab_u[t - 1]]
+        if all(seq[i] != seq[i + 1] for i in range(R - 1)) and R <= T:
+            assert collapsed == seq
+            total = sum(-S[0, lab_u[0]] if t == 0 else -(M[t, lab_u[t - 1] * 48 + lab_u[t]] + S[t, lab_u[t]]) for t in range(T))
+            assert abs(total - float(cost[T - 1, R - 1])) < 1e-4 * max(1.0, abs(total))
+            checked += 1
+    assert checked >= 2
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + _common_flags() + ["weight_file=" + out, "crf_output_labelfile=" + dec, "crf_decode_mode=align"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "hardtarget_file required" in r.stderr

@@ -1184,6 +1184,12 @@ def test_crftrain_and_fstdecode_with_three_states_per_label(tmp_path):
         arcs, ns, fin = orc.nstate_lattice_arcs(cfg, S, TD, TO, TE, T)
         ol, _ = orc.best_path(arcs, ns, fin)
         assert list(got[got[:, 0] == u][:, 2]) == list(ol)
+    # the LM decoder says that it does not take several states per label
+    olist = str(tmp_path / "olist")
+    open(olist, "w").write("u0\nu1\nu2\n")
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + flags + ["weight_file=" + out, "crf_output_labelfile=" + str(tmp_path / "d2.txt"), "crf_olist=" + olist],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_states" in (r.stderr + r.stdout)
 
 
 def test_crffstdecode_align_mode_on_bundled_fixture(tmp_path):

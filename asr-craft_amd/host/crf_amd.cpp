@@ -999,7 +999,17 @@ void CRF_LBFGSTrainer::train() {
 // ------------------------------------------------------------------------------------------
 // CRF_StateVector / CRF_StateNode: node values of one utterance from the engine's hooks
 // ------------------------------------------------------------------------------------------
+// the node view and the Viterbi decoder read getStateValue(lab, dur) / getTransValue(p, c) of the one-matrix-per-frame
+// models; the other node types keep their values per window or in sparse tables (scrf_scores documents the shapes)
+static void require_dense_model(CRF_Model* crf, const char* who) {
+  const modeltype mt = crf->getModelType();
+  const bool dense = mt == STDFRAME || mt == STDSEG_NO_DUR_NO_TRANSFTR || mt == STDSEG_NO_DUR_NO_SEGTRANSFTR;
+  if (!dense || (crf->getFeatureMap() && crf->getFeatureMap()->getNumStates() != 1))
+    throw runtime_error(string(who) + ": built for stdframe (one state per label), stdseg_no_dur_no_transftr and stdseg_no_dur_no_segtransftr");
+}
+
 CRF_StateVector::CRF_StateVector(CRF_FeatureStream* ftr_strm, CRF_Model* crf) {
+  require_dense_model(crf, "CRF_StateVector");
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();
   std::vector<HeldUtt> utts(1);
@@ -1070,6 +1080,7 @@ int CRF_LatticeBuilder::latticeArcs(bool norm, std::vector<scrf_arc>* arcs, uint
 // from the node scores -- the reference reads them off the segment's END node
 // (getFullTransValue(prev, cur, dur) = getTransValue + getStateValue of node seg_end, :2262)
 int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decode() {
+  require_dense_model(crf, "CRF_ViterbiDecoder_StdSeg_NoSegTransFtr");
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();
   std::vector<HeldUtt> utts(1);
@@ -1461,6 +1472,7 @@ void crf_amd::writeFstBinary(const char* fname, const crf_amd::ArcListFst& fst, 
 }
 
 int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst) {
+  require_dense_model(crf, "CRF_ViterbiDecoder_StdSeg_NoSegTransFtr");
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();
   std::vector<HeldUtt> utts(1);

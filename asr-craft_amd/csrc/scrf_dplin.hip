@@ -566,7 +566,27 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
     else launch_dp_lin_mw_t<40>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
     return;
   }
-  const uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * ((size_t)lay.D * lay.L + 128));
+  uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * ((size_t)lay.D * lay.L + 128));
+  if (wpb > 8) {
+    // Tail-aware workgroup size: one workgroup per CU, so the launch runs in ceil(workgroups / CUs) rounds of T steps,
+    // and a step costs a fixed latency plus a share per resident wavefront (measured on MI355X at config 2:
+    // 3.4 us + 0.31 us per wavefront).  8192 sweeps on 256 CUs: 12 wavefronts per workgroup are
+    // 2.67 -> 3 rounds of 7.1 us steps, 11 are 2.91 -> 3 rounds of 6.8 us steps.
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    uint32_t best = wpb;
+    double best_cost = 1e300;
+    for (uint32_t w = wpb; w >= 8; w--) {
+      const uint64_t blocks = 2 * (((uint64_t)n_utts + w - 1) / w);
+      const double cost = (double)((blocks + n_cu - 1) / n_cu) * (3.4 + 0.31 * w);
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = w; }
+    }
+    wpb = best;
+  }
   const uint32_t nblk = 2 * ((n_utts + wpb - 1) / wpb);
   const size_t sm = sizeof(double) * ((m_per_frame ? 0 : (size_t)lay.L * lay.L) + (size_t)wpb * (lay.D * lay.L + 128));
 #define DL_LAUNCH2(DM, MPF, LC)                                                                                    \

@@ -57,6 +57,15 @@ enum { SCRF_NCCL_DOUBLE = 8, SCRF_NCCL_SUM = 0 };  // ncclFloat64, ncclSum (rccl
 struct scrf_engine_s {
   scrf_config cfg;
   ScrfLayout lay;
+  // K states per label on a segmental model (nodes/CRF_StdSegNStateNode_WithoutDurLab_WithoutSegTransFtr.cpp): the
+  // kernels run the dense one-state layout `lay` with the bias of every transition the topology lacks pinned at
+  // log 0 (mask_w); the callers see the reference's compact layout `xlay` (CRF_StdFeatureMap.cpp:293-312), and every
+  // weight-length vector crossing the ABI is scattered / gathered through s2d (compact index -> dense index)
+  bool shadow = false;
+  ScrfLayout xlay;
+  std::vector<uint32_t> s2d, masked;
+  double mask_w = 0.0;
+  std::vector<double> xbuf;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -183,7 +192,15 @@ static uint32_t window_width(const scrf_stream_recipe& r, uint32_t D) {
 static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
   if (c.abi_version != SCRF_ABI_VERSION) { *why = "abi_version mismatch"; return SCRF_ERR_INVALID; }
   if (c.num_states == 0) { *why = "num_states must be >= 1"; return SCRF_ERR_INVALID; }
-  if (c.num_states > 1 && (c.model_type != SCRF_STDFRAME || c.lab_max_dur != 1)) { *why = "crf_states > 1 is built for the frame-level model only (the reference's segmental n-state node exists for stdseg_no_dur_no_segtransftr alone and is not built)"; return SCRF_ERR_INVALID; }
+  if (c.num_states > 1 && c.model_type != SCRF_STDFRAME && c.model_type != SCRF_STDSEG_NO_DUR_NO_TRANSFTR && c.model_type != SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR) {
+    // nodes/CRF_StateNode.cpp:496-507: "CRF_StdSegNStateNode has not been implemented yet"
+    *why = "crf_states > 1: CRF_StdSegNStateNode / CRF_StdSegNStateNode_WithoutDurLab have not been implemented (the reference has stdframe and stdseg_no_dur_no_segtransftr n-state nodes only)";
+    return SCRF_ERR_INVALID;
+  }
+  if (c.num_states > 1 && c.model_type != SCRF_STDFRAME && (!c.use_trans_bias || !(c.trans_bias_val > 0.0f))) {
+    *why = "crf_states > 1 on a segmental model needs the transition bias (crf_use_trans_bias, a positive bias value): the topology is held by it";
+    return SCRF_ERR_INVALID;
+  }
   if (c.num_states > 1 && c.num_labs % c.num_states != 0) { *why = "Invalid state/label combination while computing transitions"; return SCRF_ERR_INVALID; }  // CRF_StdFeatureMap.cpp:476-479
   if (c.num_labs == 0 || c.lab_max_dur == 0 || c.num_feas == 0) { *why = "num_labs, lab_max_dur, num_feas must be > 0"; return SCRF_ERR_INVALID; }
   if (c.model_type == SCRF_STDSEG && c.num_labs % c.lab_max_dur != 0) { *why = "stdseg: the number of all labels and the maximum duration of labels do not correspond (nLabs = nActualLabs * labMaxDur)"; return SCRF_ERR_INVALID; }
@@ -235,6 +252,25 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   scrf_handle h = new scrf_engine_s();
   h->cfg = *cfg;
   h->lay = lay;
+  h->xlay = lay;
+  if (lay.K > 1 && cfg->model_type != SCRF_STDFRAME) {
+    const uint64_t dense = (uint64_t)lay.L * lay.stride;
+    if (dense > 0xfffffff0ull) { delete h; return fail(nullptr, SCRF_ERR_INVALID, "scrf_create: lambda_len out of range"); }
+    h->shadow = true;
+    h->lay.K = 1;
+    h->lay.lambda_len = (uint32_t)dense;
+    lay = h->lay;
+    h->mask_w = -1e30 / (double)cfg->trans_bias_val;
+    h->s2d.assign(h->xlay.lambda_len, 0);
+    for (uint32_t c = 0; c < lay.L; c++) {
+      for (uint32_t f = 0; f < lay.nsf; f++) h->s2d[h->xlay.state_idx_k(c) + f] = lay.state_idx(c) + f;
+      for (uint32_t p = 0; p < lay.L; p++) {
+        const uint32_t x = h->xlay.trans_idx_k(p, c);
+        if (x == 0xffffffffu) h->masked.push_back(lay.trans_idx(p, c) + lay.ntf - 1);   // the bias is the last transition function
+        else for (uint32_t f = 0; f < lay.ntf; f++) h->s2d[x + f] = lay.trans_idx(p, c) + f;
+      }
+    }
+  }
   h->device = cfg->device_id;
   if (h->cfg.scratch_bytes == 0) h->cfg.scratch_bytes = 8ull << 30;
   if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knobs
@@ -291,6 +327,10 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   }
   h->ev_ok = true;
   CRCHK(hipStreamSynchronize(h->stream));
+  if (h->shadow) {
+    std::vector<double> z(h->xlay.lambda_len, 0.0);
+    if (scrf_set_lambda(h, z.data(), h->xlay.lambda_len) != SCRF_OK) { g_create_err = h->err; scrf_destroy(h); return SCRF_ERR_HIP; }
+  }
 #undef CRCHK
   *out = h;
   return SCRF_OK;
@@ -347,20 +387,20 @@ extern "C" int scrf_synchronize(scrf_handle h) {
 // ---------------------------------------------------------------------------------------------
 // layout hooks / model state
 // ---------------------------------------------------------------------------------------------
-extern "C" int scrf_lambda_len(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->lay.lambda_len; return SCRF_OK; }
+extern "C" int scrf_lambda_len(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->xlay.lambda_len; return SCRF_OK; }
 extern "C" int scrf_num_state_funcs(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->lay.nsf; return SCRF_OK; }
 extern "C" int scrf_num_trans_funcs(scrf_handle h, uint32_t* n) { if (!h || !n) return SCRF_ERR_INVALID; *n = h->lay.ntf; return SCRF_OK; }
 extern "C" int scrf_state_idx(scrf_handle h, uint32_t clab, uint32_t fno, uint32_t* idx) {
   if (!h || !idx) return SCRF_ERR_INVALID;
   if (clab >= h->lay.L) return fail(h, SCRF_ERR_INVALID, "scrf_state_idx: label %u >= %u", clab, h->lay.L);
-  *idx = h->lay.state_idx_k(clab) + fno;  // getStateFeatureIdx :421-423
+  *idx = h->xlay.state_idx_k(clab) + fno;  // getStateFeatureIdx :421-423
   return SCRF_OK;
 }
 extern "C" int scrf_trans_idx(scrf_handle h, uint32_t plab, uint32_t clab, uint32_t fno, uint32_t* idx) {
   if (!h || !idx) return SCRF_ERR_INVALID;
   if (clab >= h->lay.L || plab >= h->lay.L) return fail(h, SCRF_ERR_INVALID, "scrf_trans_idx: label out of range");
   {
-    const uint32_t v = h->lay.trans_idx_k(plab, clab);   // getTransFeatureIdx :435-437; 0xffffffff: no such transition (n-state topology)
+    const uint32_t v = h->xlay.trans_idx_k(plab, clab);   // getTransFeatureIdx :435-437; 0xffffffff: no such transition (n-state topology)
     *idx = v == 0xffffffffu ? v : v + fno;
   }
   return SCRF_OK;
@@ -368,8 +408,23 @@ extern "C" int scrf_trans_idx(scrf_handle h, uint32_t plab, uint32_t clab, uint3
 
 static int vec_io(scrf_handle h, double* dev, const double* in, double* out, uint32_t n, const char* what) {
   if (!h || (!in && !out)) return SCRF_ERR_INVALID;
-  if (n != h->lay.lambda_len) return fail(h, SCRF_ERR_INVALID, "%s: length %u != lambda_len %u", what, n, h->lay.lambda_len);
+  if (n != h->xlay.lambda_len) return fail(h, SCRF_ERR_INVALID, "%s: length %u != lambda_len %u", what, n, h->xlay.lambda_len);
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->shadow) {   // compact (caller) <-> dense (device)
+    const uint32_t nd = h->lay.lambda_len;
+    h->xbuf.assign(nd, 0.0);
+    if (in) {
+      for (uint32_t i = 0; i < n; i++) h->xbuf[h->s2d[i]] = in[i];
+      if (dev == h->d_lambda) for (uint32_t m : h->masked) h->xbuf[m] = h->mask_w;
+      HIPCHK(h, hipMemcpyAsync(dev, h->xbuf.data(), sizeof(double) * nd, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->xbuf.data(), dev, sizeof(double) * nd, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (uint32_t i = 0; i < n; i++) out[i] = h->xbuf[h->s2d[i]];
+    }
+    return SCRF_OK;
+  }
   if (in) HIPCHK(h, hipMemcpyAsync(dev, in, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   else HIPCHK(h, hipMemcpyAsync(out, dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -395,12 +450,19 @@ extern "C" int scrf_zero_grad(scrf_handle h) {
   return SCRF_OK;
 }
 
-extern "C" int scrf_grad_device_ptr(scrf_handle h, void** p) { if (!h || !p) return SCRF_ERR_INVALID; *p = h->d_grad; return SCRF_OK; }
+static const char* k_shadow_devptr = "%s: with crf_states > 1 on a segmental model the device gradient is kept in the dense one-state layout; use scrf_get_grad / scrf_add_grad / scrf_allreduce_grad";
+extern "C" int scrf_grad_device_ptr(scrf_handle h, void** p) {
+  if (!h || !p) return SCRF_ERR_INVALID;
+  if (h->shadow) return fail(h, SCRF_ERR_INVALID, k_shadow_devptr, "scrf_grad_device_ptr");
+  *p = h->d_grad;
+  return SCRF_OK;
+}
 
 extern "C" int scrf_set_grad_buffer(scrf_handle h, void* dptr) {
   // accumulate into caller-owned device memory (e.g. a torch tensor that torch.distributed
   // all-reduces over RCCL); NULL restores the engine's own buffer
   if (!h) return SCRF_ERR_INVALID;
+  if (h->shadow) return fail(h, SCRF_ERR_INVALID, k_shadow_devptr, "scrf_set_grad_buffer");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (dptr) {
@@ -463,6 +525,13 @@ static int upload(scrf_handle h, Tp** d, const Tp* src, size_t n) {
   HIPCHK(h, hipMalloc((void**)d, sizeof(Tp) * n));
   if (src) HIPCHK(h, hipMemcpyAsync(*d, src, sizeof(Tp) * n, hipMemcpyHostToDevice, h->stream));
   return SCRF_OK;
+}
+
+// K states per label on the segmental model: P*P + 2L - P boundary arcs per frame after the first instead of L*L
+// (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab_WithoutSegTransFtr.h:563-597)
+static uint64_t shadow_num_arcs(scrf_handle h, uint32_t T) {
+  const uint64_t L = h->xlay.L, P = L / h->xlay.K;
+  return (uint64_t)(T - 1) * (P * P + 2 * L - P) + scrf_seg_base(T, h->xlay.D) * L + L;
 }
 
 extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
@@ -545,7 +614,12 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
         nxt[f] = cur;
         const uint32_t lb = lab[f];
         if (lb != SCRF_LAB_BAD) {
-          if (t + 1 < b->T[u] && cur != SCRF_LAB_BAD && lb < lay.L * lay.D && cur < lay.L * lay.D && h->cfg.model_type != SCRF_STDSEG)
+          // K states per label: a labelled transition the topology lacks matches none of the node's transition
+          // terms (nodes/CRF_StdSegNStateNode_WithoutDurLab_WithoutSegTransFtr.cpp:822-876) and adds nothing
+          if (h->shadow && cur != SCRF_LAB_BAD && lb < lay.L * lay.D && cur < lay.L * lay.D &&
+              h->xlay.trans_idx_k(lb % lay.L, cur % lay.L) == 0xffffffffu)
+            nxt[f] = SCRF_LAB_BAD;
+          else if (t + 1 < b->T[u] && cur != SCRF_LAB_BAD && lb < lay.L * lay.D && cur < lay.L * lay.D && h->cfg.model_type != SCRF_STDSEG)
             cnt[(size_t)(lb % lay.L) * lay.L + cur % lay.L]++;
           cur = lb;
         }
@@ -665,7 +739,13 @@ extern "C" int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, ui
   if (n_utts) *n_utts = b->U;
   if (n_frames) *n_frames = b->frame_off[b->U];
   if (n_segs) *n_segs = b->seg_off[b->U];
-  if (n_arcs) *n_arcs = b->arc_off[b->U];
+  if (n_arcs) {
+    *n_arcs = b->arc_off[b->U];
+    if (h->shadow) {
+      *n_arcs = 0;
+      for (uint32_t u = 0; u < b->U; u++) *n_arcs += shadow_num_arcs(h, b->T[u]);
+    }
+  }
   return SCRF_OK;
 }
 
@@ -1555,8 +1635,14 @@ extern "C" int scrf_fb_batch(scrf_handle h, scrf_batch b, double* numer, double*
 
 extern "C" int scrf_add_grad(scrf_handle h, const double* g, uint32_t n) {
   if (!h || !g) return SCRF_ERR_INVALID;
-  if (n != h->lay.lambda_len) return fail(h, SCRF_ERR_INVALID, "scrf_add_grad: length mismatch");
+  if (n != h->xlay.lambda_len) return fail(h, SCRF_ERR_INVALID, "scrf_add_grad: length mismatch");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->shadow) {
+    h->xbuf.assign(h->lay.lambda_len, 0.0);
+    for (uint32_t i = 0; i < n; i++) h->xbuf[h->s2d[i]] = g[i];
+    g = h->xbuf.data();
+    n = h->lay.lambda_len;
+  }
   int rc = ensure_scratch(h, sizeof(double) * n);
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipMemcpyAsync(h->scratch, g, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
@@ -1817,7 +1903,7 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
   const uint32_t T = b->T[u];
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
   const uint64_t na = b->arc_off[u + 1] - b->arc_off[u];
-  if (n_arcs) *n_arcs = na;
+  if (n_arcs) *n_arcs = h->shadow ? shadow_num_arcs(h, T) : na;
   // STDSEG_NO_DUR: one state per (node, label) like the frame lattice (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab.h)
   if (n_states) *n_states = (frame_model || segtrans(h)) ? l.L * T + 2 : (uint32_t)scrf_node_start_state(T, l.L) + 1;
   if (final_state) *final_state = (frame_model || segtrans(h)) ? (int32_t)(l.L * T + 1) : scrf_node_start_state(T, l.L);
@@ -1844,10 +1930,36 @@ extern "C" int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int no
   HIPCHK(h, hipMalloc((void**)&d_arcs, sizeof(scrf_arc) * na));
   if (segtrans(h)) launch_arcs_segtrans(h->stream, l, T, cb.S, cb.M, final_w, d_arcs);
   else launch_arcs(h->stream, l, T, frame_model, cb.S, cb.M, cb.m_per_frame, final_w, d_arcs);
-  hipError_t e = hipMemcpyAsync(arcs, d_arcs, sizeof(scrf_arc) * na, hipMemcpyDeviceToHost, h->stream);
+  std::vector<scrf_arc> dense;
+  if (h->shadow) dense.resize(na);
+  hipError_t e = hipMemcpyAsync(h->shadow ? dense.data() : arcs, d_arcs, sizeof(scrf_arc) * na, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   hipFree(d_arcs);
   if (e != hipSuccess) return fail(h, SCRF_ERR_HIP, "scrf_lattice_arcs: %s", hipGetErrorString(e));
+  if (h->shadow) {
+    // nStateBuildLattice :563-597: of the L*L boundary arcs of a frame (state-major, previous label ascending) a
+    // phone's start state keeps those from the end states, ascending, and then its own; any other state the one from
+    // the state before it and then its own.  States, segment arcs and final arcs are the dense lattice's.
+    const uint32_t L = l.L, K = h->xlay.K;
+    const scrf_arc* in = dense.data();
+    scrf_arc* out = arcs;
+    for (uint32_t t = 0; t < T; t++) {
+      if (t > 0) {
+        for (uint32_t lab = 0; lab < L; lab++, in += L) {
+          if (lab % K == 0) { for (uint32_t e2 = K - 1; e2 < L; e2 += K) *out++ = in[e2]; }
+          else *out++ = in[lab - 1];
+          *out++ = in[lab];
+        }
+      }
+      const uint64_t nseg = (uint64_t)L * scrf_node_max_dur(t, l.D);
+      memcpy(out, in, sizeof(scrf_arc) * nseg);
+      out += nseg; in += nseg;
+    }
+    memcpy(out, in, sizeof(scrf_arc) * L);
+    out += L; in += L;
+    if ((uint64_t)(out - arcs) != shadow_num_arcs(h, T) || (uint64_t)(in - dense.data()) != na)
+      return fail(h, SCRF_ERR_INVALID, "scrf_lattice_arcs: arc count mismatch (internal)");
+  }
   return SCRF_OK;
 }
 

@@ -159,6 +159,13 @@ class Engine:
         lam = np.ascontiguousarray(lam, dtype=np.float64)
         self._chk(self.lib.scrf_set_lambda(self.h, _p(lam), C.c_uint32(lam.shape[0])))
 
+    def _set(self, fn, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        self._chk(fn(self.h, _p(v), C.c_uint32(v.shape[0])))
+
+    def set_lambda_acc(self, v): self._set(self.lib.scrf_set_lambda_acc, v)
+    def set_grad_sqr_acc(self, v): self._set(self.lib.scrf_set_grad_sqr_acc, v)
+
     def _get(self, fn):
         out = np.empty(self.lambda_len, dtype=np.float64)
         self._chk(fn(self.h, _p(out), C.c_uint32(self.lambda_len)))
@@ -249,7 +256,7 @@ class Engine:
     def scores(self, batch, u, T):
         """S [N_seg, L]; M [T, L*L] -- for STDSEG_NO_DUR one transition matrix per window: [N_seg, L*L]; for STDSEG
         (L = all labels, La = L / D phones) S [N_seg, La] and M [N_seg, L, La] (previous FULL label x phone)"""
-        if self.cfg.num_states > 1:   # n-state frame model: M [T, 2 L + P*P] = self | c -> c+1 | end of p -> start of q
+        if self.cfg.num_states > 1 and self.cfg.model_type == STDFRAME:   # n-state frame model: M [T, 2 L + P*P] = self | c -> c+1 | end of p -> start of q
             P = self.L // self.cfg.num_states
             S = np.zeros((T, self.L)); M = np.zeros((T, 2 * self.L + P * P))
             self._chk(self.lib.scrf_scores(self.h, batch.handle, C.c_uint32(u), _p(S), _p(M)))
@@ -270,7 +277,7 @@ class Engine:
         return X
 
     def forward_backward(self, batch, u, T, prec=PREC_EXACT):
-        if self.cfg.num_states > 1:
+        if self.cfg.num_states > 1 and self.cfg.model_type == STDFRAME:
             al = np.zeros((T, self.L)); be = np.zeros((T, self.L))
             zx = C.c_double()
             self._chk(self.lib.scrf_forward_backward(self.h, batch.handle, C.c_uint32(u), C.c_uint32(prec), None, _p(al), _p(be), C.byref(zx)))

@@ -90,7 +90,9 @@ typedef struct scrf_config {
   uint32_t map_type;        /* scrf_map_type */
   uint32_t num_labs;        /* numLabs == nActualLabs (crf_label_size) */
   uint32_t num_feas;        /* numFeas: floats per window (joined streams) */
-  uint32_t num_states;      /* crf_states: 1, or K > 1 with SCRF_STDFRAME (n-state topology over num_labs = phones * K labels) */
+  uint32_t num_states;      /* crf_states: 1, or K > 1 (n-state topology over num_labs = phones * K labels) with SCRF_STDFRAME or
+                               SCRF_STDSEG_NO_DUR_NO_(SEG)TRANSFTR; the latter needs use_trans_bias, keeps the hook shapes of the
+                               one-state model and refuses scrf_grad_device_ptr / scrf_set_grad_buffer */
   uint32_t lab_max_dur;     /* label_maximum_duration; 1 for STDFRAME */
   int32_t use_state_ftrs;
   uint32_t state_fidx_start, state_fidx_end; /* inclusive */
@@ -210,7 +212,7 @@ int scrf_get_batch_sums(scrf_handle h, double* sums3);
  * windows (no predecessor) zero (nodes/CRF_StdSegStateNode_WithoutDurLab.cpp:69-110, :570-580).  For SCRF_STDSEG
  * (La = num_labs / lab_max_dur) S is [N_seg][La] -- row (t,dur), phone = the node's stateArray[(dur-1)*La + phone] -- and
  * M is [N_seg][num_labs][La] = transMatrix[plab*num_labs + clab] (nodes/CRF_StdSegStateNode.cpp:83-127).  With num_states
- * = K > 1 (P = num_labs / K) S is [T][num_labs] and M is [T][2*num_labs + P*P]: the node's diagTransMatrix | offDiagTransMatrix
+ * = K > 1 on SCRF_STDFRAME (P = num_labs / K) S is [T][num_labs] and M is [T][2*num_labs + P*P]: the node's diagTransMatrix | offDiagTransMatrix
  * (entry c = transition c -> c+1) | denseTransMatrix (entry p*P + q = end state of phone p -> start state of phone q) */
 int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M);
 /* window synthesis of utterance u: [N_seg][num_feas] (io/CRF_InFtrStream_SeqMultiWindow.cpp) */

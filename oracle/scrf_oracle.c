@@ -380,7 +380,9 @@ void orc_seg_scores(const orc_config* cfg, const orc_layout* lay, const double* 
     double* Mt = M + (size_t)t * L * L;
     for (uint32_t lab = 0; lab < L; lab++)
       for (uint32_t plab = 0; plab < L; plab++)
-        Mt[plab * L + lab] = orc_trans_value(cfg, lay, ftrBuf, lambda, plab, lab);
+        Mt[plab * L + lab] = (cfg->num_states > 1 && lay->trans_idx[plab * L + lab] == 0xffffffffu)
+                                 ? 0.0 /* no such transition in the n-state topology: never read */
+                                 : orc_trans_value(cfg, lay, ftrBuf, lambda, plab, lab);
     const uint32_t nd = orc_node_max_dur(t, D);
     for (uint32_t dur = 1; dur <= nd; dur++) {
       const float* x = ftrBuf + (size_t)(dur - 1) * F;
@@ -392,6 +394,36 @@ void orc_seg_scores(const orc_config* cfg, const orc_layout* lay, const double* 
 
 static uint32_t num_prev(uint32_t t, uint32_t D) { return (t + 1 <= D) ? t : D; } /* gradbuilder :258-266 */
 
+/* n-state topology (cfg->num_states = K > 1, nodes/CRF_StdSegNStateNode_WithoutDurLab_WithoutSegTransFtr.cpp): the labels a
+ * transition INTO `lab` may come from, in the order the node visits them -- itself, then every phone's end state
+ * ascending (lab a start state) or the state before (:1177-1213); and the labels a transition OUT OF `lab` may go to
+ * -- itself, then every phone's start state ascending (lab an end state) or the state after (:215-234).
+ * Returns the count; K <= 1: all labels ascending. */
+static uint32_t ns_preds(const orc_config* cfg, uint32_t lab, uint32_t* out) {
+  const uint32_t L = cfg->num_labs, K = cfg->num_states;
+  uint32_t n = 0;
+  if (K <= 1) { for (uint32_t p = 0; p < L; p++) out[n++] = p; return n; }
+  out[n++] = lab;
+  if (lab % K == 0) { for (uint32_t e = K - 1; e < L; e += K) out[n++] = e; }
+  else out[n++] = lab - 1;
+  return n;
+}
+static int ns_allowed(const orc_config* cfg, uint32_t from, uint32_t to) {
+  const uint32_t K = cfg->num_states;
+  if (K <= 1 || from == to) return 1;
+  if (to % K == 0) return (from + 1) % K == 0;
+  return from + 1 == to;
+}
+static uint32_t ns_succs(const orc_config* cfg, uint32_t lab, uint32_t* out) {
+  const uint32_t L = cfg->num_labs, K = cfg->num_states;
+  uint32_t n = 0;
+  if (K <= 1) { for (uint32_t c = 0; c < L; c++) out[n++] = c; return n; }
+  out[n++] = lab;
+  if ((lab + 1) % K == 0) { for (uint32_t b = 0; b < L; b += K) out[n++] = b; }
+  else out[n++] = lab + 1;
+  return n;
+}
+
 /* computeFirstAlpha :335-382, computeAlphaPlusTrans :1077-1108, computeAlpha :123-245,
  * computeAlphaSum nodes/CRF_StdSegStateNode.cpp:447-462 */
 int orc_seg_forward(const orc_config* cfg, const double* S, const double* M, uint32_t T,
@@ -399,8 +431,9 @@ int orc_seg_forward(const orc_config* cfg, const double* S, const double* M, uin
   const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
   int err = ORC_OK;
   if (T == 0) return ORC_ERR_EMPTY;
-  uint32_t accn = L > D ? L : D;
+  uint32_t accn = (L > D ? L : D) + 2;
   double* tmp = (double*)malloc(sizeof(double) * accn);
+  uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (L + 2));
   for (uint32_t t = 0; t < T; t++) {
     const uint64_t base = orc_seg_base(t, D);
     if (t == 0) {
@@ -414,8 +447,9 @@ int orc_seg_forward(const orc_config* cfg, const double* S, const double* M, uin
     const double* Mt = M + (size_t)t * L * L;
     const double* aprev = alpha + (size_t)(t - 1) * L;
     for (uint32_t next_lab = 0; next_lab < L; next_lab++) {
-      for (uint32_t clab = 0; clab < L; clab++) tmp[clab] = aprev[clab] + Mt[clab * L + next_lab];
-      apt[(size_t)(t - 1) * L + next_lab] = orc_logadd_n(tmp, (int)L, &err);
+      const uint32_t np_ = ns_preds(cfg, next_lab, plist);
+      for (uint32_t i = 0; i < np_; i++) tmp[i] = aprev[plist[i]] + Mt[plist[i] * L + next_lab];
+      apt[(size_t)(t - 1) * L + next_lab] = orc_logadd_n(tmp, (int)np_, &err);
     }
     const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
     for (uint32_t clab = 0; clab < L; clab++) {
@@ -434,7 +468,7 @@ int orc_seg_forward(const orc_config* cfg, const double* S, const double* M, uin
     }
   }
   *Zx = orc_logadd_n(alpha + (size_t)(T - 1) * L, (int)L, &err);
-  free(tmp);
+  free(tmp); free(plist);
   return err;
 }
 
@@ -458,11 +492,13 @@ static void seg_beta_node(const orc_config* cfg, const double* S, const double* 
     sdt[nextlab] = orc_logadd_n(tmp, (int)id, err);
   }
   const double* Mn = M + (size_t)(t + 1) * L * L;
+  uint32_t* slist = (uint32_t*)malloc(sizeof(uint32_t) * (L + 2));
   for (uint32_t clab = 0; clab < L; clab++) {
-    for (uint32_t nextlab = 0; nextlab < L; nextlab++)
-      tmp[nextlab] = Mn[clab * L + nextlab] + sdt[nextlab];
-    bt[clab] = orc_logadd_n(tmp, (int)L, err);
+    const uint32_t ns_ = ns_succs(cfg, clab, slist);
+    for (uint32_t i = 0; i < ns_; i++) tmp[i] = Mn[clab * L + slist[i]] + sdt[slist[i]];
+    bt[clab] = orc_logadd_n(tmp, (int)ns_, err);
   }
+  free(slist);
 }
 
 int orc_seg_backward(const orc_config* cfg, const double* S, const double* M, uint32_t T,
@@ -470,7 +506,7 @@ int orc_seg_backward(const orc_config* cfg, const double* S, const double* M, ui
   const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
   int err = ORC_OK;
   if (T == 0) return ORC_ERR_EMPTY;
-  uint32_t accn = L > D ? L : D;
+  uint32_t accn = (L > D ? L : D) + 2;
   double* tmp = (double*)malloc(sizeof(double) * accn);
   for (uint32_t t = T; t-- > 0;) seg_beta_node(cfg, S, M, T, t, beta, sd, tmp, &err);
   free(tmp);
@@ -495,8 +531,9 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
   double* apt = (double*)malloc(sizeof(double) * (size_t)T * L);
   double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
   double* sd = (double*)malloc(sizeof(double) * (size_t)T * L);
-  uint32_t accn = L > D ? L : D;
+  uint32_t accn = (L > D ? L : D) + 2;
   double* tmp = (double*)malloc(sizeof(double) * accn);
+  uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (L + 2));
   double logLi = 0.0, Zx = 0.0;
 
   orc_seg_scores(cfg, lay, lambda, segftrs, T, S, M);       /* :284 */
@@ -540,7 +577,9 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
       const double* Mn = M + (size_t)(t + 1) * L * L;
       const float* xn = segftrs + orc_seg_base(t + 1, D) * F; /* next node's window 1 (:789) */
       for (uint32_t nl = 0; nl < L; nl++) {
-        for (uint32_t clab = 0; clab < L; clab++) {
+        const uint32_t np_ = ns_preds(cfg, nl, plist);   /* n-state: itself, then ends / the state before (:318-353) */
+        for (uint32_t i = 0; i < np_; i++) {
+          const uint32_t clab = plist[i];
           double ab = orc_expE(alpha[(size_t)t * L + clab] + Mn[clab * L + nl] + sd[(size_t)t * L + nl] - Zx, &err);
           ab_trans_tot += ab;
           int match = (clab == actualLab && nl == actualNextLab);
@@ -565,7 +604,7 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
   for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i]; /* :471-473 */
   *Zx_out = Zx;
   *numer = logLi;
-  free(ExpF); free(S); free(M); free(ad); free(alpha); free(apt); free(beta); free(sd); free(tmp);
+  free(ExpF); free(S); free(M); free(ad); free(alpha); free(apt); free(beta); free(sd); free(tmp); free(plist);
   return err;
 }
 
@@ -594,6 +633,7 @@ int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, 
       for (uint32_t c = 0; c < L; c++)
         for (uint32_t n = 0; n < L; n++)
           xi[(size_t)t * L * L + c * L + n] =
+              (cfg->num_states > 1 && !ns_allowed(cfg, c, n)) ? 0.0 :
               orc_expE(alpha[(size_t)t * L + c] + Mn[c * L + n] + sd[(size_t)t * L + n] - Zx, &err);
     }
   }
@@ -1094,6 +1134,13 @@ uint64_t orc_seg_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D) {
   if (T == 0) return 0;
   return (uint64_t)(T - 1) * L * L + orc_num_segs(T, D) * L + L;
 }
+/* K states per phone: P*P + 2L - P boundary arcs per frame after the first (P = L / K) */
+uint64_t orc_seg_lattice_num_arcs_k(uint32_t T, uint32_t L, uint32_t D, uint32_t K) {
+  if (T == 0) return 0;
+  if (K <= 1) return orc_seg_lattice_num_arcs(T, L, D);
+  const uint64_t P = L / K;
+  return (uint64_t)(T - 1) * (P * P + 2 * (uint64_t)L - P) + orc_num_segs(T, D) * L + L;
+}
 uint32_t orc_seg_lattice_num_states(uint32_t T, uint32_t L) {
   if (T == 0) return 1;
   return 1 + L + (T - 1) * 2 * L + 1;
@@ -1103,11 +1150,12 @@ uint32_t orc_seg_lattice_num_states(uint32_t T, uint32_t L) {
 uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const double* M,
                               uint32_t T, int norm, double alpha_sum, orc_arc* arcs,
                               uint32_t* n_states, int32_t* final_state) {
-  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur;
+  const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur, K = cfg->num_states;
   const int startState = 0;
   int next_state = 1; /* AddState() for the start state */
   uint64_t na = 0;
   int* nss = (int*)malloc(sizeof(int) * ((size_t)T + 2)); /* nodeStartStates */
+  uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (L + 2));
   for (uint32_t t = 0; t < T; t++) {
     const uint64_t base = orc_seg_base(t, D);
     const uint32_t np = num_prev(t, D), nd = orc_node_max_dur(t, D);
@@ -1118,7 +1166,15 @@ uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const doub
       for (uint32_t lab = 0; lab < L; lab++) {
         int cur_state = next_state++;
         num_new_states++;
-        for (uint32_t prev_lab = 0; prev_lab < L; prev_lab++) {
+        /* one state per label: every previous label ascending (:275-293); with K states per phone
+         * (nStateBuildLattice :563-597) a start state takes the end states ascending and then itself, any other
+         * state the one before it and then itself */
+        uint32_t npl = 0;
+        if (K <= 1) for (uint32_t p = 0; p < L; p++) plist[npl++] = p;
+        else if (lab % K == 0) { for (uint32_t e = K - 1; e < L; e += K) plist[npl++] = e; plist[npl++] = lab; }
+        else { plist[npl++] = lab - 1; plist[npl++] = lab; }
+        for (uint32_t i = 0; i < npl; i++) {
+          const uint32_t prev_lab = plist[i];
           float value = -1 * Mt[prev_lab * L + lab];
           int prev_state = (t == 1) ? nss[t - 1] + (int)prev_lab : nss[t - 1] + (int)L + (int)prev_lab;
           orc_arc a = {prev_state, 0, 0, value, cur_state};
@@ -1160,7 +1216,7 @@ uint64_t orc_seg_lattice_arcs(const orc_config* cfg, const double* S, const doub
   }
   *n_states = (uint32_t)next_state;
   *final_state = fin;
-  free(nss);
+  free(nss); free(plist);
   return na;
 }
 

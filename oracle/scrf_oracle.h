@@ -214,6 +214,7 @@ typedef struct {
   int32_t dst;
 } orc_arc;
 uint64_t orc_seg_lattice_num_arcs(uint32_t T, uint32_t L, uint32_t D);
+uint64_t orc_seg_lattice_num_arcs_k(uint32_t T, uint32_t L, uint32_t D, uint32_t K);
 uint32_t orc_seg_lattice_num_states(uint32_t T, uint32_t L);
 /* arcs in chronological AddArc order; decoders/...WithoutSegTransFtr.h:30-407 */
 /* norm=0: final arcs carry (float)(-0.0); norm!=0: (float)(-(-alpha_sum)) as :371,397 */

@@ -6,6 +6,21 @@ import scrf_amd
 from scrf_amd import synth
 
 
+def nstate_segment_labels(rng, L, K, T, D):
+    """A random segmentation whose labels follow the K-states-per-phone topology (stay, advance, or end state -> a
+    start state), in the segment-end labelling of the label stream: label + L*(dur-1) on a segment's last frame."""
+    out = np.full(T, 0xffffffff, dtype=np.uint32)
+    c = int(rng.randint(0, L))
+    t = -1
+    while t + 1 < T:
+        d = int(rng.randint(1, min(D, T - 1 - t) + 1))
+        t += d
+        out[t] = c + L * (d - 1)
+        if rng.rand() >= 0.3:
+            c = int(rng.randint(0, L // K)) * K if (c + 1) % K == 0 else c + 1
+    return out
+
+
 class Case:
     """L labels, max duration D, raw frame width in_w, utterance lengths Ts.
     trans_ctx=None: `stdstate` map (bias-only transitions); trans_ctx=c: `stdtrans` map whose
@@ -13,7 +28,8 @@ class Case:
     TIMIT demo's ftr2 stream (demo/segmental-timit-demo.cfg.in:21-24)."""
 
     def __init__(self, L, D, in_w, Ts, trans_ctx=None, seed=0, lam_scale=0.3, frame_model=False,
-                 scratch_bytes=0, precision=0, l1_norm=False, model_type=None, trans_share=None):
+                 scratch_bytes=0, precision=0, l1_norm=False, model_type=None, trans_share=None,
+                 num_states=1, conform_labels=True):
         self.L, self.D, self.in_w, self.Ts = L, D, in_w, list(Ts)
         self.trans_ctx = trans_ctx
         rng = np.random.RandomState(seed)
@@ -22,6 +38,8 @@ class Case:
             self.frames = [(f / f.sum(1, keepdims=True)).astype(np.float32) for f in self.frames]
         if frame_model:
             self.labels = [rng.randint(0, L, T).astype(np.uint32) for T in Ts]
+        elif num_states > 1 and conform_labels:
+            self.labels = [nstate_segment_labels(rng, L, num_states, T, D) for T in Ts]
         else:
             self.labels = [synth.group_labels(synth.frame_labels(rng, T, L, D), D, L) for T in Ts]
         Fs = orc.window_width(in_w, D, 0, 0, True)
@@ -45,6 +63,8 @@ class Case:
             self.recipes.append(scrf_amd.StreamRecipe(in_w, c, c, 0))
             kw = dict(model_type=mt, L=L, D=D, F=self.F, sfe=Fs - 1, use_trans_ftrs=True, tfs=Fs)
         self.Fs = Fs
+        if num_states > 1:
+            kw["num_states"] = num_states
         if mt == orc.STDSEG:   # the feature map and the weight layout run over all labels: nLabs = nActualLabs * D
             kw["L"] = L * D
         self.ocfg = orc.config(**kw)

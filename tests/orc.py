@@ -82,6 +82,7 @@ def lib():
         _lib.orc_seg_base.argtypes = [C.c_uint32, C.c_uint32]
         _lib.orc_window_width.restype = C.c_uint32
         _lib.orc_seg_lattice_num_arcs.restype = C.c_uint64
+        _lib.orc_seg_lattice_num_arcs_k.restype = C.c_uint64
         _lib.orc_seg_lattice_arcs.restype = C.c_uint64
         _lib.orc_segtrans_lattice_num_arcs.restype = C.c_uint64
         _lib.orc_segtrans_lattice_arcs.restype = C.c_uint64
@@ -480,7 +481,7 @@ def sgd_step(lam, lam_acc, gsa, grad, lr_or_eta, use_adagrad, eps=1e-12):
 
 def seg_lattice_arcs(cfg, S, M, T, norm=False, alpha_sum=0.0):
     L, D = cfg.num_labs, cfg.lab_max_dur
-    n = int(lib().orc_seg_lattice_num_arcs(C.c_uint32(T), C.c_uint32(L), C.c_uint32(D)))
+    n = int(lib().orc_seg_lattice_num_arcs_k(C.c_uint32(T), C.c_uint32(L), C.c_uint32(D), C.c_uint32(max(1, cfg.num_states))))
     arcs = np.zeros(n, dtype=ARC_DTYPE)
     ns = C.c_uint32(); fin = C.c_int32()
     na = lib().orc_seg_lattice_arcs(C.byref(cfg), _p(S), _p(M), C.c_uint32(T), C.c_int(int(norm)),
@@ -567,9 +568,19 @@ def bench_fb(cfg, lam, frames, labels, frame_off, in_width, n_threads):
 # --------------------------------------------------------------------------- #
 # Independent brute-force enumeration of all labelled segmentations (tiny cases)
 # --------------------------------------------------------------------------- #
-def brute_force(S, M, T, L, D):
+def ns_allowed(K, p, c):
+    """n-state topology (K states per phone): stay, advance to the next state, or end state -> any start state."""
+    if K <= 1 or p == c:
+        return True
+    if c % K == 0:
+        return (p + 1) % K == 0
+    return p + 1 == c
+
+
+def brute_force(S, M, T, L, D, K=1):
     """Enumerate every (segmentation, labelling); returns dict with Zx, gamma[N_seg,L],
-    xi[T,L*L], best (score, labels as l+L*(d-1) per segment; ties -> first found)."""
+    xi[T,L*L], best (score, labels as l+L*(d-1) per segment; ties -> first found).  K > 1: only the label
+    sequences the n-state topology allows."""
     paths = []
 
     def rec(t_next, prev_lab, score, segs):
@@ -582,6 +593,8 @@ def brute_force(S, M, T, L, D):
                 break
             row = seg_base(end, D) + d - 1
             for l in range(L):
+                if prev_lab is not None and not ns_allowed(K, prev_lab, l):
+                    continue
                 s = score + S[row, l]
                 if prev_lab is not None:
                     s = s + M[t_next, prev_lab * L + l]

@@ -1192,6 +1192,68 @@ def test_crftrain_and_fstdecode_with_three_states_per_label(tmp_path):
     assert r.returncode != 0 and "crf_states" in (r.stderr + r.stdout)
 
 
+def test_crftrain_and_fstdecode_segmental_model_with_states_per_phone(tmp_path):
+    """crf_states=2 with crf_model_type=stdseg_no_dur_no_segtransftr (nodes/CRF_StdSegNStateNode_WithoutDurLab_WithoutSegTransFtr.cpp):
+    CRFTrain against the oracle's SGD loop in the compact weight layout, CRFFstDecode against the shortest path of the
+    oracle's nStateBuildLattice restatement."""
+    from scrf_amd import synth
+    rng = np.random.RandomState(77)
+    P, K, D, W = 3, 2, 3, 2
+    L = P * K
+    Ts = [7, 5, 9]
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    utts, phones = [], []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            ph = np.zeros(T, dtype=np.uint32)
+            c = int(rng.randint(0, L))
+            for t in range(T):      # state labels along the topology: stay, advance, end state -> a start state
+                ph[t] = c
+                if rng.rand() >= 0.5:
+                    c = int(rng.randint(0, P)) * K if (c + 1) % K == 0 else c + 1
+            utts.append(X); phones.append(ph)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, ph[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdstate",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D, "crf_states=%d" % K]
+    wf = str(tmp_path / "w.out")
+    epochs, lr = 3, 0.5
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=%d" % epochs,
+                        "crf_lr=%g" % lr, "crf_bunch_size=1", "threads=1", "crf_train_order=seq"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    F = 8 * W + D
+    cfg = orc.config(model_type=orc.STDSEG_NO_DUR_NO_SEGTRANSFTR, L=L, D=D, F=F, num_states=K); lay = orc.Layout(cfg)
+    assert lay.lambda_len == L * (F + 1) + (P * P + 2 * L - P) and "FEATURES: %d" % lay.lambda_len in r.stdout
+    lam = np.zeros(lay.lambda_len); acc = np.zeros_like(lam); gsa = np.zeros_like(lam)
+    for _ in range(epochs):
+        for u, T in enumerate(Ts):
+            labs = synth.group_labels(phones[u], D, L)
+            rc, g, _, _ = orc.seg_build_gradient(cfg, lay, lam, orc.windows(utts[u], D), labs, T)
+            assert rc == 0
+            orc.sgd_step(lam, acc, gsa, g, np.float32(lr), False, 1e-12)
+    w = np.loadtxt(wf)
+    assert w.shape == lam.shape and np.abs(w).max() > 0
+    np.testing.assert_allclose(w, np.array([float("%g" % v) for v in lam]), rtol=2e-5, atol=1e-12)
+    dec = str(tmp_path / "dec.txt")
+    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_output_labelfile=" + dec], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.loadtxt(dec).astype(int).reshape(-1, 3)
+    for u, T in enumerate(Ts):
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(cfg, S, M, T)
+        ol, _ = orc.best_path(oa, ons, ofin)
+        assert list(got[got[:, 0] == u][:, 2]) == list(ol)
+        seq = [int(x) % L for x in ol]
+        assert all(orc.ns_allowed(K, a, b) for a, b in zip(seq, seq[1:]))
+    olist = str(tmp_path / "olist")
+    open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_output_labelfile=" + str(tmp_path / "dec2.txt"), "crf_olist=" + olist],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "crf_states" in (r.stderr + r.stdout)
+
+
 def test_crffstdecode_align_mode_on_bundled_fixture(tmp_path):
     """crf_decode_mode=align (CRFFstDecode/src/Main.cpp:464-471, :841-848): best path of lattice o label acceptor -- the
     label RUNS of hardtarget_file in their order, boundaries free -- against a dynamic program over the oracle's frame

@@ -174,6 +174,21 @@ def test_minibatch_reduce_and_optimizer_step():
     b.close(); eng.close()
 
 
+def test_benchmarked_path_serves_the_masked_model():
+    """Config-2 shape with 3 states per phone in FAST precision: the batch goes through the fused linear-domain kernels of
+    the one-state model (no log-domain redo: a log-0 transition flushes to an exact 0 there), gradient vs the oracle."""
+    c = Case(L=48, D=25, in_w=39, Ts=[300, 120, 64], seed=77, precision=1, num_states=3, lam_scale=0.1)
+    eng = c.engine(); b = c.batch(eng)
+    assert eng.batch_is_fused(b)
+    numer, zx = eng.fb_batch(b)
+    assert eng.train_stats() == 0
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-11 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-11 * np.abs(ozx).max()
+    assert np.abs(eng.get_grad() - og).max() <= 1e-9 * np.abs(og).max()
+    b.close(); eng.close()
+
+
 def test_refusals():
     kw = dict(L=6, D=3, F=orc.window_width(2, 3, 0, 0, True), num_states=2)
     # the device gradient pointer is a dense-layout buffer: not handed out

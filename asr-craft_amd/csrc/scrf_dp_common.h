@@ -52,6 +52,23 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
   return rdlane(v, 63);
 }
 
+// wave-wide maximum on the same DPP path; lanes outside a shift keep their own value (bound_ctrl off, old = v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return fmax(v, __hiloint2double(hi, lo));
+}
+__device__ __forceinline__ double wave_max_f64_dpp(double v) {
+  v = dpp_max_f64<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v = dpp_max_f64<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v = dpp_max_f64<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_max_f64<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_max_f64<0x142, 0xa>(v);   // row_bcast:15
+  v = dpp_max_f64<0x143, 0xc>(v);   // row_bcast:31
+  return rdlane(v, 63);
+}
+
 // exp(x) for x <= 0 (including -inf -> 0): the log-sum-exp terms are always max-shifted, so the
 // overflow/NaN handling of the library exp is dead weight in the recursion's inner loop.
 // Cody-Waite reduction by ln2 (hi/lo) + degree-13 Taylor/Horner on |r| <= ln2/2 (truncation

@@ -1350,16 +1350,16 @@ static int stdseg_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u
   sb.S = a.take<double>(nseg * La); sb.alpha = a.take<double>(nseg * La); sb.beta = a.take<double>(nseg * La);
   sb.MX = a.take<double>(nseg * (size_t)l.L * La);
   launch_stdseg_rowinfo(st, bv, b->d_frame_u, u0, nfr, l.D, sb.row_t, sb.row_d, sb.row_u);
-  launch_stdseg_scores(st, l, La, sb.X, nseg, sb.row_t, sb.row_d, h->d_lambda, sb.S, sb.MX);
-  launch_stdseg_fb(st, l, La, bv, u0, u1 - u0, sb.S, sb.MX, sb.alpha, sb.beta, b->d_zx, b->d_status);
+  KT_RUN("k_stdseg_scores", st, launch_stdseg_scores(st, l, La, sb.X, nseg, sb.row_t, sb.row_d, h->d_lambda, sb.S, sb.MX));
+  KT_RUN("k_stdseg_fb", st, launch_stdseg_fb(st, l, La, bv, u0, u1 - u0, sb.S, sb.MX, sb.alpha, sb.beta, b->d_zx, b->d_status));
   if (post) {
     sb.G = a.take<double>(nseg * La); sb.XI = a.take<double>(nseg * (size_t)l.L * La);
     sb.mass_s = a.take<double>(nfr); sb.mass_t = a.take<double>(nfr);
     HIPCHK(h, hipMemsetAsync(sb.mass_s, 0, sizeof(double) * nfr, st));
     HIPCHK(h, hipMemsetAsync(sb.mass_t, 0, sizeof(double) * nfr, st));
-    launch_stdseg_post(st, l, La, bv, u0, u1 - u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.S, sb.MX, sb.alpha, sb.beta,
-                       b->d_zx, sb.G, sb.XI, sb.mass_s, sb.mass_t, b->d_numer, b->d_status);
-    launch_stdseg_expf(st, l, La, bv, u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.X, sb.G, sb.XI, grad);
+    KT_RUN("k_stdseg_post", st, launch_stdseg_post(st, l, La, bv, u0, u1 - u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.S, sb.MX, sb.alpha, sb.beta,
+                                                   b->d_zx, sb.G, sb.XI, sb.mass_s, sb.mass_t, b->d_numer, b->d_status));
+    KT_RUN("k_stdseg_expf", st, launch_stdseg_expf(st, l, La, bv, u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.X, sb.G, sb.XI, grad));
   }
   HIPCHK(h, hipGetLastError());
   if (out) *out = sb;
@@ -1385,7 +1385,8 @@ static size_t nstate_chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nfr, bool
   size_t tot = 0;
   if (b->mode == 1) tot += pad256(nfr * l.F * sizeof(float));
   tot += 5 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * P * P * sizeof(double));              // S, TD, TO, alpha, beta, TE
-  if (post) tot += 3 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * P * P * sizeof(double)) + 2 * pad256(nfr * sizeof(double));
+  if (post) tot += 3 * pad256(nfr * l.L * sizeof(double)) + pad256(nfr * P * P * sizeof(double)) + 2 * pad256(nfr * sizeof(double)) +
+                   pad256((size_t)ns_expf_slices(nfr) * l.lambda_len * sizeof(double));   // + the gradient's frame-slice partials
   return tot;
 }
 static int nstate_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, bool post, double* grad, NstateBufs* out) {
@@ -1414,17 +1415,18 @@ static int nstate_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u
   nb.S = a.take<double>(nfr * l.L); nb.TD = a.take<double>(nfr * l.L); nb.TO = a.take<double>(nfr * l.L);
   nb.alpha = a.take<double>(nfr * l.L); nb.beta = a.take<double>(nfr * l.L);
   nb.TE = a.take<double>(nfr * P * P);
-  launch_ns_scores(st, l, nb.X, nfr, h->d_lambda, nb.S, nb.TD, nb.TO, nb.TE);
-  launch_ns_fb(st, l, bv, u0, u1 - u0, nb.S, nb.TD, nb.TO, nb.TE, nb.alpha, nb.beta, b->d_zx, b->d_status);
+  KT_RUN("k_ns_scores", st, launch_ns_scores(st, l, nb.X, nfr, h->d_lambda, nb.S, nb.TD, nb.TO, nb.TE));
+  KT_RUN("k_ns_fb", st, launch_ns_fb(st, l, bv, u0, u1 - u0, nb.S, nb.TD, nb.TO, nb.TE, nb.alpha, nb.beta, b->d_zx, b->d_status));
   if (post) {
     nb.G = a.take<double>(nfr * l.L); nb.XD = a.take<double>(nfr * l.L); nb.XO = a.take<double>(nfr * l.L);
     nb.XE = a.take<double>(nfr * P * P);
     nb.mass_s = a.take<double>(nfr); nb.mass_t = a.take<double>(nfr);
     HIPCHK(h, hipMemsetAsync(nb.mass_s, 0, sizeof(double) * nfr, st));
     HIPCHK(h, hipMemsetAsync(nb.mass_t, 0, sizeof(double) * nfr, st));
-    launch_ns_post(st, l, bv, b->d_frame_u, u0, u1 - u0, nfr, nb.S, nb.TD, nb.TO, nb.TE, nb.alpha, nb.beta, b->d_zx, nb.G, nb.XD, nb.XO,
-                   nb.XE, nb.mass_s, nb.mass_t, b->d_numer, b->d_status);
-    launch_ns_expf(st, l, bv, b->d_frame_u, u0, nfr, nb.X, nb.G, nb.XD, nb.XO, nb.XE, grad);
+    KT_RUN("k_ns_post", st, launch_ns_post(st, l, bv, b->d_frame_u, u0, u1 - u0, nfr, nb.S, nb.TD, nb.TO, nb.TE, nb.alpha, nb.beta, b->d_zx, nb.G, nb.XD, nb.XO,
+                                           nb.XE, nb.mass_s, nb.mass_t, b->d_numer, b->d_status));
+    double* slab = a.take<double>((size_t)ns_expf_slices(nfr) * l.lambda_len);
+    KT_RUN("k_ns_expf", st, launch_ns_expf(st, l, bv, b->d_frame_u, u0, nfr, nb.X, nb.G, nb.XD, nb.XO, nb.XE, slab, grad));
   }
   HIPCHK(h, hipGetLastError());
   if (out) *out = nb;

@@ -177,8 +177,9 @@ void launch_ns_post(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, con
                     uint64_t n_frames, const double* S, const double* TD, const double* TO, const double* TE, const double* alpha,
                     const double* beta, const double* zx, double* G, double* XD, double* XO, double* XE, double* mass_s,
                     double* mass_t, double* numer, int* status);
+uint32_t ns_expf_slices(uint64_t n_frames);   // frame slices of the gradient kernel: slab is [slices][lambda_len]
 void launch_ns_expf(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
-                    const float* X, const double* G, const double* XD, const double* XO, const double* XE, double* grad);
+                    const float* X, const double* G, const double* XD, const double* XO, const double* XE, double* slab, double* grad);
 uint64_t ns_num_arcs(uint32_t T, uint32_t L, uint32_t K);
 void launch_ns_arcs(hipStream_t st, const ScrfLayout& lay, uint32_t T, const double* S, const double* TD, const double* TO,
                     const double* TE, float final_w, scrf_arc* arcs);

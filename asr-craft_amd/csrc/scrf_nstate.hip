@@ -60,10 +60,26 @@ __global__ __launch_bounds__(256) void k_ns_scores(ScrfLayout lay, const float* 
 }
 
 // computeFirstAlpha / computeAlpha :100-157, computeAlphaSum, setTailBeta, computeBeta :170-207
-__global__ __launch_bounds__(256) void k_ns_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
-                                               const double* __restrict__ TD, const double* __restrict__ TO,
-                                               const double* __restrict__ TE, double* __restrict__ alpha,
-                                               double* __restrict__ beta, double* __restrict__ zx_out, int* __restrict__ status) {
+#define NSFB_G 16   // lanes that share one end -> start log-sum-exp
+__device__ __forceinline__ double ns_group_max(double v) {
+#pragma unroll
+  for (int o = NSFB_G / 2; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double ns_group_sum(double v) {
+#pragma unroll
+  for (int o = NSFB_G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// One workgroup per utterance.  Work items of a frame: one per label for the self / next-state terms, and a group of
+// NSFB_G lanes per phone for the max-shifted log-sum-exp over the P end states (forward, into the phone's start
+// state) or the P start states (backward, out of its end state); the group's lanes split the P terms, the max and the
+// sum are combined with xor shuffles, so the sum runs in a tree order instead of the node's index order.
+__global__ __launch_bounds__(1024) void k_ns_fb(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ S,
+                                                const double* __restrict__ TD, const double* __restrict__ TO,
+                                                const double* __restrict__ TE, double* __restrict__ alpha,
+                                                double* __restrict__ beta, double* __restrict__ zx_out, int* __restrict__ status) {
+  extern __shared__ double ns_dense[];   // [P]: the dense term of every phone for the frame in hand
   const uint32_t L = lay.L, K = lay.K, P = L / K;
   const uint32_t u = u0 + blockIdx.x;
   const uint32_t T = bv.T[u];
@@ -71,23 +87,27 @@ __global__ __launch_bounds__(256) void k_ns_fb(ScrfLayout lay, ScrfBatchView bv,
   const uint64_t fb = bv.frame_off[u] - bv.frame_off[u0];
   const double* Su = S + fb * L; const double* Du = TD + fb * L; const double* Ou = TO + fb * L; const double* Eu = TE + fb * P * P;
   double* au = alpha + fb * L; double* bu = beta + fb * L;
+  const uint32_t grp = threadIdx.x / NSFB_G, gl = threadIdx.x % NSFB_G, n_grp = blockDim.x / NSFB_G;
   int err = 0;
   for (uint32_t c = threadIdx.x; c < L; c += blockDim.x) au[c] = Su[c];
   __syncthreads();
   for (uint32_t t = 1; t < T; t++) {
     const double* pa = au + (uint64_t)(t - 1) * L;
+    for (uint32_t q = grp; q < P; q += n_grp) {   // into the start state of phone q
+      const double* Et = Eu + (uint64_t)t * P * P + q;
+      double m = -INFINITY;
+      for (uint32_t p = gl; p < P; p += NSFB_G) m = fmax(m, pa[p * K + K - 1] + Et[(uint64_t)p * P]);
+      m = ns_group_max(m);
+      double sum = 0.0;
+      for (uint32_t p = gl; p < P; p += NSFB_G) sum += ns_exp((pa[p * K + K - 1] + Et[(uint64_t)p * P]) - m, &err);
+      sum = ns_group_sum(sum);
+      if (gl == 0) ns_dense[q] = m + ns_log(sum, &err);
+    }
+    __syncthreads();
     for (uint32_t c = threadIdx.x; c < L; c += blockDim.x) {
       double v = pa[c] + Du[(uint64_t)t * L + c];
-      if (c % K == 0) {
-        const double* Et = Eu + (uint64_t)t * P * P + c / K;
-        double maxv = pa[K - 1] + Et[0];
-        for (uint32_t p = 1; p < P; p++) maxv = fmax(maxv, pa[p * K + K - 1] + Et[(uint64_t)p * P]);
-        double sum = 0.0;
-        for (uint32_t p = 0; p < P; p++) sum += ns_exp((pa[p * K + K - 1] + Et[(uint64_t)p * P]) - maxv, &err);
-        v = ns_logadd2(v, maxv + ns_log(sum, &err), &err);
-      } else {
-        v = ns_logadd2(v, pa[c - 1] + Ou[(uint64_t)t * L + c - 1], &err);
-      }
+      if (c % K == 0) v = ns_logadd2(v, ns_dense[c / K], &err);
+      else v = ns_logadd2(v, pa[c - 1] + Ou[(uint64_t)t * L + c - 1], &err);
       au[(uint64_t)t * L + c] = v + Su[(uint64_t)t * L + c];
     }
     __syncthreads();
@@ -105,18 +125,21 @@ __global__ __launch_bounds__(256) void k_ns_fb(ScrfLayout lay, ScrfBatchView bv,
   for (uint32_t t = T - 1; t-- > 0;) {
     const uint64_t n = t + 1;
     const double* bn = bu + n * L; const double* Sn = Su + n * L;
+    for (uint32_t pe = grp; pe < P; pe += n_grp) {   // out of the end state of phone pe
+      const double* En = Eu + n * P * P + (uint64_t)pe * P;
+      double m = -INFINITY;
+      for (uint32_t q = gl; q < P; q += NSFB_G) m = fmax(m, En[q] + (bn[q * K] + Sn[q * K]));
+      m = ns_group_max(m);
+      double sum = 0.0;
+      for (uint32_t q = gl; q < P; q += NSFB_G) sum += ns_exp((En[q] + (bn[q * K] + Sn[q * K])) - m, &err);
+      sum = ns_group_sum(sum);
+      if (gl == 0) ns_dense[pe] = m + ns_log(sum, &err);
+    }
+    __syncthreads();
     for (uint32_t p = threadIdx.x; p < L; p += blockDim.x) {
       double v = (bn[p] + Sn[p]) + Du[n * L + p];
-      if ((p + 1) % K == 0) {
-        const double* En = Eu + n * P * P + (uint64_t)((p + 1) / K - 1) * P;
-        double maxv = En[0] + (bn[0] + Sn[0]);
-        for (uint32_t q = 1; q < P; q++) maxv = fmax(maxv, En[q] + (bn[q * K] + Sn[q * K]));
-        double sum = 0.0;
-        for (uint32_t q = 0; q < P; q++) sum += ns_exp((En[q] + (bn[q * K] + Sn[q * K])) - maxv, &err);
-        v = ns_logadd2(v, maxv + ns_log(sum, &err), &err);
-      } else {
-        v = ns_logadd2(v, Ou[n * L + p] + (bn[p + 1] + Sn[p + 1]), &err);
-      }
+      if ((p + 1) % K == 0) v = ns_logadd2(v, ns_dense[(p + 1) / K - 1], &err);
+      else v = ns_logadd2(v, Ou[n * L + p] + (bn[p + 1] + Sn[p + 1]), &err);
       bu[(uint64_t)t * L + p] = v;
     }
     __syncthreads();
@@ -206,7 +229,9 @@ __global__ void k_ns_numer(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32
 __global__ __launch_bounds__(256) void k_ns_expf(ScrfLayout lay, ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0,
                                                  uint64_t n_frames, const float* __restrict__ X, const double* __restrict__ G,
                                                  const double* __restrict__ XD, const double* __restrict__ XO,
-                                                 const double* __restrict__ XE, double* __restrict__ grad) {
+                                                 const double* __restrict__ XE, uint64_t frames_per_slice, double* __restrict__ slab) {
+  // blockIdx.y: a slice of frames_per_slice frames whose partial sums go to slab[slice][weight]; k_ns_expf_reduce adds
+  // the slices in order (fixed summation order: runs are reproducible)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lay.lambda_len) return;
   const uint32_t L = lay.L, K = lay.K, P = L / K;
@@ -224,7 +249,9 @@ __global__ __launch_bounds__(256) void k_ns_expf(ScrfLayout lay, ScrfBatchView b
   const uint32_t col = is_state ? lay.sfs + k : lay.tfs + k;
   const double bval = is_state ? lay.sbv : lay.tbv;
   double expected = 0.0, observed = 0.0;
-  for (uint64_t fr = 0; fr < n_frames; fr++) {
+  const uint64_t f0 = (uint64_t)blockIdx.y * frames_per_slice;
+  const uint64_t f1 = f0 + frames_per_slice < n_frames ? f0 + frames_per_slice : n_frames;
+  for (uint64_t fr = f0; fr < f1; fr++) {
     const double x = bias ? bval : (double)X[fr * lay.F + col];
     const uint64_t gf = bv.frame_off[u0] + fr;
     const uint32_t u = frame_u[gf];
@@ -239,7 +266,15 @@ __global__ __launch_bounds__(256) void k_ns_expf(ScrfLayout lay, ScrfBatchView b
       if (tl == c && bv.labels[gf - 1] == plab) observed += x;
     }
   }
-  grad[i] += observed - expected;
+  slab[(uint64_t)blockIdx.y * lay.lambda_len + i] = observed - expected;
+}
+__global__ __launch_bounds__(256) void k_ns_expf_reduce(const double* __restrict__ slab, uint32_t n_slices, uint32_t n,
+                                                        double* __restrict__ grad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (uint32_t s = 0; s < n_slices; s++) v += slab[(uint64_t)s * n + i];
+  grad[i] += v;
 }
 
 // decoders/CRF_LatticeBuilder.h nStateBuildLattice: one thread per (frame, label) writes that state's incoming arcs
@@ -371,7 +406,10 @@ void launch_ns_scores(hipStream_t st, const ScrfLayout& lay, const float* X, uin
 void launch_ns_fb(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* S,
                   const double* TD, const double* TO, const double* TE, double* alpha, double* beta, double* zx, int* status) {
   if (n_utts == 0) return;
-  hipLaunchKernelGGL(k_ns_fb, dim3(n_utts), dim3(256), 0, st, lay, bv, u0, S, TD, TO, TE, alpha, beta, zx, status);
+  const uint32_t P = lay.L / lay.K;
+  uint32_t nt = 256;
+  while (nt < 1024 && nt < P * NSFB_G) nt *= 2;   // a lane group per phone when they fit
+  hipLaunchKernelGGL(k_ns_fb, dim3(n_utts), dim3(nt), sizeof(double) * P, st, lay, bv, u0, S, TD, TO, TE, alpha, beta, zx, status);
 }
 void launch_ns_post(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint32_t n_utts,
                     uint64_t n_frames, const double* S, const double* TD, const double* TO, const double* TE, const double* alpha,
@@ -384,11 +422,18 @@ void launch_ns_post(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, con
   hipLaunchKernelGGL(k_ns_numer, dim3((n_utts + 63) / 64), dim3(64), 0, st, lay, bv, u0, n_utts, S, TD, TO, TE, mass_s, mass_t, numer,
                      status);
 }
+uint32_t ns_expf_slices(uint64_t n_frames) {
+  const uint64_t n = (n_frames + 127) / 128;   // at least 128 frames per slice
+  return (uint32_t)(n < 1 ? 1 : (n > 256 ? 256 : n));
+}
 void launch_ns_expf(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
-                    const float* X, const double* G, const double* XD, const double* XO, const double* XE, double* grad) {
+                    const float* X, const double* G, const double* XD, const double* XO, const double* XE, double* slab, double* grad) {
   if (n_frames == 0) return;
-  hipLaunchKernelGGL(k_ns_expf, dim3((lay.lambda_len + 255) / 256), dim3(256), 0, st, lay, bv, frame_u, u0, n_frames, X, G, XD, XO,
-                     XE, grad);
+  const uint32_t ns = ns_expf_slices(n_frames);
+  const uint64_t fps = (n_frames + ns - 1) / ns;
+  hipLaunchKernelGGL(k_ns_expf, dim3((lay.lambda_len + 255) / 256, ns), dim3(256), 0, st, lay, bv, frame_u, u0, n_frames, X, G, XD, XO,
+                     XE, fps, slab);
+  hipLaunchKernelGGL(k_ns_expf_reduce, dim3((lay.lambda_len + 255) / 256), dim3(256), 0, st, slab, ns, lay.lambda_len, grad);
 }
 uint64_t ns_num_arcs(uint32_t T, uint32_t L, uint32_t K) {
   if (T == 0) return 0;

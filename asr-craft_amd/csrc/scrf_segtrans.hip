@@ -17,6 +17,7 @@
 // transition mass each within [-1e-6, 1 + 1e-6]; no state == transition check in this node).
 // The recursion costs L*L*D per frame against L*(L+D) of the TIMIT-demo model: this is the reference's
 // "secondary" model type, served for completeness, not tuned.
+#include "scrf_dp_common.h"
 #include "scrf_kernels.h"
 #include "scrf_lse.h"
 
@@ -226,6 +227,254 @@ __global__ void k_fb_segtrans(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, con
   if (err) atomicMax(&status[u], err);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_fb_segtrans_w: the same recursion with the D windows of a node spread over the workgroup's wavefronts.  Forward:
+// wavefront w takes the windows d = w+1, w+17, ... of node t, lanes over the label l, and walks the previous node's
+// labels p once with a running (max, sum) per lane (M2 rows are read as whole 8*L-byte lines, 16 in flight); the
+// D window values of a label are then folded in duration order.  Backward: wavefront w takes the next windows
+// di = w, w+16, ..., per previous label c every lane folds its label's term and the lanes are combined with xor
+// shuffles; the per-window (max, sum) pairs of a label are folded in order.  The log-sum-exp shift is updated on the way
+// (not found in a first pass as in col_lse / the reference's logAdd): same value up to the rounding of the shift.
+// Two workgroup barriers per node and direction instead of two per window.  LDS: 4*D*L doubles.
+// ------------------------------------------------------------------------------------------
+#define FBW_WAVES 16
+__global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const uint32_t* __restrict__ prev_lab,
+                              const double* __restrict__ S, const double* __restrict__ M2, double* __restrict__ AD,
+                              double* __restrict__ alpha_g, double* __restrict__ beta_g, double* __restrict__ XI2,
+                              double* __restrict__ numer_out, double* __restrict__ zx_out, int* __restrict__ status,
+                              int write_post) {
+  extern __shared__ double smem[];
+  __shared__ double zx_s;
+  __shared__ double mass2[2];
+  const int L = lay.L, D = lay.D;
+  const int NT = blockDim.x, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const size_t LL = (size_t)L * L;
+  const double* Su = S + s_base * L;
+  const double* Mu = M2 + s_base * LL;
+  double* ADu = AD + s_base * L;
+  double* alu = alpha_g + f_base * L;
+  double* beu = beta_g + f_base * L;
+  const uint32_t* labs = bv.labels ? bv.labels + bv.frame_off[u] : nullptr;
+  const uint32_t* plabs = prev_lab ? prev_lab + bv.frame_off[u] : nullptr;
+  // forward: aring [D][L] alpha of the last D nodes, vd [D][L] window values of the node in hand
+  // backward (same memory): bring [D][L] beta of the next D nodes, tb [D][L] beta + S of the next windows,
+  //                         pm / ps [D][L] per-window (max, sum) of a label
+  double* aring = smem;
+  double* vd = smem + (size_t)D * L;
+  double* bring = smem;
+  double* tb = smem + (size_t)D * L;
+  double* pm = smem + (size_t)2 * D * L;
+  double* ps = smem + (size_t)3 * D * L;
+  int err = 0;
+  if (T == 0) {
+    if (tid == 0) { status[u] = SCRF_ERR_EMPTY; numer_out[u] = 0.0; zx_out[u] = 0.0; }
+    return;
+  }
+
+  // ---- forward -----------------------------------------------------------------------------
+  for (int l = tid; l < L; l += NT) {   // computeFirstAlpha :200-208
+    const double a = Su[l];
+    ADu[l] = a;
+    alu[l] = a;
+    aring[l] = a;
+  }
+  __syncthreads();
+  for (int t = 1; t < T; t++) {
+    const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+    const uint64_t base = scrf_seg_base(t, D);
+    for (int d = 1 + wave; d <= nd; d += FBW_WAVES) {
+      for (int l = lane; l < L; l += 64) {
+        double v = Su[(base + d - 1) * L + l];
+        if (d <= np) {
+          const double* pa = aring + (size_t)((t - d) % D) * L;
+          const double* Mrow = Mu + (base + d - 1) * LL + l;
+          double m = -INFINITY, sum = 0.0;
+          int p = 0;
+          for (; p + 16 <= L; p += 16) {
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) x[i] = Mrow[(size_t)(p + i) * L];
+#pragma unroll
+            for (int i = 0; i < 16; i++) x[i] += pa[p + i];
+            double bm = x[0];
+#pragma unroll
+            for (int i = 1; i < 16; i++) bm = fmax(bm, x[i]);
+            const double nm = fmax(m, bm);
+            double acc = sum * exp_nonpos(m - nm);
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc += exp_nonpos(x[i] - nm);
+            sum = acc; m = nm;
+          }
+          for (; p < L; p++) {
+            const double x = pa[p] + Mrow[(size_t)p * L];
+            const double nm = fmax(m, x);
+            sum = sum * exp_nonpos(m - nm) + exp_nonpos(x - nm);
+            m = nm;
+          }
+          if (!(sum > 0.0) || isinf(sum) || isnan(sum)) err = SCRF_ERR_NUMERIC;
+          v = (m + log(sum)) + v;
+        }
+        ADu[(base + d - 1) * L + l] = v;
+        vd[(size_t)(d - 1) * L + l] = v;
+      }
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += NT) {   // log-sum over the durations, in order (:176-190)
+      double run_m = -INFINITY, run_s = 0.0;
+      for (int d = 0; d < nd; d++) {
+        const double v = vd[(size_t)d * L + l];
+        if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }
+        else run_s += exp(v - run_m);
+      }
+      if (!(run_s > 0.0) || isinf(run_s) || isnan(run_s)) err = SCRF_ERR_NUMERIC;
+      const double a_new = run_m + log(run_s);
+      alu[(size_t)t * L + l] = a_new;
+      aring[(size_t)(t % D) * L + l] = a_new;   // the slot of node t - D, whose last readers were before the barrier
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {  // computeAlphaSum: logAdd(alphaArray, L) in index order
+    const double* al = aring + (size_t)((T - 1) % D) * L;
+    double mx = al[0];
+    for (int l = 1; l < L; l++) if (al[l] > mx) mx = al[l];
+    double sum = 0.0;
+    for (int l = 0; l < L; l++) sum += exp(al[l] - mx);
+    zx_s = mx + log(sum);
+  }
+  __threadfence();   // alpha of every node is read back from memory by the posterior pass below
+  __syncthreads();
+  const double Zx = zx_s;
+  if (isnan(Zx) || isinf(Zx)) err = SCRF_ERR_NUMERIC;
+
+  // ---- backward + posteriors -----------------------------------------------------------------
+  const double LN_MAX = 709.782712893384;  // log(DBL_MAX): expE overflow guard (CRF_LogMath.cpp:213)
+  double numer = 0.0;
+  for (int t = T - 1; t >= 0; t--) {
+    const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+    double* bt = bring + (size_t)(t % D) * L;
+    if (nn == 0) {
+      for (int l = tid; l < L; l += NT) bt[l] = 0.0;   // setTailBeta
+      __syncthreads();
+    } else {
+      for (int idx = tid; idx < nn * L; idx += NT) {   // tempBeta :262-271
+        const int di = idx / L, l = idx - di * L;
+        tb[idx] = bring[(size_t)((t + di + 1) % D) * L + l] + Su[(scrf_seg_base(t + di + 1, D) + di) * L + l];
+      }
+      __syncthreads();
+      for (int di = wave; di < nn; di += FBW_WAVES) {
+        const double* Mrow = Mu + (scrf_seg_base(t + di + 1, D) + di) * LL;
+        const double* tbd = tb + (size_t)di * L;
+        for (int c0 = 0; c0 < L; c0 += 8) {   // 8 previous labels at a time: max over the lanes, then the shifted sum
+          double wm[8], part[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) wm[i] = -INFINITY;
+          for (int l = lane; l < L; l += 64) {
+            const double tv = tbd[l];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+              if (c0 + i < L) wm[i] = fmax(wm[i], Mrow[(size_t)(c0 + i) * L + l] + tv);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; i++) { wm[i] = wave_max_f64_dpp(wm[i]); part[i] = 0.0; }
+          for (int l = lane; l < L; l += 64) {
+            const double tv = tbd[l];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+              if (c0 + i < L) part[i] += exp_nonpos((Mrow[(size_t)(c0 + i) * L + l] + tv) - wm[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const double tot = wave_sum_f64_dpp(part[i]);
+            if (lane == 0 && c0 + i < L) { pm[(size_t)di * L + c0 + i] = wm[i]; ps[(size_t)di * L + c0 + i] = tot; }
+          }
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < L; c += NT) {   // the windows of a label, in order
+        double M = pm[c];
+        for (int di = 1; di < nn; di++) M = fmax(M, pm[(size_t)di * L + c]);
+        double sum = 0.0;
+        for (int di = 0; di < nn; di++) sum += ps[(size_t)di * L + c] * exp_nonpos(pm[(size_t)di * L + c] - M);
+        if (!(sum > 0.0) || isinf(sum) || isnan(sum)) err = SCRF_ERR_NUMERIC;
+        bt[c] = M + log(sum);   // the ring slot of node t + D, whose last reader was the tempBeta fill above
+      }
+      __syncthreads();
+    }
+    for (int l = tid; l < L; l += NT) beu[(size_t)t * L + l] = bt[l];
+    if (write_post) {
+      // true labels of this node and of the nearest earlier labelled node (computeExpF :430-450)
+      const uint32_t lab = labs ? labs[t] : SCRF_LAB_BAD;
+      const uint32_t pl = plabs ? plabs[t] : SCRF_LAB_BAD;
+      uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD, apl = SCRF_LAB_BAD;
+      if (lab != SCRF_LAB_BAD) {
+        if (lab >= (uint32_t)L * D) err = SCRF_ERR_BAD_LABEL;
+        al = lab % L;
+        ld = lab / L + 1;
+      }
+      if (pl != SCRF_LAB_BAD) {
+        if (pl >= (uint32_t)L * D) err = SCRF_ERR_BAD_LABEL;
+        apl = pl % L;
+      }
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      const uint64_t base = scrf_seg_base(t, D);
+      double gs = 0.0, xs = 0.0;
+      // transition posteriors first: they read ad-free quantities; then gamma overwrites ad in place
+      for (int d = 1; d <= nd; d++) {
+        double* Xrow = XI2 + (s_base + base + d - 1) * LL;
+        if (d <= np) {
+          const double* pa = alu + (size_t)(t - d) * L;
+          const double* Mrow = Mu + (base + d - 1) * LL;
+          for (int idx = tid; idx < L * L; idx += NT) {
+            const int p = idx / L, l = idx - p * L;
+            const double a = pa[p] + Mrow[idx] + Su[(base + d - 1) * L + l] + bt[l] - Zx;
+            if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+            const double x = exp(a);
+            const double y = ((uint32_t)l == al && (uint32_t)d == ld && (uint32_t)p == apl) ? 1.0 : 0.0;
+            Xrow[idx] = y - x;
+            xs += x;
+          }
+        } else {
+          for (int idx = tid; idx < L * L; idx += NT) Xrow[idx] = 0.0;
+        }
+      }
+      for (int idx = tid; idx < nd * L; idx += NT) {
+        const int di = idx / L, l = idx - di * L;
+        const double a = ADu[(base + di) * L + l] + bt[l] - Zx;
+        if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+        const double g = exp(a);
+        const double y = ((uint32_t)l == al && (uint32_t)(di + 1) == ld) ? 1.0 : 0.0;
+        ADu[(base + di) * L + l] = y - g;
+        gs += g;
+      }
+      if (tid == 0) { mass2[0] = 0.0; mass2[1] = 0.0; }
+      __syncthreads();
+      for (int o = 32; o >= 1; o >>= 1) { gs += __shfl_xor(gs, o); xs += __shfl_xor(xs, o); }
+      if ((tid & 63) == 0) { atomicAdd(&mass2[0], gs); atomicAdd(&mass2[1], xs); }
+      __syncthreads();
+      if (tid == 0) {
+        const double sm = mass2[0], tm = np == 0 ? 1.0 : mass2[1];
+        if (!(sm <= 1.000001) || !(sm >= -0.000001) || !(tm <= 1.000001) || !(tm >= -0.000001)) err = SCRF_ERR_NUMERIC;
+        if (lab != SCRF_LAB_BAD && err == 0 && ld <= (uint32_t)nd) {
+          double nodeLi = Su[(base + ld - 1) * L + al];
+          if ((int)ld <= np && apl != SCRF_LAB_BAD) nodeLi += Mu[(base + ld - 1) * LL + (size_t)apl * L + al];
+          numer += nodeLi;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    numer_out[u] = numer;
+    zx_out[u] = Zx;
+  }
+  if (err) atomicMax(&status[u], err);
+}
+
 size_t fb_segtrans_smem_bytes(const ScrfLayout& lay, int NT) {
   int G = NT / (int)lay.L;
   if (G < 1) G = 1;
@@ -236,6 +485,13 @@ void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv,
                         const uint32_t* prev_lab, const double* S, const double* M2, double* AD, double* alpha_g,
                         double* beta_g, double* XI2, double* numer, double* zx, int* status, int write_post) {
   if (n_utts == 0) return;
+  const size_t smw = sizeof(double) * 4 * (size_t)lay.D * lay.L;
+  if (smw <= 150 * 1024) {   // the wavefront-per-window form; larger D * L keeps the column-wise kernel
+    hipFuncSetAttribute((const void*)k_fb_segtrans_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
+    hipLaunchKernelGGL(k_fb_segtrans_w, dim3(n_utts), dim3(64 * FBW_WAVES), smw, st, lay, bv, u0, prev_lab, S, M2, AD, alpha_g, beta_g,
+                       XI2, numer, zx, status, write_post);
+    return;
+  }
   const int NT = fb_block_threads(lay);
   const size_t sm = fb_segtrans_smem_bytes(lay, NT);
   hipFuncSetAttribute((const void*)k_fb_segtrans, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);

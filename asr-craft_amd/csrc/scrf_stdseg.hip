@@ -11,6 +11,7 @@
 // node); the kernels are the plain log-domain recursion in the reference's operation order -- one workgroup per
 // utterance, sums in index order -- written for parity, not for the roofline.  The lay argument is the FULL-label
 // layout (lay.L = nLabs).
+#include "scrf_dp_common.h"
 #include "scrf_kernels.h"
 
 #include <math.h>
@@ -89,10 +90,23 @@ __device__ __forceinline__ double stdseg_log(double x, int* err) {
   return log(x);
 }
 
-__global__ __launch_bounds__(256) void k_stdseg_fb(ScrfLayout lay, uint32_t La, ScrfBatchView bv, uint32_t u0,
-                                                   const double* __restrict__ S, const double* __restrict__ MX,
-                                                   double* __restrict__ alpha, double* __restrict__ beta,
-                                                   double* __restrict__ zx_out, int* __restrict__ status) {
+#define SSFB_WAVES 16
+__device__ __forceinline__ double ss_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+// Workgroup of 16 wavefronts per utterance, lanes over the phone axis (rows of MX are read as whole 8*La-byte lines).
+// Forward: a wavefront owns the window rows (t, dur) of the node, walks the previous node's full labels once and keeps
+// a running (max, sum) per lane -- the node's max-shifted log-sum-exp (computeAlpha :150-215) with the shift updated
+// on the way instead of found in a first pass, so MX streams from HBM once.  Backward: a wavefront owns full labels
+// of node t; per label every lane folds the next rows' terms of its phone into a running (max, sum), the lanes are
+// combined at the end (computeBeta :240-330).  Differences to the two-pass form are roundings of the shift only.
+__global__ __launch_bounds__(64 * SSFB_WAVES) void k_stdseg_fb(ScrfLayout lay, uint32_t La, ScrfBatchView bv, uint32_t u0,
+                                                               const double* __restrict__ S, const double* __restrict__ MX,
+                                                               double* __restrict__ alpha, double* __restrict__ beta,
+                                                               double* __restrict__ zx_out, int* __restrict__ status) {
+  extern __shared__ double ss_bs[];   // [D][La]: beta + state value of the rows (t + dur, dur)
   const uint32_t NL = lay.L, D = lay.D;
   const uint32_t u = u0 + blockIdx.x;
   const uint32_t T = bv.T[u];
@@ -100,6 +114,7 @@ __global__ __launch_bounds__(256) void k_stdseg_fb(ScrfLayout lay, uint32_t La, 
     if (threadIdx.x == 0) atomicMax(&status[u], SCRF_ERR_EMPTY);
     return;
   }
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
   const double* Su = S + s_base * La;
   const double* Mu = MX + s_base * (uint64_t)NL * La;
@@ -110,21 +125,41 @@ __global__ __launch_bounds__(256) void k_stdseg_fb(ScrfLayout lay, uint32_t La, 
   for (uint32_t t = 0; t < T; t++) {
     const uint64_t base = scrf_seg_base(t, D);
     const uint32_t nd = scrf_node_max_dur(t, D), np = scrf_num_prev(t, D);
-    for (uint32_t e = threadIdx.x; e < nd * La; e += blockDim.x) {
-      const uint32_t dur = e / La + 1, lab = e % La;
-      const uint64_t at = (base + dur - 1) * La + lab;
-      double v = Su[at];
-      if (dur <= np) {
-        const double* pa = au + scrf_seg_base(t - dur, D) * La;
-        const uint32_t pavail = La * scrf_node_max_dur(t - dur, D);
-        const double* Mrow = Mu + (base + dur - 1) * (uint64_t)NL * La + lab;
-        double maxv = pa[0] + Mrow[0];
-        for (uint32_t plab = 1; plab < pavail; plab++) maxv = fmax(maxv, pa[plab] + Mrow[(uint64_t)plab * La]);
-        double sum = 0.0;
-        for (uint32_t plab = 0; plab < pavail; plab++) sum += stdseg_exp((pa[plab] + Mrow[(uint64_t)plab * La]) - maxv, &err);
-        v = (maxv + stdseg_log(sum, &err)) + v;
+    for (uint32_t dur = 1 + wave; dur <= nd; dur += SSFB_WAVES) {
+      for (uint32_t lab = lane; lab < La; lab += 64) {
+        const uint64_t at = (base + dur - 1) * La + lab;
+        double v = Su[at];
+        if (dur <= np) {
+          const double* pa = au + scrf_seg_base(t - dur, D) * La;
+          const uint32_t pavail = La * scrf_node_max_dur(t - dur, D);
+          const double* Mrow = Mu + (base + dur - 1) * (uint64_t)NL * La + lab;
+          double m = -INFINITY, sum = 0.0;
+          uint32_t plab = 0;
+          for (; plab + 32 <= pavail; plab += 32) {   // 32 line-sized loads in flight per wavefront: the walk is HBM-latency bound
+            double x[32];
+#pragma unroll
+            for (int i = 0; i < 32; i++) x[i] = Mrow[(uint64_t)(plab + i) * La];
+#pragma unroll
+            for (int i = 0; i < 32; i++) x[i] += pa[plab + i];
+            double bm = x[0];
+#pragma unroll
+            for (int i = 1; i < 32; i++) bm = fmax(bm, x[i]);
+            const double nm = fmax(m, bm);
+            double acc = sum * exp_nonpos(m - nm);
+#pragma unroll
+            for (int i = 0; i < 32; i++) acc += exp_nonpos(x[i] - nm);
+            sum = acc; m = nm;
+          }
+          for (; plab < pavail; plab++) {
+            const double x = pa[plab] + Mrow[(uint64_t)plab * La];
+            const double nm = fmax(m, x);
+            sum = sum * exp_nonpos(m - nm) + exp_nonpos(x - nm);
+            m = nm;
+          }
+          v = (m + stdseg_log(sum, &err)) + v;
+        }
+        au[at] = v;
       }
-      au[at] = v;
     }
     __syncthreads();
   }
@@ -147,20 +182,41 @@ __global__ __launch_bounds__(256) void k_stdseg_fb(ScrfLayout lay, uint32_t La, 
     const uint32_t nn = (T - 1 - t <= D) ? T - 1 - t : D;
     const uint64_t base = scrf_seg_base(t, D);
     const uint32_t avail = La * scrf_node_max_dur(t, D);
-    for (uint32_t clab = threadIdx.x; clab < avail; clab += blockDim.x) {
-      double maxv = -INFINITY;
-      for (uint32_t dur = 1; dur <= nn; dur++) {
-        const uint64_t row = scrf_seg_base(t + dur, D) + dur - 1;
-        const double* Mrow = Mu + (row * NL + clab) * La;
-        for (uint32_t lab = 0; lab < La; lab++) maxv = fmax(maxv, Mrow[lab] + (bu[row * La + lab] + Su[row * La + lab]));
+    for (uint32_t e = threadIdx.x; e < nn * La; e += blockDim.x) {
+      const uint32_t dur = e / La + 1, lab = e - (dur - 1) * La;
+      const uint64_t row = scrf_seg_base(t + dur, D) + dur - 1;
+      ss_bs[e] = bu[row * La + lab] + Su[row * La + lab];
+    }
+    __syncthreads();
+    for (uint32_t clab = wave; clab < avail; clab += SSFB_WAVES) {
+      double m = -INFINITY, sum = 0.0;
+      for (uint32_t lab = lane; lab < La; lab += 64) {
+        for (uint32_t d0 = 1; d0 <= nn; d0 += 8) {   // the rows' loads first, then the running (max, sum)
+          double x[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const uint32_t dur = d0 + i;
+            const uint64_t row = scrf_seg_base(t + (dur <= nn ? dur : nn), D) + (dur <= nn ? dur : nn) - 1;
+            x[i] = Mu[(row * NL + clab) * La + lab];
+          }
+          double bm = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const uint32_t dur = d0 + i;
+            x[i] = dur <= nn ? x[i] + ss_bs[(dur - 1) * La + lab] : -INFINITY;
+            bm = fmax(bm, x[i]);
+          }
+          const double nm = fmax(m, bm);
+          double acc = sum * exp_nonpos(m - nm);
+#pragma unroll
+          for (int i = 0; i < 8; i++) acc += exp_nonpos(x[i] - nm);
+          sum = acc; m = nm;
+        }
       }
-      double sum = 0.0;
-      for (uint32_t dur = 1; dur <= nn; dur++) {
-        const uint64_t row = scrf_seg_base(t + dur, D) + dur - 1;
-        const double* Mrow = Mu + (row * NL + clab) * La;
-        for (uint32_t lab = 0; lab < La; lab++) sum += stdseg_exp((Mrow[lab] + (bu[row * La + lab] + Su[row * La + lab])) - maxv, &err);
-      }
-      bu[base * La + clab] = maxv + stdseg_log(sum, &err);
+      const double wm = wave_max_f64_dpp(m);
+      double part = (m == -INFINITY) ? 0.0 : sum * exp_nonpos(m - wm);   // lanes past the phone count hold nothing
+      part = wave_sum_f64_dpp(part);
+      if (lane == 0) bu[base * La + clab] = wm + stdseg_log(part, &err);
     }
     __syncthreads();
   }
@@ -179,31 +235,43 @@ __global__ __launch_bounds__(256) void k_stdseg_post(ScrfLayout lay, uint32_t La
                                                      const double* __restrict__ zx, double* __restrict__ G,
                                                      double* __restrict__ XI, double* __restrict__ mass_s,
                                                      double* __restrict__ mass_t, int* __restrict__ status) {
+  // one workgroup per window row: its (NL + 1) * La entries in strides, the two posterior masses of the row summed in
+  // the workgroup and added to the frame's totals once (a frame has at most D rows)
+  __shared__ double red[2][4];
   const uint32_t NL = lay.L, D = lay.D;
-  const uint64_t per_row = (uint64_t)(NL + 1) * La;
-  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_rows * per_row) return;
-  const uint64_t row = e / per_row;
-  const uint32_t r = (uint32_t)(e % per_row), q = r / La, lab = r % La;
+  const uint64_t row = blockIdx.x;
   const uint32_t t = row_t[row], dur = row_d[row], u = row_u[row];
   const double Zx = zx[u];
   const uint64_t fidx = (bv.frame_off[u] - bv.frame_off[u0]) + t;
-  const uint64_t at = row * La + lab;
+  const uint32_t np = scrf_num_prev(t, D);
+  const bool has_prev = dur <= np;
+  const uint32_t pavail = has_prev ? La * scrf_node_max_dur(t - dur, D) : 0;
+  const double* pa = has_prev ? alpha + ((bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t - dur, D)) * La : nullptr;
   int err = 0;
-  if (q == NL) {
+  double ms = 0.0, mt = 0.0;
+  for (uint32_t lab = threadIdx.x; lab < La; lab += blockDim.x) {
+    const uint64_t at = row * La + lab;
     const double g = stdseg_exp(alpha[at] + beta[at] - Zx, &err);
     G[at] = g;
-    atomicAdd(&mass_s[fidx], g);
-  } else {
-    const uint32_t plab = q, np = scrf_num_prev(t, D);
+    ms += g;
+  }
+  for (uint32_t r = threadIdx.x; r < NL * La; r += blockDim.x) {
+    const uint32_t plab = r / La, lab = r - plab * La;
+    const uint64_t at = row * La + lab;
     double x = 0.0;
-    if (dur <= np && plab < La * scrf_node_max_dur(t - dur, D)) {
-      const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
-      const double pa = alpha[(s_base + scrf_seg_base(t - dur, D)) * La + plab];
-      x = stdseg_exp(pa + MX[(row * NL + plab) * La + lab] + S[at] + beta[at] - Zx, &err);
-      atomicAdd(&mass_t[fidx], x);
+    if (plab < pavail) {
+      x = stdseg_exp(pa[plab] + MX[(row * NL + plab) * La + lab] + S[at] + beta[at] - Zx, &err);
+      mt += x;
     }
     XI[(row * NL + plab) * La + lab] = x;
+  }
+  ms = wave_sum_f64(ms);
+  mt = wave_sum_f64(mt);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ms; red[1][threadIdx.x >> 6] = mt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&mass_s[fidx], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    if (has_prev) atomicAdd(&mass_t[fidx], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
   }
   if (err) atomicMax(&status[u], SCRF_ERR_NUMERIC);
 }
@@ -444,15 +512,14 @@ void launch_stdseg_scores(hipStream_t st, const ScrfLayout& lay, uint32_t La, co
 void launch_stdseg_fb(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                       const double* S, const double* MX, double* alpha, double* beta, double* zx, int* status) {
   if (n_utts == 0) return;
-  hipLaunchKernelGGL(k_stdseg_fb, dim3(n_utts), dim3(256), 0, st, lay, La, bv, u0, S, MX, alpha, beta, zx, status);
+  hipLaunchKernelGGL(k_stdseg_fb, dim3(n_utts), dim3(64 * SSFB_WAVES), sizeof(double) * lay.D * La, st, lay, La, bv, u0, S, MX, alpha, beta, zx, status);
 }
 void launch_stdseg_post(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                         uint64_t n_rows, const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u,
                         const uint32_t* prev_lab, const double* S, const double* MX, const double* alpha, const double* beta,
                         const double* zx, double* G, double* XI, double* mass_s, double* mass_t, double* numer, int* status) {
-  const uint64_t n = n_rows * (uint64_t)(lay.L + 1) * La;
-  if (n == 0) return;
-  hipLaunchKernelGGL(k_stdseg_post, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, lay, La, bv, u0, n_rows, row_t, row_d,
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(k_stdseg_post, dim3((uint32_t)n_rows), dim3(256), 0, st, lay, La, bv, u0, n_rows, row_t, row_d,
                      row_u, S, MX, alpha, beta, zx, G, XI, mass_s, mass_t, status);
   hipLaunchKernelGGL(k_stdseg_numer, dim3((n_utts + 63) / 64), dim3(64), 0, st, lay, La, bv, u0, n_utts, prev_lab, S, MX, mass_s,
                      mass_t, numer, status);

@@ -762,6 +762,13 @@ static uint64_t expf_rows_per_chunk(uint64_t nseg) {
   return rpc < EXPF_ROWS_PER_CHUNK ? EXPF_ROWS_PER_CHUNK : rpc;
 }
 
+// K-chunks of the per-window transition contraction (STDSEG_NO_DUR: [N_seg][L*L] posteriors x a few feature functions):
+// one per 2048 rows while the partial-sum slabs stay within 128 MB (at least 4)
+static uint32_t segtrans_chunks(uint64_t nseg, size_t LL, uint32_t ntf) {
+  const uint64_t cap = std::max<uint64_t>(4, (128ull << 20) / (LL * ntf * sizeof(double)));
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cap, (nseg + 2047) / 2048));
+}
+
 // K-chunks of the transition-bias contraction: one wavefront each, about 1024 of them
 static uint64_t atb_rows_per_chunk(uint64_t nfr) {
   uint64_t rpc = ((nfr + 1023) / 1024 + 3) & ~3ull;
@@ -886,8 +893,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
       tot += pad256(nfr * sizeof(double));                            // mass_s
       if (segtrans(h)) {
         tot += pad256(nseg * LL * sizeof(double));                    // XI2
-        uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nseg + 2047) / 2048);
-        tot += pad256((size_t)std::max(1u, nch_t) * LL * l.ntf * sizeof(double));
+        tot += pad256((size_t)segtrans_chunks(nseg, LL, l.ntf) * LL * l.ntf * sizeof(double));
       } else if (l.use_tf) {
         tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
         uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
@@ -1005,8 +1011,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       cb->mass_s = a.take<double>(nfr);
       if (segtrans(h)) {
         cb->XI = a.take<double>(nseg * LL);
-        cb->nch_t = (uint32_t)std::min<uint64_t>(4, (nseg + 2047) / 2048);
-        if (cb->nch_t == 0) cb->nch_t = 1;
+        cb->nch_t = segtrans_chunks(nseg, LL, l.ntf);
         cb->rpc_t = (nseg + cb->nch_t - 1) / cb->nch_t;
         cb->slab_t = a.take<double>((size_t)cb->nch_t * LL * l.ntf);
       } else if (l.use_tf) {

@@ -199,21 +199,24 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 // that the staging/barrier cost per MFMA stays low when few wavefronts share one R tile.
 // F32 = 1: operands rounded to f32 (R is in [-1,1]), v_mfma_f32_16x16x4_f32 within a staged chunk of
 // EM_KC rows, chunk results flushed into f64 accumulators (so the K = millions-of-rows sum is f64).
-template <int HAS_XROW, int NW, int EM_KC, int F32>
+template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0>
 __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                       ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
                                                       double* __restrict__ slab) {
   constexpr int NT = 64 * NW;            // threads
-  constexpr int NF = 48 * NW;            // feature columns per workgroup
+  // SPLIT_OUT: the wavefronts share one 48-column feature tile and own 48 outputs each (few feature functions, many
+  // outputs: the per-window transition posteriors, n_out = L * L); otherwise 48 outputs and 48 feature columns per wavefront
+  constexpr int NF = SPLIT_OUT ? 48 : 48 * NW;   // feature columns per workgroup
+  constexpr int NO = SPLIT_OUT ? EM_NO * NW : EM_NO;   // outputs per workgroup
   constexpr int XS = NF + 16;            // float row stride of the X image (== 16 mod 32)
   constexpr int QR = NF / 4;             // 16-byte quads per row
-  constexpr int XIT = EM_KC * QR / NT;   // X quads per thread per chunk (= 6)
-  constexpr int AIT = (EM_KC * EM_NO + NT - 1) / NT;
+  constexpr int XIT = (EM_KC * QR + NT - 1) / NT;   // X quads per thread per chunk (= 6; the split form has threads without one)
+  constexpr int AIT = (EM_KC * NO + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
-  double* Rs = (double*)em_smem;                                  // [EM_KC][EM_NO]
-  float* Xs = (float*)(em_smem + sizeof(double) * EM_KC * EM_NO);  // [EM_KC][XS]
+  double* Rs = (double*)em_smem;                                  // [EM_KC][NO]
+  float* Xs = (float*)(em_smem + sizeof(double) * EM_KC * NO);  // [EM_KC][XS]
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t fs = sp.fs;
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   const float bias = sp.use_bias ? (float)sp.bias : 0.0f;
   const bool bias_exact = (double)bias == sp.bias;
   const uint32_t fb = blockIdx.x * NF;
-  const uint32_t o0 = blockIdx.y * EM_NO;
+  const uint32_t o0 = blockIdx.y * NO;
+  const uint32_t wo = SPLIT_OUT ? wave * 48 : 0, wf = SPLIT_OUT ? 0 : wave * 48;   // this wavefront's output / feature offset in the tile
   const uint64_t r_begin = (uint64_t)blockIdx.z * rows_per_chunk;
   const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
 
@@ -258,9 +262,9 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
 #pragma unroll
   for (int k = 0; k < AIT; k++) {
     const uint32_t idx = tid + k * NT;
-    arw[k] = idx / EM_NO;
-    const uint32_t o = o0 + idx % EM_NO;
-    aok[k] = idx < EM_KC * EM_NO && o < n_out;
+    arw[k] = idx / NO;
+    const uint32_t o = o0 + idx % NO;
+    aok[k] = idx < EM_KC * NO && o < n_out;
     acol[k] = o < n_out ? o : n_out - 1;
   }
   // branch-free loads: rows past the chunk end re-read its last row (may read <= 12 B past the
@@ -293,11 +297,11 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       float o[4];
 #pragma unroll
       for (int c = 0; c < 4; c++) o[c] = !rok ? 0.0f : (xkeep[k][c] ? e[c] : xfill[k][c]);
-      *(float4*)(&Xs[xlds[k]]) = make_float4(o[0], o[1], o[2], o[3]);
+      if (EM_KC * QR % NT == 0 || tid + k * NT < EM_KC * QR) *(float4*)(&Xs[xlds[k]]) = make_float4(o[0], o[1], o[2], o[3]);
     }
 #pragma unroll
     for (int k = 0; k < AIT; k++)
-      if (tid + k * NT < EM_KC * EM_NO) Rs[tid + k * NT] = ar_[k];
+      if (tid + k * NT < EM_KC * NO) Rs[tid + k * NT] = ar_[k];
   };
 
   if (r_begin < r_end) load_chunk(r_begin);
@@ -315,9 +319,9 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       for (int ks = 0; ks < EM_KC / 4; ks++) {
         float a[3], b[3];
 #pragma unroll
-        for (int m = 0; m < 3; m++) a[m] = (float)Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
+        for (int m = 0; m < 3; m++) a[m] = (float)Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
 #pragma unroll
-        for (int n = 0; n < 3; n++) b[n] = Xs[(ks * 4 + lk) * XS + wave * 48 + n * 16 + li];
+        for (int n = 0; n < 3; n++) b[n] = Xs[(ks * 4 + lk) * XS + wf + n * 16 + li];
 #pragma unroll
         for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -334,9 +338,9 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       for (int ks = 0; ks < EM_KC / 4; ks++) {
         double a[3], b[3];
 #pragma unroll
-        for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * EM_NO + m * 16 + li];
+        for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
 #pragma unroll
-        for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wave * 48 + n * 16 + li];
+        for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wf + n * 16 + li];
 #pragma unroll
         for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -349,14 +353,14 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   const double bfix = (bias_exact || !sp.use_bias) ? 1.0 : sp.bias / (double)bias;
 #pragma unroll
   for (int n = 0; n < 3; n++) {
-    const uint32_t col = fb + wave * 48 + n * 16 + li;
+    const uint32_t col = fb + wf + n * 16 + li;
     if (col >= nfun) continue;
     const double sc = (col == nfe) ? bfix : 1.0;
 #pragma unroll
     for (int m = 0; m < 3; m++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const uint32_t o = o0 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
+        const uint32_t o = o0 + wo + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
         if (o < n_out) slab[((uint64_t)blockIdx.z * n_out + o) * nfun + col] = acc[m][n][r] * sc;
       }
   }
@@ -380,6 +384,21 @@ static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out,
   }
 }
 
+// few feature functions (<= 48) and many outputs: 4 wavefronts share the feature tile and split 192 outputs
+template <int F32>
+static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                                   const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
+                                   uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+  constexpr int NW = 4, KC = 16;
+  dim3 grid(1, (n_out + EM_NO * NW - 1) / (EM_NO * NW), n_chunks);
+  const size_t sm = sizeof(double) * KC * EM_NO * NW + sizeof(float) * KC * (48 + 16);
+  if (xrow)
+    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab);
+  else
+    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32, 1>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab);
+}
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int f32) {
@@ -387,6 +406,11 @@ void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const flo
   const uint32_t nfun = sp.nfun();
   const uint32_t tiles = (nfun + 47) / 48;  // 48-column wave tiles needed
 #define EXPF_ARGS st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab
+  if (tiles <= 1 && n_out >= 4 * EM_NO) {
+    if (f32) launch_expf_mfma_split<1>(EXPF_ARGS);
+    else launch_expf_mfma_split<0>(EXPF_ARGS);
+    return;
+  }
   if (f32) {
     if (tiles <= 1) launch_expf_mfma_nw<1, 32, 1>(EXPF_ARGS);
     else if (tiles <= 2) launch_expf_mfma_nw<2, 64, 1>(EXPF_ARGS);

@@ -22,6 +22,7 @@
 #include "scrf_lse.h"
 
 #include <float.h>
+#include <stdlib.h>
 #include <math.h>
 
 __global__ void k_zero_initial_rows(ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0, uint64_t n_frames,
@@ -231,11 +232,12 @@ __global__ void k_fb_segtrans(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, con
 // k_fb_segtrans_w: the same recursion with the D windows of a node spread over the workgroup's wavefronts.  Forward:
 // wavefront w takes the windows d = w+1, w+17, ... of node t, lanes over the label l, and walks the previous node's
 // labels p once with a running (max, sum) per lane (M2 rows are read as whole 8*L-byte lines, 16 in flight); the
-// D window values of a label are then folded in duration order.  Backward: wavefront w takes the next windows
-// di = w, w+16, ..., per previous label c every lane folds its label's term and the lanes are combined with xor
-// shuffles; the per-window (max, sum) pairs of a label are folded in order.  The log-sum-exp shift is updated on the way
-// (not found in a first pass as in col_lse / the reference's logAdd): same value up to the rounding of the shift.
-// Two workgroup barriers per node and direction instead of two per window.  LDS: 4*D*L doubles.
+// D window values of a label are then folded in duration order.  Backward: wavefront w takes the previous labels
+// c = w, w+16, ...; per label every lane folds its label's terms of all next windows (maximum first, then the shifted
+// sum), and the lanes are combined once with DPP max / sum.  Posteriors: previous label over the wavefronts, label over
+// the lanes.  In the forward walk the log-sum-exp shift is updated on the way (not found in a first pass as in col_lse
+// / the reference's logAdd): same value up to the rounding of the shift.  Two workgroup barriers per node and
+// direction instead of two per window.  LDS: 2*D*L doubles.
 // ------------------------------------------------------------------------------------------
 #define FBW_WAVES 16
 __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const uint32_t* __restrict__ prev_lab,
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay
   __shared__ double mass2[2];
   const int L = lay.L, D = lay.D;
   const int NT = blockDim.x, tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n_waves = NT >> 6;
   const uint32_t u = u0 + blockIdx.x;
   const int T = (int)bv.T[u];
   const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
@@ -262,14 +264,11 @@ __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay
   const uint32_t* labs = bv.labels ? bv.labels + bv.frame_off[u] : nullptr;
   const uint32_t* plabs = prev_lab ? prev_lab + bv.frame_off[u] : nullptr;
   // forward: aring [D][L] alpha of the last D nodes, vd [D][L] window values of the node in hand
-  // backward (same memory): bring [D][L] beta of the next D nodes, tb [D][L] beta + S of the next windows,
-  //                         pm / ps [D][L] per-window (max, sum) of a label
+  // backward (same memory): bring [D][L] beta of the next D nodes, tb [D][L] beta + S of the next windows
   double* aring = smem;
   double* vd = smem + (size_t)D * L;
   double* bring = smem;
   double* tb = smem + (size_t)D * L;
-  double* pm = smem + (size_t)2 * D * L;
-  double* ps = smem + (size_t)3 * D * L;
   int err = 0;
   if (T == 0) {
     if (tid == 0) { status[u] = SCRF_ERR_EMPTY; numer_out[u] = 0.0; zx_out[u] = 0.0; }
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay
   for (int t = 1; t < T; t++) {
     const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
     const uint64_t base = scrf_seg_base(t, D);
-    for (int d = 1 + wave; d <= nd; d += FBW_WAVES) {
+    for (int d = 1 + wave; d <= nd; d += n_waves) {
       for (int l = lane; l < L; l += 64) {
         double v = Su[(base + d - 1) * L + l];
         if (d <= np) {
@@ -366,42 +365,19 @@ __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay
         tb[idx] = bring[(size_t)((t + di + 1) % D) * L + l] + Su[(scrf_seg_base(t + di + 1, D) + di) * L + l];
       }
       __syncthreads();
-      for (int di = wave; di < nn; di += FBW_WAVES) {
-        const double* Mrow = Mu + (scrf_seg_base(t + di + 1, D) + di) * LL;
-        const double* tbd = tb + (size_t)di * L;
-        for (int c0 = 0; c0 < L; c0 += 8) {   // 8 previous labels at a time: max over the lanes, then the shifted sum
-          double wm[8], part[8];
-#pragma unroll
-          for (int i = 0; i < 8; i++) wm[i] = -INFINITY;
-          for (int l = lane; l < L; l += 64) {
-            const double tv = tbd[l];
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-              if (c0 + i < L) wm[i] = fmax(wm[i], Mrow[(size_t)(c0 + i) * L + l] + tv);
-          }
-#pragma unroll
-          for (int i = 0; i < 8; i++) { wm[i] = wave_max_f64_dpp(wm[i]); part[i] = 0.0; }
-          for (int l = lane; l < L; l += 64) {
-            const double tv = tbd[l];
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-              if (c0 + i < L) part[i] += exp_nonpos((Mrow[(size_t)(c0 + i) * L + l] + tv) - wm[i]);
-          }
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const double tot = wave_sum_f64_dpp(part[i]);
-            if (lane == 0 && c0 + i < L) { pm[(size_t)di * L + c0 + i] = wm[i]; ps[(size_t)di * L + c0 + i] = tot; }
-          }
-        }
-      }
-      __syncthreads();
-      for (int c = tid; c < L; c += NT) {   // the windows of a label, in order
-        double M = pm[c];
-        for (int di = 1; di < nn; di++) M = fmax(M, pm[(size_t)di * L + c]);
-        double sum = 0.0;
-        for (int di = 0; di < nn; di++) sum += ps[(size_t)di * L + c] * exp_nonpos(pm[(size_t)di * L + c] - M);
-        if (!(sum > 0.0) || isinf(sum) || isnan(sum)) err = SCRF_ERR_NUMERIC;
-        bt[c] = M + log(sum);   // the ring slot of node t + D, whose last reader was the tempBeta fill above
+      for (int c = wave; c < L; c += n_waves) {   // previous label c: every lane folds its label's terms of all next windows
+        double wm = -INFINITY;
+        for (int l = lane; l < L; l += 64)
+          for (int di = 0; di < nn; di++)
+            wm = fmax(wm, Mu[(scrf_seg_base(t + di + 1, D) + di) * LL + (size_t)c * L + l] + tb[(size_t)di * L + l]);
+        wm = wave_max_f64_dpp(wm);
+        double part = 0.0;
+        for (int l = lane; l < L; l += 64)
+          for (int di = 0; di < nn; di++)
+            part += exp_nonpos((Mu[(scrf_seg_base(t + di + 1, D) + di) * LL + (size_t)c * L + l] + tb[(size_t)di * L + l]) - wm);
+        part = wave_sum_f64_dpp(part);
+        if (!(part > 0.0) || isinf(part) || isnan(part)) err = SCRF_ERR_NUMERIC;
+        if (lane == 0) bt[c] = wm + log(part);   // the ring slot of node t + D, whose last reader was the tempBeta fill above
       }
       __syncthreads();
     }
@@ -429,14 +405,17 @@ __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay
         if (d <= np) {
           const double* pa = alu + (size_t)(t - d) * L;
           const double* Mrow = Mu + (base + d - 1) * LL;
-          for (int idx = tid; idx < L * L; idx += NT) {
-            const int p = idx / L, l = idx - p * L;
-            const double a = pa[p] + Mrow[idx] + Su[(base + d - 1) * L + l] + bt[l] - Zx;
-            if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
-            const double x = exp(a);
-            const double y = ((uint32_t)l == al && (uint32_t)d == ld && (uint32_t)p == apl) ? 1.0 : 0.0;
-            Xrow[idx] = y - x;
-            xs += x;
+          for (int p = wave; p < L; p += n_waves) {
+            const double pap = pa[p];
+            for (int l = lane; l < L; l += 64) {
+              const int idx = p * L + l;
+              const double a = pap + Mrow[idx] + Su[(base + d - 1) * L + l] + bt[l] - Zx;
+              if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
+              const double x = a <= 0.0 ? exp_nonpos(a) : exp(a);
+              const double y = ((uint32_t)l == al && (uint32_t)d == ld && (uint32_t)p == apl) ? 1.0 : 0.0;
+              Xrow[idx] = y - x;
+              xs += x;
+            }
           }
         } else {
           for (int idx = tid; idx < L * L; idx += NT) Xrow[idx] = 0.0;
@@ -485,10 +464,15 @@ void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv,
                         const uint32_t* prev_lab, const double* S, const double* M2, double* AD, double* alpha_g,
                         double* beta_g, double* XI2, double* numer, double* zx, int* status, int write_post) {
   if (n_utts == 0) return;
-  const size_t smw = sizeof(double) * 4 * (size_t)lay.D * lay.L;
+  const size_t smw = sizeof(double) * 2 * (size_t)lay.D * lay.L;
   if (smw <= 150 * 1024) {   // the wavefront-per-window form; larger D * L keeps the column-wise kernel
     hipFuncSetAttribute((const void*)k_fb_segtrans_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
-    hipLaunchKernelGGL(k_fb_segtrans_w, dim3(n_utts), dim3(64 * FBW_WAVES), smw, st, lay, bv, u0, prev_lab, S, M2, AD, alpha_g, beta_g,
+    // wavefronts per workgroup: the D windows in one round when every CU has at most one utterance, in two rounds
+    // with two workgroups per CU when there are more utterances than CUs
+    int nw = (int)lay.D < FBW_WAVES ? (int)lay.D : FBW_WAVES;
+    if (n_utts > 256 && nw > 2) nw = (nw + 1) / 2;
+    if (const char* e = getenv("SCRF_FBW_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= FBW_WAVES) nw = v; }
+    hipLaunchKernelGGL(k_fb_segtrans_w, dim3(n_utts), dim3(64 * nw), smw, st, lay, bv, u0, prev_lab, S, M2, AD, alpha_g, beta_g,
                        XI2, numer, zx, status, write_post);
     return;
   }

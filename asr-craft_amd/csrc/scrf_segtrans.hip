@@ -467,10 +467,8 @@ void launch_fb_segtrans(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv,
   const size_t smw = sizeof(double) * 2 * (size_t)lay.D * lay.L;
   if (smw <= 150 * 1024) {   // the wavefront-per-window form; larger D * L keeps the column-wise kernel
     hipFuncSetAttribute((const void*)k_fb_segtrans_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
-    // wavefronts per workgroup: the D windows in one round when every CU has at most one utterance, in two rounds
-    // with two workgroups per CU when there are more utterances than CUs
-    int nw = (int)lay.D < FBW_WAVES ? (int)lay.D : FBW_WAVES;
-    if (n_utts > 256 && nw > 2) nw = (nw + 1) / 2;
+    // wavefronts per workgroup: 16 when every CU has at most one utterance, 8 (two workgroups per CU) beyond that
+    int nw = n_utts > 256 ? FBW_WAVES / 2 : FBW_WAVES;
     if (const char* e = getenv("SCRF_FBW_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= FBW_WAVES) nw = v; }
     hipLaunchKernelGGL(k_fb_segtrans_w, dim3(n_utts), dim3(64 * nw), smw, st, lay, bv, u0, prev_lab, S, M2, AD, alpha_g, beta_g,
                        XI2, numer, zx, status, write_post);

@@ -45,7 +45,8 @@ class NCase:
 
 
 CASES = [dict(P=2, K=2, F=3, Ts=[1, 2, 5]), dict(P=3, K=3, F=4, Ts=[4, 9, 3]), dict(P=16, K=3, F=6, Ts=[20, 7], scale=0.1),
-         dict(P=4, K=2, F=3, Ts=[6, 6], trans_ftrs=False), dict(P=2, K=5, F=2, Ts=[12])]
+         dict(P=4, K=2, F=3, Ts=[6, 6], trans_ftrs=False), dict(P=2, K=5, F=2, Ts=[12]),
+         dict(P=70, K=2, F=3, Ts=[9, 4], scale=0.1)]     # more phones than lane groups in the workgroup
 
 
 @pytest.mark.parametrize("ci", range(len(CASES)))

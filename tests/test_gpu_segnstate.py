@@ -189,6 +189,38 @@ def test_benchmarked_path_serves_the_masked_model():
     b.close(); eng.close()
 
 
+def test_random_shape_sweep():
+    """20 seeded random shapes (phones, states per phone, durations, stream width, lengths incl. shorter than D; with
+    and without transition features; both precisions; labels on and off the topology): gradient, numerator, Zx, lattice
+    arcs and best path against the oracle."""
+    rng = np.random.RandomState(2024)
+    for it in range(20):
+        K = int(rng.randint(2, 5)); P = int(rng.randint(1, 9)); D = int(rng.randint(1, 13)); W = int(rng.randint(1, 6))
+        Ts = [int(rng.randint(1, 3 * D + 4)) for _ in range(int(rng.randint(1, 5)))]
+        kw = dict(L=P * K, D=D, in_w=W, Ts=Ts, num_states=K, seed=9000 + it, precision=int(rng.randint(0, 2)),
+                  conform_labels=bool(rng.randint(0, 2)), lam_scale=float(rng.choice([0.05, 0.3, 1.0])))
+        if rng.randint(0, 2):
+            kw["trans_ctx"] = int(rng.randint(0, 3))
+        c = Case(**kw)
+        eng = c.engine(); b = c.batch(eng)
+        numer, zx = eng.fb_batch(b)
+        g = eng.get_grad()
+        og, onumer, ozx = c.oracle_gradient()
+        assert np.abs(numer - onumer).max() <= 1e-10 * max(1, np.abs(onumer).max()), kw
+        assert np.abs(zx - ozx).max() <= 1e-10 * max(1, np.abs(ozx).max()), kw
+        assert np.abs(g - og).max() <= 1e-8 * max(1e-300, np.abs(og).max()), kw
+        labs, cost = eng.viterbi_batch(b)
+        for u, T in enumerate(c.Ts):
+            So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+            oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+            ga, gns, gfin = eng.lattice_arcs(b, u)
+            assert (gns, gfin) == (ons, ofin) and ga.tobytes() == oa.tobytes(), kw
+            ol, oc = orc.best_path(oa, ons, ofin)
+            assert np.float32(cost[u]).tobytes() == np.float32(oc).tobytes(), kw
+            assert list(labs[u]) == list(ol), kw
+        b.close(); eng.close()
+
+
 def test_refusals():
     kw = dict(L=6, D=3, F=orc.window_width(2, 3, 0, 0, True), num_states=2)
     # the device gradient pointer is a dense-layout buffer: not handed out

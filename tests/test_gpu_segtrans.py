@@ -25,6 +25,8 @@ CASES = [
     dict(L=7, D=10, in_w=3, Ts=[9, 10, 11, 30], trans_share=(0, 9)),              # T = D-1, D, D+1, 3D
     dict(L=48, D=10, in_w=8, Ts=[40, 25], trans_ctx=1, lam_scale=0.05),           # TIMIT-like label count
     dict(L=4, D=3, in_w=2, Ts=[5, 8]),                                            # bias-only transitions
+    dict(L=70, D=3, in_w=2, Ts=[7, 4], trans_share=(0, 3), lam_scale=0.1),        # more labels than lanes; 16-deep load batches + tail
+    dict(L=5, D=20, in_w=2, Ts=[50, 19], trans_share=(0, 5), lam_scale=0.2),      # more windows than wavefronts
 ]
 
 

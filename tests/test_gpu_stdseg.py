@@ -24,6 +24,8 @@ CASES = [
     dict(L=5, D=2, in_w=4, Ts=[1, 6, 9], trans_share=(4, 9)),
     dict(L=4, D=5, in_w=3, Ts=[4, 5, 6, 15]),                                 # T = D-1, D, D+1, 3D; bias-only transitions
     dict(L=12, D=4, in_w=4, Ts=[20, 9], lam_scale=0.1),                       # 48 full labels
+    dict(L=70, D=2, in_w=2, Ts=[5, 3], lam_scale=0.1),                        # more phones than lanes (two lane rounds), 33+ previous labels per walk
+    dict(L=9, D=12, in_w=2, Ts=[30], lam_scale=0.1),                          # 108 previous labels: the 32-deep load batches and their tail
 ]
 
 

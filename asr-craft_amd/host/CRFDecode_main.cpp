@@ -88,8 +88,6 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> sents;
   try {
     if (m.mtype == STDFRAME && m.D != 1) throw std::runtime_error("the maximum duration of labels must be 1 for \"stdframe\" CRF model.");
-    if (m.fmap.numStates != 1)
-      throw std::runtime_error("CRFDecode: crf_states > 1 is not built in the Viterbi decoder (CRFTrain and CRFFstDecode take it for the frame-level model)");
     if (m.mtype != STDFRAME && m.mtype != STDSEG_NO_DUR_NO_SEGTRANSFTR)
       throw std::runtime_error("CRF_ViterbiDecoder for CRF models other than \"stdframe\" and \"stdseg_no_dur_no_segtransftr\" have not been implmented.");
     crf.setFeatureMap(CRF_FeatureMap::createFeatureMap(&m.fmap));

@@ -1471,6 +1471,76 @@ void crf_amd::writeFstBinary(const char* fname, const crf_amd::ArcListFst& fst, 
   }
 }
 
+int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeNState(const crf_amd::ArcListFst* lm, crf_amd::ArcListFst* result_fst) {
+  const modeltype mt = crf->getModelType();
+  if (mt != STDFRAME && mt != STDSEG_NO_DUR_NO_TRANSFTR && mt != STDSEG_NO_DUR_NO_SEGTRANSFTR)
+    throw runtime_error("nStateDecode: crf_states > 1 is built for stdframe and stdseg_no_dur_no_segtransftr");
+  crf_amd::Engine* e = crf->engine();
+  crf->pushLambda();
+  std::vector<HeldUtt> utts(1);
+  grab(ftr_strm, crf, &utts[0]);
+  BatchGuard g{e};
+  make_batch(e, ftr_strm, utts, &g);
+  const uint32_t T = utts[0].u.T, L = crf->getNActualLabs() ? crf->getNActualLabs() : crf->getNLabs();
+  const uint32_t K = crf->getFeatureMap()->getNumStates(), P = L / K;
+  segs.clear();
+  zx = 0.0;
+  best_weight = 0.0f;
+  if (T == 0) return 0;
+  uint64_t na = 0;
+  uint32_t n_states = 0;
+  int32_t fin = -1;
+  e->check(scrf_lattice_arcs(e->h, g.b, 0, 0, nullptr, &na, &n_states, &fin), "nStateDecode");
+  std::vector<scrf_arc> arcs(na);
+  e->check(scrf_lattice_arcs(e->h, g.b, 0, 0, arcs.data(), &na, &n_states, &fin), "nStateDecode");
+  e->check(scrf_forward_backward(e->h, g.b, 0, SCRF_PREC_EXACT, nullptr, nullptr, nullptr, &zx), "nStateDecode");
+  // every state but the start (0) and the final one belongs to a label: (state - 1) % L in the frame lattice
+  // (1 + t*L + c) and in the segmental one (boundary and segment states of a node are two runs of L)
+  crf_amd::ArcListFst lat;
+  lat.n_states = (int)n_states;
+  lat.start = 0;
+  lat.arcs.reserve(arcs.size());
+  for (const scrf_arc& a : arcs) {
+    if (a.dst == fin) {   // leave the utterance from a phone's end state
+      const uint32_t p = (uint32_t)(a.src - 1) % L;
+      if ((p + 1) % K == 0) lat.finals.push_back(std::make_pair((int)a.src, a.w));
+      continue;
+    }
+    const uint32_t c = (uint32_t)(a.dst - 1) % L;
+    scrf_arc x = a;
+    x.olabel = 0;
+    if (a.src == 0) {     // the utterance opens with a phone's start state
+      if (c % K != 0) continue;
+      x.olabel = (int32_t)(c / K) + 1;
+    } else {
+      const uint32_t p = (uint32_t)(a.src - 1) % L;
+      if (p != c && c % K == 0) x.olabel = (int32_t)(c / K) + 1;   // end state of a phone -> start state of the next
+    }
+    lat.arcs.push_back(x);
+  }
+  crf_amd::ArcListFst loop;
+  if (!lm) {   // createFreePhoneLmFst: one state, every phone, weight 0
+    const int s0 = loop.AddState();
+    loop.SetStart(s0);
+    for (uint32_t p = 0; p < P; p++) loop.AddArc(s0, crf_amd::ArcListFst::Arc((int)p + 1, (int)p + 1, 0.0f, s0));
+    loop.SetFinal(s0, 0.0f);
+    lm = &loop;
+  }
+  float total = 0.0f;
+  if (!crf_amd::composeShortestPath(lat, *lm, result_fst, &total)) {   // "Could not reach end of utterance" (:2141-2147)
+    *result_fst = crf_amd::ArcListFst();
+    const int s0 = result_fst->AddState(), s1 = result_fst->AddState();
+    result_fst->SetStart(s0);
+    result_fst->AddArc(s0, crf_amd::ArcListFst::Arc(0, 0, 8, s1));
+    result_fst->SetFinal(s1, (float)zx);
+    return (int)T;
+  }
+  best_weight = total;
+  result_fst->final_weight += (float)zx;
+  for (auto& f : result_fst->finals) f.second += (float)zx;
+  return (int)T;
+}
+
 int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst) {
   require_dense_model(crf, "CRF_ViterbiDecoder_StdSeg_NoSegTransFtr");
   crf_amd::Engine* e = crf->engine();

@@ -602,6 +602,7 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   int nStateDecode(Fst* result_fst, Fst* lm_fst, Fst* out_full_fst, double input_beam, unsigned min_hyps = 0, unsigned max_hyps = 0, float beam_inc = 0.05f) {
     (void)out_full_fst; (void)min_hyps; (void)max_hyps; (void)beam_inc;
     if (if_output_full_fst) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: the full output lattice is not built (use CRF_LatticeBuilder)");
+    if (crf->getFeatureMap() && crf->getFeatureMap()->getNumStates() > 1) return decodeNState(lm_fst, result_fst);
     if (lm_fst != nullptr) return decodeLm(*lm_fst, input_beam, result_fst);
     const int T = decode();
     typedef typename Fst::Arc Arc;
@@ -640,6 +641,20 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
     throw std::runtime_error("nStateDecode: an LM FST must be a crf_amd::ArcListFst");
   }
   int decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst);
+  // crf_states = K > 1 (CRF_ViterbiDecoder::nStateDecode, decoders/CRF_ViterbiDecoder.cpp:398-960, and the n-state
+  // branches of this class's :246-735): a phone is its K states in order, each held for one or more frames (segments);
+  // a hypothesis enters a phone at its start state along an LM arc with ilabel phone+1, leaves it from its end state,
+  // an utterance starts at a start state and ends at an end state (:452-453, :899-906).  Searched here WITHOUT pruning,
+  // as the shortest path of [the n-state lattice of the utterance, with the phone's LM token on every arc that enters a
+  // start state from outside its phone and the final arcs of the end states only] composed with the LM (or the free
+  // phone loop when lm_fst == NULL): the reference's beam search returns the same path whenever its beam does not
+  // prune it (ties: unpinned).  Result: one arc per lattice arc that carries a label and per LM word, StdArc(state
+  // label + 1 [+ nLabs*(dur-1) for a segmental model], word where a phone starts else 0, weight, next); final weight
+  // Zx + the LM's final weight.
+  template <class Fst> int decodeNState(const Fst*, Fst*) {
+    throw std::runtime_error("nStateDecode: with crf_states > 1 the result and LM FSTs must be crf_amd::ArcListFst");
+  }
+  int decodeNState(const crf_amd::ArcListFst* lm, crf_amd::ArcListFst* result_fst);
   size_t lastNumHyps() const { return n_hyps; }   // hypotheses kept, summed over frames (beam diagnostics)
 
  protected:

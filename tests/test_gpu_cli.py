@@ -1184,12 +1184,23 @@ def test_crftrain_and_fstdecode_with_three_states_per_label(tmp_path):
         arcs, ns, fin = orc.nstate_lattice_arcs(cfg, S, TD, TO, TE, T)
         ol, _ = orc.best_path(arcs, ns, fin)
         assert list(got[got[:, 0] == u][:, 2]) == list(ol)
-    # the LM decoder says that it does not take several states per label
+    # CRFDecode (free phone loop): phones are entered at their start state and left from their end state, the utterance
+    # too -- the shortest path of the oracle's lattice under those restrictions; words where a phone starts
     olist = str(tmp_path / "olist")
     open(olist, "w").write("u0\nu1\nu2\n")
-    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + flags + ["weight_file=" + out, "crf_output_labelfile=" + str(tmp_path / "d2.txt"), "crf_olist=" + olist],
-                       capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "crf_states" in (r.stderr + r.stdout)
+    latdir = tmp_path / "lat"; latdir.mkdir()
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + flags + ["weight_file=" + out, "crf_olist=" + olist, "crf_lat_outdir=" + str(latdir),
+                        "crf_output_mlffile=" + str(tmp_path / "o.mlf")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for u, (X, _) in enumerate(utts):
+        T = X.shape[0]
+        S, TD, TO, TE = orc.nstate_scores(cfg, lay, w, X, T)
+        arcs, ns, fin = orc.nstate_lattice_arcs(cfg, S, TD, TO, TE, T)
+        want_labs, want_words, want_cost = _nstate_restricted_best_path(arcs, ns, fin, 48, K)
+        got = [x.split() for x in open(str(latdir / ("u%d.fst.txt" % u))).read().strip().split("\n")]
+        assert [int(g[2]) - 1 for g in got[:-1]] == want_labs
+        assert [int(g[3]) for g in got[:-1]] == want_words
+        assert abs(sum(float(g[4]) for g in got[:-1]) - want_cost) <= 1e-4 * max(1.0, abs(want_cost))
 
 
 def test_crftrain_and_fstdecode_segmental_model_with_states_per_phone(tmp_path):
@@ -1247,11 +1258,99 @@ def test_crftrain_and_fstdecode_segmental_model_with_states_per_phone(tmp_path):
         assert list(got[got[:, 0] == u][:, 2]) == list(ol)
         seq = [int(x) % L for x in ol]
         assert all(orc.ns_allowed(K, a, b) for a, b in zip(seq, seq[1:]))
+    # CRFDecode, free phone loop and a phone-bigram LM: the restricted shortest path / exhaustive enumeration
     olist = str(tmp_path / "olist")
     open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
-    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_output_labelfile=" + str(tmp_path / "dec2.txt"), "crf_olist=" + olist],
-                       capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "crf_states" in (r.stderr + r.stdout)
+    lmf = str(tmp_path / "lm.txt")
+    lmw = np.round(rng.random_sample((P + 1, P)) * 2, 3)      # state 0 = start, state 1 + p = after phone p
+    with open(lmf, "w") as f:
+        for q in range(P + 1):
+            for p in range(P):
+                f.write("%d %d %d %d %.3f\n" % (q, 1 + p, p + 1, 10 + p, lmw[q, p]))
+        for q in range(1, P + 1):
+            f.write("%d %.3f\n" % (q, 0.25 * q))
+    for use_lm in (False, True):
+        latdir = tmp_path / ("lat%d" % use_lm); latdir.mkdir()
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_lat_outdir=" + str(latdir),
+                            "crf_output_mlffile=" + str(tmp_path / ("o%d.mlf" % use_lm))] + (["crf_lm_txt=" + lmf] if use_lm else []),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for u, T in enumerate(Ts):
+            S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+            oa, ons, ofin = orc.seg_lattice_arcs(cfg, S, M, T)
+            got = [x.split() for x in open(str(latdir / ("u%d.fst.txt" % u))).read().strip().split("\n")]
+            glabs = [int(g[2]) - 1 for g in got[:-1] if int(g[2]) != 0]
+            gwords = [int(g[3]) for g in got[:-1] if int(g[3]) != 0]
+            gcost = sum(float(g[4]) for g in got[:-1])
+            if not use_lm:
+                want_labs, want_words, want_cost = _nstate_restricted_best_path(oa, ons, ofin, L, K)
+                assert glabs == [x for x in want_labs if x >= 0] and gwords == [x for x in want_words if x]
+                assert abs(gcost - want_cost) <= 1e-4 * max(1.0, abs(want_cost))
+            elif T <= 7:     # exhaustive enumeration of the topology's labelled segmentations x the LM
+                bf = orc.brute_force(S, M, T, L, D, K=K)
+                best = None
+                for sc, segs in bf["paths"]:
+                    seq = [l for (_, _, l) in segs]
+                    if seq[0] % K != 0 or (seq[-1] + 1) % K != 0:
+                        continue
+                    phones = [seq[0] // K] + [b // K for a, b in zip(seq, seq[1:]) if a != b and b % K == 0]
+                    q, lw = 0, 0.0
+                    for ph in phones:
+                        lw += lmw[q, ph]; q = 1 + ph
+                    tot = -sc + lw + 0.25 * q
+                    if best is None or tot < best[0]:
+                        best = (tot, [l + L * (d - 1) for (_, d, l) in segs], [10 + ph for ph in phones])
+                assert abs(gcost + float(got[-1][1]) - float(np.float32(ozx_of(cfg, S, M, T))) - best[0]) <= 1e-3 * max(1.0, abs(best[0]))
+                assert glabs == best[1] and gwords == best[2]
+
+
+def ozx_of(cfg, S, M, T):
+    rc, _, _, _, zx = orc.seg_forward(cfg, S, M, T)
+    assert rc == 0
+    return zx
+
+
+def _nstate_restricted_best_path(arcs, n_states, fin, L, K):
+    """Shortest path of an n-state lattice (frame or segmental) when a phone may only be entered at its start state --
+    from outside the lattice's start or from a phone's end state -- and the utterance ends in an end state: labels
+    (ilabel - 1 of every arc of the path that carries one, -1 for epsilon arcs), the phone token (phone + 1) on the arcs
+    that enter a phone (0 elsewhere), total cost.  Float accumulation start -> end, first relaxed wins."""
+    INF = np.float32(np.inf)
+    dist = np.full(n_states, INF, dtype=np.float32); dist[0] = 0
+    back = [None] * n_states
+    order = np.argsort(arcs["src"], kind="stable")
+    for a in arcs[order]:
+        src, dst = int(a["src"]), int(a["dst"])
+        if dist[src] == INF:
+            continue
+        tok = 0
+        if dst == fin:
+            if (((src - 1) % L) + 1) % K != 0:
+                continue
+        else:
+            c = (dst - 1) % L
+            if src == 0:
+                if c % K != 0:
+                    continue
+                tok = c // K + 1
+            else:
+                p = (src - 1) % L
+                if p != c and c % K == 0:
+                    tok = c // K + 1
+        w = np.float32(dist[src] + np.float32(a["w"]))
+        if w < dist[dst]:
+            dist[dst] = w; back[dst] = (src, int(a["ilabel"]), tok)
+    labs, words = [], []
+    at = fin
+    while back[at] is not None:
+        src, il, tok = back[at]
+        if at != fin:
+            labs.append(il - 1 if il else -1); words.append(tok)
+        at = src
+    labs.reverse(); words.reverse()
+    # epsilon arcs that carry neither a label nor a token vanish from the decoder's chain
+    keep = [(l, t) for l, t in zip(labs, words) if l >= 0 or t]
+    return [l for l, _ in keep], [t for _, t in keep], float(dist[fin])
 
 
 def test_crffstdecode_align_mode_on_bundled_fixture(tmp_path):

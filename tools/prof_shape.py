@@ -16,3 +16,5 @@ eng.enable_timing(True)
 for _ in range(reps):
     eng.zero_grad(); eng.fb_batch(b)
 print(name, {k: round(v[0], 2) for k, v in eng.last_timing().items()})
+for nm, ms, nl in sorted(eng.kernel_timing(), key=lambda x: -x[1])[:12]:
+    print("   %-44s %9.3f ms  (%d launches)" % (nm, ms, nl))

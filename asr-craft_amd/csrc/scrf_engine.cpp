@@ -1364,7 +1364,7 @@ static int stdseg_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u
     HIPCHK(h, hipMemsetAsync(sb.mass_t, 0, sizeof(double) * nfr, st));
     KT_RUN("k_stdseg_post", st, launch_stdseg_post(st, l, La, bv, u0, u1 - u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.S, sb.MX, sb.alpha, sb.beta,
                                                    b->d_zx, sb.G, sb.XI, sb.mass_s, sb.mass_t, b->d_numer, b->d_status));
-    KT_RUN("k_stdseg_expf", st, launch_stdseg_expf(st, l, La, bv, u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.X, sb.G, sb.XI, grad));
+    KT_RUN("k_stdseg_expf", st, launch_stdseg_expf(st, l, La, bv, u0, u1 - u0, nseg, sb.row_t, sb.row_d, sb.row_u, b->d_prev_lab, sb.X, sb.G, sb.XI, grad));
   }
   HIPCHK(h, hipGetLastError());
   if (out) *out = sb;

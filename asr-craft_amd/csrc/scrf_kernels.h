@@ -156,7 +156,7 @@ void launch_stdseg_post(hipStream_t st, const ScrfLayout& lay, uint32_t La, Scrf
                         uint64_t n_rows, const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u,
                         const uint32_t* prev_lab, const double* S, const double* MX, const double* alpha, const double* beta,
                         const double* zx, double* G, double* XI, double* mass_s, double* mass_t, double* numer, int* status);
-void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint64_t n_rows,
+void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint64_t n_rows,
                         const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u, const uint32_t* prev_lab,
                         const float* X, const double* G, const double* XI, double* grad);
 void launch_stdseg_sums(hipStream_t st, const double* numer, const double* zx, uint32_t u0, uint32_t n, double* sums);

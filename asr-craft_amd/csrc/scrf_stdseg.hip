@@ -314,17 +314,21 @@ __global__ void k_stdseg_numer(ScrfLayout lay, uint32_t La, ScrfBatchView bv, ui
 // gradient: one thread per weight: grad[i] += (observed count) - (expected count) over the chunk's rows, rows ascending
 // (computeStateExpF / computeTransExpF of ftrmaps/CRF_StdFeatureMap.cpp:130-223 summed over nodes and labels)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stdseg_expf(ScrfLayout lay, uint32_t La, ScrfBatchView bv, uint32_t u0,
+__global__ __launch_bounds__(256) void k_stdseg_expf(ScrfLayout lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                                                      uint64_t n_rows, const uint32_t* __restrict__ row_t,
                                                      const uint32_t* __restrict__ row_d, const uint32_t* __restrict__ row_u,
                                                      const uint32_t* __restrict__ prev_lab, const float* __restrict__ X,
                                                      const double* __restrict__ G, const double* __restrict__ XI,
                                                      double* __restrict__ grad) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= lay.lambda_len) return;
+  // thread -> weight with the phone fastest: the lanes of a wavefront read consecutive phones of one (row, previous
+  // label) line of XI / one row of G (a weight-major assignment reads one 128-byte line per lane and row)
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= lay.lambda_len) return;
   const uint32_t NL = lay.L;
-  const uint32_t clab = i / lay.stride, r = i % lay.stride;
-  const uint32_t dur = clab / La + 1, lab = clab % La;
+  const uint32_t lab = tid % La, q = tid / La;
+  const uint32_t dur = q / lay.stride + 1, r = q % lay.stride;
+  const uint32_t clab = (dur - 1) * La + lab;
+  const uint32_t i = clab * lay.stride + r;
   const bool is_state = r < lay.nsf;
   uint32_t plab = 0, k = r;
   if (!is_state) { plab = (r - lay.nsf) / lay.ntf; k = (r - lay.nsf) % lay.ntf; }
@@ -333,10 +337,13 @@ __global__ __launch_bounds__(256) void k_stdseg_expf(ScrfLayout lay, uint32_t La
   const uint32_t col = is_state ? lay.sfs + k : lay.tfs + k;
   const double bval = is_state ? lay.sbv : lay.tbv;
   double expected = 0.0, observed = 0.0;
-  for (uint64_t row = 0; row < n_rows; row++) {
-    if (row_d[row] != dur) continue;
+  // the rows of this weight's duration, in row order: window (t, dur) of every node t >= dur - 1 of every utterance
+  for (uint32_t u = u0; u < u0 + n_utts; u++) {
+   const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+   const uint32_t T = bv.T[u];
+   for (uint32_t t = dur - 1; t < T; t++) {
+    const uint64_t row = s_base + scrf_seg_base(t, lay.D) + dur - 1;
     const double x = bias ? bval : (double)X[row * lay.F + col];
-    const uint32_t u = row_u[row], t = row_t[row];
     const uint32_t tl = bv.labels ? bv.labels[bv.frame_off[u] + t] : SCRF_LAB_BAD;
     if (is_state) {
       expected += G[row * La + lab] * x;
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(256) void k_stdseg_expf(ScrfLayout lay, uint32_t La
           dur <= scrf_num_prev(t, lay.D) && plab < La * scrf_node_max_dur(t - dur, lay.D))
         observed += x;
     }
+   }
   }
   grad[i] += observed - expected;
 }
@@ -524,11 +532,11 @@ void launch_stdseg_post(hipStream_t st, const ScrfLayout& lay, uint32_t La, Scrf
   hipLaunchKernelGGL(k_stdseg_numer, dim3((n_utts + 63) / 64), dim3(64), 0, st, lay, La, bv, u0, n_utts, prev_lab, S, MX, mass_s,
                      mass_t, numer, status);
 }
-void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint64_t n_rows,
+void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint64_t n_rows,
                         const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u, const uint32_t* prev_lab,
                         const float* X, const double* G, const double* XI, double* grad) {
   if (n_rows == 0) return;
-  hipLaunchKernelGGL(k_stdseg_expf, dim3((lay.lambda_len + 255) / 256), dim3(256), 0, st, lay, La, bv, u0, n_rows, row_t, row_d,
+  hipLaunchKernelGGL(k_stdseg_expf, dim3((lay.lambda_len + 255) / 256), dim3(256), 0, st, lay, La, bv, u0, n_utts, n_rows, row_t, row_d,
                      row_u, prev_lab, X, G, XI, grad);
 }
 void launch_stdseg_sums(hipStream_t st, const double* numer, const double* zx, uint32_t u0, uint32_t n, double* sums) {

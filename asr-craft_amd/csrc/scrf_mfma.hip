@@ -38,32 +38,34 @@ typedef float v4f32 __attribute__((ext_vector_type(4)));
 // launch bound 2 waves per SIMD: left alone the compiler takes 210 VGPRs + 96 AGPRs for the f64 form
 // (one wavefront per SIMD, matrix pipe 47 % busy at the TIMIT transition scores); capped at 256 it
 // needs 218 with no spills and the second workgroup per CU hides staging and barriers (1.35x)
-template <int F32>
+// NT: N-tiles (16 outputs each) of this launch's workgroups: 3, or the 1 / 2 of the remainder launch when the output
+// count is not a multiple of 48 (200 outputs = 4 x 48 + 8: empty tiles would cost 2/15 of the matrix time)
+template <int F32, int NT>
 __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      const double* __restrict__ lambda, ScrfLayout lay,
-                                                     ScrfGemmSpec sp, uint32_t n_out, double* __restrict__ out) {
+                                                     ScrfGemmSpec sp, uint32_t n_out, uint32_t o_base, double* __restrict__ out) {
   __shared__ float Xs[SM_ROWS * SM_XS];
   __shared__ double Ws[SM_KC * SM_WS];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint64_t row0 = (uint64_t)blockIdx.x * SM_ROWS;
-  const uint32_t o0 = blockIdx.y * SM_NO;
+  const uint32_t o0 = o_base + blockIdx.y * SM_NO;
   const uint32_t fs = sp.fs;
   const uint32_t nfe = sp.nfe;
   const int use_b = sp.use_bias;
   const double bv = sp.bias;
 
-  v4f64 acc[F32 ? 1 : 4][F32 ? 1 : 3];
-  v4f32 acc32[F32 ? 4 : 1][F32 ? 3 : 1];
+  v4f64 acc[F32 ? 1 : 4][F32 ? 1 : NT];
+  v4f32 acc32[F32 ? 4 : 1][F32 ? NT : 1];
 #pragma unroll
   for (int m = 0; m < (F32 ? 1 : 4); m++)
 #pragma unroll
-    for (int n = 0; n < (F32 ? 1 : 3); n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < (F32 ? 1 : NT); n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int m = 0; m < (F32 ? 4 : 1); m++)
 #pragma unroll
-    for (int n = 0; n < (F32 ? 3 : 1); n++) acc32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = 0; n < (F32 ? NT : 1); n++) acc32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
   float* Wsf = (float*)Ws;  // F32: the lambda image holds floats, row stride 2*SM_WS floats
 
   // staging coordinates: 8 threads cover one row's 32-float chunk, 32 rows per pass, 8 passes
@@ -132,26 +134,26 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
 #pragma unroll
     for (int ks = 0; ks < SM_KC / 4; ks++) {
       if (F32) {
-        float b[3];
+        float b[NT];
 #pragma unroll
-        for (int n = 0; n < 3; n++) b[n] = Wsf[(ks * 4 + lk) * (2 * SM_WS) + n * 16 + li];
+        for (int n = 0; n < NT; n++) b[n] = Wsf[(ks * 4 + lk) * (2 * SM_WS) + n * 16 + li];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
           const float a = Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
 #pragma unroll
-          for (int n = 0; n < 3; n++)
+          for (int n = 0; n < NT; n++)
             acc32[F32 ? m : 0][F32 ? n : 0] =
                 __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc32[F32 ? m : 0][F32 ? n : 0], 0, 0, 0);
         }
       } else {
-        double b[3];
+        double b[NT];
 #pragma unroll
-        for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SM_WS + n * 16 + li];
+        for (int n = 0; n < NT; n++) b[n] = Ws[(ks * 4 + lk) * SM_WS + n * 16 + li];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
           const double a = (double)Xs[(wave * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
 #pragma unroll
-          for (int n = 0; n < 3; n++)
+          for (int n = 0; n < NT; n++)
             acc[F32 ? 0 : m][F32 ? 0 : n] =
                 __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
         }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
     __syncthreads();
   }
 #pragma unroll
-  for (int n = 0; n < 3; n++) {
+  for (int n = 0; n < NT; n++) {
     const uint32_t o = o0 + n * 16 + li;
     if (o >= n_out) continue;
     double bias = 0.0;
@@ -178,15 +180,27 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
   }
 }
 
+template <int F32>
+static void launch_scores_mfma_f(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
+                                 const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out, double* out) {
+  const uint32_t gx = (uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS);
+  const uint32_t n_full = n_out / SM_NO, rem = n_out % SM_NO;
+  if (n_full)
+    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx, n_full), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, 0u, out);
+  // the outputs past the last full 48: a launch whose workgroups carry only the N-tiles that hold outputs
+  if (rem > 32)
+    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx, 1), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, out);
+  else if (rem > 16)
+    hipLaunchKernelGGL((k_scores_mfma<F32, 2>), dim3(gx, 1), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, out);
+  else if (rem > 0)
+    hipLaunchKernelGGL((k_scores_mfma<F32, 1>), dim3(gx, 1), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, out);
+}
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
                         double* out, int f32) {
   if (n_rows == 0 || n_out == 0) return;
-  dim3 grid((uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS), (n_out + SM_NO - 1) / SM_NO);
-  if (f32)
-    hipLaunchKernelGGL(k_scores_mfma<1>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
-  else
-    hipLaunchKernelGGL(k_scores_mfma<0>, grid, dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
+  if (f32) launch_scores_mfma_f<1>(st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
+  else launch_scores_mfma_f<0>(st, X, F, xrow, n_rows, lambda, lay, sp, n_out, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -199,12 +213,13 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 // that the staging/barrier cost per MFMA stays low when few wavefronts share one R tile.
 // F32 = 1: operands rounded to f32 (R is in [-1,1]), v_mfma_f32_16x16x4_f32 within a staged chunk of
 // EM_KC rows, chunk results flushed into f64 accumulators (so the K = millions-of-rows sum is f64).
-template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0>
+// MT: M-tiles (16 outputs each) a wavefront carries: 3, or the 1 / 2 of the remainder launch (o_base = its first output)
+template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0, int MT = 3>
 __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                       ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
-                                                      double* __restrict__ slab) {
+                                                      double* __restrict__ slab, uint32_t o_base) {
   constexpr int NT = 64 * NW;            // threads
   // SPLIT_OUT: the wavefronts share one 48-column feature tile and own 48 outputs each (few feature functions, many
   // outputs: the per-window transition posteriors, n_out = L * L); otherwise 48 outputs and 48 feature columns per wavefront
@@ -225,14 +240,14 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   const float bias = sp.use_bias ? (float)sp.bias : 0.0f;
   const bool bias_exact = (double)bias == sp.bias;
   const uint32_t fb = blockIdx.x * NF;
-  const uint32_t o0 = blockIdx.y * NO;
+  const uint32_t o0 = o_base + blockIdx.y * NO;
   const uint32_t wo = SPLIT_OUT ? wave * 48 : 0, wf = SPLIT_OUT ? 0 : wave * 48;   // this wavefront's output / feature offset in the tile
   const uint64_t r_begin = (uint64_t)blockIdx.z * rows_per_chunk;
   const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
 
-  v4f64 acc[3][3];
+  v4f64 acc[MT][3];
 #pragma unroll
-  for (int m = 0; m < 3; m++)
+  for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
@@ -310,25 +325,25 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     __syncthreads();
     if (r0 + EM_KC < r_end) load_chunk(r0 + EM_KC);
     if (F32) {
-      v4f32 c32[3][3];
+      v4f32 c32[MT][3];
 #pragma unroll
-      for (int m = 0; m < 3; m++)
+      for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int n = 0; n < 3; n++) c32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int ks = 0; ks < EM_KC / 4; ks++) {
-        float a[3], b[3];
+        float a[MT], b[3];
 #pragma unroll
-        for (int m = 0; m < 3; m++) a[m] = (float)Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
+        for (int m = 0; m < MT; m++) a[m] = (float)Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
 #pragma unroll
         for (int n = 0; n < 3; n++) b[n] = Xs[(ks * 4 + lk) * XS + wf + n * 16 + li];
 #pragma unroll
-        for (int m = 0; m < 3; m++)
+        for (int m = 0; m < MT; m++)
 #pragma unroll
           for (int n = 0; n < 3; n++) c32[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], c32[m][n], 0, 0, 0);
       }
 #pragma unroll
-      for (int m = 0; m < 3; m++)
+      for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int n = 0; n < 3; n++)
 #pragma unroll
@@ -336,13 +351,13 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     } else {
 #pragma unroll
       for (int ks = 0; ks < EM_KC / 4; ks++) {
-        double a[3], b[3];
+        double a[MT], b[3];
 #pragma unroll
-        for (int m = 0; m < 3; m++) a[m] = Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
+        for (int m = 0; m < MT; m++) a[m] = Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
 #pragma unroll
         for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wf + n * 16 + li];
 #pragma unroll
-        for (int m = 0; m < 3; m++)
+        for (int m = 0; m < MT; m++)
 #pragma unroll
           for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
       }
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     if (col >= nfun) continue;
     const double sc = (col == nfe) ? bfix : 1.0;
 #pragma unroll
-    for (int m = 0; m < 3; m++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint32_t o = o0 + wo + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
@@ -366,22 +381,38 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   }
 }
 
+template <int HAS_XROW, int NW, int KC, int F32, int MT>
+static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                                 const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
+                                 uint64_t rows_per_chunk, double* slab, uint32_t o_base) {
+  hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                     rows_per_chunk, slab, o_base);
+}
+template <int HAS_XROW, int NW, int KC, int F32>
+static void launch_expf_mfma_x(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
+                               const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
+                               uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+  const uint32_t nfun = sp.nfun();
+  const uint32_t gx = (nfun + 48 * NW - 1) / (48 * NW);
+  const size_t sm = sizeof(double) * KC * EM_NO + sizeof(float) * KC * (48 * NW + 16);
+  const uint32_t n_full = n_out / EM_NO, rem = n_out % EM_NO;
+  if (n_full)
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 3>(st, dim3(gx, n_full, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, 0u);
+  // the outputs past the last full 48: workgroups that carry only the M-tiles holding outputs
+  if (rem > 32)
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 3>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * EM_NO);
+  else if (rem > 16)
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 2>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * EM_NO);
+  else if (rem > 0)
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 1>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * EM_NO);
+}
 template <int NW, int KC, int F32>
 static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                 const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
-  const uint32_t nfun = sp.nfun();
-  dim3 grid((nfun + 48 * NW - 1) / (48 * NW), (n_out + EM_NO - 1) / EM_NO, n_chunks);
-  const size_t sm = sizeof(double) * KC * EM_NO + sizeof(float) * KC * (48 * NW + 16);
-  if (xrow) {
-    hipFuncSetAttribute((const void*)k_expf_mfma<1, NW, KC, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab);
-  } else {
-    hipFuncSetAttribute((const void*)k_expf_mfma<0, NW, KC, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab);
-  }
+  if (xrow) launch_expf_mfma_x<1, NW, KC, F32>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
+  else launch_expf_mfma_x<0, NW, KC, F32>(st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab);
 }
 
 // few feature functions (<= 48) and many outputs: 4 wavefronts share the feature tile and split 192 outputs
@@ -394,10 +425,10 @@ static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_o
   const size_t sm = sizeof(double) * KC * EM_NO * NW + sizeof(float) * KC * (48 + 16);
   if (xrow)
     hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab);
+                       rows_per_chunk, slab, 0u);
   else
     hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32, 1>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab);
+                       rows_per_chunk, slab, 0u);
 }
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,

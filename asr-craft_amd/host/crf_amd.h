@@ -582,8 +582,8 @@ typedef CRF_LatticeBuilder CRF_LatticeBuilder_StdSeg_WithoutDurLab_WithoutSegTra
 // viterbiDurs / isPhoneStartBoundary, nodes/CRF_StateNode.h:60-65) exist here in their dense form
 // on the device (best weight, back pointer and duration per frame x label) and bestSegments()
 // is the backtrace (:2204-2290).  The search is exhaustive: a positive beam cannot lose the best
-// path here, whereas the reference's pruned search can.  LM-constrained decoding (lm_fst != NULL)
-// needs an FST library and is refused.
+// path here, whereas the reference's pruned search can.  With an LM (lm_fst != NULL): decodeLm below; with
+// several states per label: decodeNState.
 class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
  public:
   CRF_ViterbiDecoder_StdSeg_NoSegTransFtr(CRF_FeatureStream* ftr_strm_in, CRF_Model* crf_in) : ftr_strm(ftr_strm_in), crf(crf_in) {}

@@ -21,6 +21,15 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 
+// XCD-aware workgroup order (cdna_hip_programming.md T1): workgroup ids go round-robin over the 8 XCDs, each with its own
+// L2, so neighbours in launch order do not share a cache.  swz gives every XCD a contiguous run of the logical order
+// (bijective for any workgroup count); the kernels below order their tiles so that a run holds the tiles that read the
+// same rows of X.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nwg) {
+  const uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
 #define SM_ROWS 256  // rows per workgroup (4 waves x 4 M-tiles)
 #define SM_KC 32     // features per staged chunk (8 MFMA k-steps)
 #define SM_XS 34     // float row stride of the X image (== 2 mod 32: conflict-free A fragments)
@@ -44,13 +53,16 @@ template <int F32, int NT>
 __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      const double* __restrict__ lambda, ScrfLayout lay,
-                                                     ScrfGemmSpec sp, uint32_t n_out, uint32_t o_base, double* __restrict__ out) {
+                                                     ScrfGemmSpec sp, uint32_t n_out, uint32_t o_base, uint32_t gy, double* __restrict__ out) {
   __shared__ float Xs[SM_ROWS * SM_XS];
   __shared__ double Ws[SM_KC * SM_WS];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
-  const uint64_t row0 = (uint64_t)blockIdx.x * SM_ROWS;
-  const uint32_t o0 = o_base + blockIdx.y * SM_NO;
+  // 1-D launch: the gy output tiles of a row block are neighbours in the swizzled order (one XCD reads the block's X
+  // rows once for all of them; the lambda tiles come from L2 / the Infinity Cache)
+  const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const uint64_t row0 = (uint64_t)(swz / gy) * SM_ROWS;
+  const uint32_t o0 = o_base + (swz % gy) * SM_NO;
   const uint32_t fs = sp.fs;
   const uint32_t nfe = sp.nfe;
   const int use_b = sp.use_bias;
@@ -186,14 +198,14 @@ static void launch_scores_mfma_f(hipStream_t st, const float* X, uint32_t F, con
   const uint32_t gx = (uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS);
   const uint32_t n_full = n_out / SM_NO, rem = n_out % SM_NO;
   if (n_full)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx, n_full), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, 0u, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx * n_full), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, 0u, n_full, out);
   // the outputs past the last full 48: a launch whose workgroups carry only the N-tiles that hold outputs
   if (rem > 32)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx, 1), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, 1u, out);
   else if (rem > 16)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 2>), dim3(gx, 1), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 2>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, 1u, out);
   else if (rem > 0)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 1>), dim3(gx, 1), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 1>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, 1u, out);
 }
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                       ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
-                                                      double* __restrict__ slab, uint32_t o_base) {
+                                                      double* __restrict__ slab, uint32_t o_base, uint32_t gx, uint32_t gy) {
   constexpr int NT = 64 * NW;            // threads
   // SPLIT_OUT: the wavefronts share one 48-column feature tile and own 48 outputs each (few feature functions, many
   // outputs: the per-window transition posteriors, n_out = L * L); otherwise 48 outputs and 48 feature columns per wavefront
@@ -239,10 +251,14 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   const uint32_t nfun = sp.nfun();
   const float bias = sp.use_bias ? (float)sp.bias : 0.0f;
   const bool bias_exact = (double)bias == sp.bias;
-  const uint32_t fb = blockIdx.x * NF;
-  const uint32_t o0 = o_base + blockIdx.y * NO;
+  // 1-D launch: the gx * gy tiles of a row chunk are neighbours in the swizzled order (they walk the same rows of A and X
+  // at the same time: one XCD's L2 serves them)
+  const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const uint32_t bx = swz % gx, by = (swz / gx) % gy, bz = swz / (gx * gy);
+  const uint32_t fb = bx * NF;
+  const uint32_t o0 = o_base + by * NO;
   const uint32_t wo = SPLIT_OUT ? wave * 48 : 0, wf = SPLIT_OUT ? 0 : wave * 48;   // this wavefront's output / feature offset in the tile
-  const uint64_t r_begin = (uint64_t)blockIdx.z * rows_per_chunk;
+  const uint64_t r_begin = (uint64_t)bz * rows_per_chunk;
   const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
 
   v4f64 acc[MT][3];
@@ -376,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint32_t o = o0 + wo + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
-        if (o < n_out) slab[((uint64_t)blockIdx.z * n_out + o) * nfun + col] = acc[m][n][r] * sc;
+        if (o < n_out) slab[((uint64_t)bz * n_out + o) * nfun + col] = acc[m][n][r] * sc;
       }
   }
 }
@@ -386,8 +402,8 @@ static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const dou
                                  const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                                  uint64_t rows_per_chunk, double* slab, uint32_t o_base) {
   hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                     rows_per_chunk, slab, o_base);
+  hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow,
+                     n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);
 }
 template <int HAS_XROW, int NW, int KC, int F32>
 static void launch_expf_mfma_x(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
@@ -424,11 +440,11 @@ static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_o
   dim3 grid(1, (n_out + EM_NO * NW - 1) / (EM_NO * NW), n_chunks);
   const size_t sm = sizeof(double) * KC * EM_NO * NW + sizeof(float) * KC * (48 + 16);
   if (xrow)
-    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab, 0u);
+    hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab, 0u, grid.x, grid.y);
   else
-    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32, 1>), grid, dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab, 0u);
+    hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab, 0u, grid.x, grid.y);
 }
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,

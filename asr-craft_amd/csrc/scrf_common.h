@@ -165,4 +165,14 @@ struct ScrfDecodeOut {
   double bound_scale;   // gamma_n + gamma_m, see above
 };
 
+// XCD-aware workgroup order (cdna_hip_programming.md T1): workgroup ids go round-robin over the 8 XCDs, each with its own
+// L2, so neighbours in launch order do not share a cache.  swz gives every XCD a contiguous run of the logical order
+// (bijective for any workgroup count); the kernels below order their tiles so that a run holds the tiles that read the
+// same rows of X.
+__host__ __device__ inline uint32_t xcd_swizzle(uint32_t bid, uint32_t nwg) {
+  const uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+
 #endif  // SCRF_COMMON_H_

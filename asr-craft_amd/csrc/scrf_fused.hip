@@ -165,7 +165,10 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t o0 = blockIdx.y * 48;
-  const FuTile ft = fu_tile(fa, fa.tiles[fa.tile0 + blockIdx.x]);
+  // the tiles of an utterance are neighbours in the tile list and gather the same P rows and raw frames: with one
+  // output block (L <= 48) the XCD-aware order keeps them on one XCD's L2
+  const uint32_t tix = gridDim.y == 1 ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  const FuTile ft = fu_tile(fa, fa.tiles[fa.tile0 + tix]);
   float* Wgf = (float*)Wg;
   const uint32_t cpg = (W + FU_GC - 1) / FU_GC;  // chunks per group
   // lambda chunk prefetch registers: element e = tid + 512*q of the [48][40] chunk

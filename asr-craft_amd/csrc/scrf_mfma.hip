@@ -21,15 +21,6 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 
-// XCD-aware workgroup order (cdna_hip_programming.md T1): workgroup ids go round-robin over the 8 XCDs, each with its own
-// L2, so neighbours in launch order do not share a cache.  swz gives every XCD a contiguous run of the logical order
-// (bijective for any workgroup count); the kernels below order their tiles so that a run holds the tiles that read the
-// same rows of X.
-__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nwg) {
-  const uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-}
-
 #define SM_ROWS 256  // rows per workgroup (4 waves x 4 M-tiles)
 #define SM_KC 32     // features per staged chunk (8 MFMA k-steps)
 #define SM_XS 34     // float row stride of the X image (== 2 mod 32: conflict-free A fragments)

@@ -1008,7 +1008,9 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
 #pragma unroll
     for (int q = 0; q < FE_NFP; q++) fp[q] = (tid + FE_NT * q < n) ? src[tid + FE_NT * q] : 0.0f;
   };
-  uint64_t tile = blockIdx.x;
+  // tiles k*G .. (k+1)*G - 1 are in flight together; the XCD-aware slot order puts neighbours (tiles of one utterance,
+  // whose raw-frame ranges overlap) on one XCD
+  uint64_t tile = gridDim.y == 1 ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   FuTile ft, nft;
   ScrfTileDesc dn;   // descriptor of the tile after next
   if (tile < n_tiles) {

@@ -213,7 +213,9 @@ int scrf_get_batch_sums(scrf_handle h, double* sums3);
  * (La = num_labs / lab_max_dur) S is [N_seg][La] -- row (t,dur), phone = the node's stateArray[(dur-1)*La + phone] -- and
  * M is [N_seg][num_labs][La] = transMatrix[plab*num_labs + clab] (nodes/CRF_StdSegStateNode.cpp:83-127).  With num_states
  * = K > 1 on SCRF_STDFRAME (P = num_labs / K) S is [T][num_labs] and M is [T][2*num_labs + P*P]: the node's diagTransMatrix | offDiagTransMatrix
- * (entry c = transition c -> c+1) | denseTransMatrix (entry p*P + q = end state of phone p -> start state of phone q) */
+ * (entry c = transition c -> c+1) | denseTransMatrix (entry p*P + q = end state of phone p -> start state of phone q).
+ * With num_states = K > 1 on SCRF_STDSEG_NO_DUR_NO_(SEG)TRANSFTR the shapes are the one-state model's; M holds -1e30 (log 0)
+ * for the transitions the topology lacks (the reference's getTransValue throws there) */
 int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, double* M);
 /* window synthesis of utterance u: [N_seg][num_feas] (io/CRF_InFtrStream_SeqMultiWindow.cpp) */
 int scrf_windows(scrf_handle h, scrf_batch b, uint32_t u, float* windows);
@@ -227,7 +229,9 @@ int scrf_forward_backward(scrf_handle h, scrf_batch b, uint32_t u, uint32_t prec
 /* ---- decode -------------------------------------------------------------------------------- */
 /* replaces: buildLattice<StdArc> (decoders/CRF_LatticeBuilder_StdSeg_WithoutDurLab_
  * WithoutSegTransFtr.h:30-407; frame model decoders/CRF_LatticeBuilder.h:97-204): arcs in
- * the reference's AddArc order, weights float(-double).  Call with arcs==NULL to get counts. */
+ * the reference's AddArc order, weights float(-double).  Call with arcs==NULL to get counts.
+ * num_states = K > 1: nStateBuildLattice (decoders/CRF_LatticeBuilder.h:715-840 for SCRF_STDFRAME; ...StdSeg_WithoutDurLab_
+ * WithoutSegTransFtr.h:409-690 for the segmental model): the topology's arcs only, in that function's AddArc order */
 int scrf_lattice_arcs(scrf_handle h, scrf_batch b, uint32_t u, int norm, scrf_arc* arcs,
                       uint64_t* n_arcs, uint32_t* n_states, int32_t* final_state);
 /* replaces: buildLattice + ShortestPath/Project/RmEpsilon/TopSort + (olabel-1)

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
     double* pu = p_g + f_base * L;
     double a = ESu[lc];        // node 0: the only window is the initial segment of length 1
     double ga = smu[0];
-    if (act) au[lane] = a;
+    if (act) __builtin_nontemporal_store(a, &au[lane]);
     // the per-frame log-scales are wave-uniform: lane (frame & 63) keeps them and 64 frames go out in one store
     // (a store instruction per frame and scalar costs the wavefront as much as a 384-byte one)
     double ga_keep = ga, gp_keep = 0.0;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       const double gp = ga + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
       ring[rpos * L + lc] = p;  // idle lanes rewrite lane L-1's value with the same number
       if (lane == rpos) gslot = gp;
-      if (act) pu[(size_t)(t - 1) * L + lane] = p;
+      if (act) __builtin_nontemporal_store(p, &pu[(size_t)(t - 1) * L + lane]);
       if (lane == ((t - 1) & 63)) gp_keep = gp;
       if (((t - 1) & 63) == 63) gp_g[f_base + (t - 1 - 63) + lane] = gp_keep;   // 64 frames' log-scales in one store
       // per-duration scales: lane d0 looks at predecessor node t-1-d0 (ring slot rpos-d0)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       }
       a = acc0 + acc1;
       ga = G;
-      if (act) au[(size_t)t * L + lane] = a;
+      if (act) __builtin_nontemporal_store(a, &au[(size_t)t * L + lane]);
       if (lane == (t & 63)) ga_keep = ga;
       if ((t & 63) == 63) ga_g[f_base + (t - 63) + lane] = ga_keep;
     }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
       const double gb = G + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
       ring[tpos * L + lc] = b;
       if (lane == tpos) gslot = gb;
-      if (act) { sdu[(size_t)t * L + lane] = sd; bu[(size_t)t * L + lane] = b; }
+      if (act) { __builtin_nontemporal_store(sd, &sdu[(size_t)t * L + lane]); __builtin_nontemporal_store(b, &bu[(size_t)t * L + lane]); }
       if (lane == (t & 63)) { gsd_keep = G; gb_keep = gb; }
       if ((t & 63) == 0 && t + lane < T) { gsd_g[f_base + t + lane] = gsd_keep; gb_g[f_base + t + lane] = gb_keep; }   // frames t .. t+63 (descending walk)
     }

@@ -398,14 +398,14 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
           const uint32_t o = o0 + n * 16 + li;
           const double e = fu_exp(sv[n] - ref, ek);
           if (mine && lab % n_out == o) s_true[ft.fr0 + b0 + d - 1] = sv[n];
-          if (valid && o < n_out) Srow[n * 16] = e;
+          if (valid && o < n_out) __builtin_nontemporal_store(e, &Srow[n * 16]);
         }
         if (valid && li == 0) smax[ft.row0 + rl] = ref;
       } else {
 #pragma unroll
         for (int n = 0; n < 3; n++) {
           const uint32_t o = o0 + n * 16 + li;
-          if (valid && o < n_out) S[(ft.row0 + rl) * n_out + o] = sv[n];
+          if (valid && o < n_out) __builtin_nontemporal_store(sv[n], &S[(ft.row0 + rl) * n_out + o]);
         }
       }
     }
@@ -498,7 +498,7 @@ struct LzWin {
   __device__ __forceinline__ void add(const double (&r)[DMAX]) { add_seq(r, std::make_integer_sequence<int, DMAX>{}); }
   // after frame t: frame t - MO is final; slide by one frame
   __device__ __forceinline__ void retire(double* Zk, int t, size_t zstride) {
-    if (t >= MO) Zk[(size_t)(t - MO) * zstride] = v[MO];
+    if (t >= MO) __builtin_nontemporal_store(v[MO], &Zk[(size_t)(t - MO) * zstride]);
 #pragma unroll
     for (int j = MO; j >= 1; j--) v[j] = v[j - 1];
     v[0] = 0.0;
@@ -507,7 +507,7 @@ struct LzWin {
   __device__ __forceinline__ void flush(double* Zk, int T, size_t zstride) {
 #pragma unroll
     for (int j = 1; j <= MO; j++)
-      if (T - j >= 0) Zk[(size_t)(T - j) * zstride] = v[j];
+      if (T - j >= 0) __builtin_nontemporal_store(v[j], &Zk[(size_t)(T - j) * zstride]);
   }
 };
 
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(64) void k_pframe(const float* __restrict__ F, uint
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint64_t fr_ = f0 + lk + 4 * r;
-        if (fr_ < f_end && o < n_out) P[fr_ * n_out + o] = acc[nt][r];
+        if (fr_ < f_end && o < n_out) __builtin_nontemporal_store((double)acc[nt][r], &P[fr_ * n_out + o]);
       }
     }
   };
@@ -786,8 +786,9 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
     const uint32_t nd = scrf_node_max_dur((uint32_t)t, D), np = scrf_num_prev((uint32_t)t, D);
     const uint64_t row0 = scrf_seg_base((uint32_t)t, D);
     double r[DMAX];
+    // streamed once each way: non-temporal loads and stores (5.85 -> 5.34 ms on one box; the stores are what counts)
 #pragma unroll
-    for (int d0 = 0; d0 < DMAX; d0++) r[d0] = ((uint32_t)d0 < nd) ? ESu[(row0 + d0) * L] : 0.0;
+    for (int d0 = 0; d0 < DMAX; d0++) r[d0] = ((uint32_t)d0 < nd) ? __builtin_nontemporal_load(&ESu[(row0 + d0) * L]) : 0.0;
     const double b = o_.b[(f_base + t) * L + oc];
     const double pnew = (t + 1 < T) ? o_.p[(f_base + t) * L + oc] : 0.0;
     // scale factor of duration d0 = lane
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
       const double g = (pv * r[d0]) * (b * fsb[d0]);
       const double y = (o == al && (uint32_t)d0 + 1 == ld) ? 1.0 : 0.0;
       const double rv = ((uint32_t)d0 < nd) ? y - g : 0.0;
-      if (act && (uint32_t)d0 < nd) ESu[(row0 + d0) * L] = rv;
+      if (act && (uint32_t)d0 < nd) __builtin_nontemporal_store(rv, &ESu[(row0 + d0) * L]);
       r[d0] = rv;
       gs += g;   // r[d0] = 0 and fsb[d0] = 0 past nd
     }

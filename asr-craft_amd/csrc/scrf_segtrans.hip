@@ -413,12 +413,12 @@ __global__ __launch_bounds__(64 * FBW_WAVES) void k_fb_segtrans_w(ScrfLayout lay
               if (a >= LN_MAX) err = SCRF_ERR_NUMERIC;
               const double x = a <= 0.0 ? exp_nonpos(a) : exp(a);
               const double y = ((uint32_t)l == al && (uint32_t)d == ld && (uint32_t)p == apl) ? 1.0 : 0.0;
-              Xrow[idx] = y - x;
+              __builtin_nontemporal_store(y - x, &Xrow[idx]);   // 18 KB per window, read once by the contraction
               xs += x;
             }
           }
         } else {
-          for (int idx = tid; idx < L * L; idx += NT) Xrow[idx] = 0.0;
+          for (int idx = tid; idx < L * L; idx += NT) __builtin_nontemporal_store(0.0, &Xrow[idx]);
         }
       }
       for (int idx = tid; idx < nd * L; idx += NT) {

@@ -769,9 +769,10 @@ static uint32_t segtrans_chunks(uint64_t nseg, size_t LL, uint32_t ntf) {
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cap, (nseg + 2047) / 2048));
 }
 
-// K-chunks of the transition-bias contraction: one wavefront each, about 1024 of them
+// K-chunks of the transition-bias contraction: one wavefront each, about 4096 of them (four per SIMD: a wavefront's
+// next operands are only one 576-cycle group of MFMAs ahead, the others cover the rest of the load latency)
 static uint64_t atb_rows_per_chunk(uint64_t nfr) {
-  uint64_t rpc = ((nfr + 1023) / 1024 + 3) & ~3ull;
+  uint64_t rpc = ((nfr + 4095) / 4096 + 3) & ~3ull;
   return rpc < 64 ? 64 : rpc;
 }
 

@@ -193,8 +193,9 @@ def test_random_shape_sweep():
     """20 seeded random shapes (phones, states per phone, durations, stream width, lengths incl. shorter than D; with
     and without transition features; both precisions; labels on and off the topology): gradient, numerator, Zx, lattice
     arcs and best path against the oracle."""
-    rng = np.random.RandomState(2024)
-    for it in range(20):
+    import os
+    rng = np.random.RandomState(int(os.environ.get("SCRF_SWEEP_SEED", "2024")))
+    for it in range(int(os.environ.get("SCRF_SWEEP_N", "20"))):
         K = int(rng.randint(2, 5)); P = int(rng.randint(1, 9)); D = int(rng.randint(1, 13)); W = int(rng.randint(1, 6))
         Ts = [int(rng.randint(1, 3 * D + 4)) for _ in range(int(rng.randint(1, 5)))]
         kw = dict(L=P * K, D=D, in_w=W, Ts=Ts, num_states=K, seed=9000 + it, precision=int(rng.randint(0, 2)),

@@ -88,6 +88,23 @@ __device__ __forceinline__ double fu_exp(double x, const FuExpC& k) {
   return ldexp(p, (int)n);
 }
 
+// The same through a 256-entry table of 2^(j/256) in LDS: x = (256 e + j) ln2/256 + r, |r| <= ln2/512, so a degree-4
+// polynomial is exact to 4e-17 and the whole thing is 14 vector instructions and one LDS read instead of 21.  The
+// reduction uses ln2/256 as one constant: its rounding error times n is below 1e-14 for every x above -100 (what lies
+// further down is below e^-100 of the row maximum).
+#define FU_EXPT_N 256
+__device__ __forceinline__ double fu_exp_tab(double x, const double* tab) {
+  x = fmax(x, -1000.0);
+  const double n = rint(x * 369.32993046756268);             // 256 / ln 2
+  const double r = fma(n, -2.7076061740622863e-3, x);        // ln 2 / 256
+  const int ni = (int)n;
+  const double t = tab[ni & (FU_EXPT_N - 1)];
+  double q = fma(r, 4.1666666666666664e-02, 1.6666666666666666e-01);
+  q = fma(r, q, 0.5);
+  q = fma(r, q, 1.0);
+  return ldexp(fma(t * r, q, t), ni >> 8);
+}
+
 // Window statistics of one (frame, column): the values F[t-j][c], j = 0 .. nd-1, are read from LDS
 // in one batch (no load sits inside the dependent chain), then walked with compile-time durations.
 // The window average is sum / d in float: q0 = sum * y, r = fma(-q0, d, sum), q = fma(r, y, q0) with
@@ -113,15 +130,53 @@ __device__ __forceinline__ void fu_scan_avg(const float (&v)[DMAX], float* o, ui
     *w = q;
   }
 }
+// running extremum as one instruction: fmaxf / fminf make the compiler canonicalise both operands first (values
+// loaded from memory are not known to be quiet), tripling the count.  For finite data v_max_f32 / v_min_f32 give
+// what the reference's `if (v > a) a = v` gives.
+__device__ __forceinline__ float fu_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fu_vmaxd(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fu_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int DMAX, int IS_MAX>
 __device__ __forceinline__ void fu_scan_ext(const float (&v)[DMAX], float* o, uint32_t stride, uint32_t d_lo,
                                             uint32_t d_hi, float* dump) {
   float a = v[0];
 #pragma unroll
   for (int j = 0; j < DMAX; j++) {
-    if (IS_MAX) { if (v[j] > a) a = v[j]; } else { if (v[j] < a) a = v[j]; }
+    a = IS_MAX ? fu_vmax(a, v[j]) : fu_vmin(a, v[j]);
     float* w = ((uint32_t)(j + 1) >= d_lo && (uint32_t)(j + 1) <= d_hi) ? o + j * stride : dump;
     *w = a;
+  }
+}
+// Steady-state forms (every duration 1 .. DMAX exists and lies inside the tile): no clamped loads, no select per
+// store -- the LDS offsets are immediates.
+template <int DMAX>
+__device__ __forceinline__ void fu_load_vals_full(const float* last, uint32_t W, float (&v)[DMAX]) {
+  // a running address (one subtraction per load); j * W would be a quarter-rate integer multiply each
+#pragma unroll
+  for (int j = 0; j < DMAX; j++) {
+    v[j] = *last;
+    last -= W;
+    asm volatile("" : "+v"(last));
+  }
+}
+template <int DMAX, uint32_t STRIDE>
+__device__ __forceinline__ void fu_scan_avg_full(const float (&v)[DMAX], float* o) {
+  float a = 0.0f;
+#pragma unroll
+  for (int j = 0; j < DMAX; j++) {
+    a = __fadd_rn(a, v[j]);
+    const float df = (float)(j + 1), y = 1.0f / df;
+    const float q0 = __fmul_rn(a, y);
+    o[j * STRIDE] = __fmaf_rn(__fmaf_rn(-q0, df, a), y, q0);
+  }
+}
+template <int DMAX, int IS_MAX, uint32_t STRIDE>
+__device__ __forceinline__ void fu_scan_ext_full(const float (&v)[DMAX], float* o) {
+  float a = v[0];
+#pragma unroll
+  for (int j = 0; j < DMAX; j++) {
+    a = IS_MAX ? fu_vmax(a, v[j]) : fu_vmin(a, v[j]);
+    o[j * STRIDE] = a;
   }
 }
 
@@ -133,11 +188,19 @@ __device__ __forceinline__ void fu_scan_ext(const float (&v)[DMAX], float* o, ui
 // After the last chunk the tile's rows of P are staged over the dead operand images for the gather.
 // ------------------------------------------------------------------------------------------
 #define FU_NT 512
+#define FU_PS 242       // double row stride of the staged P image: 5 x 48 + 2, so that consecutive frames start 9 16-byte
+                        // slots apart (odd): the 16 rows a ds_read_b128 lane group gathers fall on distinct slots
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 // smax != nullptr (n_out <= 48 only): the epilogue writes exp(S - smax[row]) instead of S, with
 // smax[row] the float-rounded row maximum, and the labelled windows' scores to s_true -- the inputs
 // of the linear-domain recursion (scrf_dplin.hip), saving a read-modify-write pass over S.
 // DEC (decode, F32 == 0 only): write float(-1 * score) and the list of entries to recompute
 // (ScrfDecodeOut, scrf_common.h) instead of S.
+//
+// The MFMAs compute the TRANSPOSED tile (A = lambda^T, B = X^T): a lane then holds 12 outputs of ONE window row
+// (o = 12 lk + 4 n + r) instead of 3 outputs of 8 rows, so everything the epilogue does per row -- the five gather
+// offsets, the duration weights, the row maximum, the label test -- is paid once per 12 outputs, the gathers and the
+// stores are 16-byte accesses, and the row maximum needs two lane swaps.
 template <int DMAX, int F32, int DEC>
 __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, ScrfLayout lay,
                                                            const double* __restrict__ lambda,
@@ -152,16 +215,17 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   float* Xg = (float*)fsm;                                              // [256 + dump row][FU_XS]
   double* Wg = (double*)(fsm + sizeof(float) * (FU_ROWS + 1) * FU_XS);  // [40][FU_WS] (floats when F32)
   float* fr = (float*)(Wg + FU_GC * FU_WS);                             // [nfmax][W]
-  double* Pl = (double*)fsm;                                            // [nfmax][5][48]
-  double* Dt = Pl + nfmax * 240;                                        // [D+1][48] duration weights, bias term
+  double* Pl = (double*)fsm;                                            // [nfmax][FU_PS]: [5][48] used
+  double* Dt = Pl + nfmax * FU_PS;                                      // [D][48] duration weight + bias term
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
-  const size_t pb = sizeof(double) * (nfmax * 240 + (D + 1) * 48);
+  const size_t pb = sizeof(double) * (nfmax * FU_PS + D * 48);
   if (pb > opn) opn = pb;
-  uint32_t* labs = (uint32_t*)(fsm + ((opn + 15) & ~(size_t)15));       // [TB] labels of the tile's frames
-  uint16_t* rfirst = (uint16_t*)(labs + fa.TB);
-  uint16_t* rbase = rfirst + FU_ROWS;
-  uint8_t* rdur = (uint8_t*)(rbase + FU_ROWS);
-  uint8_t* steps = rdur + FU_ROWS;                                      // [D][5]
+  // per-row record (16 bytes, one ds_read_b128 in the epilogue): the five gather offsets into Pl (in doubles, block
+  // offset k * 48 included), the duration, the frame inside the tile, and the output whose score is the labelled
+  // window's (0xffff: none)
+  uint4* recs = (uint4*)(fsm + ((opn + 15) & ~(size_t)15));             // [FU_ROWS]
+  uint16_t* rbase = (uint16_t*)(recs + FU_ROWS);                        // [TB] first row of each frame
+  double* etab = (double*)(rbase + ((fa.TB + 3) & ~3u));                // [256] 2^(j/256) (exp epilogue only)
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t o0 = blockIdx.y * 48;
@@ -171,6 +235,9 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   const FuTile ft = fu_tile(fa, fa.tiles[fa.tile0 + tix]);
   float* Wgf = (float*)Wg;
   const uint32_t cpg = (W + FU_GC - 1) / FU_GC;  // chunks per group
+  // MFMA row li of output tile n carries output phi(n, li), chosen so that the accumulators a lane ends up with
+  // (rows lk + 4r of the f64 tile, 4 lk + r of the f32 tile) are its 12 consecutive outputs 12 lk + 4 n + r
+  const uint32_t phi0 = F32 ? (li >> 2) * 12 + (li & 3) : (li & 3) * 12 + (li >> 2);
   // lambda chunk prefetch registers: element e = tid + 512*q of the [48][40] chunk
   double wp[4];
   auto load_w = [&](uint32_t ci) {
@@ -186,6 +253,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   load_w(0);
 
   // stage raw frames f0 .. t0+nfr-1 (loads batched ahead of the LDS stores), decode rows
+  const uint32_t back = ft.t0 - ft.f0;
   {
     const float* src = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
     const uint32_t n = (ft.t0 + ft.nfr - ft.f0) * W;
@@ -201,15 +269,20 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       const uint32_t t = ft.t0 + tl;
       if (d <= scrf_node_max_dur(t, D)) {
         const uint32_t row = (uint32_t)(scrf_seg_base(t, D) - ft.r0) + d - 1;
-        rfirst[row] = (uint16_t)(t - d + 1 - ft.f0);
-        rdur[row] = (uint8_t)d;
+        const uint32_t b0 = t - d + 1 - ft.f0;
+        uint32_t q[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) q[k] = (b0 + fu_sample_step(d, k)) * FU_PS + k * 48;
+        uint32_t mine_o = 0xffffu;
+        if (labels) {
+          const uint32_t lab = labels[fa.frame_base + ft.fr0 + back + tl];
+          if (lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d) mine_o = lab % n_out;
+        }
+        recs[row] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (d << 16) | (tl << 24), mine_o);
       }
     }
-    for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) {
-      rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
-      labs[tl] = labels ? labels[fa.frame_base + ft.fr0 + (ft.t0 - ft.f0) + tl] : SCRF_LAB_BAD;
-    }
-    for (uint32_t i = tid; i < D * 5; i += FU_NT) steps[i] = (uint8_t)fu_sample_step(i / 5 + 1, i % 5);
+    for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
+    if (!DEC && smax && tid < FU_EXPT_N) etab[tid] = exp2((double)tid * (1.0 / FU_EXPT_N));
     // rows past the tile and pad columns of the chunk image stay zero for the whole kernel
     for (uint32_t i = tid; i < (FU_ROWS + 1) * FU_XS; i += FU_NT) Xg[i] = 0.0f;
   }
@@ -227,6 +300,8 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     for (int n = 0; n < (F32 ? 3 : 1); n++) acc32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
 
   float* dump = Xg + FU_ROWS * FU_XS + FU_GC;   // pad column of the spare row: never an operand
+  // steady state: every frame of the tile has all DMAX durations (no clamped loads, no dumped stores)
+  const bool full = (D == (uint32_t)DMAX) && ft.t0 + 1 >= D;
   for (uint32_t ci = 0; ci < 3 * cpg; ci++) {
     const uint32_t ty = ci / cpg, c0 = (ci % cpg) * FU_GC;   // 0 avg, 1 max, 2 min
     const uint32_t nc = min((uint32_t)FU_GC, W - c0);
@@ -236,16 +311,26 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         const uint32_t row = i / (FU_GC - nc), c = nc + i % (FU_GC - nc);
         Xg[row * FU_XS + c] = 0.0f;
       }
+    const uint32_t mnc = fu_magic(nc);
     for (uint32_t i = tid; i < ft.nfr * nc; i += FU_NT) {
-      const uint32_t tl = i / nc, c = i % nc;
+      const uint32_t tl = fu_div(i, mnc), c = i - tl * nc;
       const uint32_t t = ft.t0 + tl;
-      const uint32_t nd = scrf_node_max_dur(t, D);
       float v[DMAX];
-      fu_load_vals<DMAX>(fr + (t - ft.f0) * W + c0 + c, W, nd, v);
-      float* o = Xg + rbase[tl] * FU_XS + c;
-      if (ty == 0) fu_scan_avg<DMAX>(v, o, FU_XS, 1, nd, dump);
-      else if (ty == 1) fu_scan_ext<DMAX, 1>(v, o, FU_XS, 1, nd, dump);
-      else fu_scan_ext<DMAX, 0>(v, o, FU_XS, 1, nd, dump);
+      const float* last = fr + (t - ft.f0) * W + c0 + c;
+      if (full) {
+        float* o = Xg + tl * (DMAX * FU_XS) + c;
+        fu_load_vals_full<DMAX>(last, W, v);
+        if (ty == 0) fu_scan_avg_full<DMAX, FU_XS>(v, o);
+        else if (ty == 1) fu_scan_ext_full<DMAX, 1, FU_XS>(v, o);
+        else fu_scan_ext_full<DMAX, 0, FU_XS>(v, o);
+      } else {
+        const uint32_t nd = scrf_node_max_dur(t, D);
+        fu_load_vals<DMAX>(last, W, nd, v);
+        float* o = Xg + rbase[tl] * FU_XS + c;
+        if (ty == 0) fu_scan_avg<DMAX>(v, o, FU_XS, 1, nd, dump);
+        else if (ty == 1) fu_scan_ext<DMAX, 1>(v, o, FU_XS, 1, nd, dump);
+        else fu_scan_ext<DMAX, 0>(v, o, FU_XS, 1, nd, dump);
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -260,28 +345,28 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
     for (int ks = 0; ks < FU_GC / 4; ks++) {
       if (F32) {
-        float b[3];
+        float wv[3];
 #pragma unroll
-        for (int n = 0; n < 3; n++) b[n] = Wgf[(ks * 4 + lk) * (2 * FU_WS) + n * 16 + li];
+        for (int n = 0; n < 3; n++) wv[n] = Wgf[(ks * 4 + lk) * (2 * FU_WS) + n * 4 + phi0];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-          const float a = Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
+          const float x = Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
 #pragma unroll
           for (int n = 0; n < 3; n++)
             acc32[F32 ? m : 0][F32 ? n : 0] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc32[F32 ? m : 0][F32 ? n : 0], 0, 0, 0);
+                __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n], x, acc32[F32 ? m : 0][F32 ? n : 0], 0, 0, 0);
         }
       } else {
-        double b[3];
+        double wv[3];
 #pragma unroll
-        for (int n = 0; n < 3; n++) b[n] = Wg[(ks * 4 + lk) * FU_WS + n * 16 + li];
+        for (int n = 0; n < 3; n++) wv[n] = Wg[(ks * 4 + lk) * FU_WS + n * 4 + phi0];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-          const double a = (double)Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
+          const double x = (double)Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
 #pragma unroll
           for (int n = 0; n < 3; n++)
             acc[F32 ? 0 : m][F32 ? 0 : n] =
-                __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
+                __builtin_amdgcn_mfma_f64_16x16x4f64(wv[n], x, acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
         }
       }
     }
@@ -289,135 +374,162 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   }
   // stage the tile's projections, Pl[f - f0][k][ol] = P[frame f][k * n_out + o0 + ol] (threads 0..239
   // and 240..479 take alternate frames, nine frames in flight per thread), and the per-duration
-  // weights + bias term of the 48 outputs
+  // weights (+ bias term) of the 48 outputs
   {
     const uint32_t nf = ft.t0 + ft.nfr - ft.f0;
     const uint32_t half = tid / 240, e = tid % 240, k = e / 48, ol = e % 48;
     const double* src = P + ft.fr0 * (uint64_t)(5 * n_out) + k * n_out + o0 + ol;
     const bool live = tid < 480 && o0 + ol < n_out;
+    auto dur_w = [&](uint32_t i) {
+      const uint32_t dd = i / 48, oo = i % 48;
+      double v = -1e300;   // outputs past n_out: never the row maximum, exp -> 0, masked at the stores
+      if (o0 + oo < n_out) {
+        const uint32_t base = lay.state_idx(o0 + oo) + 8 * W;
+        v = lambda[base + dd];
+        if (lay.use_sb) v += lambda[base + D] * lay.sbv;
+      }
+      return v;
+    };
     double dtv[3];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const uint32_t i = tid + FU_NT * q, dd = i / 48, oo = i % 48;
-      double v = 0.0;
-      if (dd <= D && o0 + oo < n_out) {
-        v = lambda[lay.state_idx(o0 + oo) + 8 * W + dd];
-        if (dd == D) v = lay.use_sb ? v * lay.sbv : 0.0;
-      }
-      dtv[q] = v;
-    }
+    for (int q = 0; q < 3; q++) dtv[q] = (tid + FU_NT * q < D * 48) ? dur_w(tid + FU_NT * q) : 0.0;
     // sample position k reaches back at most off_k(D) = D - 1 - s_k(D) frames before the tile's
     // first frame: older rows of its block are never gathered, so they are not fetched
-    const uint32_t back = ft.t0 - ft.f0, reach = D - 1 - fu_sample_step(D, (int)(k < 5 ? k : 4));
+    const uint32_t reach = D - 1 - fu_sample_step(D, (int)(k < 5 ? k : 4));
     const uint32_t fbeg = back > reach ? back - reach : 0;
     for (uint32_t f0 = fbeg + half; f0 < nf; f0 += 18) {
       double tmp[9];
 #pragma unroll
       for (int q = 0; q < 9; q++) tmp[q] = (live && f0 + 2 * q < nf) ? src[(uint64_t)(f0 + 2 * q) * 5 * n_out] : 0.0;
 #pragma unroll
-      for (int q = 0; q < 9; q++) if (tid < 480 && f0 + 2 * q < nf) Pl[(f0 + 2 * q) * 240 + e] = tmp[q];
+      for (int q = 0; q < 9; q++) if (tid < 480 && f0 + 2 * q < nf) Pl[(f0 + 2 * q) * FU_PS + e] = tmp[q];
     }
 #pragma unroll
-    for (int q = 0; q < 3; q++) if (tid + FU_NT * q < (D + 1) * 48) Dt[tid + FU_NT * q] = dtv[q];
-    for (uint32_t i = tid + 3 * FU_NT; i < (D + 1) * 48; i += FU_NT) {   // D > 31 only
-      const uint32_t dd = i / 48, oo = i % 48;
-      double v = 0.0;
-      if (o0 + oo < n_out) {
-        v = lambda[lay.state_idx(o0 + oo) + 8 * W + dd];
-        if (dd == D) v = lay.use_sb ? v * lay.sbv : 0.0;
-      }
-      Dt[i] = v;
-    }
+    for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * 48) Dt[tid + FU_NT * q] = dtv[q];
+    for (uint32_t i = tid + 3 * FU_NT; i < D * 48; i += FU_NT) Dt[i] = dur_w(i);   // D > 32 only
   }
   __syncthreads();
-  // epilogue: + sampled-frame projections + one-hot duration weight + bias (all fp64), write S.
-  // Branch-free per row: every lane gathers (rows past the tile and outputs past n_out read valid
-  // table entries and are masked at the stores), so the 18 LDS reads of a row are in flight together.
-  double dbias[3];
+  // epilogue: + sampled-frame projections + (one-hot duration weight + bias) (all fp64), write S.
+  // Branch-free per row: every lane gathers (rows past the tile read row 0's valid table entries and are masked at
+  // the stores), so the 36 16-byte LDS reads of a row are in flight together.
+  const uint32_t ob = o0 + lk * 12;                 // first of the lane's 12 outputs
+  const bool vec_ok = (n_out & 3) == 0;             // 16-byte stores need aligned rows (outputs come in whole fours then)
+  const bool all_out = vec_ok && o0 + 48 <= n_out;  // every lane's 12 outputs exist
 #pragma unroll
-  for (int n = 0; n < 3; n++) dbias[n] = Dt[D * 48 + n * 16 + li];
-  const FuExpC ek = fu_exp_consts();
+  for (int m = 0; m < 2; m++) {
+    const uint32_t rl = wave * 32 + m * 16 + li;
+    const bool valid = rl < ft.nrows;
+    const uint4 rec = recs[valid ? rl : 0];
+    const uint32_t d = (rec.z >> 16) & 0xffu, tl = rec.z >> 24;
+    const double* pl = Pl + lk * 12;
+    const double* p0 = pl + (rec.x & 0xffffu);
+    const double* p1 = pl + (rec.x >> 16);
+    const double* p2 = pl + (rec.y & 0xffffu);
+    const double* p3 = pl + (rec.y >> 16);
+    const double* p4 = pl + (rec.z & 0xffffu);
+    const double* dp = Dt + (d - 1) * 48 + lk * 12;
+    double sv[12];
 #pragma unroll
-  for (int m = 0; m < 2; m++)
+    for (int j = 0; j < 6; j++) {
+      const v2f64 a0 = *(const v2f64*)(p0 + 2 * j), a1 = *(const v2f64*)(p1 + 2 * j), a2 = *(const v2f64*)(p2 + 2 * j),
+                  a3 = *(const v2f64*)(p3 + 2 * j), a4 = *(const v2f64*)(p4 + 2 * j), dw = *(const v2f64*)(dp + 2 * j);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint32_t rl = wave * 32 + m * 16 + (F32 ? 4 * lk + r : lk + 4 * r);
-      const bool valid = rl < ft.nrows;
-      const uint32_t rc = valid ? rl : 0;
-      const uint32_t d = rdur[rc], b0 = rfirst[rc];
-      const uint8_t* sp = steps + (d - 1) * 5;
-      const uint32_t q0 = (b0 + sp[0]) * 240, q1 = (b0 + sp[1]) * 240 + 48, q2 = (b0 + sp[2]) * 240 + 96,
-                     q3 = (b0 + sp[3]) * 240 + 144, q4 = (b0 + sp[4]) * 240 + 192;
-      double pv[3][5], dt[3];
-#pragma unroll
-      for (int n = 0; n < 3; n++) {
-        const uint32_t ol = n * 16 + li;
-        pv[n][0] = Pl[q0 + ol]; pv[n][1] = Pl[q1 + ol]; pv[n][2] = Pl[q2 + ol];
-        pv[n][3] = Pl[q3 + ol]; pv[n][4] = Pl[q4 + ol];
-        dt[n] = Dt[(d - 1) * 48 + ol];
-      }
-      double sv[3];
-#pragma unroll
-      for (int n = 0; n < 3; n++) {
-        const double lin = (((pv[n][0] + pv[n][1]) + pv[n][2]) + pv[n][3]) + pv[n][4];
+      for (int h = 0; h < 2; h++) {
+        const int c = 2 * j + h, n = c >> 2, r = c & 3;
+        const double lin = (((a0[h] + a1[h]) + a2[h]) + a3[h]) + a4[h];
         const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
-        sv[n] = ((v + lin) + dt[n]) + dbias[n];
-      }
-      if (DEC) {
-        const double xm = (double)dz.xm_f[ft.fr0 + (ft.t0 - ft.f0)] * dz.bound_scale;   // a tile lies in one utterance
-#pragma unroll
-        for (int n = 0; n < 3; n++) {
-          const uint32_t o = o0 + n * 16 + li;
-          if (valid && o < n_out) {
-            const double v = -1 * sv[n];
-            const float w = (float)v;
-            const double B = xm * dz.w1[o];
-            if ((float)(v - B) != w || (float)(v + B) != w) {
-              const uint32_t at = atomicAdd(dz.cnt, 1u);
-              if (at < dz.cap) dz.list[at] = ((ft.row0 + rl) << 16) | o;
-            }
-            dz.wneg[(ft.row0 + rl) * n_out + o] = w;
-          }
-        }
-      } else if (smax) {
-        // row maximum over the 16 lanes that share this row (and the 3 output tiles), as a float,
-        // on the DPP path: quad permutes, then the half-row and row mirrors
-        float mx = -INFINITY;
-#pragma unroll
-        for (int n = 0; n < 3; n++) mx = fmaxf(mx, (o0 + n * 16 + li < n_out) ? (float)sv[n] : -INFINITY);
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xb1, 0xf, 0xf, false)));
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4e, 0xf, 0xf, false)));
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x141, 0xf, 0xf, false)));
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x140, 0xf, 0xf, false)));
-        const double ref = (double)mx;
-        const uint32_t lab = labs[b0 + d - 1 - (ft.t0 - ft.f0)];
-        const bool mine = valid && lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d;
-        double* Srow = S + (ft.row0 + rc) * n_out + o0 + li;
-#pragma unroll
-        for (int n = 0; n < 3; n++) {
-          const uint32_t o = o0 + n * 16 + li;
-          const double e = fu_exp(sv[n] - ref, ek);
-          if (mine && lab % n_out == o) s_true[ft.fr0 + b0 + d - 1] = sv[n];
-          if (valid && o < n_out) __builtin_nontemporal_store(e, &Srow[n * 16]);
-        }
-        if (valid && li == 0) smax[ft.row0 + rl] = ref;
-      } else {
-#pragma unroll
-        for (int n = 0; n < 3; n++) {
-          const uint32_t o = o0 + n * 16 + li;
-          if (valid && o < n_out) __builtin_nontemporal_store(sv[n], &S[(ft.row0 + rl) * n_out + o]);
-        }
+        sv[c] = (v + lin) + dw[h];
       }
     }
+    const uint64_t grow = ft.row0 + rl;
+    if (DEC) {
+      const double xm = (double)dz.xm_f[ft.fr0 + back] * dz.bound_scale;   // a tile lies in one utterance
+      float wv[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) {
+        const uint32_t o = ob + c;
+        const double v = -1 * sv[c];
+        const float w = (float)v;
+        wv[c] = w;
+        if (valid && o < n_out) {
+          const double B = xm * dz.w1[o];
+          if ((float)(v - B) != w || (float)(v + B) != w) {
+            const uint32_t at = atomicAdd(dz.cnt, 1u);
+            if (at < dz.cap) dz.list[at] = (grow << 16) | o;
+          }
+        }
+      }
+      float* wrow = dz.wneg + grow * n_out + ob;
+      if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          if (valid && ob + 4 * j < n_out) *(v4f32*)(wrow + 4 * j) = (v4f32){wv[4 * j], wv[4 * j + 1], wv[4 * j + 2], wv[4 * j + 3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 12; c++) if (valid && ob + c < n_out) wrow[c] = wv[c];
+      }
+    } else if (smax) {
+      // row maximum as a float: over the lane's 12 outputs, then over the 4 lanes (li, lk = 0..3) that share the row --
+      // two half-swaps (v_permlane32_swap / v_permlane16_swap, CDNA4)
+      double mxd = sv[0];
+#pragma unroll
+      for (int c = 1; c < 12; c++) mxd = fu_vmaxd(mxd, sv[c]);
+      float mx = (float)mxd;
+      {
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fu_vmax(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fu_vmax(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+      }
+      const double ref = (double)mx;
+      const uint32_t cm = rec.w - ob;               // < 12: the labelled window's output is one of this lane's
+      if (__any(valid && cm < 12u)) {
+        if (valid && cm < 12u) {
+          double v = sv[0];
+#pragma unroll
+          for (int c = 1; c < 12; c++) v = (cm == (uint32_t)c) ? sv[c] : v;
+          s_true[ft.fr0 + back + tl] = v;
+        }
+      }
+      double ev[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) ev[c] = fu_exp_tab(sv[c] - ref, etab);
+      double* Srow = S + grow * n_out + ob;
+      if (all_out) {
+        if (valid) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) __builtin_nontemporal_store((v2f64){ev[2 * j], ev[2 * j + 1]}, (v2f64*)(Srow + 2 * j));
+        }
+      } else if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          if (valid && ob + 2 * j < n_out) __builtin_nontemporal_store((v2f64){ev[2 * j], ev[2 * j + 1]}, (v2f64*)(Srow + 2 * j));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 12; c++) if (valid && ob + c < n_out) __builtin_nontemporal_store(ev[c], &Srow[c]);
+      }
+      if (valid && lk == 0) smax[grow] = ref;
+    } else {
+      double* Srow = S + grow * n_out + ob;
+      if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          if (valid && ob + 2 * j < n_out) __builtin_nontemporal_store((v2f64){sv[2 * j], sv[2 * j + 1]}, (v2f64*)(Srow + 2 * j));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 12; c++) if (valid && ob + c < n_out) __builtin_nontemporal_store(sv[c], &Srow[c]);
+      }
+    }
+  }
 }
 
 static size_t fused_scores_smem_tb(uint32_t W, uint32_t D, uint32_t TB) {
   const uint32_t nfmax = TB + D - 1;
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
-  const size_t pb = sizeof(double) * (nfmax * 240 + (D + 1) * 48);
+  const size_t pb = sizeof(double) * (nfmax * FU_PS + D * 48);
   if (pb > opn) opn = pb;
   opn = (opn + 15) & ~(size_t)15;
-  return opn + sizeof(uint32_t) * TB + sizeof(uint16_t) * 2 * FU_ROWS + FU_ROWS + D * 5 + 64;
+  return opn + sizeof(uint4) * FU_ROWS + sizeof(uint16_t) * ((TB + 3) & ~3u) + sizeof(double) * FU_EXPT_N + 16;
 }
 // frames per score tile: as many whole frames as give <= 256 rows and keep the workgroup's LDS
 // (the staged P rows grow with TB + D - 1) within 80 KB, i.e. two workgroups per CU; 0 = no fit

@@ -1,7 +1,8 @@
 // Test translation unit for asr-craft_amd/host/lbfgs.h (the optimiser behind CRF_LBFGSTrainer; the reference links
 // libLBFGS with default parameters, trainers/CRF_LBFGSTrainer.cpp:55-62).  Prints one line per problem:
 //   <name> ret=<code> fx=<value> iters=<k> evals=<n> x=<x0> <x1> ...
-// tests/test_host_lbfgs.py checks the minima against closed forms and scipy's L-BFGS on the same functions.
+// tests/test_host_lbfgs.py checks the minima against closed forms (the iterates themselves are pinned to the reference's
+// library by lbfgs_trace.cpp).
 #include <math.h>
 #include <stdio.h>
 

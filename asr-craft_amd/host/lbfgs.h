@@ -17,7 +17,7 @@
 // the cubic's theta term, lbfgs.c:1046, not from the side of the trial point), the first step 1/|g| -- follows the
 // vendored library, because its iterates are the contract: tests/test_host_lbfgs.py compares this file's iterates with
 // golden vectors produced by that library compiled from the reference tree (tests/golden/lbfgs_ref.npz, generator
-// committed) to 1e-12, and live against oracle/_ref/liblbfgs_ref.so when it is present.  Status codes are the
+// committed) to 1e-12, and against the library itself where the test infrastructure has built it.  Status codes are the
 // library's numeric values (utils/lbfgs.h:75-145) so that a log line "LBFGS returned: -999" reads the same.
 // Vector algebra is plain host code on lambda_len doubles: O(m n) per iteration next to a full pass of the GPU over
 // the training set.

@@ -47,3 +47,14 @@ def test_product_never_references_the_oracle():
                 if re.search(r"oracle|orc_|libscrf_oracle", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_host_classes_keep_the_reference_shaped_signatures(tmp_path):
+    """tests/host/interface_conformance.cpp carries static_asserts on constructor argument lists and member-function
+    pointer types of asr-craft_amd/host/crf_amd.h (the reference interfaces of SURVEY 8b); compiling it is the check.
+    (Linking and running it needs the GPU: tests/test_gpu_cli.py.)"""
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "asr-craft_amd", "host"),
+                        os.path.join(ROOT, "tests", "host", "interface_conformance.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr

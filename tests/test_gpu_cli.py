@@ -701,15 +701,16 @@ def _files(d):
 
 
 @pytest.mark.parametrize("threads,bunch", [(1, 1), (2, 3)])
-def test_reference_main_sequence_compiles_links_and_trains(tmp_path, threads, bunch):
-    """tests/host/reference_main_sequence.cpp reproduces the object / call sequence of the reference's
-    CRFTrain main (Main.cpp:508-684) against asr-craft_amd/host/crf_amd.h: it must compile, link against
-    libcrf_amd_host + libscrf_amd, train the bundled fixture, and write the weight files bin/CRFTrain
-    writes for the same flags.  Its CRF_StateNode view of utterance 0 is compared with the oracle."""
+def test_interface_conformance_unit_compiles_links_and_trains(tmp_path, threads, bunch):
+    """tests/host/interface_conformance.cpp: static_asserts on the reference-shaped signatures of
+    asr-craft_amd/host/crf_amd.h plus a small caller of our own that builds the stream managers (joined), the model,
+    the feature map and CRF_SGTrainer through those interfaces.  It must compile, link against libcrf_amd_host +
+    libscrf_amd, train the bundled fixture, and write the weight files bin/CRFTrain writes for the same settings,
+    byte for byte.  Its CRF_StateNode view of utterance 0 is compared with the oracle."""
     lib = os.path.join(ROOT, "asr-craft_amd", "lib")
     exe = str(tmp_path / "refmain")
     r = subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "asr-craft_amd", "host"),
-                        os.path.join(ROOT, "tests", "host", "reference_main_sequence.cpp"), "-o", exe, "-L" + lib,
+                        os.path.join(ROOT, "tests", "host", "interface_conformance.cpp"), "-o", exe, "-L" + lib,
                         "-Wl,-rpath," + lib, "-lcrf_amd_host", "-lscrf_amd"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     d1, d2 = tmp_path / "tu", tmp_path / "cli"

@@ -687,8 +687,8 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
       BCHK(upload(h, &b->d_xm_f, xm.data(), NF));
       BSYNC();
     }
-    // score tiles: the windows of TB whole frames; expected-count tiles: 64 consecutive windows
-    const uint32_t D = lay.D, TB = fused_scores_tb(recipes[0].in_width, D);
+    // score tiles: the windows of TB whole frames; expected-count tiles: those of TBE whole frames (<= 64 windows)
+    const uint32_t D = lay.D, TB = fused_scores_tb(recipes[0].in_width, D), TBE = fused_expf_frames(D);
     for (int k = 0; k < 2; k++) {
       std::vector<ScrfTileDesc> td;
       b->tile_off[k].assign(n + 1, 0);
@@ -701,22 +701,15 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
           memset(&q, 0, sizeof(q));
           uint32_t t_end;   // one past the last frame touched
           uint64_t r1;
-          if (k == 0) {
-            t_end = std::min(T, t + TB);
-            r1 = scrf_seg_base(t_end, D);
-          } else {
-            while (scrf_seg_base(t + 1, D) <= r0) t++;
-            r1 = std::min(nseg, r0 + SCRF_FUSED_ROWS_EXPF);
-            t_end = t;
-            while (scrf_seg_base(t_end, D) < r1) t_end++;
-          }
+          t_end = std::min(T, t + (k == 0 ? TB : TBE));
+          r1 = scrf_seg_base(t_end, D);
           q.r0 = (uint32_t)r0; q.t0 = t; q.back = (uint16_t)std::min(t, D - 1);
           q.nfr = (uint16_t)(t_end - t); q.nrows = (uint16_t)(r1 - r0);
           q.row_abs = b->seg_off[u] + r0;
           q.fr_abs = b->frame_off[u] + t - q.back;
           td.push_back(q);
           r0 = r1;
-          if (k == 0) t = t_end;
+          t = t_end;
         }
         b->tile_off[k][u + 1] = td.size();
       }

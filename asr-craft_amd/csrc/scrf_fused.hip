@@ -39,14 +39,43 @@ typedef float v4f32 __attribute__((ext_vector_type(4)));
 #define FU_WS 49        // row stride of the transposed lambda image
 #define FU_ROWS SCRF_FUSED_ROWS_SCORES
 #define FE_ROWS SCRF_FUSED_ROWS_EXPF
-#define FE_RS 50        // double row stride of the R image
+#define FE_RSF 80       // float row stride of the R image in the f32 form: == 16 (mod 32), the b32 counterpart
+#define FE_RS 48        // double row stride of the R image: 96 dwords = 32 (mod 64), so the two k-rows a 32-lane half of a
+                        // ds_read_b64 A-fragment covers fall on disjoint banks (50 overlapped four of them)
 
 __host__ __device__ inline uint32_t fu_sample_step(uint32_t d, int k) {
   const float ot = (float)((double)d * 0.1);
   return (uint32_t)ceilf(ot * (float)(2 * k + 1)) - 1u;
 }
 __device__ __forceinline__ uint32_t fu_div(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }   // magic 0: d == 1 (2^32 does not fit)
-__device__ __forceinline__ uint32_t fu_magic(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ uint32_t fu_magic(uint32_t d) { return d < 2 ? 0u : 0xffffffffu / d + 1u; }   // ceil(2^32 / d) in 32-bit arithmetic
+// FU_PROF (debug builds only): wave 0 of every workgroup stamps the phase boundaries with s_memtime and adds the
+// differences to fu_prof[phase]; fu_prof[15] counts tiles.  Read with scrf_debug_fused_prof (tools/fused_phases.py).
+#ifndef FU_PROF
+#define FU_PROF 0
+#endif
+#if FU_PROF
+__device__ unsigned long long fu_prof[16];
+#define FU_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) {                                                                              \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                      \
+      atomicAdd(&fu_prof[i], now_ - stamp_);                                                             \
+      stamp_ = now_;                                                                                     \
+    }                                                                                                    \
+  } while (0)
+extern "C" int scrf_debug_fused_prof(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(fu_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fu_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define FU_STAMP(i) do {} while (0)
+#endif
+
 // A row tile (ScrfTileDesc, built on the host with the batch): rows [r0, r0+nrows) of an utterance,
 // touching frames t0 .. t0+nfr-1; raw frames are staged from f0 = t0 - back.
 struct FuTile {
@@ -150,13 +179,15 @@ __device__ __forceinline__ void fu_scan_ext(const float (&v)[DMAX], float* o, ui
 // Steady-state forms (every duration 1 .. DMAX exists and lies inside the tile): no clamped loads, no select per
 // store -- the LDS offsets are immediates.
 template <int DMAX>
-__device__ __forceinline__ void fu_load_vals_full(const float* last, uint32_t W, float (&v)[DMAX]) {
-  // a running address (one subtraction per load); j * W would be a quarter-rate integer multiply each
+__device__ __forceinline__ void fu_load_vals_full(const float* img, uint32_t at, uint32_t W, float (&v)[DMAX]) {
+  // a running index into the LDS image (one subtraction per load; j * W would be a quarter-rate integer multiply
+  // each).  The opaque value is the INDEX, not the pointer: an opaque pointer loses its address space and the loads
+  // become flat loads.
 #pragma unroll
   for (int j = 0; j < DMAX; j++) {
-    v[j] = *last;
-    last -= W;
-    asm volatile("" : "+v"(last));
+    v[j] = img[at];
+    at -= W;
+    asm volatile("" : "+v"(at));
   }
 }
 template <int DMAX, uint32_t STRIDE>
@@ -188,9 +219,25 @@ __device__ __forceinline__ void fu_scan_ext_full(const float (&v)[DMAX], float* 
 // After the last chunk the tile's rows of P are staged over the dead operand images for the gather.
 // ------------------------------------------------------------------------------------------
 #define FU_NT 512
-#define FU_PS 242       // double row stride of the staged P image: 5 x 48 + 2, so that consecutive frames start 9 16-byte
-                        // slots apart (odd): the 16 rows a ds_read_b128 lane group gathers fall on distinct slots
+// experiment switches (defaults = the shipped configuration)
+#ifndef FU_PHI
+#define FU_PHI 1        // 1: a lane's outputs are the pairs 8j + 2lk + {0,1}: the 4 lanes of a row store 64 contiguous bytes
+#endif                  //    per instruction; 0: 12 consecutive outputs per lane (96-byte pieces 96 bytes apart)
+#ifndef FU_EXPTAB
+#define FU_EXPTAB 0     // 1: table-based exp in the epilogue (14 instructions + a gathered LDS read instead of 21; measured
+                        // equal -- the epilogue is not instruction-bound -- and the table costs 2 KB of LDS and bank conflicts)
+#endif
+#ifndef FU_FULLSCAN
+#define FU_FULLSCAN 1   // steady-state scan without clamps and dumps
+#endif
+#ifndef FU_ABL
+#define FU_ABL 0        // ablations (wrong results): 1 = no global loads in the P staging, 2 = nor in the frame staging
+#endif
+#define FU_DS 50        // double row stride of the P image and of the duration-weight table: 25 16-byte slots, odd, so
+                        // that the rows of consecutive frames / durations a ds_read_b128 lane group gathers start on
+                        // distinct slots (48 would put them on two)
 typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef float v2f32 __attribute__((ext_vector_type(2)));
 // smax != nullptr (n_out <= 48 only): the epilogue writes exp(S - smax[row]) instead of S, with
 // smax[row] the float-rounded row maximum, and the labelled windows' scores to s_true -- the inputs
 // of the linear-domain recursion (scrf_dplin.hip), saving a read-modify-write pass over S.
@@ -201,6 +248,14 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 // (o = 12 lk + 4 n + r) instead of 3 outputs of 8 rows, so everything the epilogue does per row -- the five gather
 // offsets, the duration weights, the row maximum, the label test -- is paid once per 12 outputs, the gathers and the
 // stores are 16-byte accesses, and the row maximum needs two lane swaps.
+// rows of the staged P image: block k holds the frames sample position k can reach, TB + off_k(D) of them
+__host__ __device__ inline uint32_t fu_p_rows(uint32_t D, uint32_t TB) {
+  uint32_t n = 0;
+  for (int k = 0; k < 5; k++) n += TB + (D - 1 - fu_sample_step(D, k));
+  return n;
+}
+#define FU_NPQ 12       // P rows per thread held in registers between their loads and their LDS stores (slot + 10 q)
+
 template <int DMAX, int F32, int DEC>
 __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, ScrfLayout lay,
                                                            const double* __restrict__ lambda,
@@ -211,21 +266,26 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const uint32_t W = fa.W, D = lay.D;
   const uint32_t nfmax = fa.TB + D - 1;
-  // operand images (live until the last MFMA) and, over them, the gather tables of the epilogue
+  // operand images (live until the last MFMA) and, over them, the P rows the epilogue gathers: block k = the frames
+  // sample position k can reach (off_k(D) = D - 1 - s_k(D) before the tile's first frame), rows of FU_DS doubles
   float* Xg = (float*)fsm;                                              // [256 + dump row][FU_XS]
   double* Wg = (double*)(fsm + sizeof(float) * (FU_ROWS + 1) * FU_XS);  // [40][FU_WS] (floats when F32)
   float* fr = (float*)(Wg + FU_GC * FU_WS);                             // [nfmax][W]
-  double* Pl = (double*)fsm;                                            // [nfmax][FU_PS]: [5][48] used
-  double* Dt = Pl + nfmax * FU_PS;                                      // [D][48] duration weight + bias term
+  double* Pl = (double*)fsm;                                            // [fu_p_rows][FU_DS]: 48 used
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
-  const size_t pb = sizeof(double) * (nfmax * FU_PS + D * 48);
+  const uint32_t nprmax = fu_p_rows(D, fa.TB);
+  const size_t pb = sizeof(double) * nprmax * FU_DS;
   if (pb > opn) opn = pb;
-  // per-row record (16 bytes, one ds_read_b128 in the epilogue): the five gather offsets into Pl (in doubles, block
-  // offset k * 48 included), the duration, the frame inside the tile, and the output whose score is the labelled
-  // window's (0xffff: none)
-  uint4* recs = (uint4*)(fsm + ((opn + 15) & ~(size_t)15));             // [FU_ROWS]
+  // outside the union (staged with the raw frames, read by the epilogue):
+  double* Dt = (double*)(fsm + ((opn + 15) & ~(size_t)15));             // [D][FU_DS] duration weight + bias term
+  // per-row record (16 bytes, one ds_read_b128 in the epilogue): the five gather offsets into Pl (in doubles), the
+  // duration, the frame inside the tile, and the output whose score is the labelled window's (0xffff: none)
+  uint4* recs = (uint4*)(Dt + D * FU_DS);                               // [FU_ROWS]
   uint16_t* rbase = (uint16_t*)(recs + FU_ROWS);                        // [TB] first row of each frame
-  double* etab = (double*)(rbase + ((fa.TB + 3) & ~3u));                // [256] 2^(j/256) (exp epilogue only)
+  uint16_t* rowmap = rbase + ((fa.TB + 3) & ~3u);                       // [fu_p_rows] P image row -> 5 * (frame - f0) + k
+#if FU_EXPTAB
+  double* etab = (double*)(rowmap + ((nprmax + 3) & ~3u));              // [256] 2^(j/256) (exp epilogue only)
+#endif
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t o0 = blockIdx.y * 48;
@@ -237,7 +297,17 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   const uint32_t cpg = (W + FU_GC - 1) / FU_GC;  // chunks per group
   // MFMA row li of output tile n carries output phi(n, li), chosen so that the accumulators a lane ends up with
   // (rows lk + 4r of the f64 tile, 4 lk + r of the f32 tile) are its 12 consecutive outputs 12 lk + 4 n + r
+#if FU_PHI
+  // o = 16 n + 8 (r >> 1) + 2 lk + (r & 1) for accumulator r of tile n: value c = 4n + r of a lane is output
+  // 8 (c >> 1) + 2 lk + (c & 1), so the lane's values come in the adjacent pairs (8j + 2lk, 8j + 2lk + 1), j = 0..5
+  const uint32_t phi0 = F32 ? 8 * ((li & 3) >> 1) + 2 * (li >> 2) + (li & 1) : 8 * (li >> 3) + 2 * (li & 3) + ((li >> 2) & 1);
+#else
   const uint32_t phi0 = F32 ? (li >> 2) * 12 + (li & 3) : (li & 3) * 12 + (li >> 2);
+#endif
+#if FU_PROF
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) atomicAdd(&fu_prof[15], 1ull);
+#endif
   // lambda chunk prefetch registers: element e = tid + 512*q of the [48][40] chunk
   double wp[4];
   auto load_w = [&](uint32_t ci) {
@@ -251,42 +321,98 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     }
   };
   load_w(0);
+#if FU_PROF
+  asm volatile("" :: "v"(ft.t0));   // the descriptor has arrived
+  FU_STAMP(5);
+#endif
 
-  // stage raw frames f0 .. t0+nfr-1 (loads batched ahead of the LDS stores), decode rows
-  const uint32_t back = ft.t0 - ft.f0;
+  // geometry of the P image: block k starts at image row prow0[k] with frame pf0[k] (relative to f0)
+  const uint32_t back = ft.t0 - ft.f0, nf = back + ft.nfr;
+  uint32_t prow0[5], pf0[5], nprows = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t reach = D - 1 - fu_sample_step(D, k);
+    pf0[k] = back > reach ? back - reach : 0;
+    prow0[k] = nprows;
+    nprows += nf - pf0[k];
+  }
+  // stage raw frames f0 .. t0+nfr-1 and the duration weights (loads batched ahead of the LDS stores), decode rows
   {
+    auto dur_w = [&](uint32_t i) {
+      const uint32_t dd = i / 48, oo = i % 48;
+      double v = -1e300;   // outputs past n_out: never the row maximum, exp -> 0, masked at the stores
+      if (o0 + oo < n_out) {
+        const uint32_t base = lay.state_idx(o0 + oo) + 8 * W;
+        v = lambda[base + dd];
+        if (lay.use_sb) v += lambda[base + D] * lay.sbv;
+      }
+      return v;
+    };
+    double dtv[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) dtv[q] = (tid + FU_NT * q < D * 48) ? dur_w(tid + FU_NT * q) : 0.0;
     const float* src = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
-    const uint32_t n = (ft.t0 + ft.nfr - ft.f0) * W;
+    const uint32_t n = nf * W;
     for (uint32_t i0 = 0; i0 < n; i0 += 4 * FU_NT) {
       float tmp[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) tmp[q] = (i0 + tid + FU_NT * q < n) ? src[i0 + tid + FU_NT * q] : 0.0f;
+      for (int q = 0; q < 4; q++) tmp[q] = (FU_ABL < 2 && i0 + tid + FU_NT * q < n) ? src[i0 + tid + FU_NT * q] : 0.5f;
 #pragma unroll
       for (int q = 0; q < 4; q++) if (i0 + tid + FU_NT * q < n) fr[i0 + tid + FU_NT * q] = tmp[q];
     }
+#pragma unroll
+    for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * 48) Dt[((tid + FU_NT * q) / 48) * FU_DS + (tid + FU_NT * q) % 48] = dtv[q];
+    for (uint32_t i = tid + 3 * FU_NT; i < D * 48; i += FU_NT) Dt[(i / 48) * FU_DS + i % 48] = dur_w(i);   // D > 32 only
+    FU_STAMP(6);   // frames and duration weights in LDS
+    const uint32_t mD = fu_magic(D);
     for (uint32_t i = tid; i < ft.nfr * D; i += FU_NT) {
-      const uint32_t tl = i / D, d = i % D + 1;
+      const uint32_t tl = fu_div(i, mD), d = i - tl * D + 1;
       const uint32_t t = ft.t0 + tl;
       if (d <= scrf_node_max_dur(t, D)) {
         const uint32_t row = (uint32_t)(scrf_seg_base(t, D) - ft.r0) + d - 1;
         const uint32_t b0 = t - d + 1 - ft.f0;
         uint32_t q[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) q[k] = (b0 + fu_sample_step(d, k)) * FU_PS + k * 48;
+        for (int k = 0; k < 5; k++) q[k] = (prow0[k] - pf0[k] + b0 + fu_sample_step(d, k)) * FU_DS;
         uint32_t mine_o = 0xffffu;
         if (labels) {
+          // label = n_out * (duration - 1) + phone: this row's iff it lies in [n_out (d-1), n_out d)
           const uint32_t lab = labels[fa.frame_base + ft.fr0 + back + tl];
-          if (lab != SCRF_LAB_BAD && lab < n_out * D && lab / n_out + 1 == d) mine_o = lab % n_out;
+          const uint32_t rel = lab - (d - 1) * n_out;
+          if (lab != SCRF_LAB_BAD && rel < n_out) mine_o = rel;
         }
         recs[row] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (d << 16) | (tl << 24), mine_o);
       }
     }
+    FU_STAMP(7);   // row records
     for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
+    for (uint32_t r = tid; r < nprows; r += FU_NT) {
+      uint32_t k = 0;
+#pragma unroll
+      for (int kk = 1; kk < 5; kk++) k += r >= prow0[kk] ? 1u : 0u;
+      uint32_t base = prow0[0], f0k = pf0[0];
+#pragma unroll
+      for (int kk = 1; kk < 5; kk++) if (k == (uint32_t)kk) { base = prow0[kk]; f0k = pf0[kk]; }
+      rowmap[r] = (uint16_t)(5 * (f0k + r - base) + k);
+    }
+#if FU_EXPTAB
     if (!DEC && smax && tid < FU_EXPT_N) etab[tid] = exp2((double)tid * (1.0 / FU_EXPT_N));
-    // rows past the tile and pad columns of the chunk image stay zero for the whole kernel
-    for (uint32_t i = tid; i < (FU_ROWS + 1) * FU_XS; i += FU_NT) Xg[i] = 0.0f;
+#endif
+    // The image region held the previous occupant's P rows (any bit pattern).  What the MFMAs read and the scans do
+    // not write must be finite: the pad columns [min(W, FU_GC), FU_GC) of every row (their lambda rows are zero) --
+    // rows past the tile are masked at the stores, so their garbage only has to stay in its own row, which a matrix
+    // product guarantees; and the whole image before an edge tile, whose scans skip durations.
+    {
+      const uint32_t ncf = min(W, (uint32_t)FU_GC);
+      if (ft.t0 + 1 >= D && ncf < FU_GC) {
+        for (uint32_t i = tid; i < FU_ROWS * (FU_GC - ncf); i += FU_NT) Xg[(i / (FU_GC - ncf)) * FU_XS + ncf + i % (FU_GC - ncf)] = 0.0f;
+      } else {
+        for (uint32_t i = tid; i < (FU_ROWS + 1) * FU_XS; i += FU_NT) Xg[i] = 0.0f;
+      }
+    }
   }
   __syncthreads();
+  FU_STAMP(0);   // stage
 
   v4f64 acc[F32 ? 1 : 2][F32 ? 1 : 3];
   v4f32 acc32[F32 ? 2 : 1][F32 ? 3 : 1];
@@ -299,10 +425,34 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
     for (int n = 0; n < (F32 ? 3 : 1); n++) acc32[m][n] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
 
+  // P rows travel through registers after the last MFMA: thread (slot = tid / 48, ol = tid % 48) takes image rows
+  // slot + 10 q, all loads of a batch in flight together.  (Requesting the batch BEFORE the last chunk's MFMAs hides
+  // its latency -- the staging phase fell from 20 k to 4 k cycles per tile -- but the 24 registers it holds across
+  // the loop spill the scans: 10.2 -> 11.7 ms.  Measured, not kept.)
+  double pr[FU_NPQ];
+  const uint32_t pslot = tid / 48, pol = tid % 48;
+  const bool plive = tid < 480 && o0 + pol < n_out;
+  auto p_load = [&](uint32_t r0) {
+#pragma unroll
+    for (int q = 0; q < FU_NPQ; q++) {
+      const uint32_t r = r0 + pslot + 10 * q;
+      pr[q] = (FU_ABL < 1 && plive && r < nprows) ? P[(ft.fr0 * 5 + rowmap[r < nprows ? r : 0]) * (uint64_t)n_out + o0 + pol] : 0.0;
+    }
+  };
+  auto p_store = [&](uint32_t r0) {
+#pragma unroll
+    for (int q = 0; q < FU_NPQ; q++) {
+      const uint32_t r = r0 + pslot + 10 * q;
+      if (tid < 480 && r < nprows) Pl[r * FU_DS + pol] = pr[q];
+    }
+  };
+
   float* dump = Xg + FU_ROWS * FU_XS + FU_GC;   // pad column of the spare row: never an operand
   // steady state: every frame of the tile has all DMAX durations (no clamped loads, no dumped stores)
-  const bool full = (D == (uint32_t)DMAX) && ft.t0 + 1 >= D;
-  for (uint32_t ci = 0; ci < 3 * cpg; ci++) {
+  const bool full = FU_FULLSCAN && (D == (uint32_t)DMAX) && ft.t0 + 1 >= D;
+  const uint32_t ncw = min(W, (uint32_t)FU_GC), mncw = fu_magic(ncw);   // width of a full chunk
+  const uint32_t nchunks = 3 * cpg;
+  for (uint32_t ci = 0; ci < nchunks; ci++) {
     const uint32_t ty = ci / cpg, c0 = (ci % cpg) * FU_GC;   // 0 avg, 1 max, 2 min
     const uint32_t nc = min((uint32_t)FU_GC, W - c0);
     // a narrower last chunk of a group leaves stale columns behind: clear them
@@ -311,15 +461,16 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         const uint32_t row = i / (FU_GC - nc), c = nc + i % (FU_GC - nc);
         Xg[row * FU_XS + c] = 0.0f;
       }
-    const uint32_t mnc = fu_magic(nc);
+    const uint32_t mnc = nc == ncw ? mncw : fu_magic(nc);
     for (uint32_t i = tid; i < ft.nfr * nc; i += FU_NT) {
       const uint32_t tl = fu_div(i, mnc), c = i - tl * nc;
       const uint32_t t = ft.t0 + tl;
       float v[DMAX];
-      const float* last = fr + (t - ft.f0) * W + c0 + c;
+      const uint32_t at = (t - ft.f0) * W + c0 + c;
+      const float* last = fr + at;
       if (full) {
         float* o = Xg + tl * (DMAX * FU_XS) + c;
-        fu_load_vals_full<DMAX>(last, W, v);
+        fu_load_vals_full<DMAX>(fr, at, W, v);
         if (ty == 0) fu_scan_avg_full<DMAX, FU_XS>(v, o);
         else if (ty == 1) fu_scan_ext_full<DMAX, 1, FU_XS>(v, o);
         else fu_scan_ext_full<DMAX, 0, FU_XS>(v, o);
@@ -341,13 +492,14 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       }
     }
     __syncthreads();
-    if (ci + 1 < 3 * cpg) load_w(ci + 1);   // lands under the MFMAs
+    FU_STAMP(1);   // scans (+ barrier)
+    if (ci + 1 < nchunks) load_w(ci + 1);   // lands under the MFMAs
 #pragma unroll
     for (int ks = 0; ks < FU_GC / 4; ks++) {
       if (F32) {
         float wv[3];
 #pragma unroll
-        for (int n = 0; n < 3; n++) wv[n] = Wgf[(ks * 4 + lk) * (2 * FU_WS) + n * 4 + phi0];
+        for (int n = 0; n < 3; n++) wv[n] = Wgf[(ks * 4 + lk) * (2 * FU_WS) + n * (FU_PHI ? 16 : 4) + phi0];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
           const float x = Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
@@ -359,7 +511,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       } else {
         double wv[3];
 #pragma unroll
-        for (int n = 0; n < 3; n++) wv[n] = Wg[(ks * 4 + lk) * FU_WS + n * 4 + phi0];
+        for (int n = 0; n < 3; n++) wv[n] = Wg[(ks * 4 + lk) * FU_WS + n * (FU_PHI ? 16 : 4) + phi0];
 #pragma unroll
         for (int m = 0; m < 2; m++) {
           const double x = (double)Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
@@ -371,68 +523,48 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       }
     }
     __syncthreads();
+    FU_STAMP(2);   // MFMA loops (+ barrier)
   }
-  // stage the tile's projections, Pl[f - f0][k][ol] = P[frame f][k * n_out + o0 + ol] (threads 0..239
-  // and 240..479 take alternate frames, nine frames in flight per thread), and the per-duration
-  // weights (+ bias term) of the 48 outputs
-  {
-    const uint32_t nf = ft.t0 + ft.nfr - ft.f0;
-    const uint32_t half = tid / 240, e = tid % 240, k = e / 48, ol = e % 48;
-    const double* src = P + ft.fr0 * (uint64_t)(5 * n_out) + k * n_out + o0 + ol;
-    const bool live = tid < 480 && o0 + ol < n_out;
-    auto dur_w = [&](uint32_t i) {
-      const uint32_t dd = i / 48, oo = i % 48;
-      double v = -1e300;   // outputs past n_out: never the row maximum, exp -> 0, masked at the stores
-      if (o0 + oo < n_out) {
-        const uint32_t base = lay.state_idx(o0 + oo) + 8 * W;
-        v = lambda[base + dd];
-        if (lay.use_sb) v += lambda[base + D] * lay.sbv;
-      }
-      return v;
-    };
-    double dtv[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) dtv[q] = (tid + FU_NT * q < D * 48) ? dur_w(tid + FU_NT * q) : 0.0;
-    // sample position k reaches back at most off_k(D) = D - 1 - s_k(D) frames before the tile's
-    // first frame: older rows of its block are never gathered, so they are not fetched
-    const uint32_t reach = D - 1 - fu_sample_step(D, (int)(k < 5 ? k : 4));
-    const uint32_t fbeg = back > reach ? back - reach : 0;
-    for (uint32_t f0 = fbeg + half; f0 < nf; f0 += 18) {
-      double tmp[9];
-#pragma unroll
-      for (int q = 0; q < 9; q++) tmp[q] = (live && f0 + 2 * q < nf) ? src[(uint64_t)(f0 + 2 * q) * 5 * n_out] : 0.0;
-#pragma unroll
-      for (int q = 0; q < 9; q++) if (tid < 480 && f0 + 2 * q < nf) Pl[(f0 + 2 * q) * FU_PS + e] = tmp[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * 48) Dt[tid + FU_NT * q] = dtv[q];
-    for (uint32_t i = tid + 3 * FU_NT; i < D * 48; i += FU_NT) Dt[i] = dur_w(i);   // D > 32 only
+  // the P image over the dead operand images
+  for (uint32_t r0 = 0; r0 < nprows; r0 += 10 * FU_NPQ) {   // one batch unless the tile is wider than the registers hold
+    p_load(r0);
+    p_store(r0);
   }
   __syncthreads();
+  FU_STAMP(3);   // P staging
   // epilogue: + sampled-frame projections + (one-hot duration weight + bias) (all fp64), write S.
   // Branch-free per row: every lane gathers (rows past the tile read row 0's valid table entries and are masked at
   // the stores), so the 36 16-byte LDS reads of a row are in flight together.
-  const uint32_t ob = o0 + lk * 12;                 // first of the lane's 12 outputs
-  const bool vec_ok = (n_out & 3) == 0;             // 16-byte stores need aligned rows (outputs come in whole fours then)
+  // value c of a lane is output o0 + OL(c); pair j = (c >> 1) is adjacent in memory at o0 + OB(j)
+#if FU_PHI
+#define FU_OB(j) (8 * (j) + 2 * lk)
+#else
+#define FU_OB(j) (lk * 12 + 2 * (j))
+#endif
+#define FU_OL(c) (FU_OB((c) >> 1) + ((c) & 1))
+  const bool vec_ok = (n_out & 1) == 0;             // 16-byte stores of fp64 pairs need even row lengths
   const bool all_out = vec_ok && o0 + 48 <= n_out;  // every lane's 12 outputs exist
+#if !FU_EXPTAB
+  const FuExpC ek = fu_exp_consts();
+#endif
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     const uint32_t rl = wave * 32 + m * 16 + li;
     const bool valid = rl < ft.nrows;
     const uint4 rec = recs[valid ? rl : 0];
     const uint32_t d = (rec.z >> 16) & 0xffu, tl = rec.z >> 24;
-    const double* pl = Pl + lk * 12;
-    const double* p0 = pl + (rec.x & 0xffffu);
-    const double* p1 = pl + (rec.x >> 16);
-    const double* p2 = pl + (rec.y & 0xffffu);
-    const double* p3 = pl + (rec.y >> 16);
-    const double* p4 = pl + (rec.z & 0xffffu);
-    const double* dp = Dt + (d - 1) * 48 + lk * 12;
+    const double* p0 = Pl + (rec.x & 0xffffu);
+    const double* p1 = Pl + (rec.x >> 16);
+    const double* p2 = Pl + (rec.y & 0xffffu);
+    const double* p3 = Pl + (rec.y >> 16);
+    const double* p4 = Pl + (rec.z & 0xffffu);
+    const double* dp = Dt + (d - 1) * FU_DS;
     double sv[12];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const v2f64 a0 = *(const v2f64*)(p0 + 2 * j), a1 = *(const v2f64*)(p1 + 2 * j), a2 = *(const v2f64*)(p2 + 2 * j),
-                  a3 = *(const v2f64*)(p3 + 2 * j), a4 = *(const v2f64*)(p4 + 2 * j), dw = *(const v2f64*)(dp + 2 * j);
+      const uint32_t ob = FU_OB(j);
+      const v2f64 a0 = *(const v2f64*)(p0 + ob), a1 = *(const v2f64*)(p1 + ob), a2 = *(const v2f64*)(p2 + ob),
+                  a3 = *(const v2f64*)(p3 + ob), a4 = *(const v2f64*)(p4 + ob), dw = *(const v2f64*)(dp + ob);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int c = 2 * j + h, n = c >> 2, r = c & 3;
@@ -447,7 +579,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       float wv[12];
 #pragma unroll
       for (int c = 0; c < 12; c++) {
-        const uint32_t o = ob + c;
+        const uint32_t o = o0 + FU_OL(c);
         const double v = -1 * sv[c];
         const float w = (float)v;
         wv[c] = w;
@@ -459,14 +591,14 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
           }
         }
       }
-      float* wrow = dz.wneg + grow * n_out + ob;
-      if (vec_ok) {
+      float* wrow = dz.wneg + grow * n_out + o0;
+      if (vec_ok) {   // 8-byte stores of float pairs
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-          if (valid && ob + 4 * j < n_out) *(v4f32*)(wrow + 4 * j) = (v4f32){wv[4 * j], wv[4 * j + 1], wv[4 * j + 2], wv[4 * j + 3]};
+        for (int j = 0; j < 6; j++)
+          if (valid && o0 + FU_OB(j) < n_out) *(v2f32*)(wrow + FU_OB(j)) = (v2f32){wv[2 * j], wv[2 * j + 1]};
       } else {
 #pragma unroll
-        for (int c = 0; c < 12; c++) if (valid && ob + c < n_out) wrow[c] = wv[c];
+        for (int c = 0; c < 12; c++) if (valid && o0 + FU_OL(c) < n_out) wrow[FU_OL(c)] = wv[c];
       }
     } else if (smax) {
       // row maximum as a float: over the lane's 12 outputs, then over the 4 lanes (li, lk = 0..3) that share the row --
@@ -482,9 +614,17 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         mx = fu_vmax(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
       }
       const double ref = (double)mx;
-      const uint32_t cm = rec.w - ob;               // < 12: the labelled window's output is one of this lane's
-      if (__any(valid && cm < 12u)) {
-        if (valid && cm < 12u) {
+      // the labelled window's score: value cm of this lane, if the output is one of the lane's
+#if FU_PHI
+      const uint32_t tm = rec.w - o0 - 2 * lk;
+      const bool has = valid && tm < 48u && (tm & 6u) == 0;
+      const uint32_t cm = 2 * (tm >> 3) + (tm & 1u);
+#else
+      const uint32_t cm = rec.w - o0 - lk * 12;
+      const bool has = valid && cm < 12u;
+#endif
+      if (__any(has)) {
+        if (has) {
           double v = sv[0];
 #pragma unroll
           for (int c = 1; c < 12; c++) v = (cm == (uint32_t)c) ? sv[c] : v;
@@ -493,43 +633,54 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       }
       double ev[12];
 #pragma unroll
-      for (int c = 0; c < 12; c++) ev[c] = fu_exp_tab(sv[c] - ref, etab);
-      double* Srow = S + grow * n_out + ob;
+      for (int c = 0; c < 12; c++) {
+#if FU_EXPTAB
+        ev[c] = fu_exp_tab(sv[c] - ref, etab);
+#else
+        ev[c] = fu_exp(sv[c] - ref, ek);
+#endif
+      }
+      double* Srow = S + grow * n_out + o0;
       if (all_out) {
         if (valid) {
 #pragma unroll
-          for (int j = 0; j < 6; j++) __builtin_nontemporal_store((v2f64){ev[2 * j], ev[2 * j + 1]}, (v2f64*)(Srow + 2 * j));
+          for (int j = 0; j < 6; j++) __builtin_nontemporal_store((v2f64){ev[2 * j], ev[2 * j + 1]}, (v2f64*)(Srow + FU_OB(j)));
         }
       } else if (vec_ok) {
 #pragma unroll
         for (int j = 0; j < 6; j++)
-          if (valid && ob + 2 * j < n_out) __builtin_nontemporal_store((v2f64){ev[2 * j], ev[2 * j + 1]}, (v2f64*)(Srow + 2 * j));
+          if (valid && o0 + FU_OB(j) < n_out) __builtin_nontemporal_store((v2f64){ev[2 * j], ev[2 * j + 1]}, (v2f64*)(Srow + FU_OB(j)));
       } else {
 #pragma unroll
-        for (int c = 0; c < 12; c++) if (valid && ob + c < n_out) __builtin_nontemporal_store(ev[c], &Srow[c]);
+        for (int c = 0; c < 12; c++) if (valid && o0 + FU_OL(c) < n_out) __builtin_nontemporal_store(ev[c], &Srow[FU_OL(c)]);
       }
       if (valid && lk == 0) smax[grow] = ref;
     } else {
-      double* Srow = S + grow * n_out + ob;
+      double* Srow = S + grow * n_out + o0;
       if (vec_ok) {
 #pragma unroll
         for (int j = 0; j < 6; j++)
-          if (valid && ob + 2 * j < n_out) __builtin_nontemporal_store((v2f64){sv[2 * j], sv[2 * j + 1]}, (v2f64*)(Srow + 2 * j));
+          if (valid && o0 + FU_OB(j) < n_out) __builtin_nontemporal_store((v2f64){sv[2 * j], sv[2 * j + 1]}, (v2f64*)(Srow + FU_OB(j)));
       } else {
 #pragma unroll
-        for (int c = 0; c < 12; c++) if (valid && ob + c < n_out) __builtin_nontemporal_store(sv[c], &Srow[c]);
+        for (int c = 0; c < 12; c++) if (valid && o0 + FU_OL(c) < n_out) __builtin_nontemporal_store(sv[c], &Srow[FU_OL(c)]);
       }
     }
   }
+  FU_STAMP(4);   // epilogue of wave 0
+#undef FU_OB
+#undef FU_OL
 }
 
 static size_t fused_scores_smem_tb(uint32_t W, uint32_t D, uint32_t TB) {
   const uint32_t nfmax = TB + D - 1;
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
-  const size_t pb = sizeof(double) * (nfmax * FU_PS + D * 48);
+  const uint32_t npr = fu_p_rows(D, TB);
+  const size_t pb = sizeof(double) * npr * FU_DS;
   if (pb > opn) opn = pb;
   opn = (opn + 15) & ~(size_t)15;
-  return opn + sizeof(uint4) * FU_ROWS + sizeof(uint16_t) * ((TB + 3) & ~3u) + sizeof(double) * FU_EXPT_N + 16;
+  return opn + sizeof(double) * D * FU_DS + sizeof(uint4) * FU_ROWS + sizeof(uint16_t) * ((TB + 3) & ~3u) +
+         sizeof(uint16_t) * ((npr + 3) & ~3u) + (FU_EXPTAB ? sizeof(double) * FU_EXPT_N : 0) + 16;
 }
 // frames per score tile: as many whole frames as give <= 256 rows and keep the workgroup's LDS
 // (the staged P rows grow with TB + D - 1) within 80 KB, i.e. two workgroups per CU; 0 = no fit
@@ -1005,13 +1156,13 @@ void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
 // hand: operands of step ks+1 are in flight while the MFMAs of step ks issue.
 // ------------------------------------------------------------------------------------------
 #define FE_NT 256
-#define FE_NRP 12       // R elements per thread in prefetch registers (64*48 / 256)
+#define FE_NRP 15       // R elements per thread in prefetch registers (76*48 / 256, rounded up)
 #define FE_NFP 6        // raw-frame floats per thread held in prefetch registers
 
 // one wave's share of a tile: slot j = output tile (wave + j) % 3 (== (wave + 4j) % 3), column tile
 // (wave + 4j) / 3.  The three R^T fragments are loaded in the wave's rotation, so slot j always
 // multiplies register a[j % 3]; every LDS address is a per-slot base + a compile-time offset.
-template <int NT, int F32, uint32_t XS>
+template <int NT, int F32, uint32_t XS, int NKS>
 __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, uint32_t wave, uint32_t lk,
                                              uint32_t li, uint32_t n_ot, v4f64* acc, v4f32* acc32) {
   const float* ap32[3];
@@ -1021,7 +1172,7 @@ __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, 
   for (int i = 0; i < 3; i++) {
     const uint32_t n = (wave + i) % 3;
     ap[i] = Rs + lk * FE_RS + n * 16 + li;
-    ap32[i] = (const float*)Rs + lk * (2 * FE_RS) + n * 16 + li;
+    ap32[i] = (const float*)Rs + lk * FE_RSF + n * 16 + li;
   }
   // slots past the last output tile repeat its column tile (their sums are never written)
 #pragma unroll
@@ -1030,7 +1181,6 @@ __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, 
   // ks+1 are converted fp32 -> fp64 and the raw operands of step ks+2 are loaded.  The group
   // barriers pin the interleaving (one MFMA, one conversion, one or two LDS reads) so that the
   // matrix pipe does not idle behind a block of conversions and loads at every step.
-  constexpr int NKS = FE_ROWS / 4;
   double a_c[3], a_n[3], bd_c[F32 ? 1 : NT], bd_n[F32 ? 1 : NT];
   float af_c[3], af_n[3], b_c[F32 ? NT : 1], b_r[NT];
 #pragma unroll
@@ -1038,7 +1188,7 @@ __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, 
 #pragma unroll
   for (int j = 0; j < NT; j++) { const float x = *bp[j]; if (F32) b_c[F32 ? j : 0] = x; else bd_c[F32 ? 0 : j] = (double)x; }
 #pragma unroll
-  for (int i = 0; i < 3; i++) { if (F32) af_n[i] = ap32[i][4 * (2 * FE_RS)]; else a_n[i] = ap[i][4 * FE_RS]; }
+  for (int i = 0; i < 3; i++) { if (F32) af_n[i] = ap32[i][4 * FE_RSF]; else a_n[i] = ap[i][4 * FE_RS]; }
 #pragma unroll
   for (int j = 0; j < NT; j++) b_r[j] = bp[j][4 * XS];
   __builtin_amdgcn_sched_barrier(0);
@@ -1056,7 +1206,7 @@ __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, 
       if (ks + 2 < NKS) b_r[j] = bp[j][(ks + 2) * 4 * XS];
       if (F32) b_c[F32 ? j : 0] = held;   // (consumed by the next step's MFMA j, after this step's)
       if (j < 3 && ks + 2 < NKS) {
-        if (F32) af_nn[j] = ap32[j][(ks + 2) * 4 * (2 * FE_RS)]; else a_nn[j] = ap[j][(ks + 2) * 4 * FE_RS];
+        if (F32) af_nn[j] = ap32[j][(ks + 2) * 4 * FE_RSF]; else a_nn[j] = ap[j][(ks + 2) * 4 * FE_RS];
       }
     }
 #pragma unroll
@@ -1076,7 +1226,7 @@ __device__ __forceinline__ void fe_mfma_tile(const double* Rs, const float* Xs, 
   }
 }
 
-template <int NT, int DMAX, int F32>
+template <int NT, int DMAX, int F32, int NKS>
 __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R,
                                                          uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
                                                          uint32_t nfmax, double* __restrict__ slab) {
@@ -1085,8 +1235,8 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
   // row stride of the column image: 80 / 144 / 208 == 16 (mod 64), so the 4 k-rows of a B fragment
   // hit disjoint banks, and compile-time, so every operand address is base + immediate
   constexpr uint32_t xs = (NT == 4 ? 5 : NT == 7 ? 9 : 13) * 16;
-  float* Xs = (float*)fsm;                                    // [64 + dump row][xs]
-  double* Rs = (double*)(Xs + (FE_ROWS + 1) * xs);            // [64][FE_RS] (floats when F32)
+  float* Xs = (float*)fsm;                                    // [76 + dump row][xs]
+  double* Rs = (double*)(Xs + (FE_ROWS + 1) * xs);            // [76][FE_RS] (floats when F32)
   float* Rsf = (float*)Rs;
   float* fr = (float*)(Rs + FE_ROWS * FE_RS);                 // [nfmax][W]
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1106,7 +1256,7 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
 #pragma unroll
   for (int j = 0; j < (F32 ? NT : 1); j++) acc32[j] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
 
-  // prefetch registers: R element e = tid + 256*q of the [64][48] tile, raw-frame float tid + 256*q
+  // prefetch registers: R element e = tid + 256*q of the [76][48] tile, raw-frame float tid + 256*q
   double rp[FE_NRP];
   float fp[FE_NFP];
   const uint32_t nfw = nfmax * W;
@@ -1134,7 +1284,13 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
   uint32_t dur_prev = 0;   // thread tid < 64: duration whose one-hot column is set in row tid
   float* dump = Xs + FE_ROWS * xs;
   __syncthreads();
+#if FU_PROF
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
   while (tile < n_tiles) {
+#if FU_PROF
+    if (threadIdx.x == 0) atomicAdd(&fu_prof[14], 1ull);
+#endif
     // stage: raw frames f0 .. t0+nfr-1, R, the rows' one-hot duration and bias columns
     {
 #pragma unroll
@@ -1147,7 +1303,7 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
 #pragma unroll
       for (int q = 0; q < FE_NRP; q++) {
         const uint32_t e = tid + FE_NT * q, row = e / 48, ol = e % 48;
-        if (F32) Rsf[row * (2 * FE_RS) + ol] = (float)rp[q];
+        if (F32) Rsf[row * FE_RSF + ol] = (float)rp[q];
         else Rs[row * FE_RS + ol] = rp[q];
       }
       if (tid < ft.nrows) {
@@ -1163,23 +1319,41 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
       }
     }
     __syncthreads();
-    // rebuild avg | max | min of the tile's rows: thread = (frame, column); only rows inside the
-    // tile are kept
-    for (uint32_t i = tid; i < ft.nfr * W; i += FE_NT) {
-      const uint32_t tl = fu_div(i, mW), c = i - tl * W;
-      const uint32_t t = ft.t0 + tl;
-      const uint32_t nd = scrf_node_max_dur(t, D);
-      const int32_t lbase = (int32_t)scrf_seg_base(t, D) - (int32_t)ft.r0;
-      const uint32_t d_lo = lbase < 0 ? (uint32_t)(1 - lbase) : 1u;
-      const uint32_t d_hi = min(nd, (uint32_t)((int32_t)ft.nrows - lbase));
-      float v[DMAX];
-      fu_load_vals<DMAX>(fr + (t - ft.f0) * W + c, W, nd, v);
-      float* o = Xs + lbase * (int32_t)xs + c;   // row of d = 1 (may lie before the tile: dumped)
-      fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dump + c);
-      fu_scan_ext<DMAX, 1>(v, o + W, xs, d_lo, d_hi, dump + W + c);
-      fu_scan_ext<DMAX, 0>(v, o + 2 * W, xs, d_lo, d_hi, dump + 2 * W + c);
+    FU_STAMP(8);    // expf: stage
+    // rebuild avg | max | min of the tile's rows: task = (statistic, frame, column), statistic-major, so that the
+    // tile's 3 nfr W tasks fill the workgroup's four waves and a wave runs one statistic's code (two at a seam).
+    // Tiles are whole frames; in the steady state (every duration exists) the LDS offsets are immediates.
+    {
+      const uint32_t nfW = ft.nfr * W, mfW = fu_magic(nfW);
+      const bool full = FU_FULLSCAN && D == (uint32_t)DMAX && ft.t0 + 1 >= D;
+      for (uint32_t i = tid; i < 3 * nfW; i += FE_NT) {
+        const uint32_t st = fu_div(i, mfW), rem = i - st * nfW;
+        const uint32_t tl = fu_div(rem, mW), c = rem - tl * W;
+        const uint32_t t = ft.t0 + tl;
+        const uint32_t at = (t - ft.f0) * W + c;
+        float v[DMAX];
+        if (full) {
+          float* o = Xs + tl * (DMAX * xs) + st * W + c;
+          fu_load_vals_full<DMAX>(fr, at, W, v);
+          if (st == 0) fu_scan_avg_full<DMAX, xs>(v, o);
+          else if (st == 1) fu_scan_ext_full<DMAX, 1, xs>(v, o);
+          else fu_scan_ext_full<DMAX, 0, xs>(v, o);
+        } else {
+          const uint32_t nd = scrf_node_max_dur(t, D);
+          const int32_t lbase = (int32_t)scrf_seg_base(t, D) - (int32_t)ft.r0;
+          const uint32_t d_lo = lbase < 0 ? (uint32_t)(1 - lbase) : 1u;
+          const uint32_t d_hi = min(nd, (uint32_t)((int32_t)ft.nrows - lbase));
+          fu_load_vals<DMAX>(fr + at, W, nd, v);
+          float* o = Xs + lbase * (int32_t)xs + st * W + c;   // row of d = 1 (may lie before the tile: dumped)
+          float* dmp = dump + st * W + c;
+          if (st == 0) fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dmp);
+          else if (st == 1) fu_scan_ext<DMAX, 1>(v, o, xs, d_lo, d_hi, dmp);
+          else fu_scan_ext<DMAX, 0>(v, o, xs, d_lo, d_hi, dmp);
+        }
+      }
     }
     __syncthreads();
+    FU_STAMP(9);    // expf: scans
     // next tile's R and frames, and the descriptor after that, are fetched under the MFMAs
     const uint64_t ntile = tile + gridDim.x;
     if (ntile < n_tiles) {
@@ -1193,8 +1367,9 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
         dn = fa.tiles[ti];
       }
     }
-    fe_mfma_tile<NT, F32, xs>(Rs, Xs, wave, lk, li, n_ot, acc, acc32);
+    fe_mfma_tile<NT, F32, xs, NKS>(Rs, Xs, wave, lk, li, n_ot, acc, acc32);   // depth 4 NKS rows (fused_expf_nks)
     __syncthreads();
+    FU_STAMP(10);   // expf: prefetch issue + MFMAs
     tile = ntile;
     ft = nft;
   }
@@ -1225,22 +1400,16 @@ static uint32_t fused_expf_xs(const ScrfLayout& lay, uint32_t W, uint32_t* n_ct)
   return (*n_ct <= 5 ? 5 : *n_ct <= 9 ? 9 : 13) * 16;
 }
 
-// most raw frames a 64-row tile can need (t_last - f0 + 1), by walking the tiles of a long utterance
-static uint32_t fused_expf_nfmax(uint32_t D) {
-  const uint32_t T = 3 * D + FE_ROWS + 8;
-  const uint64_t nseg = scrf_seg_base(T, D);
-  uint32_t best = 1, t = 0;
-  for (uint64_t r0 = 0; r0 < nseg; r0 += FE_ROWS) {
-    while (scrf_seg_base(t + 1, D) <= r0) t++;
-    uint32_t tl = t;
-    const uint64_t rl = (r0 + FE_ROWS < nseg ? r0 + FE_ROWS : nseg) - 1;
-    while (scrf_seg_base(tl + 1, D) <= rl) tl++;
-    const uint32_t f0 = t - (t < D - 1 ? t : D - 1);
-    if (tl - f0 + 1 > best) best = tl - f0 + 1;
-  }
-  return best;
+// Expected-count tiles are whole frames: as many as give <= 76 rows (what two workgroups per CU can hold at config 2);
+// the depth the kernel runs is the next of 52 / 64 / 76 rows (rows past the tile are staged as zeros).
+// D = 25: 3 frames, 75 rows in 76; D = 10: 7 frames, 70 in 76.
+uint32_t fused_expf_frames(uint32_t D) { return D >= FE_ROWS ? 1u : FE_ROWS / D; }
+static uint32_t fused_expf_nks(uint32_t D) {
+  const uint32_t rows = fused_expf_frames(D) * D;
+  return rows <= 52 ? 13u : rows <= 64 ? 16u : 19u;
 }
-
+// most raw frames a tile can need (t_last - f0 + 1)
+static uint32_t fused_expf_nfmax(uint32_t D) { return fused_expf_frames(D) + D - 1; }
 static size_t fused_expf_smem(const ScrfLayout& lay, uint32_t W) {
   uint32_t n_ct;
   const uint32_t xs = fused_expf_xs(lay, W, &n_ct);
@@ -1261,12 +1430,12 @@ uint32_t fused_expf_blocks(uint64_t n_tiles) {
   return (uint32_t)(n_tiles < nb ? n_tiles : nb);
 }
 
-template <int NT, int DMAX, int F32>
+template <int NT, int DMAX, int F32, int NKS>
 static void launch_expf_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                                 uint64_t n_tiles, uint32_t n_ct, size_t sm, double* slab) {
-  hipFuncSetAttribute((const void*)k_expf_fused<NT, DMAX, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipFuncSetAttribute((const void*)k_expf_fused<NT, DMAX, F32, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   dim3 grid(fused_expf_blocks(n_tiles), (lay.L + 47) / 48);
-  hipLaunchKernelGGL((k_expf_fused<NT, DMAX, F32>), grid, dim3(FE_NT), sm, st, fa, lay, R, lay.L, n_tiles, n_ct,
+  hipLaunchKernelGGL((k_expf_fused<NT, DMAX, F32, NKS>), grid, dim3(FE_NT), sm, st, fa, lay, R, lay.L, n_tiles, n_ct,
                      fused_expf_nfmax(lay.D), slab);
 }
 
@@ -1277,20 +1446,27 @@ void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout
   uint32_t n_ct;
   fused_expf_xs(lay, fa.W, &n_ct);
   const size_t sm = fused_expf_smem(lay, fa.W);
-#define FE_GO2(N, DM)                                                                             \
-  do {                                                                                            \
-    if (f32) launch_expf_fused_t<N, DM, 1>(st, fa, lay, R, n_tiles, n_ct, sm, slab);              \
-    else launch_expf_fused_t<N, DM, 0>(st, fa, lay, R, n_tiles, n_ct, sm, slab);                  \
+  const uint32_t nks = fused_expf_nks(lay.D);
+#define FE_GO3(N, DM, KS)                                                                             \
+  do {                                                                                                \
+    if (f32) launch_expf_fused_t<N, DM, 1, KS>(st, fa, lay, R, n_tiles, n_ct, sm, slab);              \
+    else launch_expf_fused_t<N, DM, 0, KS>(st, fa, lay, R, n_tiles, n_ct, sm, slab);                  \
   } while (0)
-#define FE_GO(N)                                  \
-  do {                                            \
-    if (lay.D <= 12) FE_GO2(N, 12);               \
-    else if (lay.D <= 25) FE_GO2(N, 25);          \
-    else FE_GO2(N, 40);                           \
+  // the depths that occur per duration class: D <= 12 always fills more than 64 rows, 13..25 never stops at 52
+#define FE_GO(N)                                                   \
+  do {                                                             \
+    if (lay.D <= 12) FE_GO3(N, 12, 19);                            \
+    else if (lay.D <= 25) {                                        \
+      if (nks == 16) FE_GO3(N, 25, 16); else FE_GO3(N, 25, 19);    \
+    } else {                                                       \
+      if (nks == 13) FE_GO3(N, 40, 13);                            \
+      else if (nks == 16) FE_GO3(N, 40, 16);                       \
+      else FE_GO3(N, 40, 19);                                      \
+    }                                                              \
   } while (0)
   if (n_ct <= 5) FE_GO(4);
   else if (n_ct <= 9) FE_GO(7);
   else FE_GO(10);
 #undef FE_GO
-#undef FE_GO2
+#undef FE_GO3
 }

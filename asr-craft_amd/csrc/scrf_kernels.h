@@ -112,7 +112,8 @@ void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const doub
 // scrf_fused.hip: state contractions with the window synthesis fused in (X never materialised)
 #define SCRF_FUSED_ROWS_SCORES 256
 uint32_t fused_scores_tb(uint32_t W, uint32_t D);   // whole frames per score tile (0: shape not supported)
-#define SCRF_FUSED_ROWS_EXPF 64
+#define SCRF_FUSED_ROWS_EXPF 76
+uint32_t fused_expf_frames(uint32_t D);            // whole frames per expected-count tile (<= 76 rows)
 int fused_supported(const ScrfLayout& lay, uint32_t W);
 uint32_t fused_expf_blocks(uint64_t n_tiles);
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,

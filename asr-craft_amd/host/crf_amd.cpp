@@ -178,39 +178,55 @@ bool CRF_Model::readAverageFromFile(const char* fname, int present) {
 bool CRF_Model::readGradSqrAccFromFile(const char* fname) { return read_vec(fname, gradSqrAcc.data(), gradSqrAcc.size(), 1.0); }
 
 // ---- one process per GPU: the RCCL unique id goes from rank 0 to the others through a file ----
+// The file holds the 128-byte id followed by a LAUNCH TOKEN, and a rank accepts only a file that carries its own
+// token: a leftover of an earlier run is never mistaken for this launch's id, whatever the clocks say and however far
+// apart the ranks start.  The token is SCRF_LAUNCH_TOKEN when the launcher provides one, else what one launch's
+// processes share on a node: MASTER_ADDR, MASTER_PORT, TORCHELASTIC_RUN_ID, TORCHELASTIC_RESTART_COUNT and the
+// launcher's process id (the parent of every rank).  Waiting time: SCRF_COMM_TIMEOUT_S seconds (120).
 namespace {
 double wall_now() {
   struct timespec ts;
-  clock_gettime(CLOCK_REALTIME, &ts);
+  clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-const double g_launch_time = wall_now();   // the launcher starts all ranks within a fraction of a second
+string launch_token() {
+  if (const char* t = getenv("SCRF_LAUNCH_TOKEN")) return string("token:") + t;
+  string t = "launch";
+  for (const char* k : {"MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) {
+    const char* v = getenv(k);
+    t += string(":") + (v ? v : "-");
+  }
+  return t + ":ppid" + std::to_string((long)getppid());
+}
 
 void exchange_comm_id(int rank, const string& path, unsigned char id[128]) {
+  const string token = launch_token();
   if (rank == 0) {
+    remove(path.c_str());   // whatever an earlier run left behind
     if (scrf_comm_unique_id(id) != SCRF_OK) throw runtime_error(string("scrf_comm_unique_id: ") + scrf_last_error(nullptr));
     const string tmp = path + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0) throw runtime_error("cannot write the communicator id file " + tmp);
+    if (!f || fwrite(id, 1, 128, f) != 128 || fwrite(token.data(), 1, token.size(), f) != token.size() || fclose(f) != 0)
+      throw runtime_error("cannot write the communicator id file " + tmp);
     if (rename(tmp.c_str(), path.c_str()) != 0) throw runtime_error("cannot publish the communicator id file " + path);
     return;
   }
-  // a file older than this launch is the leftover of a run that died: ignored
-  const double deadline = wall_now() + 600.0;
+  const char* to = getenv("SCRF_COMM_TIMEOUT_S");
+  const double deadline = wall_now() + (to && atof(to) > 0 ? atof(to) : 120.0);
+  std::vector<char> buf(128 + token.size() + 1);
   while (wall_now() < deadline) {
-    struct stat st;
-    if (stat(path.c_str(), &st) == 0 && st.st_size == 128 &&
-        (double)st.st_mtim.tv_sec + 1e-9 * (double)st.st_mtim.tv_nsec >= g_launch_time - 2.0) {
-      FILE* f = fopen(path.c_str(), "rb");
-      if (f) {
-        const size_t n = fread(id, 1, 128, f);
-        fclose(f);
-        if (n == 128) return;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (f) {
+      const size_t n = fread(buf.data(), 1, buf.size(), f);   // one byte more than expected: a longer token is a mismatch
+      fclose(f);
+      if (n == 128 + token.size() && memcmp(buf.data() + 128, token.data(), token.size()) == 0) {
+        memcpy(id, buf.data(), 128);
+        return;
       }
     }
     usleep(20000);
   }
-  throw runtime_error("timed out waiting for rank 0's communicator id file " + path);
+  throw runtime_error("timed out waiting for rank 0's communicator id file " + path + " (launch token " + token + ")");
 }
 }  // namespace
 
@@ -715,7 +731,8 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
   if (nEnd == (int)N) throw runtime_error("All feature streams are at the end! You don't have any utterances or you forget to rewind all the streams.");
   double totNumer = 0.0;
   std::vector<double> sgrad(grad && !dist ? n : 0);
-  for (QNUInt32 s = 0; s < N; s++) {  // stream order == the reference's join/sum order
+  string local_failure;   // distributed: a rank that fails must still meet its peers in the collective (below)
+  for (QNUInt32 s = 0; s < N; s++) try {  // stream order == the reference's join/sum order
     if (dist && (int)s != crf->distRank()) continue;
     if (segids[s] == QN_SEGID_BAD) continue;
     const QNUInt32 share = crf_amd_minibatch_share(minibatch, N, s);
@@ -740,14 +757,25 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     *uttCount += (QNUInt32)utts.size();
     if (segids[s] == QN_SEGID_BAD) ++nEnd;
     if (grad && !dist) for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
+  } catch (const std::exception& ex) {
+    if (!dist) throw;
+    local_failure = ex.what();
   }
   if (dist) {
     // the other streams' state is only known through the collective: every rank sends "my stream is
-    // exhausted after this step" along with {numerator, Zx, utterances, active}
+    // exhausted after this step" and "I failed" along with {numerator, Zx, utterances, active}.  A rank that threw
+    // (a bad label, a numeric failure in its share) would otherwise leave its peers waiting in RCCL for ever; this
+    // way all of them see the flag in the same step and end together with a non-zero exit (the reference's
+    // trainer dies with the exception of whichever thread threw).
     const int r = crf->distRank();
-    const double ended_in = segids[r] == QN_SEGID_BAD ? 1.0 : 0.0;
-    double sums4[4] = {0, 0, 0, 0}, ended_out = 0.0;
-    e->check(scrf_allreduce_grad_ex(e->h, nActive, &ended_in, 1, sums4, &ended_out), "accumulateGradient (all-reduce)");
+    const double flags_in[2] = {segids[r] == QN_SEGID_BAD ? 1.0 : 0.0, local_failure.empty() ? 0.0 : 1.0};
+    double sums4[4] = {0, 0, 0, 0}, flags_out[2] = {0.0, 0.0};
+    e->check(scrf_allreduce_grad_ex(e->h, nActive, flags_in, 2, sums4, flags_out), "accumulateGradient (all-reduce)");
+    if (flags_out[1] > 0.5) {
+      if (!local_failure.empty()) throw runtime_error(local_failure);
+      throw runtime_error("CRF_Minibatch_GradAccumulator: " + std::to_string((int)(flags_out[1] + 0.5)) + " other rank(s) failed in this minibatch; rank " + std::to_string(r) + " stops with them");
+    }
+    const double ended_out = flags_out[0];
     if (grad) e->check(scrf_get_grad(e->h, grad, n), "accumulateGradient");
     totNumer = sums4[0];
     *Zx_out = sums4[1];
@@ -902,7 +930,8 @@ double CRF_GradAccumulator::accumulateGradient(CRF_FeatureStreamManager* mgr, in
     throw runtime_error("CRF_GradAccumulator: " + std::to_string(nStreams) + " streams but " + std::to_string(crf->distWorld()) + " ranks");
   crf->pushLambda();
   e->check(scrf_zero_grad(e->h), "accumulateGradient");
-  for (int s = 0; s < nStreams; s++) {
+  string local_failure;
+  for (int s = 0; s < nStreams; s++) try {
     if (dist && s != crf->distRank()) continue;
     CRF_FeatureStream* strm = nStreams == 1 ? mgr->trn_stream : mgr->getChild((size_t)s)->trn_stream;
     strm->rewind();
@@ -919,11 +948,18 @@ double CRF_GradAccumulator::accumulateGradient(CRF_FeatureStreamManager* mgr, in
       make_batch(e, strm, utts, &g);
       e->check(scrf_fb_batch(e->h, g.b, nullptr, nullptr), "CRF_GradAccumulator::accumulateGradient()");
     }
+  } catch (const std::exception& ex) {
+    if (!dist) throw;
+    local_failure = ex.what();
   }
   double sums[4] = {0, 0, 0, 0};
   if (dist) {
-    // sum over the ranks; the collective divides by the active ranks (all of them here): undone
-    e->check(scrf_allreduce_grad_ex(e->h, 1, nullptr, 0, sums, nullptr), "accumulateGradient (all-reduce)");
+    // sum over the ranks; the collective divides by the active ranks (all of them here): undone.  A failed rank
+    // still joins, with a flag, so that every rank stops in the same evaluation (see the minibatch accumulator).
+    const double failed_in = local_failure.empty() ? 0.0 : 1.0;
+    double failed_out = 0.0;
+    e->check(scrf_allreduce_grad_ex(e->h, 1, &failed_in, 1, sums, &failed_out), "accumulateGradient (all-reduce)");
+    if (failed_out > 0.5) throw runtime_error(!local_failure.empty() ? local_failure : "CRF_GradAccumulator: another rank failed in this evaluation; rank " + std::to_string(crf->distRank()) + " stops with it");
     e->check(scrf_scale_grad(e->h, sums[3]), "accumulateGradient");
   } else {
     e->check(scrf_get_batch_sums(e->h, sums), "accumulateGradient");

@@ -1303,6 +1303,7 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
 #pragma unroll
       for (int q = 0; q < FE_NRP; q++) {
         const uint32_t e = tid + FE_NT * q, row = e / 48, ol = e % 48;
+        if (row >= FE_ROWS) continue;   // 15 x 256 elements cover 80 rows
         if (F32) Rsf[row * FE_RSF + ol] = (float)rp[q];
         else Rs[row * FE_RS + ol] = rp[q];
       }

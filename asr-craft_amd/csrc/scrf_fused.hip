@@ -230,6 +230,14 @@ __device__ __forceinline__ void fu_scan_ext_full(const float (&v)[DMAX], float* 
 #ifndef FU_FULLSCAN
 #define FU_FULLSCAN 1   // steady-state scan without clamps and dumps
 #endif
+#ifndef FU_PRIO
+#define FU_PRIO 1       // waves in their vector-only phases (staging, scans, epilogue) outrank waves inside an MFMA loop
+#endif
+#if FU_PRIO
+#define FU_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define FU_SETPRIO(p) do {} while (0)
+#endif
 #ifndef FU_ABL
 #define FU_ABL 0        // ablations (wrong results): 1 = no global loads in the P staging, 2 = nor in the frame staging
 #endif
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       wp[q] = (e < 48 * FU_GC && o0 + ol < n_out && c < nc) ? lambda[lay.state_idx(o0 + ol) + woff + c] : 0.0;
     }
   };
+  FU_SETPRIO(1);
   load_w(0);
 #if FU_PROF
   asm volatile("" :: "v"(ft.t0));   // the descriptor has arrived
@@ -494,6 +503,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     __syncthreads();
     FU_STAMP(1);   // scans (+ barrier)
     if (ci + 1 < nchunks) load_w(ci + 1);   // lands under the MFMAs
+    FU_SETPRIO(0);
 #pragma unroll
     for (int ks = 0; ks < FU_GC / 4; ks++) {
       if (F32) {
@@ -522,6 +532,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
         }
       }
     }
+    FU_SETPRIO(1);
     __syncthreads();
     FU_STAMP(2);   // MFMA loops (+ barrier)
   }
@@ -1283,6 +1294,7 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
   }
   uint32_t dur_prev = 0;   // thread tid < 64: duration whose one-hot column is set in row tid
   float* dump = Xs + FE_ROWS * xs;
+  FU_SETPRIO(1);
   __syncthreads();
 #if FU_PROF
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
@@ -1368,7 +1380,9 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
         dn = fa.tiles[ti];
       }
     }
+    FU_SETPRIO(0);
     fe_mfma_tile<NT, F32, xs, NKS>(Rs, Xs, wave, lk, li, n_ot, acc, acc32);   // depth 4 NKS rows (fused_expf_nks)
+    FU_SETPRIO(1);
     __syncthreads();
     FU_STAMP(10);   // expf: prefetch issue + MFMAs
     tile = ntile;

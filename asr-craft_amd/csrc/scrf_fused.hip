@@ -233,8 +233,15 @@ __device__ __forceinline__ void fu_scan_ext_full(const float (&v)[DMAX], float* 
 #ifndef FU_PRIO
 #define FU_PRIO 1       // waves in their vector-only phases (staging, scans, epilogue) outrank waves inside an MFMA loop
 #endif
+#ifndef FU_PRIO_HI
+#define FU_PRIO_HI 1
+#endif
 #if FU_PRIO
-#define FU_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#ifdef FU_PRIO_INV      // experiment: the other way round
+#define FU_SETPRIO(p) __builtin_amdgcn_s_setprio((p) ? 0 : FU_PRIO_HI)
+#else
+#define FU_SETPRIO(p) __builtin_amdgcn_s_setprio((p) ? FU_PRIO_HI : 0)
+#endif
 #else
 #define FU_SETPRIO(p) do {} while (0)
 #endif

@@ -553,6 +553,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   HIPCHK(h, hipSetDevice(h->device));
   const ScrfLayout& lay = h->lay;
   if (n == 0) return fail(h, SCRF_ERR_EMPTY, "scrf_batch_create: empty batch");
+  if (n >= (1u << 23)) return fail(h, SCRF_ERR_INVALID, "scrf_batch_create: at most 8388607 utterances per batch (the failure latch packs utterance and code into 31 bits)");
   const bool by_windows = utts[0].windows != nullptr;
   if (!by_windows) {
     if (n_streams == 0 || n_streams > SCRF_MAX_STREAMS || !recipes)
@@ -1270,11 +1271,30 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
 // status of a batch: first failed utterance -> {code, utterance} (d_latch), copied to pinned host memory;
 // the commit of the staged gradient is a no-op when the latch is set
 // ---------------------------------------------------------------------------------------------
+// latch[0]: non-zero iff an utterance failed (what k_commit tests); latch[1]: min over the failed utterances of
+// (utterance << 8 | code), so the LOWEST failing utterance is the one reported, whichever thread gets there first --
+// the order in which the reference's per-utterance loop would have thrown.  fb_latch_reset arms it.
+#define SCRF_LATCH_IDLE 0x7fffffff
 __global__ void k_latch_status(const int* __restrict__ status, uint32_t n, int* __restrict__ latch) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   const int s = status[u];
-  if (s != 0 && atomicCAS(&latch[0], 0, s) == 0) latch[1] = (int)u;
+  if (s != 0) {
+    atomicMin(&latch[1], (int)((u << 8) | ((uint32_t)s & 0xffu)));
+    atomicOr(&latch[0], 1);
+  }
+}
+__global__ void k_latch_reset(int* __restrict__ latch) {
+  latch[0] = 0;
+  latch[1] = SCRF_LATCH_IDLE;
+}
+// {code, utterance} from the pinned copy of the latch
+static void latch_decode(const int* h_latch, int out[2]) {
+  out[0] = out[1] = 0;
+  if (h_latch[0] != 0 && h_latch[1] != SCRF_LATCH_IDLE) {
+    out[0] = h_latch[1] & 0xff;
+    out[1] = (int)((uint32_t)h_latch[1] >> 8);
+  }
 }
 __global__ void k_commit(double* __restrict__ grad, const double* __restrict__ stage, uint32_t n,
                          double* __restrict__ sums, const double* __restrict__ sums_stage,
@@ -1443,7 +1463,7 @@ static uint32_t nstate_plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, bool
 static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   const ScrfLayout& l = h->lay;
   HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_latch, 0, sizeof(int) * 2, h->stream));
+  hipLaunchKernelGGL(k_latch_reset, dim3(1), dim3(1), 0, h->stream, h->d_latch);
   HIPCHK(h, hipMemsetAsync(h->d_stage, 0, sizeof(double) * l.lambda_len, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_sums_stage, 0, sizeof(double) * 4, h->stream));
   *used_lin = false;
@@ -1461,8 +1481,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
                        h->d_sums, h->d_sums_stage, h->d_latch);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventSynchronize(h->ev_status));
-    latch[0] = h->h_latch[0];
-    latch[1] = h->h_latch[1];
+    latch_decode(h->h_latch, latch);
     return SCRF_OK;
   }
   Need nd{true, true, false, false};
@@ -1592,8 +1611,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
                      h->d_sums, h->d_sums_stage, h->d_latch);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventSynchronize(h->ev_status));
-  latch[0] = h->h_latch[0];
-  latch[1] = h->h_latch[1];
+  latch_decode(h->h_latch, latch);
   return SCRF_OK;
 }
 
@@ -1698,33 +1716,6 @@ extern "C" int scrf_scores(scrf_handle h, scrf_batch b, uint32_t u, double* S, d
   int rc = check_u(h, b, u, "scrf_scores");
   if (rc != SCRF_OK) return rc;
   HIPCHK(h, hipSetDevice(h->device));
-  if (nstate(h)) {   // S [T][nLabs]; M [T][2*nLabs + P*P]: self transitions | c -> c+1 | end state of p -> start state of q
-    NstateBufs nb;
-    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
-    rc = nstate_run_chunk(h, b, u, u + 1, false, nullptr, &nb);
-    if (rc != SCRF_OK) return rc;
-    const uint64_t T = b->T[u], L = h->lay.L, P = L / h->lay.K, w = 2 * L + P * P;
-    if (S) HIPCHK(h, hipMemcpyAsync(S, nb.S, sizeof(double) * T * L, hipMemcpyDeviceToHost, h->stream));
-    if (M) {
-      HIPCHK(h, hipMemcpy2DAsync(M, sizeof(double) * w, nb.TD, sizeof(double) * L, sizeof(double) * L, T, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipMemcpy2DAsync(M + L, sizeof(double) * w, nb.TO, sizeof(double) * L, sizeof(double) * L, T, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipMemcpy2DAsync(M + 2 * L, sizeof(double) * w, nb.TE, sizeof(double) * P * P, sizeof(double) * P * P, T, hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return SCRF_OK;
-  }
-  if (stdseg(h)) {   // S [N_seg][nActualLabs], M [N_seg][nLabs][nActualLabs]
-    StdsegBufs sb;
-    HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
-    rc = stdseg_run_chunk(h, b, u, u + 1, false, nullptr, &sb);
-    if (rc != SCRF_OK) return rc;
-    const uint64_t ns = b->seg_off[u + 1] - b->seg_off[u];
-    const uint32_t La = stdseg_La(h);
-    if (S) HIPCHK(h, hipMemcpyAsync(S, sb.S, sizeof(double) * ns * La, hipMemcpyDeviceToHost, h->stream));
-    if (M) HIPCHK(h, hipMemcpyAsync(M, sb.MX, sizeof(double) * ns * h->lay.L * La, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return SCRF_OK;
-  }
   if (nstate(h)) {   // S [T][nLabs]; M [T][2*nLabs + P*P]: self transitions | c -> c+1 | end state of p -> start state of q
     NstateBufs nb;
     HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));

@@ -32,25 +32,116 @@ def n_segs(T, Dm):
     return T * (T + 1) // 2 if T < Dm else Dm * (Dm + 1) // 2 + (T - Dm) * Dm
 
 
+def host_topology():
+    """(physical cores per socket, sockets, threads per core) from lscpu; None where it cannot be read"""
+    import subprocess
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {k.strip(): v.strip() for k, v in (ln.split(":", 1) for ln in txt.splitlines() if ":" in ln)}
+        return int(kv["Core(s) per socket"]), int(kv["Socket(s)"]), int(kv["Thread(s) per core"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(frames, labels, off, lam):
     """The oracle (CPU restatement of the reference path, `port`) timed on this box's host cores
-    over a bounded sample of the same workload.  Reported beside the GPU number, never shipped."""
+    over a bounded sample of the same workload: one worker thread per physical core of ONE socket,
+    capped by what this process may use.  Reported beside the GPU number, never shipped."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     try:
-        cores = len(os.sched_getaffinity(0))
+        allowed = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+        allowed = os.cpu_count() or 1
+    topo = host_topology()
+    cores = max(1, min(allowed, topo[0] if topo else allowed, 128))
     n = min(len(off) - 1, cores * 24)
     cfg = orc.config(L=L, D=D, F=F)
     o = np.asarray(off[:n + 1])
     rc, g, numer, zx, sec = orc.bench_fb(cfg, lam, frames[:int(o[-1])], labels[:int(o[-1])], o, IN_W, cores)
     assert rc == 0
+    ph = orc.bench_phases()
+    tot = sum(ph.values()) or 1.0
     rc1, _, _, _, sec1 = orc.bench_fb(cfg, lam, frames[:int(o[2])], labels[:int(o[2])], o[:3], IN_W, 1)
     return {"value": round(n / sec, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "%d utterances of the same batch, %d threads, %.1f s; single thread %.2f utt/s"
-                      % (n, cores, sec, 2 / sec1)}, (g, numer, zx, n)
+            "host": {"physical_cores_per_socket": topo[0] if topo else None, "sockets": topo[1] if topo else None,
+                     "threads_per_core": topo[2] if topo else None, "cpus_allowed": allowed},
+            # the reference's own phase timers (gradbuilder :155-157, :481-488), microseconds per utterance and share
+            "phase_us_per_utt": {k: round(v / n, 1) for k, v in ph.items()},
+            "phase_share": {k: round(v / tot, 4) for k, v in ph.items()},
+            "single_thread_utt_per_s": round(2 / sec1, 3),
+            "sample": "%d utterances of the same batch, %d threads (one per physical core of one socket), %.1f s"
+                      % (n, cores, sec)}, (g, numer, zx, n)
+
+
+def kernels_fingerprint():
+    """sha256 over the kernel sources: what a measured traffic figure belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "asr-craft_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def other_config(eng_mod, name, device_id, scratch_gib):
+    """One forward-backward + gradient step at another BASELINE shape (after the timed region): BASELINE config 3
+    (TIMIT demo: 48 labels, D = 10, 144-dim segment stream + +-6-frame context stream, `stdtrans`, 4 371 216 weights,
+    demo/segmental-timit-demo.cfg.in:13-33) at 256 utterances of 304 frames, or the forward-backward half of config 5
+    (200 labels, D = 40, 123-dim x 2000 frames) at 128 utterances.  Returns the entry of the line's `configs` array."""
+    from scrf_amd import synth
+    if name == "config3":
+        Lc, Dc, W, T, U, ctx = 48, 10, 144, 304, 256, 6
+    else:
+        Lc, Dc, W, T, U, ctx = 200, 40, 123, 2000, 128, None
+    rng = np.random.RandomState(4 if name == "config3" else 6)
+    frames = [rng.random_sample((T, W)).astype(np.float32) for _ in range(U)]
+    if name == "config3":   # rows L1-normalised like the MLP posteriors of the demo (SURVEY 8d)
+        frames = [(f / f.sum(1, keepdims=True)).astype(np.float32) for f in frames]
+    labels = [synth.group_labels(synth.frame_labels(rng, T, Lc, Dc), Dc, Lc) for _ in range(U)]
+    Fs = 8 * W + Dc
+    recipes = [eng_mod.StreamRecipe(W, 0, 0, 1)]
+    streams2 = None
+    kw = dict(L=Lc, D=Dc, F=Fs)
+    Ft = 0
+    if ctx:
+        Ft = (2 * ctx + 1) * W
+        kw = dict(L=Lc, D=Dc, F=Fs + Ft, sfe=Fs - 1, use_trans_ftrs=True, tfs=Fs)
+        recipes.append(eng_mod.StreamRecipe(W, ctx, ctx, 0))
+        streams2 = [[np.concatenate([np.repeat(f[:1], ctx, 0), f, np.repeat(f[-1:], ctx, 0)]) for f in frames]]
+    eng = eng_mod.Engine(eng_mod.make_config(device_id=device_id, scratch_bytes=scratch_gib << 30, precision=1, **kw))
+    eng.set_lambda(rng.normal(0, 0.01, eng.lambda_len))
+    b = eng.batch_from_frames(frames, labels, recipes, streams2)
+    eng.zero_grad(); eng.fb_batch(b, want_scalars=False); eng.synchronize()      # untimed first pass
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.zero_grad(); eng.fb_batch(b, want_scalars=False)
+    eng.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    eng.enable_timing(True)
+    eng.zero_grad(); eng.fb_batch(b, want_scalars=False); eng.synchronize()
+    kt = sorted(eng.kernel_timing(), key=lambda x: -x[1])
+    eng.enable_timing(False)
+    nseg = n_segs(T, Dc)
+    # SURVEY 8d: F_alg = 4 N_seg L Fs' + (4T - 2) L^2 Ft' (feature counts without the bias)
+    f_alg = 4.0 * nseg * Lc * Fs + (4.0 * T - 2) * Lc * Lc * Ft
+    # flops the dense contraction kernels of the general path issue on the matrix pipe (2 per MAC)
+    issued = {"k_scores_mfma(state)": 2.0 * nseg * Lc * (Fs + 1), "k_expf_mfma(state)": 2.0 * nseg * Lc * (Fs + 1),
+              "k_scores_mfma(trans)": 2.0 * T * Lc * Lc * (Ft + 1), "k_expf_mfma(trans)": 2.0 * (T - 1) * Lc * Lc * (Ft + 1)}
+    dom_name, dom_ms, _ = kt[0]
+    dom_flops = issued.get(dom_name)
+    ent = {"name": name, "workload": "%d labels, D=%d, %d-dim x %d frames, %s, lambda_len %d, %d utterances per step"
+                                     % (Lc, Dc, W, T, "stdtrans (+-%d context)" % ctx if ctx else "stdstate", eng.lambda_len, U),
+           "ms_per_step": round(ms, 3), "utt_per_s": round(U / ms * 1e3, 1),
+           "algorithmic_gflop_per_utt": round(f_alg / 1e9, 3),
+           "frac_algorithmic": round(f_alg * U / (ms * 1e-3) / (PEAK["mfma_f64_tflops"] * 1e12), 4),
+           "dominant_kernel": {"name": dom_name, "ms": round(dom_ms, 3),
+                               "frac_executed": round(dom_flops * U / (dom_ms * 1e-3) / (PEAK["mfma_f64_tflops"] * 1e12), 4) if dom_flops else None},
+           "kernels_ms": {nm: round(m_, 3) for nm, m_, _ in kt[:8]}}
+    b.close(); eng.close()
+    return ent
 
 
 def main():
@@ -64,6 +155,7 @@ def main():
     ap.add_argument("--precision", choices=["exact", "fast", "fast32"], default="fast",
                     help="exact: reference-order unfused fp64; fast: fp64 MFMA, window synthesis fused into the contractions; fast32: f32 MFMA contractions (opt-in)")
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config-3 / config-5 steps after the timed region")
     args = ap.parse_args()
 
     # the JSON line must be the only thing on stdout: until it is printed, file descriptor 1 points
@@ -216,23 +308,34 @@ def main():
         else:
             achieved = dom["gbyte"] / per_step / (avg_ms / 1e3); peak = PEAK["hbm_gbs"]; unit = "GB/s"
             per_launch = dom["gbyte"] / per_step
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tpath):   # HBM bytes per utterance from separate rocprofv3 --pmc passes (profiles/README.md)
+        # HBM bytes of the dominant kernel from separate rocprofv3 --pmc passes (profiles/README.md); the file names the
+        # kernel sources it was measured on, and a figure from other sources is not reported
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            ent = tj.get(args.precision, {}).get(dom["name"])
-            if ent:
-                traffic = round(ent["bytes_per_utt"] * U / per_step)
+            if tj.get("kernels_sha16") != kernels_fingerprint():
+                traffic_note = "profiles/r03_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("kernels_sha16")
+            else:
+                ent = tj.get(args.precision, {}).get(dom["name"])
+                if ent:
+                    traffic = round(ent["bytes_per_utt"] * U / per_step)
         frac = achieved / peak
-        assert 0.0 < frac <= 1.0, "roofline fraction %r out of range: the work model of %s is wrong" % (frac, dom["name"])
+        # SURVEY 8d's DENSE figure for the same kernel next to the executed one: the fused kernels contract only the
+        # avg | max | min (+ one-hot, bias) columns and leave the five sampled blocks to k_pframe / k_ztf, so the dense
+        # flops are not what they run (a fraction above 1 here is that re-association, not a faster pipe)
+        dense = {"k_scores_fused": 2.0 * nseg * L * F, "k_expf_fused": 2.0 * nseg * L * F}.get(dom["name"])
+        frac_alg = (dense * U / 1e12 / per_step / (avg_ms / 1e3) / peak) if (dense and dom["bound"] == "mfma") else frac
         step_ms = 1e3 * dt / args.steps
         # the whole step against its floors: matrix-pipe time of the flops the design executes, and SURVEY
         # 8d's algorithmic bytes per utterance (frames + 3 passes over S + 2 over the recursion arrays)
         b_alg = (4.0 * T_FRAMES * IN_W + 3 * 8.0 * (nseg * L + L * L) + 2 * 8.0 * (nseg * L + 2 * T_FRAMES * L)) * U
         hbm_floor = b_alg / (PEAK["hbm_gbs"] * 1e9) * 1e3
         roofline = {"kernel": dom["name"], "bound": dom["bound"], "achieved": round(achieved, 4), "peak": peak, "unit": unit,
-                    "frac": round(frac, 5), "traffic": traffic,
+                    "frac": round(frac, 5), "frac_algorithmic": round(frac_alg, 5), "traffic": traffic,
+                    "traffic_note": traffic_note, "invalid": not (0.0 < frac <= 1.0),
+                    "kernels_sha16": kernels_fingerprint(),
                     "work_per_launch": round(per_launch, 6), "work_is": "flops issued on the matrix pipe" if dom["bound"] == "mfma" else "algorithmic bytes",
                     "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
                     "kernels": kernels,
@@ -252,7 +355,9 @@ def main():
             "config": {"workload": "BASELINE config 2: segmental CRF forward-backward, 48 labels, max-seg-len 25, "
                                    "39-dim x 300-frame utterances, stdstate map (lambda_len 18528)",
                        "utts_per_rank_per_step": U, "global_minibatch": U * world, "precision": args.precision,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+                       "step_sync": "scrf_fb_batch returns once the recursion's status is known (one event wait per step)"},
             "roofline": roofline,
         }
         # decode half of the metric: best-path labels of the same resident batch, bit-identical
@@ -292,6 +397,11 @@ def main():
             out["parity_gate"] = "skipped (--no-cpu-baseline): finiteness of lambda only"
     batch.close()
     eng.close()
+    if rank == 0 and out is not None and not args.no_other_configs:
+        # the north-star training shape and the stress shape on the same clock (general path: materialised windows,
+        # dense fp64-MFMA contractions); parity cases elsewhere, throughput entries here.  After the config-2 engine
+        # has released its arena.
+        out["configs"] = [other_config(scrf_amd, nm, local_rank, max(args.scratch_gib, 160)) for nm in ("config3", "config5")]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

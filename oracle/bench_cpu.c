@@ -30,7 +30,14 @@ typedef struct {
   double* numer;  /* [U] */
   double* zx;     /* [U] */
   int err;
+  double phase_us[5];   /* featLoad, transMat, alpha, beta, expF of this worker (gradbuilder :155-157) */
 } worker_arg;
+extern __thread double* orc_phase_us;
+static double now_us(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+}
 
 static void* worker(void* p) {
   worker_arg* a = (worker_arg*)p;
@@ -38,6 +45,7 @@ static void* worker(void* p) {
   const uint32_t D = cfg->lab_max_dur, F = cfg->num_feas;
   float* seg = NULL;
   uint64_t seg_cap = 0;
+  orc_phase_us = a->phase_us;
   for (uint32_t u = a->u_begin; u < a->u_end; u++) {
     uint32_t T = (uint32_t)(a->frame_off[u + 1] - a->frame_off[u]);
     uint64_t nseg = orc_num_segs(T, D);
@@ -46,12 +54,15 @@ static void* worker(void* p) {
       seg = (float*)malloc(sizeof(float) * nseg * F);
       seg_cap = nseg;
     }
+    const double tw = now_us();
     orc_windows(a->frames + a->frame_off[u] * a->in_width, T, a->in_width, D, 0, 0, 1, seg, F, 0);
+    a->phase_us[0] += now_us() - tw;
     int e = orc_seg_build_gradient(cfg, a->lay, a->lambda, seg, a->labels + a->frame_off[u], T,
                                    a->grad, &a->numer[u], &a->zx[u]);
     if (e != ORC_OK && a->err == ORC_OK) a->err = e;
   }
   free(seg);
+  orc_phase_us = NULL;
   return NULL;
 }
 
@@ -65,6 +76,10 @@ static double now_s(void) {
  * the contiguous range [s*floor(U/N), (s+1)*floor(U/N)), the last one takes the
  * remainder.  grad_out = sum_s sgrad[s] / n_active.  Returns wall seconds of the
  * threaded region through *seconds. */
+static double g_phase_us[5];
+/* the five phase timers of the last orc_bench_fb call, microseconds summed over the workers */
+void orc_bench_phases(double* out5) { memcpy(out5, g_phase_us, sizeof(g_phase_us)); }
+
 int orc_bench_fb(const orc_config* cfg, const double* lambda, const float* frames,
                  const uint32_t* labels, const uint64_t* frame_off, uint32_t U, uint32_t in_width,
                  uint32_t n_threads, double* grad_out, double* numer, double* zx,
@@ -91,9 +106,11 @@ int orc_bench_fb(const orc_config* cfg, const double* lambda, const float* frame
     active[s] = a->u_end > a->u_begin;
     pthread_create(&th[s], NULL, worker, a);
   }
+  memset(g_phase_us, 0, sizeof(g_phase_us));
   for (uint32_t s = 0; s < n_threads; s++) {
     pthread_join(th[s], NULL);
     if (args[s].err != ORC_OK && rc == ORC_OK) rc = args[s].err;
+    for (int i = 0; i < 5; i++) g_phase_us[i] += args[s].phase_us[i];
   }
   double t1 = now_s();
   if (seconds) *seconds = t1 - t0;

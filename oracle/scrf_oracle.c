@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 const double ORC_LOG0 = -1 * DBL_MAX; /* utils/CRF_LogMath.h:26 */
 
@@ -516,6 +517,18 @@ int orc_seg_backward(const orc_config* cfg, const double* S, const double* M, ui
 /* CRF_NewGradBuilder_StdSeg_NoDur_NoTrans::buildGradient,
  * trainers/gradbuilders/CRF_NewGradBuilder_StdSeg_NoDur_NoTrans.cpp:65-492, with
  * computeExpF nodes/...WithoutSegTransFtr.cpp:616-949 inlined in its loop order. */
+/* Phase timers of the reference's buildGradient (gradbuilder :155-157, :481-488: featLoadTime, transMatTime,
+ * alphaTime, betaTime, expFTime, microseconds).  A thread that wants them points orc_phase_us at five doubles
+ * (bench_cpu.c does; slot 0, the feature load, is the caller's); NULL = no timing. */
+__thread double* orc_phase_us = NULL;
+static double phase_now_us(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+}
+#define PHASE_BEGIN() double ph_t0_ = orc_phase_us ? phase_now_us() : 0.0
+#define PHASE_END(i) do { if (orc_phase_us) { const double n_ = phase_now_us(); orc_phase_us[i] += n_ - ph_t0_; ph_t0_ = n_; } } while (0)
+
 int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
                            const float* segftrs, const uint32_t* labels, uint32_t T,
                            double* grad, double* numer, double* Zx_out) {
@@ -536,11 +549,16 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
   uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (L + 2));
   double logLi = 0.0, Zx = 0.0;
 
+  PHASE_BEGIN();
   orc_seg_scores(cfg, lay, lambda, segftrs, T, S, M);       /* :284 */
+  PHASE_END(1);
   err = orc_seg_forward(cfg, S, M, T, ad, alpha, apt, &Zx); /* :296,307,343 */
+  PHASE_END(2);
 
   for (uint32_t t = T; t-- > 0 && err == ORC_OK;) { /* :388-469 */
+    PHASE_END(4);   /* the expected-count part of the previous node (nothing before the first) */
     seg_beta_node(cfg, S, M, T, t, beta, sd, tmp, &err);
+    PHASE_END(3);
     /* label of the next node that carries one (:436-444) */
     uint32_t next_lab = ORC_LAB_BAD;
     for (uint32_t u = t + 1; u < T; u++) {
@@ -601,6 +619,7 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
     }
     logLi += nodeLi; /* :453 */
   }
+  PHASE_END(4);
   for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i]; /* :471-473 */
   *Zx_out = Zx;
   *numer = logLi;

@@ -565,6 +565,14 @@ def bench_fb(cfg, lam, frames, labels, frame_off, in_width, n_threads):
     return rc, grad, numer, zx, sec.value
 
 
+def bench_phases():
+    """the reference's five phase timers (featLoad, transMat, alpha, beta, expF) of the last bench_fb call:
+    microseconds summed over the worker threads"""
+    out = (C.c_double * 5)()
+    lib().orc_bench_phases(out)
+    return dict(zip(("featLoad", "transMat", "alpha", "beta", "expF"), [float(v) for v in out]))
+
+
 # --------------------------------------------------------------------------- #
 # Independent brute-force enumeration of all labelled segmentations (tiny cases)
 # --------------------------------------------------------------------------- #

@@ -44,6 +44,24 @@ def test_bad_label_is_reported_by_fb_batch_and_leaves_the_gradient_alone(prec, w
     bad.close(); good.close(); eng.close()
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+def test_the_lowest_failing_utterance_is_the_one_reported(prec):
+    """several bad utterances in one batch: the report names the first in batch order every time, as the reference's
+    per-utterance loop would have thrown there -- not whichever thread latched first"""
+    n = 600
+    c = Case(L=5, D=4, in_w=3, Ts=[5 + (u % 4) for u in range(n)], seed=21, precision=prec)
+    labs = [l.copy() for l in c.labels]
+    for u in (577, 123, 124, 400, 599):
+        labs[u][-1] = c.L * c.D + 1
+    eng = c.engine()
+    bad = eng.batch_from_frames(c.frames, labs, c.recipes)
+    for _ in range(5):
+        with pytest.raises(scrf_amd.ScrfError) as ei:
+            eng.fb_batch(bad, want_scalars=False)
+        assert ei.value.code == 5 and "utterance 123" in str(ei.value)
+    bad.close(); eng.close()
+
+
 def wide_spread_case(prec, fused=True):
     """Weights under which the scaled linear-domain recursion must give up where the reference's log-domain
     recursion succeeds: the state bias of label 0 is +1000 (every frame's posterior mass sits on label 0

@@ -38,5 +38,15 @@ for prec in ("fast", "fast32"):
         fr, wr = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
         b = int((2 * fr + wr) * 1024)
         res[prec][k] = {"fetch_size_kb_raw": fr, "write_size_kb": wr, "bytes_per_launch": b, "bytes_per_utt": b / U}
+# the figures belong to the kernel sources they were measured on: bench.py reports them only while that fingerprint
+# (its kernels_fingerprint(): sha256 over asr-craft_amd/csrc/*.{hip,h,cpp}) is the tree's
+sys.path.insert(0, ROOT)
+import bench
+res["kernels_sha16"] = bench.kernels_fingerprint()
+try:
+    import subprocess
+    res["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    res["commit"] = None
 json.dump(res, open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), "w"), indent=1)
-print(json.dumps({p: {k: round(v["bytes_per_launch"] / 1e9, 2) for k, v in d.items()} for p, d in res.items()}))
+print(json.dumps({p: {k: round(v["bytes_per_launch"] / 1e9, 2) for k, v in d.items()} for p, d in res.items() if isinstance(d, dict)}))

@@ -1021,7 +1021,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       }
       cb->rpc_s = expf_rows_per_chunk(nseg);
       cb->nch_s = (uint32_t)((nseg + cb->rpc_s - 1) / cb->rpc_s);
-      if (nd.fused) cb->nch_s = fused_expf_blocks(b->tile_off[1][u1] - b->tile_off[1][u0]);
+      if (nd.fused) cb->nch_s = fused_expf_blocks(l, b->recipe[0].in_width, h->cfg.train_precision == SCRF_PREC_FAST32, b->tile_off[1][u1] - b->tile_off[1][u0]);
       cb->slab_s = a.take<double>((size_t)(nd.fused ? 512 : cb->nch_s) * l.L * l.nsf);
     }
   }

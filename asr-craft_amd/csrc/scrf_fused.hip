@@ -183,11 +183,14 @@ __device__ __forceinline__ void fu_load_vals_full(const float* img, uint32_t at,
   // a running index into the LDS image (one subtraction per load; j * W would be a quarter-rate integer multiply
   // each).  The opaque value is the INDEX, not the pointer: an opaque pointer loses its address space and the loads
   // become flat loads.
+  // byte offsets in 32 bits: for an image in memory the loads then take the scalar-base + 32-bit-lane-offset form
+  uint32_t atb = at * 4u;
+  const uint32_t wb = W * 4u;
 #pragma unroll
   for (int j = 0; j < DMAX; j++) {
-    v[j] = img[at];
-    at -= W;
-    asm volatile("" : "+v"(at));
+    v[j] = *(const float*)((const char*)img + atb);
+    atb -= wb;
+    asm volatile("" : "+v"(atb));
   }
 }
 template <int DMAX, uint32_t STRIDE>
@@ -1415,6 +1418,199 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_expf_fused_ws: the same contraction with the workgroup's waves SPECIALISED.  k_expf_fused alternates three
+// barrier-separated phases per tile (stage, scans, MFMAs), and a wave that stages or scans shares its SIMD's issue
+// with a wave of the other workgroup that is inside its MFMA loop: the vector phases stretch to several times their
+// instruction time and the matrix pipe idles in between (in-kernel stamps: stage + scans = 37 % of a tile).  Here one
+// 512-thread workgroup owns the CU: waves 0-3 (one per SIMD) do nothing but MFMAs on one LDS image pair while waves
+// 4-7 (one per SIMD, s_setprio 1) build the next tile's pair -- R from memory, avg | max | min scanned straight from
+// the raw frames in memory (L2-resident; no staged frame image, so the producers need no barrier among themselves),
+// one-hot and bias columns -- and the two halves meet at ONE barrier per tile.
+// LDS: 2 x ([76+1][xs] floats + [76][48] doubles) = 147 KB at config 2.
+// ------------------------------------------------------------------------------------------
+#define FW_NT 512
+template <int NT, int DMAX, int NKS>
+__global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R,
+                                                            uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
+                                                            double* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const uint32_t W = fa.W, D = lay.D;
+  constexpr uint32_t xs = (NT == 4 ? 5 : NT == 7 ? 9 : 13) * 16;
+  constexpr uint32_t XB = (FE_ROWS + 1) * xs;   // floats per column image (row FE_ROWS: dump row)
+  constexpr uint32_t RB = FE_ROWS * FE_RS;      // doubles per R image
+  float* Xs0 = (float*)fsm;                     // [2][XB]
+  double* Rs0 = (double*)(Xs0 + 2 * XB);        // [2][RB]
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t o0 = blockIdx.y * 48;
+  const uint32_t ncol = 3 * W + D + (lay.use_sb ? 1 : 0);
+  const uint32_t n_ot = 3 * n_ct;
+  for (uint32_t i = tid; i < 2 * XB; i += FW_NT) Xs0[i] = 0.0f;
+  for (uint32_t i = tid; i < 2 * RB; i += FW_NT) Rs0[i] = 0.0;
+
+  v4f64 acc[NT];
+  v4f32 acc32_unused[1];
+#pragma unroll
+  for (int j = 0; j < NT; j++) acc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  const uint64_t first = gridDim.y == 1 ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint64_t G = gridDim.x;
+  // ---- producer state
+  const uint32_t ptid = tid - 256;
+  const uint32_t mW = fu_magic(W);
+  uint32_t dur_prev0 = 0, dur_prev1 = 0;   // producer thread ptid < nrows: the one-hot column set in row ptid of image 0 / 1
+  ScrfTileDesc dn;                         // descriptor of the tile the producers build next
+  if (producer && first < n_tiles) dn = fa.tiles[fa.tile0 + first];
+  auto build = [&](uint32_t buf, uint64_t tile_next) {
+    // fills image pair `buf` with the tile whose descriptor sits in dn; then fetches tile_next's descriptor
+    float* Xs = Xs0 + buf * XB;
+    double* Rs = Rs0 + buf * RB;
+    // the descriptor came through a vector load; everything derived from it is wave-uniform, and saying so keeps the
+    // tile's base addresses in scalar registers (global loads with a 32-bit lane offset instead of 64-bit lane
+    // addresses: with those the allocator ran out of registers and serialised the loads behind s_waitcnt vmcnt)
+    FuTile ft = fu_tile(fa, dn);
+    ft.t0 = __builtin_amdgcn_readfirstlane(ft.t0); ft.nfr = __builtin_amdgcn_readfirstlane(ft.nfr);
+    ft.nrows = __builtin_amdgcn_readfirstlane(ft.nrows); ft.f0 = __builtin_amdgcn_readfirstlane(ft.f0);
+    ft.r0 = __builtin_amdgcn_readfirstlane(ft.r0);
+    ft.row0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(ft.row0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)ft.row0);
+    ft.fr0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(ft.fr0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)ft.fr0);
+    if (tile_next < n_tiles) {
+      uint64_t ti = fa.tile0 + tile_next;
+      asm volatile("" : "+v"(ti));   // a vector load: a scalar one would wait with the LDS traffic below
+      dn = fa.tiles[ti];
+    }
+    double rp[FE_NRP];
+#pragma unroll
+    for (int q = 0; q < FE_NRP; q++) {
+      const uint32_t e = ptid + 256 * q, row = e / 48, ol = e % 48;
+      const double* Rt = R + ft.row0 * n_out + o0;   // uniform base, 32-bit lane offset
+      const uint32_t offb = (row * n_out + ol) * 8u;
+      rp[q] = (row < ft.nrows && o0 + ol < n_out) ? __builtin_nontemporal_load((const double*)((const char*)Rt + offb)) : 0.0;
+    }
+    // the rows' one-hot duration and bias columns (per image: each keeps what it set last time)
+    if (ptid < ft.nrows) {
+      const uint32_t r = ft.r0 + ptid;
+      uint32_t t = ft.t0;
+      while ((uint32_t)scrf_seg_base(t + 1, D) <= r) t++;
+      const uint32_t d = r - (uint32_t)scrf_seg_base(t, D) + 1;
+      float* xr = Xs + ptid * xs + 3 * W;
+      const uint32_t dp = buf ? dur_prev1 : dur_prev0;
+      if (dp) xr[dp - 1] = 0.0f;
+      xr[d - 1] = 1.0f;
+      if (buf) dur_prev1 = d; else dur_prev0 = d;
+      if (lay.use_sb) xr[D] = 1.0f;
+    }
+    // avg | max | min: task = (statistic, frame, column), values straight from the raw frames in memory.  A thread
+    // takes tasks ptid and ptid + 256 together: both tasks' loads are in flight at once (one memory round trip per
+    // tile instead of two).  (Interleaving the two scan chains by hand, so that the wave always has a second
+    // instruction ready beside the MFMA wave, was measured too: 9.5 -> 11.3 ms.)
+    {
+      const float* gfr = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
+      const uint32_t nfW = ft.nfr * W, mfW = fu_magic(nfW);
+      const bool full = FU_FULLSCAN && D == (uint32_t)DMAX && ft.t0 + 1 >= D;
+      float* dump = Xs + FE_ROWS * xs;
+      auto decode = [&](uint32_t i, uint32_t& st, uint32_t& tl, uint32_t& c) {
+        st = fu_div(i, mfW);
+        const uint32_t rem = i - st * nfW;
+        tl = fu_div(rem, mW);
+        c = rem - tl * W;
+      };
+      auto scan_full = [&](const float (&v)[DMAX], uint32_t st, float* o) {
+        if (st == 0) fu_scan_avg_full<DMAX, xs>(v, o);
+        else if (st == 1) fu_scan_ext_full<DMAX, 1, xs>(v, o);
+        else fu_scan_ext_full<DMAX, 0, xs>(v, o);
+      };
+      for (uint32_t i0 = ptid; i0 < 3 * nfW; i0 += 512) {
+        const uint32_t i1 = i0 + 256;
+        const bool two = i1 < 3 * nfW;
+        uint32_t st0, tl0, c0, st1, tl1, c1;
+        decode(i0, st0, tl0, c0);
+        decode(two ? i1 : i0, st1, tl1, c1);
+        if (full) {
+          float v0[DMAX], v1[DMAX];
+          fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl0 - ft.f0) * W + c0, W, v0);
+          fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl1 - ft.f0) * W + c1, W, v1);
+          scan_full(v0, st0, Xs + tl0 * (DMAX * xs) + st0 * W + c0);
+          if (two) scan_full(v1, st1, Xs + tl1 * (DMAX * xs) + st1 * W + c1);
+        } else {
+          for (int h = 0; h < (two ? 2 : 1); h++) {
+            const uint32_t st = h ? st1 : st0, tl = h ? tl1 : tl0, c = h ? c1 : c0;
+            const uint32_t t = ft.t0 + tl;
+            const uint32_t at = (t - ft.f0) * W + c;
+            float v[DMAX];
+            const uint32_t nd = scrf_node_max_dur(t, D);
+            const int32_t lbase = (int32_t)scrf_seg_base(t, D) - (int32_t)ft.r0;
+            const uint32_t d_lo = lbase < 0 ? (uint32_t)(1 - lbase) : 1u;
+            const uint32_t d_hi = min(nd, (uint32_t)((int32_t)ft.nrows - lbase));
+            fu_load_vals<DMAX>(gfr + at, W, nd, v);
+            float* o = Xs + lbase * (int32_t)xs + st * W + c;
+            float* dmp = dump + st * W + c;
+            if (st == 0) fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dmp);
+            else if (st == 1) fu_scan_ext<DMAX, 1>(v, o, xs, d_lo, d_hi, dmp);
+            else fu_scan_ext<DMAX, 0>(v, o, xs, d_lo, d_hi, dmp);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < FE_NRP; q++) {
+      const uint32_t e = ptid + 256 * q, row = e / 48, ol = e % 48;
+      if (row < FE_ROWS) Rs[row * FE_RS + ol] = rp[q];
+    }
+  };
+
+  __syncthreads();   // the cleared images
+  if (producer) {
+    FU_SETPRIO(1);
+    if (first < n_tiles) build(0, first + G);
+  }
+  __syncthreads();
+  uint32_t k = 0;
+#if FU_PROF
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#define FW_STAMP(who, i) do { if (threadIdx.x == (who)) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&fu_prof[i], n_ - stamp_); stamp_ = n_; } } while (0)
+#else
+#define FW_STAMP(who, i) do {} while (0)
+#endif
+  for (uint64_t tile = first; tile < n_tiles; tile += G, k++) {
+    const uint32_t cur = k & 1;
+#if FU_PROF
+    if (threadIdx.x == 0) atomicAdd(&fu_prof[14], 1ull);
+#endif
+    if (producer) {
+      if (FU_ABL != 4 && tile + G < n_tiles) build(cur ^ 1, tile + 2 * G);
+      FW_STAMP(256, 8);    // producers: building the next tile's images
+    } else {
+      if (FU_ABL != 3) fe_mfma_tile<NT, 0, xs, NKS>(Rs0 + cur * RB, Xs0 + cur * XB, wave, lk, li, n_ot, acc, acc32_unused);
+      FW_STAMP(0, 10);     // consumers: MFMAs
+    }
+    __syncthreads();
+    FW_STAMP(256, 9);      // producers: waiting at the barrier
+    FW_STAMP(0, 11);       // consumers: waiting at the barrier
+  }
+  if (producer) return;
+  // slab[blockIdx.x][o][f]
+  double* out = slab + (uint64_t)blockIdx.x * n_out * ncol;
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const uint32_t q = wave + 4 * j;
+    if (q >= n_ot) continue;
+    const uint32_t n = q % 3, ct = q / 3;
+    const uint32_t f = ct * 16 + li;
+    if (f >= ncol) continue;
+    const double sc = (lay.use_sb && f == 3 * W + D) ? lay.sbv : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t o = o0 + n * 16 + lk + 4 * r;
+      if (o >= n_out) continue;
+      out[(uint64_t)o * ncol + f] = acc[j][r] * sc;
+    }
+  }
+}
+
 // column tiles needed, and the row stride of the kernel instantiation that serves them (NCT * 16)
 static uint32_t fused_expf_xs(const ScrfLayout& lay, uint32_t W, uint32_t* n_ct) {
   const uint32_t ncol = 3 * W + lay.D + (lay.use_sb ? 1 : 0);
@@ -1447,16 +1643,34 @@ int fused_supported(const ScrfLayout& lay, uint32_t W) {
   return fused_scores_tb(W, lay.D) >= 1;
 }
 
-uint32_t fused_expf_blocks(uint64_t n_tiles) {
+// the wave-specialised kernel (one 512-thread workgroup per CU, two image pairs in LDS) serves the fp64 form whenever
+// its LDS fits; SCRF_EXPF_WS=0 switches it off (A/B measurements)
+static size_t fused_expf_ws_smem(const ScrfLayout& lay, uint32_t W) {
+  uint32_t n_ct;
+  const uint32_t xs = fused_expf_xs(lay, W, &n_ct);
+  return 2 * (sizeof(float) * (FE_ROWS + 1) * xs + sizeof(double) * FE_ROWS * FE_RS);
+}
+static bool fused_expf_ws(const ScrfLayout& lay, uint32_t W, int f32) {
+  static const bool on = !(getenv("SCRF_EXPF_WS") && atoi(getenv("SCRF_EXPF_WS")) == 0);
+  return on && !f32 && fused_expf_ws_smem(lay, W) <= 160 * 1024;
+}
+uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles) {
   static const uint32_t nb = getenv("SCRF_EXPF_BLOCKS") ? (uint32_t)atoi(getenv("SCRF_EXPF_BLOCKS")) : 512u;  // experiment knob (<= 512)
-  return (uint32_t)(n_tiles < nb ? n_tiles : nb);
+  const uint32_t cap = fused_expf_ws(lay, W, f32) ? std::min(nb, 256u) : nb;   // one workgroup per CU there
+  return (uint32_t)(n_tiles < cap ? n_tiles : cap);
 }
 
 template <int NT, int DMAX, int F32, int NKS>
 static void launch_expf_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                                 uint64_t n_tiles, uint32_t n_ct, size_t sm, double* slab) {
+  dim3 grid(fused_expf_blocks(lay, fa.W, F32, n_tiles), (lay.L + 47) / 48);
+  if (!F32 && fused_expf_ws(lay, fa.W, F32)) {
+    const size_t smw = fused_expf_ws_smem(lay, fa.W);
+    hipFuncSetAttribute((const void*)k_expf_fused_ws<NT, DMAX, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
+    hipLaunchKernelGGL((k_expf_fused_ws<NT, DMAX, NKS>), grid, dim3(FW_NT), smw, st, fa, lay, R, lay.L, n_tiles, n_ct, slab);
+    return;
+  }
   hipFuncSetAttribute((const void*)k_expf_fused<NT, DMAX, F32, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  dim3 grid(fused_expf_blocks(n_tiles), (lay.L + 47) / 48);
   hipLaunchKernelGGL((k_expf_fused<NT, DMAX, F32, NKS>), grid, dim3(FE_NT), sm, st, fa, lay, R, lay.L, n_tiles, n_ct,
                      fused_expf_nfmax(lay.D), slab);
 }

@@ -115,7 +115,7 @@ uint32_t fused_scores_tb(uint32_t W, uint32_t D);   // whole frames per score ti
 #define SCRF_FUSED_ROWS_EXPF 76
 uint32_t fused_expf_frames(uint32_t D);            // whole frames per expected-count tile (<= 76 rows)
 int fused_supported(const ScrfLayout& lay, uint32_t W);
-uint32_t fused_expf_blocks(uint64_t n_tiles);
+uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles);   // workgroups (= slabs) of launch_expf_fused, <= 512
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                          const double* P, uint64_t n_tiles, double* S, int f32, double* smax = nullptr,
                          double* s_true = nullptr, const uint32_t* labels = nullptr);

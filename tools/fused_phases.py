@@ -32,6 +32,5 @@ for i, name in enumerate(["stage(rest)", "scan", "mfma", "pstage", "epilogue", "
 print("  %-12s %10.1f" % ("sum", sum(v[:8]) / n))
 n = max(1, v[14])
 print("k_expf_fused: tiles", v[14])
-for i, name in [(8, "stage"), (9, "scan"), (10, "mfma")]:
-    print("  %-12s %10.1f" % (name, v[i] / n))
-print("  %-12s %10.1f" % ("sum", sum(v[8:11]) / n))
+for i, name in [(8, "stage | producers: build"), (9, "scan | producers: barrier wait"), (10, "mfma | consumers: mfma"), (11, "consumers: barrier wait")]:
+    print("  %-32s %10.1f" % (name, v[i] / n))

@@ -21,6 +21,8 @@
 // beta in k_post_lin, R = Y - gamma overwrites es in place.
 #include "scrf_dp_common.h"
 
+#include <stdlib.h>
+
 #define LN2_HI 6.93147180369123816490e-01
 #define LN2_LO 1.90821492927058770002e-10
 
@@ -345,6 +347,259 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
 }
 
 // ------------------------------------------------------------------------------------------
+// k_dp_lin_mv: the same recursion with SEVERAL wavefronts per (utterance, direction) -- time-invariant transitions,
+// L <= 64.  One wavefront per sweep (k_dp_lin) runs a step as one dependent chain -- 48 x 48 transition product, wave
+// maximum, exp, D ring reads with their multiply-adds: 3.4 us -- and 11 resident sweeps per CU are all its LDS rings
+// allow.  Here a workgroup of NW wavefronts shares ONE ring: wavefront w takes the durations d0 = w, w + NW, ... (a
+// quarter of the rows to load, of the ring reads and of the multiply-adds) and the rows c = w CQ .. of the transition
+// product, whose matrix entries it keeps in registers; the partial sums meet in LDS at two barriers per step.  The
+// chain per step is a third as long, a step's loads are requested a step ahead with 14 registers, and the per-frame
+// vectors are stored by wavefront 0 only.  Arithmetic: the same products, summed per wavefront first (results differ
+// from k_dp_lin's by reassociation, ~1e-16 relative).
+// ------------------------------------------------------------------------------------------
+#define DPV_NW 4
+template <int DMAX>
+__global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
+    ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
+    const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
+    const double* __restrict__ mshift, double* __restrict__ a_g, double* __restrict__ ga_g,
+    double* __restrict__ p_g, double* __restrict__ gp_g, double* __restrict__ b_g, double* __restrict__ gb_g,
+    double* __restrict__ sd_g, double* __restrict__ gsd_g, double* __restrict__ zx_out, int* __restrict__ status) {
+  constexpr int NW = DPV_NW;
+  constexpr int NDW = (DMAX + NW - 1) / NW;   // durations per wavefront
+  constexpr int CQ = 64 / NW;                 // transition rows per wavefront (L <= 64)
+  extern __shared__ double dsm[];
+  const int L = (int)lay.L, D = (int)lay.D;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int dir = blockIdx.x & 1;
+  const uint32_t ul = blockIdx.x >> 1;
+  double* ring = dsm;                                   // [D][L], shared by the workgroup
+  double* part = ring + (((size_t)D * L + 1) & ~(size_t)1);   // [NW][64] partial duration sums
+  double* upart = part + NW * 64;                       // [NW][64] partial transition products
+  double* abuf = upart + NW * 64 + wave * 64;           // this wavefront's broadcast line of the matvec operand
+  double* cbuf = upart + NW * 64 + NW * 64 + wave * 64; // this wavefront's per-duration scales
+  if (ul >= n_utts) return;
+  const uint32_t u = u0 + ul;
+  const int T = (int)bv.T[u];
+  if (T == 0) return;
+  const uint64_t f_base = bv.frame_off[u] - bv.frame_off[u0];
+  const uint64_t s_base = bv.seg_off[u] - bv.seg_off[u0];
+  const double* ESu = ES + s_base * L;
+  const double* smu = smax + s_base;
+  const bool act = lane < L;
+  const int lc = act ? lane : L - 1;
+  const bool w0 = wave == 0;
+  const double sh0 = mshift[0];
+  int err = 0;
+  double gslot = 0.0;   // lane j: log-scale of the vector in ring slot j (every wavefront keeps the same copy)
+  // this wavefront's rows c0 .. c0 + CQ - 1 of the transition matrix, column lc
+  const int c0 = wave * CQ;
+  double er[CQ];
+  {
+    const double* Em = dir ? ET : E;
+#pragma unroll
+    for (int i = 0; i < CQ; i++) er[i] = (c0 + i < L) ? Em[(size_t)(c0 + i) * L + lc] : 0.0;
+  }
+  // sum over all rows of v[c] * Em[c][lc]: this wavefront's share, then the four shares in wavefront order
+  auto matvec = [&](const double v) {
+    abuf[lane] = v;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < CQ; i += 2) {
+      const double2 a01 = *(const double2*)(abuf + c0 + i);
+      s0 = fma(a01.x, er[i], s0);
+      s1 = fma(a01.y, er[i + 1], s1);
+    }
+    upart[wave * 64 + lane] = s0 + s1;
+    __syncthreads();
+    double tot = upart[lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) tot += upart[w * 64 + lane];
+    return tot;
+  };
+  auto dursum = [&](const double acc) {
+    part[wave * 64 + lane] = acc;
+    __syncthreads();
+    double tot = part[lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) tot += part[w * 64 + lane];
+    return tot;
+  };
+
+  if (dir == 0) {
+    // ---------------------------------------------------------------- forward
+    double* au = a_g + f_base * L;
+    double* pu = p_g + f_base * L;
+    double a = ESu[lc];
+    double ga = smu[0];
+    if (w0 && act) __builtin_nontemporal_store(a, &au[lane]);
+    double ga_keep = ga, gp_keep = 0.0;
+    int rpos = D - 1;
+    // this wavefront's windows ending at t (durations d0 = wave + NW i) and the row maxima of all of them (lane = d0)
+    auto load_windows = [&](int t, double (&es)[NDW], double& smx) {
+      const int tt = t < T ? t : T - 1;
+      const int nd = (int)scrf_node_max_dur(tt, D);
+      const uint64_t base = scrf_seg_base(tt, D);
+#pragma unroll
+      for (int i = 0; i < NDW; i++) {
+        const int d0 = wave + NW * i;
+        const double x = ESu[(base + (d0 < nd ? d0 : 0)) * L + lc];
+        es[i] = (d0 < nd) ? x : 0.0;
+      }
+      smx = smu[base + (lane < nd ? lane : 0)];
+    };
+    double es_n[NDW], smx_n;
+    load_windows(1, es_n, smx_n);
+    for (int t = 1; t < T; t++) {
+      rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
+      const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
+      double es[NDW], smx = smx_n;
+#pragma unroll
+      for (int i = 0; i < NDW; i++) es[i] = es_n[i];
+      load_windows(t + 1, es_n, smx_n);   // the next step's rows: a step of latency cover
+      // transition out of node t-1: p = 2^-k * (a . E)
+      const double usum = matvec(a);
+      const int k = hi_exp(wave_max_hi(act ? usum : 0.0), &err);
+      const double p = ldexp(usum, -k);
+      const double gp = ga + sh0 + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      if (w0) {
+        ring[rpos * L + lc] = p;   // read by the others from the next step on (two barriers away)
+        if (act) __builtin_nontemporal_store(p, &pu[(size_t)(t - 1) * L + lane]);
+        if (lane == ((t - 1) & 63)) gp_keep = gp;
+        if (((t - 1) & 63) == 63) gp_g[f_base + (t - 1 - 63) + lane] = gp_keep;
+      }
+      if (lane == rpos) gslot = gp;
+      // per-duration scales: lane d0 looks at predecessor node t-1-d0 (ring slot rpos-d0)
+      int myslot = rpos - lane;
+      if (myslot < 0) myslot += D;
+      const double gprev = shfl_f64(gslot, (lane < np) ? myslot : 0);
+      double x = (lane < np) ? gprev + smx : smx;   // lane == np (< nd): the initial segment
+      x = (lane < nd) ? x : -INFINITY;
+      const double G = (double)wave_max_f32_dpp((float)x);
+      cbuf[lane] = exp_nonpos(x - G);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NDW; i++) {
+        const int d0 = wave + NW * i;
+        if (d0 < DMAX) {
+          int slot = rpos - d0;
+          if (slot < 0) slot += D;
+          const double r = (d0 == 0) ? p : ring[((d0 < np) ? slot : rpos) * L + lc];
+          const double pv = (d0 < np) ? r : 1.0;
+          const double w = es[i] * cbuf[d0 < D ? d0 : 0];   // es = 0 past nd
+          if (i & 1) acc1 = fma(pv, w, acc1); else acc0 = fma(pv, w, acc0);
+        }
+      }
+      a = dursum(acc0 + acc1);
+      ga = G;
+      if (w0) {
+        if (act) __builtin_nontemporal_store(a, &au[(size_t)t * L + lane]);
+        if (lane == (t & 63)) ga_keep = ga;
+        if ((t & 63) == 63) ga_g[f_base + (t - 63) + lane] = ga_keep;
+      }
+    }
+    if (w0) {
+      if (((T - 1) & 63) != 63 && lane <= ((T - 1) & 63)) ga_g[f_base + ((T - 1) & ~63) + lane] = ga_keep;
+      if (T >= 2 && ((T - 2) & 63) != 63 && lane <= ((T - 2) & 63)) gp_g[f_base + ((T - 2) & ~63) + lane] = gp_keep;
+      const double tot = wave_sum_f64(act ? a : 0.0);
+      const double Zx = ga + log(tot);
+      if (!(Zx == Zx) || isinf(Zx)) err = 1;
+      if (lane == 0) zx_out[u] = Zx;
+    }
+  } else {
+    // ---------------------------------------------------------------- backward
+    double* bu = b_g + f_base * L;
+    double* sdu = sd_g + f_base * L;
+    int tpos = (T - 1) % D;
+    if (w0) ring[tpos * L + lc] = 1.0;  // setTailBeta: beta[T-1] = 0
+    if (lane == tpos) gslot = 0.0;
+    if (w0) {
+      if (act) { bu[(size_t)(T - 1) * L + lane] = 1.0; sdu[(size_t)(T - 1) * L + lane] = 0.0; }
+      if (lane == 0) { gb_g[f_base + T - 1] = 0.0; gsd_g[f_base + T - 1] = 0.0; }
+    }
+    // (no barrier here or at the end of a step: node t's vector, written by wavefront 0 after the step's two barriers, is
+    // read at d0 = 0 by wavefront 0 itself in the next step and at d0 >= 1 by the others one or more steps -- two or
+    // more barriers -- later; the slot it overwrites, node t + D, was last read before this step's first barrier)
+    double gb_keep = 0.0, gsd_keep = 0.0;
+    // window (t+1+d0, d0+1): starts at t+1, ends at node t+1+d0
+    auto load_windows = [&](int t, double (&es)[NDW], double& smx) {
+      const int tt = t >= 0 ? t : 0;
+      const int nn = (T - 1 - tt <= D) ? T - 1 - tt : D;
+      const uint64_t sb = scrf_seg_base(tt + 1, D);
+      uint64_t myrow = sb;
+      if ((nn == D) && (tt + 1 >= D)) {
+        // every node tt+1.. carries D windows, so the window sits at row seg_base(tt+1) + d0*(D+1)
+#pragma unroll
+        for (int i = 0; i < NDW; i++) {
+          const int d0 = wave + NW * i;
+          const double x = ESu[(sb + (uint64_t)(d0 < nn ? d0 : 0) * (D + 1)) * L + lc];
+          es[i] = (d0 < nn) ? x : 0.0;
+        }
+        myrow = sb + (uint64_t)(lane < nn ? lane : 0) * (D + 1);
+      } else {
+        uint64_t r = sb;
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0++) {
+          const bool ok = d0 < nn;
+          if ((d0 % NW) == wave) {   // wave-uniform
+            const double x = ESu[(ok ? r + d0 : 0) * L + lc];
+            es[d0 / NW] = ok ? x : 0.0;
+          }
+          if (lane == d0 && ok) myrow = r + d0;
+          r += scrf_node_max_dur(tt + 1 + d0 < T ? tt + 1 + d0 : T - 1, D);
+        }
+        if (DMAX % NW) {
+#pragma unroll
+          for (int i = 0; i < NDW; i++) if (wave + NW * i >= DMAX) es[i] = 0.0;
+        }
+      }
+      smx = smu[myrow];
+    };
+    double es_n[NDW], smx_n;
+    load_windows(T - 2, es_n, smx_n);
+    for (int t = T - 2; t >= 0; t--) {
+      const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
+      tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
+      double es[NDW], smx = smx_n;
+#pragma unroll
+      for (int i = 0; i < NDW; i++) es[i] = es_n[i];
+      load_windows(t - 1, es_n, smx_n);
+      int myslot = tpos + lane + 1;  // node t + d0 + 1
+      if (myslot >= D) myslot -= D;
+      const double gnext = shfl_f64(gslot, (lane < nn) ? myslot : 0);
+      const double x = (lane < nn) ? gnext + smx : -INFINITY;
+      const double G = (double)wave_max_f32_dpp((float)x);
+      cbuf[lane] = exp_nonpos(x - G);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NDW; i++) {
+        const int d0 = wave + NW * i;
+        if (d0 < DMAX) {
+          int slot = tpos + d0 + 1;
+          if (slot >= D) slot -= D;
+          const double bv_ = ring[((d0 < nn) ? slot : tpos) * L + lc];
+          const double w = es[i] * cbuf[d0 < D ? d0 : 0];   // es = 0 past nn
+          if (i & 1) acc1 = fma((d0 < nn) ? bv_ : 0.0, w, acc1); else acc0 = fma((d0 < nn) ? bv_ : 0.0, w, acc0);
+        }
+      }
+      const double sd = dursum(acc0 + acc1);
+      const double wsum = matvec(sd);
+      const int k = hi_exp(wave_max_hi(act ? wsum : 0.0), &err);
+      const double b = ldexp(wsum, -k);
+      const double gb = G + sh0 + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      if (lane == tpos) gslot = gb;
+      if (w0) {
+        ring[tpos * L + lc] = b;
+        if (act) { __builtin_nontemporal_store(sd, &sdu[(size_t)t * L + lane]); __builtin_nontemporal_store(b, &bu[(size_t)t * L + lane]); }
+        if (lane == (t & 63)) { gsd_keep = G; gb_keep = gb; }
+        if ((t & 63) == 0 && t + lane < T) { gsd_g[f_base + t + lane] = gsd_keep; gb_g[f_base + t + lane] = gb_keep; }
+      }
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicMax(&status[u], SCRF_ERR_NUMERIC);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_dp_lin_mw: the same recursion for 64 < L <= 256: one workgroup of NW = ceil(L/64) wavefronts per
 // (utterance, direction), lane = label.  The vector that feeds the L x L transition step is
 // exchanged through LDS (two barriers per frame, one more for the wave maxima); everything a lane
@@ -564,6 +819,24 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
     if (lay.D <= 10) launch_dp_lin_mw_t<10>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
     else if (lay.D <= 25) launch_dp_lin_mw_t<25>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
     else launch_dp_lin_mw_t<40>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
+    return;
+  }
+  static const bool use_mv = !(getenv("SCRF_DPLIN_MV") && atoi(getenv("SCRF_DPLIN_MV")) == 0);
+  if (use_mv && !m_per_frame && lay.D >= 2) {
+    // several wavefronts per sweep (k_dp_lin_mv): one workgroup of 4 per (utterance, direction)
+    const size_t smv = sizeof(double) * ((((size_t)lay.D * lay.L + 1) & ~(size_t)1) + 4 * DPV_NW * 64);
+#define DV_LAUNCH(DM)                                                                                             \
+  do {                                                                                                            \
+    hipFuncSetAttribute((const void*)k_dp_lin_mv<DM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smv);      \
+    hipLaunchKernelGGL((k_dp_lin_mv<DM>), dim3(2 * n_utts), dim3(64 * DPV_NW), smv, st, lay, bv, u0, n_utts, ES,  \
+                       smax, E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);            \
+  } while (0)
+    if (lay.D <= 10) DV_LAUNCH(10);
+    else if (lay.D <= 16) DV_LAUNCH(16);
+    else if (lay.D <= 25) DV_LAUNCH(25);
+    else if (lay.D <= 32) DV_LAUNCH(32);
+    else DV_LAUNCH(40);
+#undef DV_LAUNCH
     return;
   }
   uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * ((size_t)lay.D * lay.L + 128));

@@ -207,6 +207,10 @@ static int build_layout(const scrf_config& c, ScrfLayout* l, std::string* why) {
   if (c.model_type > SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR) { *why = "unknown model_type"; return SCRF_ERR_INVALID; }
   if (c.model_type == SCRF_STDFRAME && c.lab_max_dur != 1) { *why = "the maximum duration of labels must be 1 for \"stdframe\" CRF model."; return SCRF_ERR_INVALID; }  // CRFTrain/src/Main.cpp:574-578
   if (c.map_type > SCRF_STDTRANS) { *why = "only dense stdstate/stdtrans feature maps are built"; return SCRF_ERR_INVALID; }
+  if (c.model_type == SCRF_STDSEG_NO_DUR_NO_TRANSFTR && (c.map_type != SCRF_STDSTATE || c.use_trans_ftrs)) {   // CRFTrain/src/Main.cpp:465-468
+    *why = "crf_featuremap must be \"stdstate\" for \"stdseg_no_dur_no_transftr\" CRF model.";
+    return SCRF_ERR_INVALID;
+  }
   if (c.num_labs > 1024) { *why = "num_labs > 1024 unsupported"; return SCRF_ERR_INVALID; }
   memset(l, 0, sizeof(*l));
   l->L = c.num_labs; l->D = c.lab_max_dur; l->F = c.num_feas;

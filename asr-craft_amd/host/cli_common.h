@@ -81,6 +81,10 @@ inline void set_fmap_config(const Args& a, CliModel* m) {
   const std::string fm = a.str("crf_featuremap", "stdstate");
   c.map_type = fm == "stdtrans" ? STDTRANS : STDSTATE;
   if (fm != "stdstate" && fm != "stdtrans") { std::cerr << "crf_featuremap=" << fm << " is not built" << std::endl; exit(1); }
+  if (m->mtype == STDSEG_NO_DUR_NO_TRANSFTR && fm != "stdstate") {   // CRFTrain/src/Main.cpp:465-468, exit code of its catch block
+    std::cerr << "Exception: main() in CRFTrain caught exception: crf_featuremap must be \"stdstate\" for \"stdseg_no_dur_no_transftr\" CRF model." << std::endl;
+    exit(-1);
+  }
   c.numLabs = m->L;
   c.numFeas = m->F;
   c.numStates = (QNUInt32)a.num("crf_states", 1);

@@ -145,3 +145,31 @@ def test_config5_full_length_utterances_properties():
     ol, oc = orc.best_path(oa, ons, ofin)
     assert list(labs[1]) == list(ol) and np.float32(cost[1]).tobytes() == np.float32(oc).tobytes()
     fb.close(); vb.close(); eng.close()
+
+
+def test_model_type_stdseg_no_dur_no_transftr():
+    """`stdseg_no_dur_no_transftr` -- the segmental node without transition features at all.  Served by the
+    same engine as the TIMIT-demo model with bias-only transitions: the gradient, the scores and the best path are
+    the oracle's and bit-identical to model type `..._no_segtransftr` under a `stdstate` map; a `stdtrans` map is
+    refused, as the reference's main does (CRFTrain/src/Main.cpp:465-468)."""
+    import orc
+    import scrf_amd
+    from cases import Case
+    res = {}
+    for mt in (orc.STDSEG_NO_DUR_NO_TRANSFTR, orc.STDSEG_NO_DUR_NO_SEGTRANSFTR):
+        c = Case(L=7, D=5, in_w=4, Ts=[11, 4, 17], seed=33, model_type=mt, precision=0)
+        eng = c.engine(); b = c.batch(eng)
+        numer, zx = eng.fb_batch(b)
+        g = eng.get_grad()
+        labs, cost = eng.viterbi_batch(b)
+        og, on, oz = c.oracle_gradient()
+        assert np.abs(g - og).max() <= 1e-9 * np.abs(og).max()
+        assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max() and np.abs(numer - on).max() <= 1e-11 * max(1.0, np.abs(on).max())
+        res[mt] = (g.tobytes(), numer.tobytes(), zx.tobytes(), [list(l) for l in labs], cost.tobytes())
+        b.close(); eng.close()
+    assert res[orc.STDSEG_NO_DUR_NO_TRANSFTR] == res[orc.STDSEG_NO_DUR_NO_SEGTRANSFTR]
+    # stdtrans with this model type: refused at creation with the reference's message
+    c = Case(L=7, D=5, in_w=4, Ts=[6], seed=1, trans_ctx=1, model_type=orc.STDSEG_NO_DUR_NO_TRANSFTR)
+    with pytest.raises(scrf_amd.ScrfError) as ei:
+        scrf_amd.Engine(c.gcfg)
+    assert ei.value.code == 1 and 'must be "stdstate"' in str(ei.value)

@@ -761,6 +761,14 @@ def test_crftrain_world_size_one_with_the_communicator_is_byte_identical(tmp_pat
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def test_crftrain_refuses_stdtrans_for_stdseg_no_dur_no_transftr(tmp_path):
+    """CRFTrain/src/Main.cpp:465-468: crf_featuremap must be "stdstate" for that model type"""
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + [f for f in _train_flags(str(tmp_path / "w.out")) if not f.startswith(("crf_model_type", "crf_featuremap", "label_maximum_duration"))] +
+                       ["crf_model_type=stdseg_no_dur_no_transftr", "crf_featuremap=stdtrans", "label_maximum_duration=3"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and 'crf_featuremap must be "stdstate" for "stdseg_no_dur_no_transftr"' in r.stderr
+
+
 def test_crftrain_precision_flag_and_gaussian_prior(tmp_path):
     """crf_precision=exact|fast agree to the weight file's 6 digits; crf_gauss_var applies the reference's prior
     step as written (grad -= grad / gvar, CRF_SGTrainer.cpp:300-303), checked against the oracle loop."""

@@ -119,7 +119,7 @@ def main():
              "window_extent=%d" % D, "crf_stateftr_start=0", "crf_stateftr_end=%d" % (F1 - 1), "crf_transftr_start=%d" % F1, "crf_transftr_end=-1"]
     wf = os.path.join(a.work, "weights.48_TIMIT.out")
     t_train, out = run([os.path.join(BIN, "CRFTrain"), "out_weight_file=" + wf, "hardtarget_file=" + ILAB, "train_sent_range=0-%d" % (U - 1),
-                        "cv_sent_range=0", "crf_use_adagrad=1", "crf_adagrad_eta=%g" % a.eta, "crf_lr_decay_rate=1.0", "crf_utt_rpt=%d" % (10 * a.bunch),
+                        "cv_sent_range=0", "crf_use_adagrad=1", "crf_adagrad_eta=%g" % a.eta, "crf_lr_decay_rate=1.0", "crf_utt_rpt=%d" % (a.bunch * max(1, min(10, (U // a.bunch) // 5))),   # a progress line at least five times per epoch (a count the step never hits -- 640 with 400 utterances -- leaves the trace empty)
                         "crf_states=1", "crf_epochs=%d" % a.epochs, "use_broken_class_label=0", "crf_bunch_size=%d" % a.bunch, "threads=1",
                         "crf_train_order=seq"] + model, os.path.join(a.work, "train.log"))
     lambda_len = int([l for l in out.split("\n") if l.startswith("FEATURES:")][0].split()[1])

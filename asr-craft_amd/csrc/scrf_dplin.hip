@@ -356,6 +356,14 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
 // chain per step is a third as long, a step's loads are requested a step ahead with 14 registers, and the per-frame
 // vectors are stored by wavefront 0 only.  Arithmetic: the same products, summed per wavefront first (results differ
 // from k_dp_lin's by reassociation, ~1e-16 relative).
+// MEASURED (config 2, 4096 utterances, same box): 6.08-6.32 ms against 6.04-6.14 ms for k_dp_lin -- four sweeps resident
+// per CU (128 VGPRs) at 2.5 us per step move the same bytes per microsecond as eleven at 6.8 us: a step's rows are
+// requested one step ahead and __syncthreads() drains the vector-memory counter, so every step still waits out an HBM
+// round trip.  Variants that keep two steps of rows in flight were built and are NOT in the tree: an s_barrier behind
+// s_waitcnt lgkmcnt(0) only, with the register sets rotated by copies (9.3 ms: a copy of a register whose load is in
+// flight waits for the load) or in fixed roles with the loop unrolled three times (hipcc still places
+// s_waitcnt vmcnt(<= 9) ahead of each step, and the code grows to 100 KB); capping the kernel at 128 VGPRs with the
+// third set spills into the loop (16 ms).  Hence opt-in: SCRF_DPLIN_MV=1 (the parity tests cover it that way).
 // ------------------------------------------------------------------------------------------
 #define DPV_NW 4
 template <int DMAX>
@@ -821,7 +829,8 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
     else launch_dp_lin_mw_t<40>(st, lay, bv, u0, n_utts, ES, smax, E, ET, mshift, m_per_frame, o, zx, status);
     return;
   }
-  static const bool use_mv = !(getenv("SCRF_DPLIN_MV") && atoi(getenv("SCRF_DPLIN_MV")) == 0);
+  // opt-in (SCRF_DPLIN_MV=1): parity-green, but measured no faster than one wavefront per sweep -- see the kernel's header
+  static const bool use_mv = getenv("SCRF_DPLIN_MV") && atoi(getenv("SCRF_DPLIN_MV")) != 0;
   if (use_mv && !m_per_frame && lay.D >= 2) {
     // several wavefronts per sweep (k_dp_lin_mv): one workgroup of 4 per (utterance, direction)
     const size_t smv = sizeof(double) * ((((size_t)lay.D * lay.L + 1) & ~(size_t)1) + 4 * DPV_NW * 64);

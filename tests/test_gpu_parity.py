@@ -482,6 +482,17 @@ def test_random_shape_sweep_through_the_fused_and_wavefront_kernels():
     assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") == 60
 
 
+def test_several_wavefronts_per_sweep_kernel_through_the_same_sweep():
+    """k_dp_lin_mv (SCRF_DPLIN_MV=1, opt-in: four wavefronts share one sweep's ring, durations and transition rows
+    split between them) through 30 shapes of the same sweep, in its own process (the switch is read once)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRF_DPLIN_MV="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fused_shape_sweep.py"), "30", "7"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") == 30
+
+
 @pytest.mark.parametrize("L,D,W", [(64, 25, 3), (64, 32, 2), (3, 5, 1)])
 def test_regressions_found_by_the_shape_sweep(L, D, W, monkeypatch):
     """L = 64, D >= 17: twelve wavefronts' rings do not fit the LDS (the launch used to fail);

@@ -14,6 +14,7 @@
 //   - row-major floats with stride == 2 (mod 32) words for the A operand of the score kernel.
 #include "scrf_kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -21,6 +22,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 
+#ifndef MM_PRIO
+#define MM_PRIO 1    // s_setprio level of the staging phases (0 = no priority play; A/B knob)
+#endif
 #define SM_ROWS 256  // rows per workgroup (4 waves x 4 M-tiles)
 #define SM_KC 32     // features per staged chunk (8 MFMA k-steps)
 #define SM_XS 34     // float row stride of the X image (== 2 mod 32: conflict-free A fragments)
@@ -129,11 +133,14 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
     }
   };
 
+  // waves that stage (vector work) outrank waves inside the MFMA loop of the co-resident workgroup (as in scrf_fused.hip)
+  __builtin_amdgcn_s_setprio(MM_PRIO);
   if (nfe > 0) load_chunk(0);
   for (uint32_t f0 = 0; f0 < nfe; f0 += SM_KC) {
     store_chunk(f0);
     __syncthreads();
     if (f0 + SM_KC < nfe) load_chunk(f0 + SM_KC);
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int ks = 0; ks < SM_KC / 4; ks++) {
       if (F32) {
@@ -162,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
         }
       }
     }
+    __builtin_amdgcn_s_setprio(MM_PRIO);
     __syncthreads();
   }
 #pragma unroll
@@ -326,11 +334,13 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       if (tid + k * NT < EM_KC * NO) Rs[tid + k * NT] = ar_[k];
   };
 
+  __builtin_amdgcn_s_setprio(MM_PRIO);
   if (r_begin < r_end) load_chunk(r_begin);
   for (uint64_t r0 = r_begin; r0 < r_end; r0 += EM_KC) {
     store_chunk(r0);
     __syncthreads();
     if (r0 + EM_KC < r_end) load_chunk(r0 + EM_KC);
+    __builtin_amdgcn_s_setprio(0);
     if (F32) {
       v4f32 c32[MT][3];
 #pragma unroll
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
           for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(MM_PRIO);
     __syncthreads();
   }
   // the bias column was staged as float: rescale if the bias value is not exactly representable
@@ -460,7 +471,11 @@ void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const flo
     else if (tiles <= 2) launch_expf_mfma_nw<2, 64, 0>(EXPF_ARGS);
     else if (tiles <= 3) launch_expf_mfma_nw<3, 64, 0>(EXPF_ARGS);
     else if (tiles <= 4) launch_expf_mfma_nw<4, 64, 0>(EXPF_ARGS);
-    else launch_expf_mfma_nw<8, 32, 0>(EXPF_ARGS);
+    else {
+      // (64-row chunks for the 8-wave form were tried: 256 VGPRs + 336 bytes of spills)
+      // (two 4-wave workgroups per CU with 64-row chunks instead: 18.1 ms against 14.4 at the TIMIT transition counts)
+      launch_expf_mfma_nw<8, 32, 0>(EXPF_ARGS);
+    }
   }
 #undef EXPF_ARGS
 }

@@ -225,7 +225,9 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 // F32 = 1: operands rounded to f32 (R is in [-1,1]), v_mfma_f32_16x16x4_f32 within a staged chunk of
 // EM_KC rows, chunk results flushed into f64 accumulators (so the K = millions-of-rows sum is f64).
 // MT: M-tiles (16 outputs each) a wavefront carries: 3, or the 1 / 2 of the remainder launch (o_base = its first output)
-template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0, int MT = 3>
+// DB = 1 (the 8-wave form, which owns its CU): two LDS image pairs; a chunk's MFMAs run from one while the next chunk is
+// stored into the other, one barrier per chunk instead of two
+template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0, int MT = 3, int DB = 0>
 __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   constexpr int XIT = (EM_KC * QR + NT - 1) / NT;   // X quads per thread per chunk (= 6; the split form has threads without one)
   constexpr int AIT = (EM_KC * NO + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
-  double* Rs = (double*)em_smem;                                  // [EM_KC][NO]
+  constexpr size_t IMG = sizeof(double) * EM_KC * NO + sizeof(float) * EM_KC * XS;   // bytes of one image pair
+  double* Rs = (double*)em_smem;                                  // [EM_KC][NO]   (+ IMG bytes: the second pair when DB)
   float* Xs = (float*)(em_smem + sizeof(double) * EM_KC * NO);  // [EM_KC][XS]
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       ar_[k] = ok ? v : 0.0;
     }
   };
-  auto store_chunk = [&](uint64_t r0) {
+  auto store_chunk = [&](uint64_t r0, uint32_t buf) {
+    double* Rs = (double*)(em_smem + buf * IMG);
+    float* Xs = (float*)(em_smem + buf * IMG + sizeof(double) * EM_KC * NO);
 #pragma unroll
     for (int k = 0; k < XIT; k++) {
       const bool rok = r0 + xrw[k] < r_end;
@@ -336,10 +341,23 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
 
   __builtin_amdgcn_s_setprio(MM_PRIO);
   if (r_begin < r_end) load_chunk(r_begin);
-  for (uint64_t r0 = r_begin; r0 < r_end; r0 += EM_KC) {
-    store_chunk(r0);
+  if (DB && r_begin < r_end) {
+    store_chunk(r_begin, 0);
+    if (r_begin + EM_KC < r_end) load_chunk(r_begin + EM_KC);
+  }
+  uint32_t cur = 0;
+  for (uint64_t r0 = r_begin; r0 < r_end; r0 += EM_KC, cur ^= (DB ? 1u : 0u)) {
+    if (!DB) store_chunk(r0, 0);
     __syncthreads();
-    if (r0 + EM_KC < r_end) load_chunk(r0 + EM_KC);
+    if (DB) {
+      // the next chunk into the other image pair (its loads were requested a chunk ago), then the loads after that
+      if (r0 + EM_KC < r_end) store_chunk(r0 + EM_KC, cur ^ 1u);
+      if (r0 + 2 * (uint64_t)EM_KC < r_end) load_chunk(r0 + 2 * (uint64_t)EM_KC);
+    } else if (r0 + EM_KC < r_end) {
+      load_chunk(r0 + EM_KC);
+    }
+    const double* Rs = (const double*)(em_smem + cur * IMG);
+    const float* Xs = (const float*)(em_smem + cur * IMG + sizeof(double) * EM_KC * NO);
     __builtin_amdgcn_s_setprio(0);
     if (F32) {
       v4f32 c32[MT][3];
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       }
     }
     __builtin_amdgcn_s_setprio(MM_PRIO);
-    __syncthreads();
+    if (!DB) __syncthreads();
   }
   // the bias column was staged as float: rescale if the bias value is not exactly representable
   const double bfix = (bias_exact || !sp.use_bias) ? 1.0 : sp.bias / (double)bias;
@@ -403,6 +421,14 @@ template <int HAS_XROW, int NW, int KC, int F32, int MT>
 static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                  const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                                  uint64_t rows_per_chunk, double* slab, uint32_t o_base) {
+  constexpr int DB = NW == 8 ? 1 : 0;   // the 8-wave workgroup has its CU to itself: room for a second image pair
+  static const bool db_off = getenv("SCRF_EXPF_DB") && atoi(getenv("SCRF_EXPF_DB")) == 0;   // A/B knob
+  if (DB && !db_off) {
+    hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * sm));
+    hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), 2 * sm, st, A, n_out, X, F, xrow,
+                       n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);
+    return;
+  }
   hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow,
                      n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);

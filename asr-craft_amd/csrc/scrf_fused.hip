@@ -318,7 +318,10 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #if FU_PHI
   // o = 16 n + 8 (r >> 1) + 2 lk + (r & 1) for accumulator r of tile n: value c = 4n + r of a lane is output
   // 8 (c >> 1) + 2 lk + (c & 1), so the lane's values come in the adjacent pairs (8j + 2lk, 8j + 2lk + 1), j = 0..5
-  const uint32_t phi0 = F32 ? 8 * ((li & 3) >> 1) + 2 * (li >> 2) + (li & 1) : 8 * (li >> 3) + 2 * (li & 3) + ((li >> 2) & 1);
+  // (decode keeps the untransposed product -- rows of the tile on the MFMA's row axis, phi = identity: its epilogue has
+  // the rounding screen on top of the gathers and ran out of registers in the 12-outputs-per-lane form)
+  const uint32_t phi0 = DEC ? li
+                            : (F32 ? 8 * ((li & 3) >> 1) + 2 * (li >> 2) + (li & 1) : 8 * (li >> 3) + 2 * (li & 3) + ((li >> 2) & 1));
 #else
   const uint32_t phi0 = F32 ? (li >> 2) * 12 + (li & 3) : (li & 3) * 12 + (li >> 2);
 #endif
@@ -537,8 +540,8 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
           const double x = (double)Xg[(wave * 32 + m * 16 + li) * FU_XS + ks * 4 + lk];
 #pragma unroll
           for (int n = 0; n < 3; n++)
-            acc[F32 ? 0 : m][F32 ? 0 : n] =
-                __builtin_amdgcn_mfma_f64_16x16x4f64(wv[n], x, acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
+            acc[F32 ? 0 : m][F32 ? 0 : n] = DEC ? __builtin_amdgcn_mfma_f64_16x16x4f64(x, wv[n], acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0)
+                                                : __builtin_amdgcn_mfma_f64_16x16x4f64(wv[n], x, acc[F32 ? 0 : m][F32 ? 0 : n], 0, 0, 0);
         }
       }
     }
@@ -568,6 +571,37 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #if !FU_EXPTAB
   const FuExpC ek = fu_exp_consts();
 #endif
+  if (DEC) {
+    // untransposed tile: lane (li, lk) holds rows lk + 4r of outputs n * 16 + li; per row five 8-byte gathers per output
+    // tile, the float weight, the rounding screen, a 64-byte store per (row, output tile)
+    const double xm = (double)dz.xm_f[ft.fr0 + back] * dz.bound_scale;   // a tile lies in one utterance
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t rl = wave * 32 + m * 16 + lk + 4 * r;
+        const bool valid = rl < ft.nrows;
+        const uint4 rec = recs[valid ? rl : 0];
+        const uint32_t d = (rec.z >> 16) & 0xffu;
+        const uint64_t grow = ft.row0 + rl;
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+          const uint32_t ol = n * 16 + li, o = o0 + ol;
+          const double lin = (((Pl[(rec.x & 0xffffu) + ol] + Pl[(rec.x >> 16) + ol]) + Pl[(rec.y & 0xffffu) + ol]) + Pl[(rec.y >> 16) + ol]) + Pl[(rec.z & 0xffffu) + ol];
+          const double v = -1 * ((acc[F32 ? 0 : m][F32 ? 0 : n][r] + lin) + Dt[(d - 1) * FU_DS + ol]);
+          const float w = (float)v;
+          if (valid && o < n_out) {
+            const double B = xm * dz.w1[o];
+            if ((float)(v - B) != w || (float)(v + B) != w) {
+              const uint32_t at = atomicAdd(dz.cnt, 1u);
+              if (at < dz.cap) dz.list[at] = (grow << 16) | o;
+            }
+            dz.wneg[grow * n_out + o] = w;
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     const uint32_t rl = wave * 32 + m * 16 + li;
@@ -595,33 +629,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       }
     }
     const uint64_t grow = ft.row0 + rl;
-    if (DEC) {
-      const double xm = (double)dz.xm_f[ft.fr0 + back] * dz.bound_scale;   // a tile lies in one utterance
-      float wv[12];
-#pragma unroll
-      for (int c = 0; c < 12; c++) {
-        const uint32_t o = o0 + FU_OL(c);
-        const double v = -1 * sv[c];
-        const float w = (float)v;
-        wv[c] = w;
-        if (valid && o < n_out) {
-          const double B = xm * dz.w1[o];
-          if ((float)(v - B) != w || (float)(v + B) != w) {
-            const uint32_t at = atomicAdd(dz.cnt, 1u);
-            if (at < dz.cap) dz.list[at] = (grow << 16) | o;
-          }
-        }
-      }
-      float* wrow = dz.wneg + grow * n_out + o0;
-      if (vec_ok) {   // 8-byte stores of float pairs
-#pragma unroll
-        for (int j = 0; j < 6; j++)
-          if (valid && o0 + FU_OB(j) < n_out) *(v2f32*)(wrow + FU_OB(j)) = (v2f32){wv[2 * j], wv[2 * j + 1]};
-      } else {
-#pragma unroll
-        for (int c = 0; c < 12; c++) if (valid && o0 + FU_OL(c) < n_out) wrow[FU_OL(c)] = wv[c];
-      }
-    } else if (smax) {
+    if (smax) {
       // row maximum as a float: over the lane's 12 outputs, then over the 4 lanes (li, lk = 0..3) that share the row --
       // two half-swaps (v_permlane32_swap / v_permlane16_swap, CDNA4)
       double mxd = sv[0];

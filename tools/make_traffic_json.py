@@ -15,6 +15,8 @@ def parse(path):
         if m and "launches" in line:
             cur = m.group(1)
             # the decode variant k_scores_fused<D, 0, 1> also runs once in bench.py: keep the training kernel
+            if cur == "k_expf_fused_ws":   # the wave-specialised build of the same kernel
+                cur = "k_expf_fused"
             if cur == "k_scores_fused" and m.group(2) and m.group(2).rstrip(">").split(",")[-1].strip() == "1":
                 cur = "k_scores_fused_decode"
         elif cur and line.strip():

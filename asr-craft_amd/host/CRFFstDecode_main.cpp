@@ -9,9 +9,17 @@
 // the first and last frame of each label's segments.  crf_dict_bin / crf_dict_txt: the dictionary FST composed in between
 // (lattice o dict o LM, Main.cpp:929-941); crf_align_mlffile: the utterance's transcript from an HTK MLF as a linear
 // acceptor over the output symbols, composed in before the LM (:943-952, CRF_MLFManager); crf_mlf_output_states (+
-// crf_isymbols): the phone label of every segment in front of the words.  The phone-penalty FST (crf_phn_bin: a
-// log-semiring RmEpsilon, Prune and Minimize sit behind it), ARPA LMs and the pruning weights are refused.
+// crf_isymbols): the phone label of every segment in front of the words.  crf_phn_bin / crf_phn_txt: the phone-penalty
+// FST (:614-640 reads a log-arc VectorFst, maps it to the tropical semiring, sorts its arcs), composed onto the lattice
+// first, epsilons removed on the LOG semiring, then Prune(crf_phn_wt) when that weight is not 0 (:898-926; the Minimize
+// behind the Prune changes neither the paths nor their weights and is not run).  crf_dict_wt: Prune of lattice o dictionary
+// (:935-940).  With a phone FST or a pruning weight the chain is materialised left to right as the reference does it
+// (a Prune does not commute with the compositions behind it); otherwise everything right of the lattice is one machine.
+// crf_pre_phn_wt, crf_lm_wt and crf_lm_arpa are declared by the reference (:118-128) and read by nothing there: accepted, no effect.
 #include "cli_common.h"
+
+#include <limits>
+#include <set>
 
 static std::map<long, std::string> read_symbols(const std::string& path) {   // OpenFST text symbol table: `symbol id`
   std::ifstream f(path.c_str());
@@ -28,10 +36,9 @@ int main(int argc, char** argv) {
   CliModel m;
   auto data = load_streams(a, &m);
   if (!a.has("weight_file")) { std::cerr << "weight_file is required" << std::endl; return 1; }
-  for (const char* k : {"crf_phn_bin", "crf_lm_arpa"})
-    if (a.has(k)) { std::cerr << k << ": not built (LM: crf_lm_txt / crf_lm_bin; dictionary: crf_dict_bin / crf_dict_txt)" << std::endl; return 1; }
-  for (const char* k : {"crf_pre_phn_wt", "crf_phn_wt", "crf_dict_wt", "crf_lm_wt"})
-    if (a.real(k, 0.0) != 0.0) { std::cerr << k << ": lattice pruning between the compositions is not built (the search is exhaustive)" << std::endl; return 1; }
+  for (const char* k : {"crf_pre_phn_wt", "crf_lm_wt", "crf_lm_arpa"})
+    if (a.has(k)) std::cerr << "NOTE: " << k << " is declared by the reference's CRFFstDecode and read by nothing there: no effect" << std::endl;
+  const float phn_wt = (float)a.real("crf_phn_wt", 0.0), dict_wt = (float)a.real("crf_dict_wt", 0.0);
   // crf_decode_mode=align (Main.cpp:464-471, :841-848): the best path of lattice o label acceptor -- the labels of
   // hardtarget_file in their order, every run of equal node labels stretched or shrunk to fit -- written to the label file
   const std::string mode = a.str("crf_decode_mode", "decode");
@@ -44,9 +51,12 @@ int main(int argc, char** argv) {
     catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
   }
   const bool want_mlf = a.has("crf_output_mlffile");
-  crf_amd::ArcListFst lm, dict, chain0;   // chain0: dict o lm, composed once when no per-utterance acceptor sits between them
+  crf_amd::ArcListFst lm, dict, phn, chain0;   // chain0: dict o lm, composed once when no per-utterance acceptor sits between them
   const bool have_lm = a.has("crf_lm_txt") || a.has("crf_lm_bin");
   const bool have_dict = a.has("crf_dict_txt") || a.has("crf_dict_bin");
+  const bool have_phn = a.has("crf_phn_txt") || a.has("crf_phn_bin");
+  // a log-semiring epsilon removal or a Prune between the compositions: the chain is built left to right, machine by machine
+  const bool staged = have_phn || (have_dict && dict_wt != 0.0f);
   const bool have_align = a.has("crf_align_mlffile");
   const bool out_states = a.num("crf_mlf_output_states", 0) != 0;
   std::vector<std::string> olist;
@@ -69,19 +79,22 @@ int main(int argc, char** argv) {
       else if (a.has("crf_lm_bin")) crf_amd::readFstBinary(a.str("crf_lm_bin").c_str(), &lm);
       if (a.has("crf_dict_txt")) crf_amd::readFstText(a.str("crf_dict_txt").c_str(), &dict);
       else if (a.has("crf_dict_bin")) crf_amd::readFstBinary(a.str("crf_dict_bin").c_str(), &dict);
+      if (a.has("crf_phn_txt")) crf_amd::readFstText(a.str("crf_phn_txt").c_str(), &phn);
+      else if (a.has("crf_phn_bin")) crf_amd::readFstBinary(a.str("crf_phn_bin").c_str(), &phn);   // log arcs: the float values as they are (:616-623)
       if (have_align) {
         if (!a.has("crf_osymbols")) { std::cerr << "crf_osymbols required with crf_align_mlffile" << std::endl; return -1; }
         std::string mf = a.str("crf_align_mlffile"), ol = a.str("crf_olist");
         mlf_mgr.reset(new CRF_MLFManager(mf.c_str(), ol.c_str(), &osym_ids));
       }
-      if (have_dict && have_lm && !have_align) crf_amd::composeFst(dict, lm, &chain0);
+      if (have_dict && have_lm && !have_align && !staged) crf_amd::composeFst(dict, lm, &chain0);
     } catch (std::exception& e) { std::cerr << "Exception: " << e.what() << std::endl; return -1; }
     if (have_lm) std::cout << "LM: " << lm.n_states << " states, " << lm.arcs.size() << " arcs, " << lm.finals.size() << " final" << std::endl;
     if (have_dict) std::cout << "Dictionary: " << dict.n_states << " states, " << dict.arcs.size() << " arcs" << std::endl;
+    if (have_phn) std::cout << "Phone FST: " << phn.n_states << " states, " << phn.arcs.size() << " arcs" << std::endl;
     if (chain0.n_states) std::cout << "Dictionary o LM: " << chain0.n_states << " states, " << chain0.arcs.size() << " arcs" << std::endl;
     mlf.open(a.str("crf_output_mlffile").c_str());
     mlf << "#!MLF!#" << std::endl;
-  } else if (have_lm || have_dict || have_align) { std::cerr << "crf_lm_* / crf_dict_* / crf_align_mlffile need crf_output_mlffile (the label file holds the lattice's own best path)" << std::endl; return 1; }
+  } else if (have_lm || have_dict || have_align || have_phn) { std::cerr << "crf_lm_* / crf_dict_* / crf_phn_* / crf_align_mlffile need crf_output_mlffile (the label file holds the lattice's own best path)" << std::endl; return 1; }
   const bool out_frames = a.num("crf_mlf_output_frames", 0) != 0;
   CRF_Model crf(m.L);
   crf.setLabMaxDur(m.D);
@@ -133,7 +146,38 @@ int main(int argc, char** argv) {
     crf_amd::ArcListFst best;
     float total = 0;
     bool ok;
-    if (have_lm || have_dict || have_align) {
+    if (staged) {
+      // Main.cpp:896-1006 machine by machine: working = lattice; o phone FST, RmEpsilon on the log semiring, Prune;
+      // o dictionary, Prune; o transcript; then the shortest path of working o LM
+      crf_amd::ArcListFst w = fst, t;
+      if (have_phn) {
+        crf_amd::composeFst(w, phn, &t, (size_t)1 << 22, true);
+        crf_amd::rmEpsilonLog(&t);
+        w = t;
+        if (phn_wt != 0.0f) { crf_amd::pruneFst(w, &t, phn_wt); w = t; }
+      }
+      if (have_dict && w.n_states) {
+        crf_amd::composeFst(w, dict, &t);
+        w = t;
+        if (dict_wt != 0.0f) { crf_amd::pruneFst(w, &t, dict_wt); w = t; }
+      }
+      if (have_align && w.n_states) {
+        crf_amd::ArcListFst al;
+        mlf_mgr->getFst(olist[sent], &al);
+        crf_amd::composeFst(w, al, &t);
+        w = t;
+      }
+      crf_amd::ArcListFst id;   // no LM: an acceptor of every output label the chain can emit
+      if (!have_lm) {
+        id.n_states = 1; id.start = 0; id.SetFinal(0, 0.0f);
+        std::set<int> labs;
+        for (const scrf_arc& c : w.arcs) if (c.olabel != 0) labs.insert(c.olabel);
+        for (int l : labs) id.arcs.push_back(scrf_arc{0, l, l, 0.0f, 0});
+      }
+      if (w.n_states && !crf_amd::topSortFst(&w)) throw std::runtime_error("the composed lattice has a cycle (an epsilon-input loop in the phone FST or the dictionary)");
+      total = std::numeric_limits<float>::infinity();
+      ok = w.n_states && !w.finals.empty() && crf_amd::composeShortestPath(w, have_lm ? lm : id, &best, &total);
+    } else if (have_lm || have_dict || have_align) {
       // everything right of the lattice as ONE machine: ((dict o transcript) o LM), then the product search over
       // the lattice (Compose is associative; the reference nests ComposeFst left to right, Main.cpp:929-1006)
       const crf_amd::ArcListFst* mach = chain0.n_states ? &chain0 : (have_dict ? &dict : (have_lm && !have_align ? &lm : nullptr));

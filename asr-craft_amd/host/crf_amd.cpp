@@ -1373,7 +1373,7 @@ bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd:
   return true;
 }
 
-void crf_amd::composeFst(const crf_amd::ArcListFst& A, const crf_amd::ArcListFst& B, crf_amd::ArcListFst* out, size_t max_states) {
+void crf_amd::composeFst(const crf_amd::ArcListFst& A, const crf_amd::ArcListFst& B, crf_amd::ArcListFst* out, size_t max_states, bool sequence_filter) {
   if (A.n_states <= 0 || B.n_states <= 0 || A.start < 0 || B.start < 0) throw runtime_error("composeFst: a machine has no start state");
   const float INF = std::numeric_limits<float>::infinity();
   std::vector<std::vector<int> > aout(A.n_states), bout(B.n_states);
@@ -1391,39 +1391,228 @@ void crf_amd::composeFst(const crf_amd::ArcListFst& A, const crf_amd::ArcListFst
   for (const auto& f : A.finals) if (f.first >= 0 && f.first < A.n_states) afin[f.first] = std::min(afin[f.first], f.second);
   for (const auto& f : B.finals) if (f.first >= 0 && f.first < B.n_states) bfin[f.first] = std::min(bfin[f.first], f.second);
   *out = crf_amd::ArcListFst();
-  std::map<std::pair<int, int>, int> id;
-  std::vector<std::pair<int, int> > states;
-  auto state_of = [&](int sa, int sb) -> int {
-    auto it = id.find(std::make_pair(sa, sb));
+  // a state of the result: (state of A, state of B, filter state); the filter state is 1 after `B` has moved alone and
+  // until the next label match -- `A` may not move alone there (always 0 without the filter)
+  struct Triple { int sa, sb, fs; bool operator<(const Triple& o) const { return sa != o.sa ? sa < o.sa : (sb != o.sb ? sb < o.sb : fs < o.fs); } };
+  std::map<Triple, int> id;
+  std::vector<Triple> states;
+  auto state_of = [&](int sa, int sb, int fs) -> int {
+    const Triple t{sa, sb, fs};
+    auto it = id.find(t);
     if (it != id.end()) return it->second;
     if (states.size() >= max_states) throw runtime_error("composeFst: more than " + std::to_string(max_states) + " state pairs");
     const int n = out->AddState();
-    id[std::make_pair(sa, sb)] = n;
-    states.push_back(std::make_pair(sa, sb));
+    id[t] = n;
+    states.push_back(t);
     return n;
   };
-  out->SetStart(state_of(A.start, B.start));
+  out->SetStart(state_of(A.start, B.start, 0));
   for (size_t k = 0; k < states.size(); k++) {
-    const int sa = states[k].first, sb = states[k].second, me = (int)k;
+    const int sa = states[k].sa, sb = states[k].sb, fs = states[k].fs, me = (int)k;
     if (afin[sa] < INF && bfin[sb] < INF) out->SetFinal(me, afin[sa] + bfin[sb]);
     for (int ai : aout[sa]) {
       const scrf_arc& x = A.arcs[ai];
       if (x.olabel == 0) {
-        out->AddArc(me, crf_amd::ArcListFst::Arc(x.ilabel, 0, x.w + 0.0f, state_of(x.dst, sb)));
+        if (fs == 0) out->AddArc(me, crf_amd::ArcListFst::Arc(x.ilabel, 0, x.w + 0.0f, state_of(x.dst, sb, 0)));
         continue;
       }
       for (int bi : bout[sb]) {
         const scrf_arc& y = B.arcs[bi];
         if (y.ilabel != x.olabel) continue;
-        out->AddArc(me, crf_amd::ArcListFst::Arc(x.ilabel, y.olabel, x.w + y.w, state_of(x.dst, y.dst)));
+        out->AddArc(me, crf_amd::ArcListFst::Arc(x.ilabel, y.olabel, x.w + y.w, state_of(x.dst, y.dst, 0)));
       }
     }
     for (int bi : bout[sb]) {
       const scrf_arc& y = B.arcs[bi];
       if (y.ilabel != 0) continue;
-      out->AddArc(me, crf_amd::ArcListFst::Arc(0, y.olabel, 0.0f + y.w, state_of(sa, y.dst)));
+      out->AddArc(me, crf_amd::ArcListFst::Arc(0, y.olabel, 0.0f + y.w, state_of(sa, y.dst, sequence_filter ? 1 : 0)));
     }
   }
+}
+
+// Plus of OpenFST's LogWeight on float values: -log(e^-a + e^-b)
+static inline float log_plus(float a, float b) {
+  const float INF = std::numeric_limits<float>::infinity();
+  if (a == INF) return b;
+  if (b == INF) return a;
+  const float lo = a < b ? a : b, hi = a < b ? b : a;
+  return (float)((double)lo - std::log(1.0 + std::exp(-(double)(hi - lo))));
+}
+
+void crf_amd::rmEpsilonLog(crf_amd::ArcListFst* fst) {
+  const int n = fst->n_states;
+  if (n <= 0 || fst->start < 0) return;
+  const float INF = std::numeric_limits<float>::infinity();
+  std::vector<std::vector<int> > eps(n), lab(n);
+  std::vector<int> indeg(n, 0);
+  for (size_t i = 0; i < fst->arcs.size(); i++) {
+    const scrf_arc& a = fst->arcs[i];
+    if (a.src < 0 || a.src >= n || a.dst < 0 || a.dst >= n) throw runtime_error("rmEpsilonLog: arc with a state out of range");
+    if (a.ilabel == 0 && a.olabel == 0) { eps[a.src].push_back((int)i); indeg[a.dst]++; }
+    else lab[a.src].push_back((int)i);
+  }
+  std::vector<float> fin(n, INF);
+  for (const auto& f : fst->finals) if (f.first >= 0 && f.first < n) fin[f.first] = std::min(fin[f.first], f.second);
+  // topological position of every state in the epsilon subgraph (Kahn); a state left over sits on an epsilon cycle
+  std::vector<int> pos(n, -1), ready;
+  for (int s = 0; s < n; s++) if (indeg[s] == 0) ready.push_back(s);
+  int npos = 0;
+  for (size_t k = 0; k < ready.size(); k++) {
+    const int s = ready[k];
+    pos[s] = npos++;
+    for (int ai : eps[s]) if (--indeg[fst->arcs[ai].dst] == 0) ready.push_back(fst->arcs[ai].dst);
+  }
+  if (npos != n) throw runtime_error("rmEpsilonLog: the machine has an epsilon cycle (its log-semiring closure is a series: not built)");
+  // states that stay reachable: the start state and every target of a labelled arc
+  std::vector<char> keep(n, 0);
+  keep[fst->start] = 1;
+  for (const scrf_arc& a : fst->arcs) if (!(a.ilabel == 0 && a.olabel == 0)) keep[a.dst] = 1;
+  crf_amd::ArcListFst res;
+  std::vector<float> dist(n, INF);
+  std::vector<std::pair<int, int> > heap;   // (topological position, state): min-heap, so a state pops after all its closure predecessors
+  std::vector<int> touched;
+  struct Key { int il, ol, dst; bool operator<(const Key& o) const { return il != o.il ? il < o.il : (ol != o.ol ? ol < o.ol : dst < o.dst); } };
+  std::vector<std::vector<scrf_arc> > new_arcs(n);
+  std::vector<float> new_fin(n, INF);
+  for (int p = 0; p < n; p++) {
+    if (!keep[p]) continue;
+    touched.clear();
+    heap.clear();
+    dist[p] = 0.0f;
+    touched.push_back(p);
+    heap.push_back(std::make_pair(pos[p], p));
+    std::map<Key, size_t> slot;
+    std::vector<scrf_arc>& outp = new_arcs[p];
+    float fw = INF;
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), std::greater<std::pair<int, int> >());
+      const int q = heap.back().second;
+      heap.pop_back();
+      const float d = dist[q];
+      for (int ai : eps[q]) {
+        const scrf_arc& a = fst->arcs[ai];
+        if (dist[a.dst] == INF) {
+          touched.push_back(a.dst);
+          heap.push_back(std::make_pair(pos[a.dst], a.dst));
+          std::push_heap(heap.begin(), heap.end(), std::greater<std::pair<int, int> >());
+        }
+        dist[a.dst] = log_plus(dist[a.dst], d + a.w);
+      }
+      for (int ai : lab[q]) {
+        const scrf_arc& a = fst->arcs[ai];
+        const Key k{a.ilabel, a.olabel, a.dst};
+        auto it = slot.find(k);
+        if (it == slot.end()) { slot[k] = outp.size(); outp.push_back(scrf_arc{p, a.ilabel, a.olabel, d + a.w, a.dst}); }
+        else outp[it->second].w = log_plus(outp[it->second].w, d + a.w);
+      }
+      if (fin[q] < INF) fw = log_plus(fw, d + fin[q]);
+    }
+    new_fin[p] = fw;
+    for (int t : touched) dist[t] = INF;
+  }
+  // drop what the start state no longer reaches; ids keep their relative order
+  std::vector<char> seen(n, 0);
+  std::vector<int> work(1, fst->start);
+  seen[fst->start] = 1;
+  for (size_t k = 0; k < work.size(); k++)
+    for (const scrf_arc& a : new_arcs[work[k]]) if (!seen[a.dst]) { seen[a.dst] = 1; work.push_back(a.dst); }
+  std::vector<int> renum(n, -1);
+  for (int s = 0; s < n; s++) if (seen[s]) renum[s] = res.AddState();
+  res.SetStart(renum[fst->start]);
+  for (int s = 0; s < n; s++) {
+    if (!seen[s]) continue;
+    for (const scrf_arc& a : new_arcs[s]) res.AddArc(renum[s], crf_amd::ArcListFst::Arc(a.ilabel, a.olabel, a.w, renum[a.dst]));
+    if (new_fin[s] < INF) res.SetFinal(renum[s], new_fin[s]);
+  }
+  *fst = res;
+}
+
+bool crf_amd::topSortFst(crf_amd::ArcListFst* fst) {
+  const int n = fst->n_states;
+  if (n <= 0) return true;
+  std::vector<std::vector<int> > out(n);
+  for (size_t i = 0; i < fst->arcs.size(); i++) {
+    const scrf_arc& a = fst->arcs[i];
+    if (a.src < 0 || a.src >= n || a.dst < 0 || a.dst >= n) throw runtime_error("topSortFst: arc with a state out of range");
+    out[a.src].push_back(a.dst);
+  }
+  // iterative depth-first search from the start state, then from every state not yet seen; reverse post-order
+  std::vector<char> colour(n, 0);   // 0 unseen, 1 on the stack, 2 finished
+  std::vector<int> finish;
+  std::vector<std::pair<int, size_t> > stack;
+  auto visit = [&](int root) -> bool {
+    if (colour[root]) return true;
+    stack.push_back(std::make_pair(root, (size_t)0));
+    colour[root] = 1;
+    while (!stack.empty()) {
+      const int s = stack.back().first;
+      if (stack.back().second < out[s].size()) {
+        const int d = out[s][stack.back().second++];
+        if (colour[d] == 1) return false;   // back arc: a cycle
+        if (colour[d] == 0) { colour[d] = 1; stack.push_back(std::make_pair(d, (size_t)0)); }
+      } else {
+        colour[s] = 2;
+        finish.push_back(s);
+        stack.pop_back();
+      }
+    }
+    return true;
+  };
+  if (fst->start >= 0 && !visit(fst->start)) return false;
+  for (int s = 0; s < n; s++) if (!visit(s)) return false;
+  std::vector<int> renum(n, -1);
+  for (int k = 0; k < n; k++) renum[finish[n - 1 - k]] = k;
+  for (scrf_arc& a : fst->arcs) { a.src = renum[a.src]; a.dst = renum[a.dst]; }
+  for (auto& f : fst->finals) f.first = renum[f.first];
+  if (fst->start >= 0) fst->start = renum[fst->start];
+  if (fst->final_state >= 0) fst->final_state = renum[fst->final_state];
+  return true;
+}
+
+void crf_amd::pruneFst(const crf_amd::ArcListFst& in, crf_amd::ArcListFst* out, float threshold) {
+  crf_amd::ArcListFst m = in;
+  *out = crf_amd::ArcListFst();
+  if (m.n_states <= 0 || m.start < 0) return;
+  if (!crf_amd::topSortFst(&m)) throw runtime_error("pruneFst: the machine has a cycle (acyclic lattices only)");
+  const int n = m.n_states;
+  const float INF = std::numeric_limits<float>::infinity();
+  std::vector<std::vector<int> > outa(n);
+  for (size_t i = 0; i < m.arcs.size(); i++) outa[m.arcs[i].src].push_back((int)i);
+  std::vector<float> fin(n, INF), fd(n, INF), bd(n, INF);
+  for (const auto& f : m.finals) fin[f.first] = std::min(fin[f.first], f.second);
+  fd[m.start] = 0.0f;
+  for (int s = 0; s < n; s++) {       // ids are a topological order now
+    if (fd[s] == INF) continue;
+    for (int ai : outa[s]) { const scrf_arc& a = m.arcs[ai]; fd[a.dst] = std::min(fd[a.dst], fd[s] + a.w); }
+  }
+  for (int s = n - 1; s >= 0; s--) {
+    bd[s] = fin[s];
+    for (int ai : outa[s]) { const scrf_arc& a = m.arcs[ai]; if (bd[a.dst] < INF) bd[s] = std::min(bd[s], bd[a.dst] + a.w); }
+  }
+  if (bd[m.start] == INF) return;      // no successful path: nothing survives
+  const float limit = bd[m.start] + threshold;
+  std::vector<char> seen(n, 0);
+  std::vector<int> work(1, m.start);
+  seen[m.start] = 1;
+  std::vector<char> arc_ok(m.arcs.size(), 0);
+  for (size_t k = 0; k < work.size(); k++) {
+    const int s = work[k];
+    for (int ai : outa[s]) {
+      const scrf_arc& a = m.arcs[ai];
+      if (bd[a.dst] == INF) continue;
+      const float w = (fd[s] + a.w) + bd[a.dst];
+      if (limit < w) continue;
+      arc_ok[ai] = 1;
+      if (!seen[a.dst]) { seen[a.dst] = 1; work.push_back(a.dst); }
+    }
+  }
+  std::vector<int> renum(n, -1);
+  for (int s = 0; s < n; s++) if (seen[s]) renum[s] = out->AddState();
+  out->SetStart(renum[m.start]);
+  for (size_t i = 0; i < m.arcs.size(); i++)
+    if (arc_ok[i]) { const scrf_arc& a = m.arcs[i]; out->AddArc(renum[a.src], crf_amd::ArcListFst::Arc(a.ilabel, a.olabel, a.w, renum[a.dst])); }
+  for (int s = 0; s < n; s++)
+    if (seen[s] && fin[s] < INF && !(limit < fd[s] + fin[s])) out->SetFinal(renum[s], fin[s]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -312,11 +312,31 @@ bool composeShortestPath(const ArcListFst& lat, const ArcListFst& lm, ArcListFst
 // the dictionary, the alignment acceptor and the LM): states are the reachable pairs, numbered in discovery order
 // (breadth first from the start pair); a pair of arcs with a.olabel == b.ilabel != 0 moves both machines (ilabel of a,
 // olabel of b, weight a.w + b.w), an arc of `a` with an epsilon OUTPUT moves `a` alone, an arc of `b` with an epsilon
-// INPUT moves `b` alone; a pair is final when both states are, with the sum of the final weights.  No epsilon filter:
+// INPUT moves `b` alone; a pair is final when both states are, with the sum of the final weights.  Without the filter
 // the interleavings of a's and b's epsilon moves stay as parallel paths of equal weight, which a shortest-path search
-// on the result does not care about (OpenFST's sequencing filter keeps one of them; only the machine's size differs).
+// on the result does not care about (only the machine's size differs).
 // Throws when the result would pass `max_states` pairs.
-void composeFst(const ArcListFst& a, const ArcListFst& b, ArcListFst* out, size_t max_states = (size_t)1 << 22);
+// `sequence_filter`: OpenFST's sequencing epsilon filter (the default of its ComposeFst) -- between two label matches
+// the epsilon-output moves of `a` all come before the epsilon-input moves of `b`, so every (path of a, path of b) pair
+// shows up as exactly ONE path of the result.  Needed when a log-semiring operation follows (path weights are summed:
+// the phone-penalty stage, rmEpsilonLog below); the result's states are then (a state, b state, filter state) triples.
+void composeFst(const ArcListFst& a, const ArcListFst& b, ArcListFst* out, size_t max_states = (size_t)1 << 22, bool sequence_filter = false);
+// RmEpsilon on the LOG semiring over the float weights, as CRFFstDecode's phone-penalty stage runs it between
+// Map(StdToLogMapper) and Map(LogToStdMapper) (CRFFstDecode/src/Main.cpp:904-914): arcs with epsilon on BOTH sides are
+// removed; state p gets, for every state q of its epsilon closure (distance d(p,q) = log-sum over all epsilon paths),
+// q's labelled arcs with weight d(p,q) + w and q's final weight; arcs of p that end up with the same (ilabel, olabel,
+// next state) are merged by log-addition -min(a,b) - log(1 + exp(-|a-b|)) -- so where several epsilon paths lead to the
+// same labelled arc the tropical weight that comes out is their log-sum, not their minimum.  States that are no longer
+// reachable are dropped (ids keep their relative order).  An epsilon CYCLE throws (its closure is a series, which
+// OpenFST truncates at a delta; the lattices and phone machines of this path have none).
+void rmEpsilonLog(ArcListFst* fst);
+// Prune(in, out, threshold) on the tropical semiring (CRFFstDecode/src/Main.cpp:915-919, :935-939): keeps the arcs and
+// final weights that lie on a successful path of weight <= best + threshold, (d(start,src) + w) + d(dst,final) compared
+// with the limit as OpenFST's Prune does; acyclic input only (throws otherwise).  An empty result has no states.
+void pruneFst(const ArcListFst& in, ArcListFst* out, float threshold);
+// TopSort: renumbers the states along a depth-first reverse post-order from the start state (arc order within a state
+// kept); returns false and leaves the machine alone when it has a cycle.
+bool topSortFst(ArcListFst* fst);
 void writeFstBinary(const char* fname, const ArcListFst& fst, const char* arc_type = "standard");
 
 }  // namespace crf_amd

@@ -188,6 +188,22 @@ def test_crftrain_and_fstdecode_on_pfile_and_ilab_inputs(tmp_path):
     assert r.returncode != 0 and "selects sentence" in r.stderr
 
 
+def _write_fst_bin(path, arcs, finals, n_states, arc_type="standard", start=0):
+    """OpenFST binary vector FST (the layout _read_fst_bin parses; no symbol tables): arcs as (src, dst, il, ol, w)."""
+    import struct
+
+    def fst_string(x):
+        return struct.pack("<i", len(x)) + x.encode()
+    body = b""
+    for q in range(n_states):
+        mine = [x for x in arcs if x[0] == q]
+        body += struct.pack("<f", finals.get(q, float("inf"))) + struct.pack("<q", len(mine))
+        for (_, dst, il, ol, wt) in mine:
+            body += struct.pack("<iifi", il, ol, wt, dst)
+    hdr = struct.pack("<i", 2125659606) + fst_string("vector") + fst_string(arc_type) + struct.pack("<iiQqqq", 2, 0, 0x5, start, n_states, len(arcs))
+    open(path, "wb").write(hdr + body)
+
+
 def _read_fst_bin(path):
     """Independent parser of the OpenFST binary vector-FST layout: (start, [(src, il, ol, w, dst)], {final: w})."""
     import struct
@@ -903,9 +919,9 @@ def test_crffstdecode_against_a_language_model_fst(tmp_path):
     for u in range(len(Ts)):
         labs = [int(x) for x in blocks2[u].split("\n") if x and x != "." and not x.startswith('"')]
         assert labs == [int(v) + 1 for v in got[got[:, 0] == u][:, 2]]
-    # the phone-penalty FST is refused, not ignored
+    # a phone-penalty FST without an MLF to write is refused, not ignored
     r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_phn_bin=d.fst"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "crf_phn_bin" in r.stderr
+    assert r.returncode != 0 and "crf_phn_" in r.stderr
 
 
 def _fixture_objective(gvar):
@@ -1098,11 +1114,157 @@ def test_crffstdecode_dictionary_lm_and_alignment_chain(tmp_path):
         assert abs(tot - ref[0][0]) < 2e-5 * max(1.0, abs(ref[0][0])), (u, tot, ref[0])
         lines = [x for x in blocks[u].split("\n") if x and x != "." and not x.startswith('"')]
         assert [x for x in lines if x in ("A", "B", "C")] == [names[o] for o in best_words[u]]
-    # what is not built says so
-    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_phn_bin=x.fst"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "crf_phn_bin" in r.stderr
-    r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_dict_wt=2.5"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "crf_dict_wt" in r.stderr
+    # the flags the reference declares and never reads are accepted and say so (Main.cpp:118-128)
+    r, blocks2, totals2 = run(["crf_lm_wt=3.5", "crf_pre_phn_wt=1.5"], "noeffect")
+    assert "crf_lm_wt" in r.stderr and "no effect" in r.stderr
+    r0, blocks0, totals0 = run([], "free2")
+    assert blocks2 == blocks0 and totals2 == totals0
+
+
+def test_crffstdecode_phone_penalty_fst_and_pruning(tmp_path):
+    """The phone-penalty stage and the pruning weights of CRFFstDecode's MLF path (Main.cpp:896-940): lattice o phone
+    FST, epsilons removed on the LOG semiring, Prune(crf_phn_wt); o dictionary, Prune(crf_dict_wt); o LM, shortest path
+    -- against an exhaustive enumeration on the oracle's lattice.  The phone FST charges a penalty per phone-duration
+    label and returns to its loop state over TWO parallel epsilon arcs: on the log semiring they merge into
+    -log(e^-a + e^-b) per segment (the tropical removal would leave min(a, b)), which is what the totals must show."""
+    import math
+    from test_host_compose import machine_walks
+    rng = np.random.RandomState(78)
+    L, D, W = 3, 2, 2
+    Ts = [2, 3, 4, 3]
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    utts = []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdstate",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=2", "crf_lr=1.0",
+                        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    NL = L * D
+    pen = [float(np.float32(x)) for x in rng.rand(NL) * 1.5]
+    EA, EB = 0.3125, 0.875
+    phn = [(0, 1, l + 1, l + 1, pen[l]) for l in range(NL)] + [(1, 0, 0, 0, EA), (1, 0, 0, 0, EB)]
+    pfin = {0: 0.0625}
+    back = -math.log(math.exp(-EA) + math.exp(-EB))       # the two epsilon arcs, log-summed
+    WA, WB, WC = 31, 32, 33
+    dic = []
+    for d in range(D):
+        dic.append((0, 1, 0 + L * d + 1, WA, 0.25))
+        dic.append((1, 3, 1 + L * d + 1, 0, 0.0))
+        dic.append((0, 3, 2 + L * d + 1, WB, 0.5))
+        dic.append((0, 3, 1 + L * d + 1, WC, 0.75))
+    dic.append((3, 0, 0, 0, 0.125))
+    dfin = {0: 0.0}
+    ids = {WA: 1, WB: 2, WC: 3}
+    cost = rng.rand(4, 4)
+    lm = [(q, ids[w], w, w, float(np.float32(cost[q, ids[w]] * 4))) for q in range(4) for w in (WA, WB, WC)]
+    mfin = {1: 0.1, 2: 0.2, 3: 0.3}
+
+    def wr(path, arcs, fin):
+        with open(path, "w") as fh:
+            for a in arcs:
+                fh.write("%d %d %d %d %.9g\n" % a)
+            for s_, w_ in fin.items():
+                fh.write("%d %.9g\n" % (s_, w_))
+    pf, df, mf = str(tmp_path / "phn.txt"), str(tmp_path / "dict.txt"), str(tmp_path / "lm.txt")
+    wr(pf, phn, pfin); wr(df, dic, dfin); wr(mf, lm, mfin)
+    olist, osym = str(tmp_path / "olist"), str(tmp_path / "osym.txt")
+    open(olist, "w").write("".join("u%d.lab\n" % i for i in range(len(Ts))))
+    open(osym, "w").write("<eps> 0\nA %d\nB %d\nC %d\n" % (WA, WB, WC))
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+
+    def triples(u, with_phn):
+        """[(lattice + phone cost, dictionary cost, LM cost, labels, words)] over every lattice path / dictionary walk"""
+        T = Ts[u]
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(cfg, S, M, T)
+        lout = {}
+        for a in oa:
+            lout.setdefault(int(a["src"]), []).append((int(a["dst"]), int(a["olabel"]), float(a["w"])))
+        res = []
+
+        def paths(s, c, ols):
+            if s == ofin:
+                labs = [o for o in ols if o]
+                cp = (sum(pen[o - 1] + back for o in labs) + pfin[0]) if with_phn else 0.0
+                for c1, words in machine_walks(dic, dfin, 0, labs, 2):
+                    for c2, outs in machine_walks(lm, mfin, 0, words, 0):
+                        res.append((c + cp, c1, c2, labs, outs))
+            for d_, o_, w_ in lout.get(s, []):
+                paths(d_, c + w_, ols + [o_])
+        paths(0, 0.0, [])
+        return res
+
+    def run(extra, tag):
+        mlf = str(tmp_path / (tag + ".mlf"))
+        r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym,
+                            "crf_dict_txt=" + df, "crf_lm_txt=" + mf, "crf_output_mlffile=" + mlf,
+                            "crf_output_labelfile=" + str(tmp_path / (tag + ".lab"))] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        blocks = open(mlf).read().split('"\n')[1:]
+        totals = [x for x in r.stdout.split("\n") if x.startswith('"u')]
+        assert len(blocks) == len(Ts) and len(totals) == len(Ts)
+        words = [[x for x in b.split("\n") if x in ("A", "B", "C")] for b in blocks]
+        return r, words, [float(t.split("(weight")[1].split(")")[0]) for t in totals]
+
+    names = {WA: "A", WB: "B", WC: "C"}
+
+    def check(words, totals, refs, what):
+        for u in range(len(Ts)):
+            ref = sorted(refs[u], key=lambda t: t[0])
+            if not ref:
+                assert totals[u] == float("inf"), (what, u)
+                continue
+            assert abs(totals[u] - ref[0][0]) < 3e-5 * max(1.0, abs(ref[0][0])), (what, u, totals[u], ref[0])
+            if len(ref) == 1 or ref[1][0] - ref[0][0] > 1e-4:
+                assert words[u] == [names[o] for o in ref[0][1]], (what, u)
+
+    # 1. the phone FST in the chain: totals carry the penalties and the LOG-summed return arcs
+    r, words, totals = run(["crf_phn_txt=" + pf], "phn")
+    assert "Phone FST: 2 states" in r.stdout
+    full = [triples(u, True) for u in range(len(Ts))]
+    check(words, totals, [[(c + c1 + c2, outs) for c, c1, c2, labs, outs in full[u]] for u in range(len(Ts))], "phn")
+    # ... and that differs from what the tropical removal would have given (min instead of the log-sum), by construction
+    assert abs(back - min(EA, EB)) > 0.2
+    # 2. a generous crf_phn_wt prunes nothing that matters; the same answer
+    r, words_w, totals_w = run(["crf_phn_txt=" + pf, "crf_phn_wt=1000"], "phn_wide")
+    assert words_w == words and np.allclose(totals_w, totals, rtol=1e-6)
+    # 3. the OpenFST binary of the same machine over LOG arcs (what the reference reads, :616)
+    pb = str(tmp_path / "phn.fst")
+    _write_fst_bin(pb, phn, pfin, 2, arc_type="log")
+    r, words_b, totals_b = run(["crf_phn_bin=" + pb], "phn_bin")
+    assert words_b == words and totals_b == totals
+    # 4. crf_dict_wt: Prune of (lattice o phone o dictionary) BEFORE the LM sees it -- with a hair's width only the best
+    # path of that machine is left and the LM can no longer trade it for another word sequence
+    r, words_p, totals_p = run(["crf_phn_txt=" + pf, "crf_dict_wt=0.0001"], "dict_pruned")
+    changed = 0
+    for u in range(len(Ts)):
+        pre = sorted(((c + c1, c2, outs) for c, c1, c2, labs, outs in full[u]), key=lambda t: t[0])
+        if not pre:
+            continue
+        if len(pre) > 1 and pre[1][0] - pre[0][0] < 1e-3 and pre[1][2] != pre[0][2]:
+            continue    # two word sequences within the threshold: either may survive
+        want = pre[0][0] + pre[0][1]
+        assert abs(totals_p[u] - want) < 3e-5 * max(1.0, abs(want)), (u, totals_p[u], want)
+        assert words_p[u] == [names[o] for o in pre[0][2]]
+        changed += abs(totals_p[u] - totals[u]) > 1e-3
+    assert changed >= 1, "the LM never preferred another path: the pruning case shows nothing (change the seed)"
+    # 5. pruning without a phone FST takes the same staged route: lattice o dictionary pruned, then the LM
+    r, words_q, totals_q = run(["crf_dict_wt=1000"], "dict_wide")
+    r, words_0, totals_0 = run([], "plain")
+    assert words_q == words_0 and np.allclose(totals_q, totals_0, rtol=1e-6, atol=1e-6)
+    plain = [triples(u, False) for u in range(len(Ts))]
+    check(words_0, totals_0, [[(c + c1 + c2, outs) for c, c1, c2, labs, outs in plain[u]] for u in range(len(Ts))], "plain")
 
 
 def test_crftrain_stdseg_model_type(tmp_path):

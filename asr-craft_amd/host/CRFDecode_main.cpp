@@ -3,9 +3,11 @@
 // CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode, written as an HTK MLF
 // (crf_output_mlffile + crf_olist + crf_osymbols, Main.cpp:803-835,1176-1330) and, with
 // crf_lat_outdir, as a text arc list `src dst ilabel olabel weight` + `final weight` per
-// utterance (the reference writes OpenFST binaries there).  crf_lm_bin / crf_lm_arpa need an FST
-// library and are refused.
+// utterance (the reference writes OpenFST binaries there).  crf_if_output_full_lat: the search lattice instead of the
+// best path goes to crf_lat_outdir (Main.cpp:1094-1141); htk_lat_outdir: that lattice (or the best path) as an HTK SLF
+// file <name from crf_olist>.slf (Main.cpp:1143-1170, htk_lattice.h).  crf_lm_arpa is refused.
 #include "cli_common.h"
+#include "htk_lattice.h"
 
 // OpenFST text symbol table: `symbol id` per line
 static std::map<long, std::string> read_symbols(const std::string& path) {
@@ -108,24 +110,39 @@ int main(int argc, char** argv) {
       if (u >= olist.size()) throw std::runtime_error("main() in CRFDecode caught exception: eval sentence range goes out of the olist size.");
       std::cout << "Processing file: " << olist[u] << " (" << u << " in the olist) (" << count << " in the current test set)" << std::endl;
       CRF_ViterbiDecoder_StdSeg_NoSegTransFtr vd(&strm, &crf);
-      vd.setIfOutputFullFst(a.num("crf_if_output_full_lat", 0) != 0);
-      crf_amd::ArcListFst best_lat;
-      vd.nStateDecode(&best_lat, have_lm ? &lm : (crf_amd::ArcListFst*)nullptr, (crf_amd::ArcListFst*)nullptr, a.real("crf_decode_beam", 0.0),
+      const bool full_lat = a.num("crf_if_output_full_lat", 0) != 0;
+      vd.setIfOutputFullFst(full_lat);
+      crf_amd::ArcListFst best_lat, out_full_lat;
+      vd.nStateDecode(&best_lat, have_lm ? &lm : (crf_amd::ArcListFst*)nullptr, &out_full_lat, a.real("crf_decode_beam", 0.0),
                       (unsigned)a.num("crf_decode_min_hyp", 0), (unsigned)a.num("crf_decode_max_hyp", 0), (float)a.real("crf_decode_hyp_inc", 0.05));
+      const crf_amd::ArcListFst& dump_lat = full_lat ? out_full_lat : best_lat;   // what the lattice directories receive (:1131-1139, :1156-1168)
       std::cout << "Acoustic model weight (negative log potential) = " << vd.getBestWeight() << ", -Z(X) = " << -1 * vd.getZx()
                 << ", language model weight (negative log probability) = " << 0 << std::endl;
       if (a.has("crf_lat_outdir")) {
-        crf_amd::writeFstBinary((a.str("crf_lat_outdir") + "/" + olist[u] + ".fst").c_str(), best_lat);   // Main.cpp:1126-1136
+        crf_amd::writeFstBinary((a.str("crf_lat_outdir") + "/" + olist[u] + ".fst").c_str(), dump_lat);   // Main.cpp:1126-1136
         const std::string fn = a.str("crf_lat_outdir") + "/" + olist[u] + ".fst.txt";
         std::ofstream lf(fn.c_str());
         if (!lf.is_open()) throw std::runtime_error("cannot write " + fn);
         char buf[64];
-        for (const scrf_arc& c : best_lat.arcs) {
+        for (const scrf_arc& c : dump_lat.arcs) {
           snprintf(buf, sizeof buf, "%.9g", (double)c.w);
           lf << c.src << " " << c.dst << " " << c.ilabel << " " << c.olabel << " " << buf << "\n";
         }
-        snprintf(buf, sizeof buf, "%.9g", (double)best_lat.final_weight);
-        lf << best_lat.final_state << " " << buf << "\n";
+        for (const auto& fw : dump_lat.finals) {
+          snprintf(buf, sizeof buf, "%.9g", (double)fw.second);
+          lf << fw.first << " " << buf << "\n";
+        }
+      }
+      if (a.has("htk_lat_outdir")) {   // Main.cpp:1143-1170
+        const std::string slf = a.str("htk_lat_outdir") + "/" + olist[u] + ".slf";
+        try {
+          FST2HTK_lat to_htk;
+          to_htk.convert(dump_lat);
+          to_htk.Write(slf, olist[u], have_osym ? &osym : (const std::map<long, std::string>*)nullptr);
+        } catch (HtkLatticeError& e) {   // the reference prints these and exits with -1 (:566-592, :619-621, :686-689)
+          std::cerr << e.what() << std::endl;
+          return -1;
+        }
       }
       if (mlf.is_open()) {
         // the arc walk of Main.cpp:1176-1330 on the (already linear, epsilon-free on the input side)

@@ -1766,7 +1766,26 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeNState(const crf_amd::ArcList
   return (int)T;
 }
 
-int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst) {
+int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeFull(const crf_amd::ArcListFst* lm, double beam, crf_amd::ArcListFst* result_fst, crf_amd::ArcListFst* out_full_fst) {
+  if (lm != nullptr) return decodeLm(*lm, beam, result_fst, out_full_fst);
+  // the free phone loop (createFreePhoneLmFst, one state per label): state 0 -> phone p on p+1:p+1, phone -> any OTHER
+  // phone, every phone state final
+  const uint32_t L = crf->getNActualLabs() ? crf->getNActualLabs() : crf->getNLabs();
+  crf_amd::ArcListFst loop;
+  const int s0 = loop.AddState();
+  loop.SetStart(s0);
+  for (uint32_t p = 0; p < L; p++) {
+    const int sp = loop.AddState();
+    loop.AddArc(s0, crf_amd::ArcListFst::Arc((int)p + 1, (int)p + 1, 0.0f, sp));
+    loop.SetFinal(sp, 0.0f);
+  }
+  for (uint32_t p = 0; p < L; p++)
+    for (uint32_t n = 0; n < L; n++)
+      if (n != p) loop.AddArc(s0 + 1 + (int)p, crf_amd::ArcListFst::Arc((int)n + 1, (int)n + 1, 0.0f, s0 + 1 + (int)n));
+  return decodeLm(loop, beam, result_fst, out_full_fst);
+}
+
+int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst, crf_amd::ArcListFst* out_full_fst) {
   require_dense_model(crf, "CRF_ViterbiDecoder_StdSeg_NoSegTransFtr");
   crf_amd::Engine* e = crf->engine();
   crf->pushLambda();
@@ -1902,6 +1921,88 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst&
       }
   }
   best_weight = min_weight;
+  if (out_full_fst != nullptr) {
+    // the search lattice: every transition the loops above expanded, for every duration, between hypothesis states
+    crf_amd::ArcListFst full;
+    const int fs0 = full.AddState();
+    full.SetStart(fs0);
+    std::vector<int32_t> sid((size_t)T * QL, -1);
+    auto state_of = [&](uint32_t t, size_t idx) -> int {
+      int32_t& s_ = sid[(size_t)t * QL + idx];
+      if (s_ < 0) s_ = full.AddState();
+      return s_;
+    };
+    auto word_of = [&](const Eps& c, const scrf_arc& a) -> int {   // one word per arc, as the reference's wrdId: the phone arc's, else the last on the epsilon path
+      if (a.olabel != 0) return a.olabel;
+      for (size_t i = c.path.size(); i-- > 0;) if (lm.arcs[c.path[i]].olabel != 0) return lm.arcs[c.path[i]].olabel;
+      return 0;
+    };
+    auto fan_out = [&](int from, uint32_t t, size_t idx, float trans, int word) {
+      const uint32_t l = (uint32_t)(idx % L);
+      for (uint32_t d = 1; d <= D && t + d - 1 < T; d++) {
+        const uint32_t te = t + d - 1;
+        full.AddArc(from, crf_amd::ArcListFst::Arc((int)l + 1, word, trans + (float)(-1 * S[seg_row(te, d) * L + l]), state_of(te, idx)));
+      }
+    };
+    for (uint32_t t = 0; t < T; t++) {
+      if (t == 0) {
+        const std::vector<Eps>& c = closure[lm.start];
+        for (size_t k = 0; k < c.size(); k++)
+          for (int ai : out[c[k].state]) {
+            const scrf_arc& a = lm.arcs[ai];
+            if (a.ilabel <= 0 || a.ilabel > (int)L) continue;
+            fan_out(fs0, 0, (size_t)a.dst * L + (a.ilabel - 1), (0.0f + c[k].w) + a.w, word_of(c[k], a));
+          }
+        continue;
+      }
+      const float* Fp = &F[(size_t)(t - 1) * QL];
+      const double* Mt = &M[(size_t)t * L * L];
+      float best_prev = INF;
+      if (beam > 0) for (size_t i = 0; i < QL; i++) best_prev = std::min(best_prev, Fp[i]);
+      for (int q = 0; q < Q; q++)
+        for (uint32_t p = 0; p < L; p++) {
+          const float old = Fp[(size_t)q * L + p];
+          if (old >= INF || (beam > 0 && !(old < best_prev + beam))) continue;
+          const int from = state_of(t - 1, (size_t)q * L + p);
+          fan_out(from, t, (size_t)q * L + p, (float)(-1 * Mt[(size_t)p * L + p]), 0);
+          const std::vector<Eps>& c = closure[q];
+          for (size_t k = 0; k < c.size(); k++)
+            for (int ai : out[c[k].state]) {
+              const scrf_arc& a = lm.arcs[ai];
+              if (a.ilabel <= 0 || a.ilabel > (int)L) continue;
+              const uint32_t l = (uint32_t)a.ilabel - 1;
+              fan_out(from, t, (size_t)a.dst * L + l, (c[k].w + a.w) + (float)(-1 * Mt[(size_t)p * L + l]), word_of(c[k], a));
+            }
+        }
+    }
+    if (T > 0) {
+      const float* Fl = &F[(size_t)(T - 1) * QL];
+      float best_last = INF;
+      if (beam > 0) for (size_t i = 0; i < QL; i++) best_last = std::min(best_last, Fl[i]);
+      for (size_t idx = 0; idx < QL; idx++) {
+        if (Fl[idx] >= INF || (beam > 0 && !(Fl[idx] < best_last + beam))) continue;
+        if (sid[(size_t)(T - 1) * QL + idx] >= 0) full.SetFinal(sid[(size_t)(T - 1) * QL + idx], (float)zx);
+      }
+    }
+    // Connect: keep the states that lie on a path from the start state to a final state
+    const int NS = full.n_states;
+    std::vector<std::vector<int> > rin(NS);
+    for (const scrf_arc& a : full.arcs) rin[a.dst].push_back(a.src);
+    std::vector<char> live(NS, 0);
+    std::vector<int> work;
+    for (const auto& fw : full.finals) if (!live[fw.first]) { live[fw.first] = 1; work.push_back(fw.first); }
+    for (size_t k = 0; k < work.size(); k++)
+      for (int s_ : rin[work[k]]) if (!live[s_]) { live[s_] = 1; work.push_back(s_); }
+    *out_full_fst = crf_amd::ArcListFst();
+    if (live[fs0]) {
+      std::vector<int> renum(NS, -1);
+      for (int s_ = 0; s_ < NS; s_++) if (live[s_]) renum[s_] = out_full_fst->AddState();
+      out_full_fst->SetStart(renum[fs0]);
+      for (const scrf_arc& a : full.arcs)
+        if (live[a.src] && live[a.dst]) out_full_fst->AddArc(renum[a.src], crf_amd::ArcListFst::Arc(a.ilabel, a.olabel, a.w, renum[a.dst]));
+      for (const auto& fw : full.finals) out_full_fst->SetFinal(renum[fw.first], fw.second);
+    }
+  }
   int cur = result_fst->AddState();
   result_fst->SetStart(cur);
   if (best_idx < 0) {  // "Could not reach end of utterance" (:2141-2147)

@@ -620,8 +620,13 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   // the free-phone LM :2294).  Returns the number of frames.
   template <class Fst>
   int nStateDecode(Fst* result_fst, Fst* lm_fst, Fst* out_full_fst, double input_beam, unsigned min_hyps = 0, unsigned max_hyps = 0, float beam_inc = 0.05f) {
-    (void)out_full_fst; (void)min_hyps; (void)max_hyps; (void)beam_inc;
-    if (if_output_full_fst) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: the full output lattice is not built (use CRF_LatticeBuilder)");
+    (void)min_hyps; (void)max_hyps; (void)beam_inc;
+    if (if_output_full_fst) {
+      if (out_full_fst == nullptr) throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: setIfOutputFullFst(true) needs an out_full_fst to fill");
+      if (crf->getFeatureMap() && crf->getFeatureMap()->getNumStates() > 1)
+        throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: the full output lattice is built for crf_states = 1 only");
+      return decodeFull(lm_fst, input_beam, result_fst, out_full_fst);
+    }
     if (crf->getFeatureMap() && crf->getFeatureMap()->getNumStates() > 1) return decodeNState(lm_fst, result_fst);
     if (lm_fst != nullptr) return decodeLm(*lm_fst, input_beam, result_fst);
     const int T = decode();
@@ -660,7 +665,20 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   template <class Fst> int decodeLm(const Fst&, double, Fst*) {
     throw std::runtime_error("nStateDecode: an LM FST must be a crf_amd::ArcListFst");
   }
-  int decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst);
+  int decodeLm(const crf_amd::ArcListFst& lm, double beam, crf_amd::ArcListFst* result_fst, crf_amd::ArcListFst* out_full_fst = nullptr);
+  // setIfOutputFullFst(true): the search lattice next to the best path (output_full_fst, :1163-1215 insertArcToOutputFullFst,
+  // :168-222 stateValueUpdate_onOutputFullFst, :1974-1990 final states).  States: one start state (the reference's time -1)
+  // and one per hypothesis (end frame, LM state, phone) that a segment reaches -- the reference keys its states by (end
+  // frame, LM state) alone; with its own free phone loop and with LMs whose states are entered on one phone the two are
+  // the same thing.  Arcs: one per transition the search expands (a kept hypothesis x [its internal continuation | an LM
+  // arc behind the epsilon closure] x duration), StdArc(phone + 1, word if the LM moved else 0, (LM weights + float(-M)) +
+  // float(-S of the segment), target); every hypothesis kept at the last frame is final with weight Zx (LM final weights
+  // are NOT in it, as there); then Connect (states off every successful path dropped).  Without an LM the search runs
+  // against the free phone loop of createFreePhoneLmFst (:1270-1350) built here.  crf_states = 1 only.
+  template <class Fst> int decodeFull(const Fst*, double, Fst*, Fst*) {
+    throw std::runtime_error("nStateDecode: the full output lattice needs crf_amd::ArcListFst machines");
+  }
+  int decodeFull(const crf_amd::ArcListFst* lm, double beam, crf_amd::ArcListFst* result_fst, crf_amd::ArcListFst* out_full_fst);
   // crf_states = K > 1 (CRF_ViterbiDecoder::nStateDecode, decoders/CRF_ViterbiDecoder.cpp:398-960, and the n-state
   // branches of this class's :246-735): a phone is its K states in order, each held for one or more frames (segments);
   // a hypothesis enters a phone at its start state along an LM arc with ilabel phone+1, leaves it from its end state,

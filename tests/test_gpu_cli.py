@@ -308,6 +308,225 @@ def test_crfdecode_free_phone_loop_mlf_and_best_path_chain(tmp_path):
         assert r.returncode == rc and msg in r.stderr, (r.returncode, r.stderr)
 
 
+def _lattice_paths(arcs, finals, start):
+    """every start -> final path of an acyclic arc list [(src, dst, il, ol, w)]: [(sum of arc weights, ilabels, olabels)]"""
+    out = {}
+    for a in arcs:
+        out.setdefault(a[0], []).append(a)
+    res = []
+
+    def go(s, w, il, ol):
+        if s in finals:
+            res.append((w, il, ol))
+        for a in out.get(s, []):
+            go(a[1], w + a[4], il + (a[2],), ol + (a[3],))
+    go(start, 0.0, (), ())
+    return res
+
+
+def _read_lat_txt(path):
+    rows = [x.split() for x in open(path).read().strip().split("\n")]
+    arcs = [(int(x[0]), int(x[1]), int(x[2]), int(x[3]), float(x[4])) for x in rows if len(x) == 5]
+    finals = {int(x[0]): float(x[1]) for x in rows if len(x) == 2}
+    return arcs, finals
+
+
+def _read_slf(path):
+    lines = open(path).read().split("\n")
+    nodes = [dict(kv.split("=", 1) for kv in ln.split()) for ln in lines if ln.startswith("I=")]
+    arcs = [dict(kv.split("=", 1) for kv in ln.split()) for ln in lines if ln.startswith("J=")]
+    head = [ln for ln in lines if ln.startswith("N=")][0].split()
+    assert head == ["N=%d" % len(nodes), "L=%d" % len(arcs)]
+    return lines, nodes, arcs
+
+
+def test_crfdecode_full_search_lattice_and_htk_slf(tmp_path):
+    """crf_if_output_full_lat / htk_lat_outdir (CRFDecode/src/Main.cpp:1094-1170; the decoder's output_full_fst,
+    decoders/CRF_ViterbiDecoder_StdSeg_NoSegTransFtr.cpp:168-222, :1163-1215, :1974-1990): the search lattice of an
+    exhaustive decode holds exactly the hypotheses of an independent enumeration -- every labelled segmentation x every
+    way through the LM (a phone continuing through its internal transition, or an LM arc behind the cheapest epsilon
+    path), arc weights (LM + float(-M)) + float(-S), every state of the last frame final with Zx -- and the best path and
+    MLF do not change when it is asked for.  The HTK SLF writer: the best path of a segmental decode, the full lattice of
+    a frame-level decode (path sums preserved, negated), and the reference's refusal of a lattice whose states are
+    reached after different numbers of arcs (a segmental full lattice)."""
+    rng = np.random.RandomState(12)
+    L, D, W = 3, 2, 2
+    f = str(tmp_path / "f.ascii"); lbl = str(tmp_path / "l.ascii")
+    Ts = [1, 3, 4]
+    utts = []
+    with open(f, "w") as ff, open(lbl, "w") as lf:
+        for u, T in enumerate(Ts):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T]
+            utts.append(X)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    model = ["ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "crf_label_size=%d" % L, "crf_featuremap=stdtrans",
+             "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D]
+    wf = str(tmp_path / "w.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + model + ["hardtarget_file=" + lbl, "out_weight_file=" + wf, "crf_epochs=2", "crf_lr=1.0",
+                        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # LM: words on the phone arcs, one phone arc without a word behind an epsilon arc that carries one (3 -> 0 : 15, 0 -> 2 on phone 3)
+    arcs = [(0, 1, 1, 11, 0.5), (0, 2, 2, 12, 0.2), (1, 2, 2, 12, 0.3), (1, 3, 0, 0, 0.7), (2, 1, 1, 11, 0.1), (2, 2, 2, 13, 0.9),
+            (3, 1, 1, 14, 0.4), (3, 0, 0, 15, 0.25), (2, 3, 3, 16, 0.6), (3, 2, 2, 12, 1.1), (1, 1, 3, 17, 0.35), (0, 2, 3, 0, 0.15)]
+    finals = {1: 0.05, 2: 0.3}
+    lmf = str(tmp_path / "lm.fst.txt")
+    with open(lmf, "w") as fh:
+        for a in arcs:
+            fh.write("%d %d %d %d %g\n" % a)
+        for s_, w_ in finals.items():
+            fh.write("%d %g\n" % (s_, w_))
+    olist, osym = str(tmp_path / "olist"), str(tmp_path / "osym.txt")
+    open(olist, "w").write("".join("u%d\n" % i for i in range(len(Ts))))
+    open(osym, "w").write("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, 18)))
+    F = 8 * W + D
+    cfg = orc.config(L=L, D=D, F=F, use_trans_ftrs=True, tfs=0, tfe=F - 1); lay = orc.Layout(cfg)
+    w = np.loadtxt(wf)
+
+    def decode(extra, tag, lm=True):
+        latdir = tmp_path / ("lat_" + tag); latdir.mkdir()
+        mlf = str(tmp_path / (tag + ".mlf"))
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_osymbols=" + osym,
+                            "crf_output_mlffile=" + mlf, "crf_lat_outdir=" + str(latdir)] + (["crf_lm_txt=" + lmf] if lm else []) + extra,
+                           capture_output=True, text=True, timeout=300)
+        return r, latdir, (open(mlf).read() if os.path.exists(mlf) else None)
+
+    r0, lat0, mlf0 = decode([], "best")
+    r1, lat1, mlf1 = decode(["crf_if_output_full_lat=1"], "full")
+    assert r0.returncode == 0 and r1.returncode == 0, r0.stderr + r1.stderr
+    assert mlf1 == mlf0
+    assert [x for x in r1.stdout.split("\n") if x.startswith("Acoustic")] == [x for x in r0.stdout.split("\n") if x.startswith("Acoustic")]
+    Q = 4
+    lout = [[a for a in arcs if a[0] == q] for q in range(Q)]
+
+    def closure(q):   # cheapest epsilon path to every state reachable on epsilon inputs: state -> (cost, arcs)
+        best = {q: (0.0, [])}
+        changed = True
+        while changed:
+            changed = False
+            for s_, (c_, path) in list(best.items()):
+                for a in lout[s_]:
+                    if a[2] == 0 and (a[1] not in best or c_ + a[4] < best[a[1]][0] - 1e-12):
+                        best[a[1]] = (c_ + a[4], path + [a]); changed = True
+        return best
+    clo = [closure(q) for q in range(Q)]
+    for u, T in enumerate(Ts):
+        S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+        rc, _, _, _, zx = orc.seg_forward(cfg, S, M, T)
+        want = []
+
+        def rec(t_next, q, prev, cost, ils, ols):
+            if t_next == T:
+                want.append((cost, ils, ols))
+                return
+            for d in range(1, D + 1):
+                end = t_next + d - 1
+                if end >= T:
+                    break
+                row = orc.seg_base(end, D) + d - 1
+                moves = []
+                if prev is not None:
+                    moves.append((q, prev, 0.0, 0))            # the phone goes on: no LM move, no word
+                for s_, (ce, path) in clo[q].items():
+                    for a in lout[s_]:
+                        if a[2] != 0:
+                            word = a[3] if a[3] else ([x[3] for x in path if x[3]] or [0])[-1]
+                            moves.append((a[1], a[2] - 1, ce + a[4], word))
+                for (q2, l, lmw, word) in moves:
+                    c = lmw - (M[t_next, prev * L + l] if prev is not None else 0.0) - S[row, l]
+                    rec(end + 1, q2, l, cost + c, ils + (l + 1,), ols + (word,))
+        rec(0, 0, None, 0.0, (), ())
+        larcs, lfin = _read_lat_txt(str(lat1 / ("u%d.fst.txt" % u)))
+        got = _lattice_paths(larcs, lfin, 0)
+        assert len(got) == len(want) and len(want) > 0
+        key = lambda p: (p[1], p[2], round(p[0], 3))
+        assert sorted(map(key, got)) == sorted(map(key, want))
+        gs, ws = sorted(got), sorted(want)
+        assert np.allclose([g_[0] for g_ in gs], [w_[0] for w_ in ws], rtol=1e-5, atol=2e-5)
+        assert all(np.float32(v) == np.float32(zx) for v in lfin.values()) and len(lfin) >= 1
+        # the binary next to it holds the same machine
+        start, barcs, bfin = _read_fst_bin(str(lat1 / ("u%d.fst" % u)))
+        assert start == 0 and len(barcs) == len(larcs) and sorted(bfin) == sorted(lfin)
+        # the best-path file of the other run is still the chain
+        carcs, cfin = _read_lat_txt(str(lat0 / ("u%d.fst.txt" % u)))
+        assert [a[0] for a in carcs] == list(range(len(carcs))) and list(cfin) == [len(carcs)]
+
+    # a beam keeps a sub-lattice: fewer or as many paths, none invented, the kept best path among them when it survives
+    r2, lat2, _ = decode(["crf_if_output_full_lat=1", "crf_decode_beam=0.5"], "beam")
+    assert r2.returncode == 0, r2.stderr
+    for u in range(len(Ts)):
+        a_full = _lattice_paths(*_read_lat_txt(str(lat1 / ("u%d.fst.txt" % u))), 0)
+        a_beam = _lattice_paths(*_read_lat_txt(str(lat2 / ("u%d.fst.txt" % u))), 0)
+        ks = set((p[1], p[2], round(p[0], 3)) for p in a_full)
+        assert len(a_beam) <= len(a_full) and all((p[1], p[2], round(p[0], 3)) in ks for p in a_beam)
+
+    # HTK SLF, free phone loop (no LM): the best path of the segmental decode, one word arc per run of a phone
+    slfdir = tmp_path / "slf"; slfdir.mkdir()
+    r3, lat3, _ = decode(["htk_lat_outdir=" + str(slfdir)], "slfbest", lm=False)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    for u, T in enumerate(Ts):
+        carcs, cfin = _read_lat_txt(str(lat3 / ("u%d.fst.txt" % u)))
+        lines, nodes, sarcs = _read_slf(str(slfdir / ("u%d.slf" % u)))
+        assert lines[:5] == ["VERSION=1.0", "UTTERANCE=u%d" % u, "lmscale=1.00  wdpenalty=0.00", "prscale=1.00", "acscale=1.00"]
+        words, sums, ends = [], [], []
+        for k, a in enumerate(carcs):
+            if a[3]:
+                words.append(a[3]); sums.append(0.0); ends.append(k)
+            sums[-1] += -a[4]; ends[-1] = k
+        assert [n_["W"] for n_ in nodes] == ["!NULL"] + ["w%d" % x for x in words]
+        assert [n_["t"] for n_ in nodes] == ["0"] + ["%g" % (0.01 * (e_ + 1)) for e_ in ends]
+        assert [(int(a["S"]), int(a["E"])) for a in sarcs] == [(i, i + 1) for i in range(len(words))]
+        assert np.allclose([float(a["a"]) for a in sarcs], sums, rtol=1e-5, atol=1e-5) and all(a["l"] == "-0" and a["r"] == "0.00" for a in sarcs)
+    # ... the segmental FULL lattice has states reached after different numbers of arcs: the reference's converter stops (exit -1)
+    r4, _, _ = decode(["crf_if_output_full_lat=1", "htk_lat_outdir=" + str(slfdir), "crf_eval_range=2"], "slffull", lm=False)
+    assert r4.returncode == 255 and "FST2HTK_lat::findOrInsertFstNode() ERROR" in r4.stderr, (r4.returncode, r4.stderr)
+
+    # frame-level model (the bundled fixture): the full lattice of the free phone loop converts; its path sums are the lattice's, negated
+    (tmp_path / "frame").mkdir()   # its own weight directory: the first run left .done.train in tmp_path
+    wf2 = str(tmp_path / "frame" / "w2.out")
+    r = subprocess.run([os.path.join(BIN, "CRFTrain")] + _common_flags() + [
+        "hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + wf2, "crf_epochs=1", "crf_lr=0.2",
+        "crf_bunch_size=1", "threads=1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    open(olist, "w").write("a\nb\nc\n")
+    open(osym, "w").write("<eps> 0\n" + "".join("p%d %d\n" % (i, i + 1) for i in range(48)))
+    latf = tmp_path / "lat_frame"; latf.mkdir()
+    slff = tmp_path / "slf_frame"; slff.mkdir()
+    r = subprocess.run([os.path.join(BIN, "CRFDecode")] + _common_flags() + ["weight_file=" + wf2, "crf_olist=" + olist, "crf_osymbols=" + osym,
+                        "crf_output_mlffile=" + str(tmp_path / "frame.mlf"), "crf_lat_outdir=" + str(latf), "htk_lat_outdir=" + str(slff),
+                        "crf_if_output_full_lat=1", "crf_decode_beam=0.75", "crf_eval_range=0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    larcs, lfin = _read_lat_txt(str(latf / "a.fst.txt"))
+    lines, nodes, sarcs = _read_slf(str(slff / "a.slf"))
+    assert len(larcs) > 0 and len(sarcs) > 0 and nodes[0]["W"] == "!NULL" and nodes[0]["t"] == "0"
+
+    import sys
+    sys.setrecursionlimit(20000)
+
+    def best(arcs_, finals_, start_):   # max-sum path of an acyclic graph by memoised recursion
+        out = {}
+        for a in arcs_:
+            out.setdefault(a[0], []).append(a)
+        memo = {}
+
+        def go(s_):
+            if s_ not in memo:
+                cands = [a[2] + go(a[1]) for a in out.get(s_, []) if go(a[1]) is not None]
+                if s_ in finals_:
+                    cands.append(0.0)
+                memo[s_] = max(cands) if cands else None
+            return memo[s_]
+        return go(start_)
+    lat_best = best([(a[0], a[1], -a[4]) for a in larcs], set(lfin), 0)
+    ends_ = set(int(a["E"]) for a in sarcs) - set(int(a["S"]) for a in sarcs)
+    slf_best = best([(int(a["S"]), int(a["E"]), float(a["a"])) for a in sarcs], ends_, 0)
+    assert abs(lat_best - slf_best) < 1e-3 * max(1.0, abs(lat_best)), (lat_best, slf_best)
+    # every HTK node lies one arc-count further than the word start it hangs on; word nodes carry v=1
+    assert all(("v" in n_) == (n_["W"] != "!NULL") for n_ in nodes)
+
+
 def test_crfdecode_frame_model_on_bundled_fixture(tmp_path):
     """CRFDecode on BASELINE config 1 (frame-level CRF, the reference's bundled fixture): one arc per
     frame, olabel only where the phone changes, weights float(-(M + S)), final weight Zx."""

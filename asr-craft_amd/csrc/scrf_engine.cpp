@@ -767,6 +767,29 @@ static uint32_t segtrans_chunks(uint64_t nseg, size_t LL, uint32_t ntf) {
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cap, (nseg + 2047) / 2048));
 }
 
+// K-chunks (row chunks) of the per-frame transition contraction (stdtrans: [frames][L*L] posteriors x the transition
+// feature functions).  The wide form of k_expf_mfma holds one 8-wavefront workgroup per CU, so the launch runs in rounds
+// of 256 workgroups: with the TIMIT demo's 240 tiles per chunk, 4 chunks are 3.75 rounds (the last one three quarters
+// full), 16 chunks are 15 whole rounds.  Smallest count from 4 up to 16 (at least 1024 rows each) whose last round is >= 97 %
+// full, else the fullest; SCRF_TRANS_CHUNKS overrides (A/B runs).
+static uint32_t transframe_chunks(uint64_t nfr, uint32_t n_out, uint32_t nfun, int f32) {
+  const uint32_t base = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, (nfr + 2047) / 2048));
+  static const int forced = getenv("SCRF_TRANS_CHUNKS") ? atoi(getenv("SCRF_TRANS_CHUNKS")) : 0;
+  if (forced > 0) return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)forced, std::max<uint64_t>(1, nfr / 64)));
+  const uint32_t tiles = expf_mfma_wide_tiles(n_out, nfun, f32);
+  if (tiles == 0 || base < 4) return base;
+  const uint32_t cus = 256;
+  uint32_t best = base;
+  double best_fill = 0.0;
+  for (uint32_t n = base; n <= 16 && nfr / n >= 1024; n++) {
+    const uint64_t wg = (uint64_t)tiles * n;
+    const double fill = (double)wg / (double)(((wg + cus - 1) / cus) * cus);
+    if (fill > best_fill + 1e-9) { best_fill = fill; best = n; }
+    if (fill >= 0.97) { best = n; break; }
+  }
+  return best;
+}
+
 // K-chunks of the transition-bias contraction: one wavefront each, about 4096 of them (four per SIMD: a wavefront's
 // next operands are only one 576-cycle group of MFMAs ahead, the others cover the rest of the load latency)
 static uint64_t atb_rows_per_chunk(uint64_t nfr) {
@@ -895,7 +918,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
         tot += pad256((size_t)segtrans_chunks(nseg, LL, l.ntf) * LL * l.ntf * sizeof(double));
       } else if (l.use_tf) {
         tot += pad256(nfr * LL * sizeof(double)) + pad256(nfr * 8);  // XI, xrow_next
-        uint32_t nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
+        uint32_t nch_t = transframe_chunks(nfr, (uint32_t)LL, scrf_spec_trans(l).nfun(), h->cfg.train_precision == SCRF_PREC_FAST32);
         tot += pad256((size_t)nch_t * LL * l.ntf * sizeof(double));
       } else if (!wave_path(h, nd.post)) {
         tot += pad256(nutt * LL * sizeof(double));
@@ -1016,8 +1039,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       } else if (l.use_tf) {
         cb->XI = a.take<double>(nfr * LL);
         cb->xrow_next = a.take<uint64_t>(nfr);
-        cb->nch_t = (uint32_t)std::min<uint64_t>(4, (nfr + 2047) / 2048);
-        if (cb->nch_t == 0) cb->nch_t = 1;
+        cb->nch_t = transframe_chunks(nfr, (uint32_t)LL, scrf_spec_trans(l).nfun(), h->cfg.train_precision == SCRF_PREC_FAST32);
         cb->rpc_t = (nfr + cb->nch_t - 1) / cb->nch_t;
         cb->slab_t = a.take<double>((size_t)cb->nch_t * LL * l.ntf);
       } else if (!cb->wave) {
@@ -1141,8 +1163,13 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     uint32_t col = 0;
     for (uint32_t s = 0; s < b->n_streams; s++) {
       const scrf_stream_recipe& r = b->recipe[s];
+      // FAST training path with per-frame transition features: a stream whose columns hold no state feature is read through
+      // the frame rows (k_frame_rows: the node's first window) only -- its other window rows are not written (the TIMIT
+      // demo's +-6-frame context stream: 5.8 GB of the 9.3 GB window image).  The window hook (scrf_windows) and EXACT
+      // precision materialise every row.
+      const bool first_only = fast && l.use_tf && !segtrans(h) && l.D > 1 && (col > l.sfe || col + b->width[s] <= l.sfs);
       KT_RUN("k_windows", cb.st, launch_windows(cb.st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
-                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col));
+                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col, first_only ? 1 : 0));
       col += b->width[s];
     }
     tm.stop(b->n_streams);

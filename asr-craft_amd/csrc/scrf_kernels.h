@@ -8,7 +8,7 @@
 
 void launch_windows(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
                     uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, uint32_t lctx,
-                    uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col);
+                    uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col, int first_only = 0);
 void launch_frame_rows(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t u1, uint32_t D,
                        uint64_t n_frames, uint64_t* xrow, int next);
 void launch_scores_exact(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
@@ -59,6 +59,9 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int f32 = 0);
+// workgroups launch_expf_mfma starts per row chunk when it takes the 8-wavefront form (one workgroup per CU), else 0:
+// the engine sizes the number of row chunks so that the launch fills whole rounds of the chip's CUs
+uint32_t expf_mfma_wide_tiles(uint32_t n_out, uint32_t nfun, int f32);
 
 // scrf_dp.hip: wavefront-per-utterance DP and the parallel posterior kernels
 int dp_wave_supported(const ScrfLayout& lay);

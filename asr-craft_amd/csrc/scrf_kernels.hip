@@ -40,11 +40,12 @@ __device__ __forceinline__ uint32_t find_utt(const uint64_t* off, uint32_t u0, u
 __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __restrict__ sframe_off,
                           ScrfBatchView bv, uint32_t u0, uint32_t u1, uint32_t W, uint32_t D,
                           uint32_t lctx, uint32_t rctx, int extract, float* __restrict__ X,
-                          uint32_t F, uint32_t out_col) {
+                          uint32_t F, uint32_t out_col, int first_only) {
   const uint64_t gf = bv.frame_off[u0] + blockIdx.x;
   const uint32_t u = find_utt(bv.frame_off, u0, u1, gf);
   const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
-  const uint32_t avail = scrf_node_max_dur(t, D);
+  // first_only: the caller reads this stream's columns from the node's FIRST window row alone (per-frame transition features)
+  const uint32_t avail = first_only ? 1u : scrf_node_max_dur(t, D);
   const uint64_t rowbase = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
   const float* last = frames + (sframe_off[u] + lctx + t) * (uint64_t)W;
   const bool segftr = (D != 1) && extract;
@@ -91,11 +92,11 @@ __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __re
 
 void launch_windows(hipStream_t st, const float* frames, const uint64_t* sframe_off, ScrfBatchView bv,
                     uint32_t u0, uint32_t u1, uint64_t n_frames, uint32_t W, uint32_t D, uint32_t lctx,
-                    uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col) {
+                    uint32_t rctx, int extract, float* X, uint32_t F, uint32_t out_col, int first_only) {
   if (n_frames == 0) return;
   uint32_t bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   hipLaunchKernelGGL(k_windows, dim3((uint32_t)n_frames), dim3(bs), 0, st, frames, sframe_off, bv, u0, u1,
-                     W, D, lctx, rctx, extract, X, F, out_col);
+                     W, D, lctx, rctx, extract, X, F, out_col, first_only);
 }
 
 // first window row (d=1) of every frame of the chunk: the transition features of node t

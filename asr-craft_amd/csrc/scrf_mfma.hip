@@ -215,7 +215,14 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 }
 
 // ------------------------------------------------------------------------------------------
-#define EM_NO 48    // outputs per workgroup (3 M-tiles)
+// M-tiles (16 outputs each) of a workgroup tile of the unsplit form.  f64: 4 -- a wavefront carries 64 outputs x 48 feature
+// columns, 12 MFMAs per 7 operand loads and 96 per barrier (3: 9 per 6, 72 per barrier; measured at the TIMIT transition
+// counts 14.8 -> 13.5 ms, config 5's state counts 96.6 -> 91.1 ms; 231 VGPRs, no spills).  The f32 form spills at 4 and stays at 3.
+#ifndef EM_MTF
+#define EM_MTF 4
+#endif
+#define EM_MTW(F32) ((F32) ? 3 : EM_MTF)
+#define EM_SPLIT_NO 48        // outputs per wavefront of the split form (3 M-tiles)
 
 // NW wavefronts per workgroup, each owning 48 feature columns (3 N-tiles): NW = 8 covers 384
 // columns (the full 338-wide state block of config 2 in one workgroup, so R is read once);
@@ -227,7 +234,7 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 // MT: M-tiles (16 outputs each) a wavefront carries: 3, or the 1 / 2 of the remainder launch (o_base = its first output)
 // DB = 1 (the 8-wave form, which owns its CU): two LDS image pairs; a chunk's MFMAs run from one while the next chunk is
 // stored into the other, one barrier per chunk instead of two
-template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0, int MT = 3, int DB = 0>
+template <int HAS_XROW, int NW, int EM_KC, int F32, int SPLIT_OUT = 0, int MT = 3, int DB = 0, int MTW = 3>
 __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict__ A, uint32_t n_out,
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   // SPLIT_OUT: the wavefronts share one 48-column feature tile and own 48 outputs each (few feature functions, many
   // outputs: the per-window transition posteriors, n_out = L * L); otherwise 48 outputs and 48 feature columns per wavefront
   constexpr int NF = SPLIT_OUT ? 48 : 48 * NW;   // feature columns per workgroup
-  constexpr int NO = SPLIT_OUT ? EM_NO * NW : EM_NO;   // outputs per workgroup
+  constexpr int NO = SPLIT_OUT ? EM_SPLIT_NO * NW : 16 * MTW;   // outputs per workgroup (MTW M-tiles wide; MT <= MTW of them hold outputs)
   constexpr int XS = NF + 16;            // float row stride of the X image (== 16 mod 32)
   constexpr int QR = NF / 4;             // 16-byte quads per row
   constexpr int XIT = (EM_KC * QR + NT - 1) / NT;   // X quads per thread per chunk (= 6; the split form has threads without one)
@@ -423,14 +430,15 @@ static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const dou
                                  uint64_t rows_per_chunk, double* slab, uint32_t o_base) {
   constexpr int DB = NW == 8 ? 1 : 0;   // the 8-wave workgroup has its CU to itself: room for a second image pair
   static const bool db_off = getenv("SCRF_EXPF_DB") && atoi(getenv("SCRF_EXPF_DB")) == 0;   // A/B knob
+  constexpr int MTW = EM_MTW(F32);
   if (DB && !db_off) {
-    hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * sm));
-    hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), 2 * sm, st, A, n_out, X, F, xrow,
+    hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB, MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * sm));
+    hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB, MTW>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), 2 * sm, st, A, n_out, X, F, xrow,
                        n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);
     return;
   }
-  hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow,
+  hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, 0, MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, 0, MTW>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow,
                      n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);
 }
 template <int HAS_XROW, int NW, int KC, int F32>
@@ -439,17 +447,21 @@ static void launch_expf_mfma_x(hipStream_t st, const double* A, uint32_t n_out, 
                                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   const uint32_t nfun = sp.nfun();
   const uint32_t gx = (nfun + 48 * NW - 1) / (48 * NW);
-  const size_t sm = sizeof(double) * KC * EM_NO + sizeof(float) * KC * (48 * NW + 16);
-  const uint32_t n_full = n_out / EM_NO, rem = n_out % EM_NO;
+  constexpr int MTW = EM_MTW(F32);
+  constexpr uint32_t NO = 16 * MTW;
+  const size_t sm = sizeof(double) * KC * NO + sizeof(float) * KC * (48 * NW + 16);
+  const uint32_t n_full = n_out / NO, rem = n_out % NO;
   if (n_full)
-    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 3>(st, dim3(gx, n_full, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, 0u);
-  // the outputs past the last full 48: workgroups that carry only the M-tiles holding outputs
-  if (rem > 32)
-    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 3>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * EM_NO);
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, MTW>(st, dim3(gx, n_full, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, 0u);
+  // the outputs past the last full tile: workgroups that carry only the M-tiles holding outputs
+  if (MTW > 3 && rem > 48)
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, MTW>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * NO);
+  else if (rem > 32)
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 3>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * NO);
   else if (rem > 16)
-    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 2>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * EM_NO);
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 2>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * NO);
   else if (rem > 0)
-    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 1>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * EM_NO);
+    launch_expf_mfma_one<HAS_XROW, NW, KC, F32, 1>(st, dim3(gx, 1, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, n_full * NO);
 }
 template <int NW, int KC, int F32>
 static void launch_expf_mfma_nw(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
@@ -465,8 +477,8 @@ static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_o
                                    const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                                    uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   constexpr int NW = 4, KC = 16;
-  dim3 grid(1, (n_out + EM_NO * NW - 1) / (EM_NO * NW), n_chunks);
-  const size_t sm = sizeof(double) * KC * EM_NO * NW + sizeof(float) * KC * (48 + 16);
+  dim3 grid(1, (n_out + EM_SPLIT_NO * NW - 1) / (EM_SPLIT_NO * NW), n_chunks);
+  const size_t sm = sizeof(double) * KC * EM_SPLIT_NO * NW + sizeof(float) * KC * (48 + 16);
   if (xrow)
     hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab, 0u, grid.x, grid.y);
@@ -474,6 +486,14 @@ static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_o
     hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab, 0u, grid.x, grid.y);
 }
+uint32_t expf_mfma_wide_tiles(uint32_t n_out, uint32_t nfun, int f32) {
+  const uint32_t tiles = (nfun + 47) / 48;
+  if (tiles <= 4) return 0;   // split and narrow forms: several workgroups per CU, no round structure to fit
+  const uint32_t gx = (nfun + 48 * 8 - 1) / (48 * 8);
+  const uint32_t NO = 16 * (uint32_t)EM_MTW(f32);
+  return gx * ((n_out + NO - 1) / NO);
+}
+
 void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                       const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
                       uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int f32) {
@@ -481,7 +501,7 @@ void launch_expf_mfma(hipStream_t st, const double* A, uint32_t n_out, const flo
   const uint32_t nfun = sp.nfun();
   const uint32_t tiles = (nfun + 47) / 48;  // 48-column wave tiles needed
 #define EXPF_ARGS st, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, n_chunks, slab
-  if (tiles <= 1 && n_out >= 4 * EM_NO) {
+  if (tiles <= 1 && n_out >= 4 * EM_SPLIT_NO) {
     if (f32) launch_expf_mfma_split<1>(EXPF_ARGS);
     else launch_expf_mfma_split<0>(EXPF_ARGS);
     return;

@@ -1464,20 +1464,29 @@ def test_crffstdecode_phone_penalty_fst_and_pruning(tmp_path):
     r, words_b, totals_b = run(["crf_phn_bin=" + pb], "phn_bin")
     assert words_b == words and totals_b == totals
     # 4. crf_dict_wt: Prune of (lattice o phone o dictionary) BEFORE the LM sees it -- with a hair's width only the best
-    # path of that machine is left and the LM can no longer trade it for another word sequence
-    r, words_p, totals_p = run(["crf_phn_txt=" + pf, "crf_dict_wt=0.0001"], "dict_pruned")
+    # path of that machine is left and the LM can no longer trade it for another word sequence.  Three LMs, each with a
+    # heavy charge on one of the words: the pre-LM best path of an utterance holds at least one word, so under the LM
+    # that charges it the unpruned search walks around it while the pruned one cannot
     changed = 0
-    for u in range(len(Ts)):
-        pre = sorted(((c + c1, c2, outs) for c, c1, c2, labs, outs in full[u]), key=lambda t: t[0])
-        if not pre:
-            continue
-        if len(pre) > 1 and pre[1][0] - pre[0][0] < 1e-3 and pre[1][2] != pre[0][2]:
-            continue    # two word sequences within the threshold: either may survive
-        want = pre[0][0] + pre[0][1]
-        assert abs(totals_p[u] - want) < 3e-5 * max(1.0, abs(want)), (u, totals_p[u], want)
-        assert words_p[u] == [names[o] for o in pre[0][2]]
-        changed += abs(totals_p[u] - totals[u]) > 1e-3
-    assert changed >= 1, "the LM never preferred another path: the pruning case shows nothing (change the seed)"
+    for wk, word in enumerate((WA, WB, WC)):
+        lm_k = [(a[0], a[1], a[2], a[3], a[4] + (40.0 if a[3] == word else 0.0)) for a in lm]
+        mf_k = str(tmp_path / ("lm_pen%d.txt" % wk))
+        wr(mf_k, lm_k, mfin)
+        r, words_u, totals_u = run(["crf_phn_txt=" + pf, "crf_lm_txt=" + mf_k], "pen%d_free" % wk)
+        r, words_p, totals_p = run(["crf_phn_txt=" + pf, "crf_lm_txt=" + mf_k, "crf_dict_wt=0.0001"], "pen%d_pruned" % wk)
+        for u in range(len(Ts)):
+            pre = sorted(set((round(c + c1, 6), tuple(outs)) for c, c1, c2, labs, outs in full[u]))
+            if not pre:
+                continue
+            if len(pre) > 1 and pre[1][0] - pre[0][0] < 1e-3 and pre[1][1] != pre[0][1]:
+                continue    # two word sequences within the threshold: either may survive
+            lmc = sorted(c for c, _ in machine_walks(lm_k, mfin, 0, list(pre[0][1]), 0))
+            want = pre[0][0] + lmc[0]
+            assert abs(totals_p[u] - want) < 3e-5 * max(1.0, abs(want)), (wk, u, totals_p[u], want)
+            assert words_p[u] == [names[o] for o in pre[0][1]]
+            assert totals_u[u] <= totals_p[u] + 1e-4
+            changed += totals_p[u] - totals_u[u] > 1e-3
+    assert changed >= 1, "no LM preferred another path than the pre-LM best: the pruning case shows nothing"
     # 5. pruning without a phone FST takes the same staged route: lattice o dictionary pruned, then the LM
     r, words_q, totals_q = run(["crf_dict_wt=1000"], "dict_wide")
     r, words_0, totals_0 = run([], "plain")

@@ -22,6 +22,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 
+#ifndef EM_ABL
+#define EM_ABL 0     // timing ablations of k_expf_mfma (wrong results): 1 = no MFMA loop, 2 = no staging after the first chunks
+#endif
 #ifndef MM_PRIO
 #define MM_PRIO 1    // s_setprio level of the staging phases (0 = no priority play; A/B knob)
 #endif
@@ -358,8 +361,10 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     __syncthreads();
     if (DB) {
       // the next chunk into the other image pair (its loads were requested a chunk ago), then the loads after that
+#if EM_ABL != 2
       if (r0 + EM_KC < r_end) store_chunk(r0 + EM_KC, cur ^ 1u);
       if (r0 + 2 * (uint64_t)EM_KC < r_end) load_chunk(r0 + 2 * (uint64_t)EM_KC);
+#endif
     } else if (r0 + EM_KC < r_end) {
       load_chunk(r0 + EM_KC);
     }
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
         for (int n = 0; n < 3; n++)
 #pragma unroll
           for (int r = 0; r < 4; r++) acc[m][n][r] += (double)c32[m][n][r];
-    } else {
+    } else if (EM_ABL != 1) {
 #pragma unroll
       for (int ks = 0; ks < EM_KC / 4; ks++) {
         double a[MT], b[3];
@@ -424,6 +429,163 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_expf_mfma_ws: the wide f64 form (8 x 48 feature columns, 64 outputs per workgroup) with the roles split between
+// wavefronts -- ablations of the single-role kernel at the TIMIT transition counts: 13.1 ms complete, 10.0 ms with the
+// staging of all but the first chunks removed, 4.0 ms with the MFMA loop removed: staging and matrix work ran back to
+// back.  Here wavefronts 0-7 only run the MFMA k-loop over the current LDS image pair while wavefronts 8-11 (one per
+// SIMD: a workgroup is 12 wavefronts, three per SIMD, 168 VGPRs each) fetch the chunk after the next from memory and
+// store the next one into the other image pair: 192 of their threads own one 16-byte column of the X tile and 16 of its
+// rows each (column masks are per-thread constants), 64 own two columns of the posterior tile.  One barrier per chunk.
+// MT: M-tiles that hold outputs (the remainder launch carries fewer).
+#define EW_KC 32
+#define EW_NO 64
+#define EW_NF 384
+#define EW_XS (EW_NF + 16)
+#define EW_IMG (sizeof(double) * EW_KC * EW_NO + sizeof(float) * EW_KC * EW_XS)
+template <int HAS_XROW, int MT>
+__global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__ A, uint32_t n_out,
+                                                     const float* __restrict__ X, uint32_t F,
+                                                     const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                     ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
+                                                     double* __restrict__ slab, uint32_t o_base, uint32_t gx, uint32_t gy) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t fs = sp.fs, nfe = sp.nfe, nfun = sp.nfun();
+  const float bias = sp.use_bias ? (float)sp.bias : 0.0f;
+  const bool bias_exact = (double)bias == sp.bias;
+  const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const uint32_t bx = swz % gx, by = (swz / gx) % gy, bz = swz / (gx * gy);
+  const uint32_t fb = bx * EW_NF;
+  const uint32_t o0 = o_base + by * EW_NO;
+  const uint64_t r_begin = (uint64_t)bz * rows_per_chunk;
+  const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
+  const uint32_t n_it = r_begin < r_end ? (uint32_t)((r_end - r_begin + EW_KC - 1) / EW_KC) : 0u;
+
+  if (wave >= 8) {
+    // ---------------- producers ----------------
+    __builtin_amdgcn_s_setprio(2);
+    const uint32_t pt = tid - 512;
+    if (pt < 192) {
+      const uint32_t q = pt % 96, rg = pt / 96;   // 16-byte column of the X tile, rows rg, rg + 2, ...
+      const uint32_t col = fb + q * 4;
+      const uint32_t xcl = col < nfe ? col : (nfe >= 4 ? nfe - 4 : 0);   // columns outside the range re-read a valid quad (masked below)
+      bool keep[4];
+      float fill[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        keep[c] = col + c < nfe;
+        fill[c] = (col + c == nfe && sp.use_bias) ? bias : 0.0f;
+      }
+      const float* xb = X + fs + xcl;
+      f4u v[16];
+      auto load = [&](uint64_t r0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          uint64_t row = r0 + rg + 2 * k;
+          row = row < r_end ? row : r_end - 1;
+          const uint64_t xr = HAS_XROW ? xrow[row] : row;
+          v[k] = *(const f4u*)(xb + xr * F);
+        }
+      };
+      auto store = [&](uint64_t r0, uint32_t buf) {
+        float* Xs = (float*)(em_smem + buf * EW_IMG + sizeof(double) * EW_KC * EW_NO);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const bool rok = r0 + rg + 2 * k < r_end;
+          const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          float o[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) o[c] = !rok ? 0.0f : (keep[c] ? e[c] : fill[c]);
+          *(float4*)(&Xs[(rg + 2 * k) * EW_XS + q * 4]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      };
+      if (n_it) { load(r_begin); store(r_begin, 0); }
+      if (n_it > 1) load(r_begin + EW_KC);
+      __syncthreads();
+      for (uint32_t i = 0; i < n_it; i++) {
+        if (i + 1 < n_it) store(r_begin + (uint64_t)(i + 1) * EW_KC, (i + 1) & 1u);
+        if (i + 2 < n_it) load(r_begin + (uint64_t)(i + 2) * EW_KC);
+        __syncthreads();
+      }
+    } else {
+      const uint32_t at = pt - 192;               // 0..63: output columns 2c, 2c + 1 of the posterior tile, rows rg, rg + 2, ...
+      const uint32_t c2 = at % 32, rg = at / 32;
+      const uint32_t oa = o0 + 2 * c2, ob = oa + 1;
+      const bool oka = oa < n_out, okb = ob < n_out;
+      const double* pa = A + (oka ? oa : n_out - 1);
+      const double* pb = A + (okb ? ob : n_out - 1);
+      double va[16], vb[16];
+      auto load = [&](uint64_t r0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          uint64_t row = r0 + rg + 2 * k;
+          row = row < r_end ? row : r_end - 1;
+          va[k] = pa[row * n_out];
+          vb[k] = pb[row * n_out];
+        }
+      };
+      auto store = [&](uint64_t r0, uint32_t buf) {
+        double* Rs = (double*)(em_smem + buf * EW_IMG);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const bool rok = r0 + rg + 2 * k < r_end;
+          *(double2*)(&Rs[(rg + 2 * k) * EW_NO + 2 * c2]) = make_double2(rok && oka ? va[k] : 0.0, rok && okb ? vb[k] : 0.0);
+        }
+      };
+      if (n_it) { load(r_begin); store(r_begin, 0); }
+      if (n_it > 1) load(r_begin + EW_KC);
+      __syncthreads();
+      for (uint32_t i = 0; i < n_it; i++) {
+        if (i + 1 < n_it) store(r_begin + (uint64_t)(i + 1) * EW_KC, (i + 1) & 1u);
+        if (i + 2 < n_it) load(r_begin + (uint64_t)(i + 2) * EW_KC);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  // ---------------- consumers ----------------
+  const uint32_t wf = wave * 48;
+  v4f64 acc[MT][3];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  __syncthreads();
+  for (uint32_t i = 0; i < n_it; i++) {
+    const double* Rs = (const double*)(em_smem + (i & 1u) * EW_IMG);
+    const float* Xs = (const float*)(em_smem + (i & 1u) * EW_IMG + sizeof(double) * EW_KC * EW_NO);
+#pragma unroll
+    for (int ks = 0; ks < EW_KC / 4; ks++) {
+      double a[MT], b[3];
+#pragma unroll
+      for (int m = 0; m < MT; m++) a[m] = Rs[(ks * 4 + lk) * EW_NO + m * 16 + li];
+#pragma unroll
+      for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * EW_XS + wf + n * 16 + li];
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const double bfix = (bias_exact || !sp.use_bias) ? 1.0 : sp.bias / (double)bias;
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    const uint32_t col = fb + wf + n * 16 + li;
+    if (col >= nfun) continue;
+    const double sc = (col == nfe) ? bfix : 1.0;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t o = o0 + m * 16 + lk + 4 * r;
+        if (o < n_out) slab[((uint64_t)bz * n_out + o) * nfun + col] = acc[m][n][r] * sc;
+      }
+  }
+}
+
 template <int HAS_XROW, int NW, int KC, int F32, int MT>
 static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                  const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
@@ -431,6 +593,14 @@ static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const dou
   constexpr int DB = NW == 8 ? 1 : 0;   // the 8-wave workgroup has its CU to itself: room for a second image pair
   static const bool db_off = getenv("SCRF_EXPF_DB") && atoi(getenv("SCRF_EXPF_DB")) == 0;   // A/B knob
   constexpr int MTW = EM_MTW(F32);
+  static const bool ws_off = getenv("SCRF_EXPF_MFMA_WS") && atoi(getenv("SCRF_EXPF_MFMA_WS")) == 0;   // A/B knob
+  if (NW == 8 && !F32 && KC == EW_KC && MTW * 16 == EW_NO && !ws_off) {
+    constexpr int MTC = MT > 4 ? 4 : MT;
+    hipFuncSetAttribute((const void*)k_expf_mfma_ws<HAS_XROW, MTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * EW_IMG));
+    hipLaunchKernelGGL((k_expf_mfma_ws<HAS_XROW, MTC>), dim3(grid.x * grid.y * grid.z), dim3(768), 2 * EW_IMG, st, A, n_out, X, F, xrow, n_rows, lay, sp,
+                       rows_per_chunk, slab, o_base, grid.x, grid.y);
+    return;
+  }
   if (DB && !db_off) {
     hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB, MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * sm));
     hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB, MTW>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), 2 * sm, st, A, n_out, X, F, xrow,

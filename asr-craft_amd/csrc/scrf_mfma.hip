@@ -194,20 +194,166 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_scores_mfma_ws: the f64 score contraction with the roles split between wavefronts, like k_expf_mfma_ws below.  A
+// workgroup tile is 256 rows x 96 outputs: consumer wavefront w (0-7) owns rows 64 (w & 3) and outputs 48 (w >> 2)
+// (12 MFMAs per k-step from 4 + 3 operand reads), wavefronts 8-11 stage the X chunk (8 quads per thread) and the
+// lambda chunk (12 weights per thread) of the NEXT 32 features into the other LDS image pair and request the chunk after
+// it; one barrier per chunk.  The X rows are read from L2 once per 96 outputs instead of once per 48.
+// lambda image [k][SW_WS] doubles, SW_WS = 113 (== 17 mod 32): the consumers' fragment reads (k = lane >> 4 rows, 16
+// consecutive outputs) and the producers' transposed stores (32 lanes = 32 values of k for one output) both spread over
+// all banks.
+#define SW_ROWS 256
+#define SW_NO 96
+#define SW_WS 113
+#define SW_IMG (sizeof(float) * SW_ROWS * SM_XS + sizeof(double) * SM_KC * SW_WS)
+__global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict__ X, uint32_t F,
+                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
+                                                       const double* __restrict__ lambda, ScrfLayout lay,
+                                                       ScrfGemmSpec sp, uint32_t n_out, uint32_t gy, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const uint64_t row0 = (uint64_t)(swz / gy) * SW_ROWS;
+  const uint32_t o0 = (swz % gy) * SW_NO;
+  const uint32_t fs = sp.fs, nfe = sp.nfe;
+  const uint32_t n_it = (nfe + SM_KC - 1) / SM_KC;
+
+  if (wave >= 8) {
+    // ---------------- producers ----------------
+    __builtin_amdgcn_s_setprio(2);
+    const uint32_t pt = tid - 512;
+    const uint32_t sq = pt & 7, sr = pt >> 3;   // 8 threads cover one row's 32-float chunk, 32 rows per pass, 8 passes
+    const float* xbase[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const uint64_t r = row0 + sr + it * 32;
+      const uint64_t rr = r < n_rows ? r : (n_rows - 1);
+      const uint64_t xr = xrow ? xrow[rr] : rr;
+      xbase[it] = X + xr * F + fs + sq * 4;
+    }
+    // lambda chunk: W[o][c] for idx = pt + k * 256 -> c = idx % 32 (the same for every k), o = idx / 32
+    const uint32_t wc = pt % SM_KC;
+    const double* wbase[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      uint32_t o = o0 + (pt + k * 256) / SM_KC;
+      if (o >= n_out) o = n_out - 1;
+      wbase[k] = lambda + sp.woff(lay, o) + wc;
+    }
+    f4u xr_[8];
+    double wr_[12];
+    const uint32_t fclamp = (nfe > sq * 4 + 4) ? ((nfe - sq * 4 - 1) & ~31u) : 0;
+    auto load = [&](uint32_t f0) {
+      // as in k_scores_mfma: a quad that starts inside the feature range may read <= 12 B past it, quads outside re-read
+      // a valid quad; both are masked at the store (buffers carry tail padding)
+      const uint32_t fo = (f0 + sq * 4 < nfe) ? f0 : fclamp;
+#pragma unroll
+      for (int it = 0; it < 8; it++) xr_[it] = *(const f4u*)(xbase[it] + fo);
+      const bool wok = f0 + wc < nfe;
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const double w = wbase[k][wok ? f0 : 0];
+        wr_[k] = wok ? w : 0.0;
+      }
+    };
+    auto store = [&](uint32_t f0, uint32_t buf) {
+      float* Xs = (float*)(sw_smem + buf * SW_IMG);
+      double* Ws = (double*)(sw_smem + buf * SW_IMG + sizeof(float) * SW_ROWS * SM_XS);
+      const uint32_t c0 = f0 + sq * 4;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        f4u v = xr_[it];
+        if (c0 + 0 >= nfe) v.x = 0.0f;
+        if (c0 + 1 >= nfe) v.y = 0.0f;
+        if (c0 + 2 >= nfe) v.z = 0.0f;
+        if (c0 + 3 >= nfe) v.w = 0.0f;
+        float* d = &Xs[(sr + it * 32) * SM_XS + sq * 4];
+        *(float2*)(d) = make_float2(v.x, v.y);
+        *(float2*)(d + 2) = make_float2(v.z, v.w);
+      }
+#pragma unroll
+      for (int k = 0; k < 12; k++) Ws[wc * SW_WS + (pt + k * 256) / SM_KC] = wr_[k];
+    };
+    if (n_it) { load(0); store(0, 0); }
+    if (n_it > 1) load(SM_KC);
+    __syncthreads();
+    for (uint32_t i = 0; i < n_it; i++) {
+      if (i + 1 < n_it) store((i + 1) * SM_KC, (i + 1) & 1u);
+      if (i + 2 < n_it) load((i + 2) * SM_KC);
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------- consumers ----------------
+  const uint32_t rg = wave & 3, og = wave >> 2;
+  v4f64 acc[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  __syncthreads();
+  for (uint32_t i = 0; i < n_it; i++) {
+    const float* Xs = (const float*)(sw_smem + (i & 1u) * SW_IMG);
+    const double* Ws = (const double*)(sw_smem + (i & 1u) * SW_IMG + sizeof(float) * SW_ROWS * SM_XS);
+#pragma unroll
+    for (int ks = 0; ks < SM_KC / 4; ks++) {
+      double b[3];
+#pragma unroll
+      for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SW_WS + og * 48 + n * 16 + li];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const double a = (double)Xs[(rg * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
+#pragma unroll
+        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int use_b = sp.use_bias;
+  const double bv = sp.bias;
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    const uint32_t o = o0 + og * 48 + n * 16 + li;
+    if (o >= n_out) continue;
+    double bias = 0.0;
+    if (use_b) bias = lambda[sp.woff(lay, o) + nfe] * bv;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint64_t row = row0 + rg * 64 + m * 16 + lk + 4 * r;
+        if (row >= n_rows) continue;
+        out[row * n_out + o] = acc[m][n][r] + bias;
+      }
+  }
+}
+
 template <int F32>
 static void launch_scores_mfma_f(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                                  const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out, double* out) {
   const uint32_t gx = (uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS);
-  const uint32_t n_full = n_out / SM_NO, rem = n_out % SM_NO;
+  uint32_t o_base = 0;
+  static const bool ws_off = getenv("SCRF_SCORES_MFMA_WS") && atoi(getenv("SCRF_SCORES_MFMA_WS")) == 0;   // A/B knob
+  if (!F32 && !ws_off && n_out >= SW_NO && sp.nfe > 0) {
+    // whole 96-output tiles through the wave-specialised form (its output tiles start at 0)
+    const uint32_t n96 = n_out / SW_NO;
+    hipFuncSetAttribute((const void*)k_scores_mfma_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * SW_IMG));
+    hipLaunchKernelGGL(k_scores_mfma_ws, dim3(gx * n96), dim3(768), 2 * SW_IMG, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n96, out);
+    o_base = n96 * SW_NO;
+  }
+  const uint32_t left = n_out - o_base;
+  const uint32_t n_full = left / SM_NO, rem = left % SM_NO;
   if (n_full)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx * n_full), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, 0u, n_full, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx * n_full), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, o_base, n_full, out);
   // the outputs past the last full 48: a launch whose workgroups carry only the N-tiles that hold outputs
   if (rem > 32)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, 1u, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 3>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, o_base + n_full * SM_NO, 1u, out);
   else if (rem > 16)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 2>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, 1u, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 2>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, o_base + n_full * SM_NO, 1u, out);
   else if (rem > 0)
-    hipLaunchKernelGGL((k_scores_mfma<F32, 1>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n_full * SM_NO, 1u, out);
+    hipLaunchKernelGGL((k_scores_mfma<F32, 1>), dim3(gx), dim3(256), 0, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, o_base + n_full * SM_NO, 1u, out);
 }
 void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64_t* xrow, uint64_t n_rows,
                         const double* lambda, const ScrfLayout& lay, const ScrfGemmSpec& sp, uint32_t n_out,
@@ -226,6 +372,9 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 #endif
 #define EM_MTW(F32) ((F32) ? 3 : EM_MTF)
 #define EM_SPLIT_NO 48        // outputs per wavefront of the split form (3 M-tiles)
+// row stride (doubles) of the posterior image [k][outputs]: == 16 (mod 32), so that the two k rows a 32-lane half of a
+// ds_read_b64 fragment read covers fall on disjoint bank halves (a stride of 64 or 192 doubles puts them on the same banks)
+constexpr int em_rss(int no) { return no % 32 == 16 ? no : no + 16; }
 
 // NW wavefronts per workgroup, each owning 48 feature columns (3 N-tiles): NW = 8 covers 384
 // columns (the full 338-wide state block of config 2 in one workgroup, so R is read once);
@@ -253,9 +402,10 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   constexpr int XIT = (EM_KC * QR + NT - 1) / NT;   // X quads per thread per chunk (= 6; the split form has threads without one)
   constexpr int AIT = (EM_KC * NO + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
-  constexpr size_t IMG = sizeof(double) * EM_KC * NO + sizeof(float) * EM_KC * XS;   // bytes of one image pair
-  double* Rs = (double*)em_smem;                                  // [EM_KC][NO]   (+ IMG bytes: the second pair when DB)
-  float* Xs = (float*)(em_smem + sizeof(double) * EM_KC * NO);  // [EM_KC][XS]
+  constexpr int RSS = em_rss(NO);        // double row stride of the posterior image
+  constexpr size_t IMG = sizeof(double) * EM_KC * RSS + sizeof(float) * EM_KC * XS;   // bytes of one image pair
+  double* Rs = (double*)em_smem;                                  // [EM_KC][RSS]   (+ IMG bytes: the second pair when DB)
+  float* Xs = (float*)(em_smem + sizeof(double) * EM_KC * RSS);  // [EM_KC][XS]
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t fs = sp.fs;
@@ -333,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   };
   auto store_chunk = [&](uint64_t r0, uint32_t buf) {
     double* Rs = (double*)(em_smem + buf * IMG);
-    float* Xs = (float*)(em_smem + buf * IMG + sizeof(double) * EM_KC * NO);
+    float* Xs = (float*)(em_smem + buf * IMG + sizeof(double) * EM_KC * RSS);
 #pragma unroll
     for (int k = 0; k < XIT; k++) {
       const bool rok = r0 + xrw[k] < r_end;
@@ -346,7 +496,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     }
 #pragma unroll
     for (int k = 0; k < AIT; k++)
-      if (tid + k * NT < EM_KC * NO) Rs[tid + k * NT] = ar_[k];
+      if (tid + k * NT < EM_KC * NO) Rs[arw[k] * RSS + (tid + k * NT) % NO] = ar_[k];
   };
 
   __builtin_amdgcn_s_setprio(MM_PRIO);
@@ -369,7 +519,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       load_chunk(r0 + EM_KC);
     }
     const double* Rs = (const double*)(em_smem + cur * IMG);
-    const float* Xs = (const float*)(em_smem + cur * IMG + sizeof(double) * EM_KC * NO);
+    const float* Xs = (const float*)(em_smem + cur * IMG + sizeof(double) * EM_KC * RSS);
     __builtin_amdgcn_s_setprio(0);
     if (F32) {
       v4f32 c32[MT][3];
@@ -381,7 +531,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       for (int ks = 0; ks < EM_KC / 4; ks++) {
         float a[MT], b[3];
 #pragma unroll
-        for (int m = 0; m < MT; m++) a[m] = (float)Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
+        for (int m = 0; m < MT; m++) a[m] = (float)Rs[(ks * 4 + lk) * RSS + wo + m * 16 + li];
 #pragma unroll
         for (int n = 0; n < 3; n++) b[n] = Xs[(ks * 4 + lk) * XS + wf + n * 16 + li];
 #pragma unroll
@@ -400,7 +550,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
       for (int ks = 0; ks < EM_KC / 4; ks++) {
         double a[MT], b[3];
 #pragma unroll
-        for (int m = 0; m < MT; m++) a[m] = Rs[(ks * 4 + lk) * NO + wo + m * 16 + li];
+        for (int m = 0; m < MT; m++) a[m] = Rs[(ks * 4 + lk) * RSS + wo + m * 16 + li];
 #pragma unroll
         for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * XS + wf + n * 16 + li];
 #pragma unroll
@@ -442,7 +592,8 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
 #define EW_NO 64
 #define EW_NF 384
 #define EW_XS (EW_NF + 16)
-#define EW_IMG (sizeof(double) * EW_KC * EW_NO + sizeof(float) * EW_KC * EW_XS)
+#define EW_RS 80   // em_rss(EW_NO)
+#define EW_IMG (sizeof(double) * EW_KC * EW_RS + sizeof(float) * EW_KC * EW_XS)
 template <int HAS_XROW, int MT>
 __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__ A, uint32_t n_out,
                                                      const float* __restrict__ X, uint32_t F,
@@ -490,7 +641,7 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
         }
       };
       auto store = [&](uint64_t r0, uint32_t buf) {
-        float* Xs = (float*)(em_smem + buf * EW_IMG + sizeof(double) * EW_KC * EW_NO);
+        float* Xs = (float*)(em_smem + buf * EW_IMG + sizeof(double) * EW_KC * EW_RS);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           const bool rok = r0 + rg + 2 * k < r_end;
@@ -531,7 +682,7 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           const bool rok = r0 + rg + 2 * k < r_end;
-          *(double2*)(&Rs[(rg + 2 * k) * EW_NO + 2 * c2]) = make_double2(rok && oka ? va[k] : 0.0, rok && okb ? vb[k] : 0.0);
+          *(double2*)(&Rs[(rg + 2 * k) * EW_RS + 2 * c2]) = make_double2(rok && oka ? va[k] : 0.0, rok && okb ? vb[k] : 0.0);
         }
       };
       if (n_it) { load(r_begin); store(r_begin, 0); }
@@ -555,12 +706,12 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
   __syncthreads();
   for (uint32_t i = 0; i < n_it; i++) {
     const double* Rs = (const double*)(em_smem + (i & 1u) * EW_IMG);
-    const float* Xs = (const float*)(em_smem + (i & 1u) * EW_IMG + sizeof(double) * EW_KC * EW_NO);
+    const float* Xs = (const float*)(em_smem + (i & 1u) * EW_IMG + sizeof(double) * EW_KC * EW_RS);
 #pragma unroll
     for (int ks = 0; ks < EW_KC / 4; ks++) {
       double a[MT], b[3];
 #pragma unroll
-      for (int m = 0; m < MT; m++) a[m] = Rs[(ks * 4 + lk) * EW_NO + m * 16 + li];
+      for (int m = 0; m < MT; m++) a[m] = Rs[(ks * 4 + lk) * EW_RS + m * 16 + li];
 #pragma unroll
       for (int n = 0; n < 3; n++) b[n] = (double)Xs[(ks * 4 + lk) * EW_XS + wf + n * 16 + li];
 #pragma unroll
@@ -619,7 +770,7 @@ static void launch_expf_mfma_x(hipStream_t st, const double* A, uint32_t n_out, 
   const uint32_t gx = (nfun + 48 * NW - 1) / (48 * NW);
   constexpr int MTW = EM_MTW(F32);
   constexpr uint32_t NO = 16 * MTW;
-  const size_t sm = sizeof(double) * KC * NO + sizeof(float) * KC * (48 * NW + 16);
+  const size_t sm = sizeof(double) * KC * em_rss((int)NO) + sizeof(float) * KC * (48 * NW + 16);
   const uint32_t n_full = n_out / NO, rem = n_out % NO;
   if (n_full)
     launch_expf_mfma_one<HAS_XROW, NW, KC, F32, MTW>(st, dim3(gx, n_full, n_chunks), sm, A, n_out, X, F, xrow, n_rows, lay, sp, rows_per_chunk, slab, 0u);
@@ -648,7 +799,7 @@ static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_o
                                    uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   constexpr int NW = 4, KC = 16;
   dim3 grid(1, (n_out + EM_SPLIT_NO * NW - 1) / (EM_SPLIT_NO * NW), n_chunks);
-  const size_t sm = sizeof(double) * KC * EM_SPLIT_NO * NW + sizeof(float) * KC * (48 + 16);
+  const size_t sm = sizeof(double) * KC * em_rss(EM_SPLIT_NO * NW) + sizeof(float) * KC * (48 + 16);
   if (xrow)
     hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
                        rows_per_chunk, slab, 0u, grid.x, grid.y);

@@ -203,20 +203,30 @@ __global__ __launch_bounds__(256, 2) void k_scores_mfma(const float* __restrict_
 // lambda image [k][SW_WS] doubles, SW_WS = 113 (== 17 mod 32): the consumers' fragment reads (k = lane >> 4 rows, 16
 // consecutive outputs) and the producers' transposed stores (32 lanes = 32 values of k for one output) both spread over
 // all banks.
+// Two shapes of the 8 consumer wavefronts: <4, 3> -- rows 64 (w & 3), outputs 48 (w >> 2): 96 outputs per workgroup; <2, 7> --
+// rows 32 w, all 7 N-tiles: 112 outputs per workgroup (14 MFMAs per 2 + 7 reads).  An output count of 16 T is cut into
+// a tiles of 6 and b tiles of 7 N-tiles (T = 6a + 7b: 200 outputs = 96 + 112 with 8 masked), so that no thin remainder
+// launch re-reads all of X for a handful of outputs (config 5: 9 ms for 8 of 200).
 #define SW_ROWS 256
 #define SW_NO 96
 #define SW_WS 113
 #define SW_IMG (sizeof(float) * SW_ROWS * SM_XS + sizeof(double) * SM_KC * SW_WS)
+template <int MW, int NTW>
 __global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict__ X, uint32_t F,
                                                        const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                        const double* __restrict__ lambda, ScrfLayout lay,
-                                                       ScrfGemmSpec sp, uint32_t n_out, uint32_t gy, double* __restrict__ out) {
+                                                       ScrfGemmSpec sp, uint32_t n_out, uint32_t o_base, uint32_t gy, double* __restrict__ out) {
+  constexpr int RG = 256 / (16 * MW);            // row groups: 4 (64 rows each) or 8 (32 rows each)
+  constexpr int OG = 8 / RG;                     // output groups
+  constexpr int NOW = 16 * NTW * OG;             // outputs per workgroup
+  constexpr int WPT = NOW * SM_KC / 256;         // lambda weights per producer thread and chunk
+  static_assert(NOW <= SW_WS - 1 && NOW * SM_KC % 256 == 0, "tile does not fit the lambda image");
   extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
   const uint64_t row0 = (uint64_t)(swz / gy) * SW_ROWS;
-  const uint32_t o0 = (swz % gy) * SW_NO;
+  const uint32_t o0 = o_base + (swz % gy) * NOW;
   const uint32_t fs = sp.fs, nfe = sp.nfe;
   const uint32_t n_it = (nfe + SM_KC - 1) / SM_KC;
 
@@ -235,15 +245,15 @@ __global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict_
     }
     // lambda chunk: W[o][c] for idx = pt + k * 256 -> c = idx % 32 (the same for every k), o = idx / 32
     const uint32_t wc = pt % SM_KC;
-    const double* wbase[12];
+    const double* wbase[WPT];
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
+    for (int k = 0; k < WPT; k++) {
       uint32_t o = o0 + (pt + k * 256) / SM_KC;
       if (o >= n_out) o = n_out - 1;
       wbase[k] = lambda + sp.woff(lay, o) + wc;
     }
     f4u xr_[8];
-    double wr_[12];
+    double wr_[WPT];
     const uint32_t fclamp = (nfe > sq * 4 + 4) ? ((nfe - sq * 4 - 1) & ~31u) : 0;
     auto load = [&](uint32_t f0) {
       // as in k_scores_mfma: a quad that starts inside the feature range may read <= 12 B past it, quads outside re-read
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict_
       for (int it = 0; it < 8; it++) xr_[it] = *(const f4u*)(xbase[it] + fo);
       const bool wok = f0 + wc < nfe;
 #pragma unroll
-      for (int k = 0; k < 12; k++) {
+      for (int k = 0; k < WPT; k++) {
         const double w = wbase[k][wok ? f0 : 0];
         wr_[k] = wok ? w : 0.0;
       }
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict_
         *(float2*)(d + 2) = make_float2(v.z, v.w);
       }
 #pragma unroll
-      for (int k = 0; k < 12; k++) Ws[wc * SW_WS + (pt + k * 256) / SM_KC] = wr_[k];
+      for (int k = 0; k < WPT; k++) Ws[wc * SW_WS + (pt + k * 256) / SM_KC] = wr_[k];
     };
     if (n_it) { load(0); store(0, 0); }
     if (n_it > 1) load(SM_KC);
@@ -287,26 +297,26 @@ __global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict_
     return;
   }
   // ---------------- consumers ----------------
-  const uint32_t rg = wave & 3, og = wave >> 2;
-  v4f64 acc[4][3];
+  const uint32_t rg = wave % RG, og = wave / RG;
+  v4f64 acc[MW][NTW];
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+  for (int m = 0; m < MW; m++)
 #pragma unroll
-    for (int n = 0; n < 3; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < NTW; n++) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
   __syncthreads();
   for (uint32_t i = 0; i < n_it; i++) {
     const float* Xs = (const float*)(sw_smem + (i & 1u) * SW_IMG);
     const double* Ws = (const double*)(sw_smem + (i & 1u) * SW_IMG + sizeof(float) * SW_ROWS * SM_XS);
 #pragma unroll
     for (int ks = 0; ks < SM_KC / 4; ks++) {
-      double b[3];
+      double b[NTW];
 #pragma unroll
-      for (int n = 0; n < 3; n++) b[n] = Ws[(ks * 4 + lk) * SW_WS + og * 48 + n * 16 + li];
+      for (int n = 0; n < NTW; n++) b[n] = Ws[(ks * 4 + lk) * SW_WS + og * (16 * NTW) + n * 16 + li];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const double a = (double)Xs[(rg * 64 + m * 16 + li) * SM_XS + ks * 4 + lk];
+      for (int m = 0; m < MW; m++) {
+        const double a = (double)Xs[(rg * (16 * MW) + m * 16 + li) * SM_XS + ks * 4 + lk];
 #pragma unroll
-        for (int n = 0; n < 3; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[n], acc[m][n], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -314,16 +324,16 @@ __global__ __launch_bounds__(768) void k_scores_mfma_ws(const float* __restrict_
   const int use_b = sp.use_bias;
   const double bv = sp.bias;
 #pragma unroll
-  for (int n = 0; n < 3; n++) {
-    const uint32_t o = o0 + og * 48 + n * 16 + li;
+  for (int n = 0; n < NTW; n++) {
+    const uint32_t o = o0 + og * (16 * NTW) + n * 16 + li;
     if (o >= n_out) continue;
     double bias = 0.0;
     if (use_b) bias = lambda[sp.woff(lay, o) + nfe] * bv;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+    for (int m = 0; m < MW; m++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const uint64_t row = row0 + rg * 64 + m * 16 + lk + 4 * r;
+        const uint64_t row = row0 + rg * (16 * MW) + m * 16 + lk + 4 * r;
         if (row >= n_rows) continue;
         out[row * n_out + o] = acc[m][n][r] + bias;
       }
@@ -337,11 +347,22 @@ static void launch_scores_mfma_f(hipStream_t st, const float* X, uint32_t F, con
   uint32_t o_base = 0;
   static const bool ws_off = getenv("SCRF_SCORES_MFMA_WS") && atoi(getenv("SCRF_SCORES_MFMA_WS")) == 0;   // A/B knob
   if (!F32 && !ws_off && n_out >= SW_NO && sp.nfe > 0) {
-    // whole 96-output tiles through the wave-specialised form (its output tiles start at 0)
-    const uint32_t n96 = n_out / SW_NO;
-    hipFuncSetAttribute((const void*)k_scores_mfma_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * SW_IMG));
-    hipLaunchKernelGGL(k_scores_mfma_ws, dim3(gx * n96), dim3(768), 2 * SW_IMG, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, n96, out);
-    o_base = n96 * SW_NO;
+    // the wave-specialised form: 16 T outputs as a tiles of 96 and b tiles of 112 (T = 6a + 7b, fewest masked outputs); when
+    // the count does not split that way, the whole 96-output tiles go here and the rest to the single-role kernels below
+    const uint32_t T = (n_out + 15) / 16;
+    uint32_t a = n_out / SW_NO, bt = 0;
+    for (uint32_t b7 = 0; b7 < 6 && 7 * b7 <= T; b7++)
+      if ((T - 7 * b7) % 6 == 0) { a = (T - 7 * b7) / 6; bt = b7; break; }
+    if (a) {
+      hipFuncSetAttribute((const void*)k_scores_mfma_ws<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * SW_IMG));
+      hipLaunchKernelGGL((k_scores_mfma_ws<4, 3>), dim3(gx * a), dim3(768), 2 * SW_IMG, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, 0u, a, out);
+    }
+    if (bt) {
+      hipFuncSetAttribute((const void*)k_scores_mfma_ws<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * SW_IMG));
+      hipLaunchKernelGGL((k_scores_mfma_ws<2, 7>), dim3(gx * bt), dim3(768), 2 * SW_IMG, st, X, F, xrow, n_rows, lambda, lay, sp, n_out, a * SW_NO, bt, out);
+    }
+    o_base = a * SW_NO + bt * 112;
+    if (o_base >= n_out) return;
   }
   const uint32_t left = n_out - o_base;
   const uint32_t n_full = left / SM_NO, rem = left % SM_NO;
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
                                                       const float* __restrict__ X, uint32_t F,
                                                       const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                       ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
-                                                      double* __restrict__ slab, uint32_t o_base, uint32_t gx, uint32_t gy) {
+                                                      double* __restrict__ slab, uint32_t o_base, uint32_t gx, uint32_t gy, uint32_t o_step) {
   constexpr int NT = 64 * NW;            // threads
   // SPLIT_OUT: the wavefronts share one 48-column feature tile and own 48 outputs each (few feature functions, many
   // outputs: the per-window transition posteriors, n_out = L * L); otherwise 48 outputs and 48 feature columns per wavefront
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
   const uint32_t bx = swz % gx, by = (swz / gx) % gy, bz = swz / (gx * gy);
   const uint32_t fb = bx * NF;
-  const uint32_t o0 = o_base + by * NO;
+  const uint32_t o0 = o_base + by * o_step;   // o_step: outputs between this launch's tiles (16 MT; the image stays NO wide)
   const uint32_t wo = SPLIT_OUT ? wave * 48 : 0, wf = SPLIT_OUT ? 0 : wave * 48;   // this wavefront's output / feature offset in the tile
   const uint64_t r_begin = (uint64_t)bz * rows_per_chunk;
   const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
@@ -599,7 +620,7 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
                                                      const float* __restrict__ X, uint32_t F,
                                                      const uint64_t* __restrict__ xrow, uint64_t n_rows,
                                                      ScrfLayout lay, ScrfGemmSpec sp, uint64_t rows_per_chunk,
-                                                     double* __restrict__ slab, uint32_t o_base, uint32_t gx, uint32_t gy) {
+                                                     double* __restrict__ slab, uint32_t o_base, uint32_t gx, uint32_t gy, uint32_t o_step) {
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t li = lane & 15, lk = lane >> 4;
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
   const uint32_t swz = xcd_swizzle(blockIdx.x, gridDim.x);
   const uint32_t bx = swz % gx, by = (swz / gx) % gy, bz = swz / (gx * gy);
   const uint32_t fb = bx * EW_NF;
-  const uint32_t o0 = o_base + by * EW_NO;
+  const uint32_t o0 = o_base + by * o_step;
   const uint64_t r_begin = (uint64_t)bz * rows_per_chunk;
   const uint64_t r_end = min(n_rows, r_begin + rows_per_chunk);
   const uint32_t n_it = r_begin < r_end ? (uint32_t)((r_end - r_begin + EW_KC - 1) / EW_KC) : 0u;
@@ -740,7 +761,7 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
 template <int HAS_XROW, int NW, int KC, int F32, int MT>
 static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                  const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
-                                 uint64_t rows_per_chunk, double* slab, uint32_t o_base) {
+                                 uint64_t rows_per_chunk, double* slab, uint32_t o_base, uint32_t o_step = 16 * EM_MTW(F32)) {
   constexpr int DB = NW == 8 ? 1 : 0;   // the 8-wave workgroup has its CU to itself: room for a second image pair
   static const bool db_off = getenv("SCRF_EXPF_DB") && atoi(getenv("SCRF_EXPF_DB")) == 0;   // A/B knob
   constexpr int MTW = EM_MTW(F32);
@@ -749,19 +770,21 @@ static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const dou
     constexpr int MTC = MT > 4 ? 4 : MT;
     hipFuncSetAttribute((const void*)k_expf_mfma_ws<HAS_XROW, MTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * EW_IMG));
     hipLaunchKernelGGL((k_expf_mfma_ws<HAS_XROW, MTC>), dim3(grid.x * grid.y * grid.z), dim3(768), 2 * EW_IMG, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab, o_base, grid.x, grid.y);
+                       rows_per_chunk, slab, o_base, grid.x, grid.y, o_step);
     return;
   }
   if (DB && !db_off) {
     hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB, MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * sm));
     hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, DB, MTW>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), 2 * sm, st, A, n_out, X, F, xrow,
-                       n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);
+                       n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y, o_step);
     return;
   }
   hipFuncSetAttribute((const void*)k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, 0, MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL((k_expf_mfma<HAS_XROW, NW, KC, F32, 0, MT, 0, MTW>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow,
-                     n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y);
+                     n_rows, lay, sp, rows_per_chunk, slab, o_base, grid.x, grid.y, o_step);
 }
+// (a mixed tiling of the outputs -- 200 = 64 + 3 x 48 instead of 3 x 64 + a thin 8-output launch -- was measured at config 5:
+// 81.8 against 80.0 ms; the thin launch costs less than the thirteenth M-tile)
 template <int HAS_XROW, int NW, int KC, int F32>
 static void launch_expf_mfma_x(hipStream_t st, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
@@ -802,10 +825,10 @@ static void launch_expf_mfma_split(hipStream_t st, const double* A, uint32_t n_o
   const size_t sm = sizeof(double) * KC * em_rss(EM_SPLIT_NO * NW) + sizeof(float) * KC * (48 + 16);
   if (xrow)
     hipLaunchKernelGGL((k_expf_mfma<1, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab, 0u, grid.x, grid.y);
+                       rows_per_chunk, slab, 0u, grid.x, grid.y, (uint32_t)(EM_SPLIT_NO * NW));
   else
     hipLaunchKernelGGL((k_expf_mfma<0, NW, KC, F32, 1>), dim3(grid.x * grid.y * grid.z), dim3(64 * NW), sm, st, A, n_out, X, F, xrow, n_rows, lay, sp,
-                       rows_per_chunk, slab, 0u, grid.x, grid.y);
+                       rows_per_chunk, slab, 0u, grid.x, grid.y, (uint32_t)(EM_SPLIT_NO * NW));
 }
 uint32_t expf_mfma_wide_tiles(uint32_t n_out, uint32_t nfun, int f32) {
   const uint32_t tiles = (nfun + 47) / 48;

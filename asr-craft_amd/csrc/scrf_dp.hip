@@ -38,9 +38,62 @@ __global__ void k_exp_m(const double* __restrict__ M, uint32_t L, double* __rest
   if (threadIdx.x == 0) mshift[blockIdx.x] = mx;
 }
 
+// the same for L <= 64 (one matrix per frame with per-frame transition features: the TIMIT demo has 77 824 of them per
+// 256-utterance step): the matrix is read ONCE into registers (the maximum needs every element before the first exp), the
+// transpose goes through an LDS tile with an odd row stride so that both E and ET leave in coalesced rows (the scattered
+// 8-byte stores of the general kernel: 1.76 ms at that size), the maximum by DPP shuffles + one LDS exchange between the wavefronts.
+// Same values as k_exp_m: fmax is exact in any order, every element is exp(M - max) by the same routine.
+template <int NE>   // elements per thread: ceil(L * L / 256)
+__global__ __launch_bounds__(256) void k_exp_m_tile(const double* __restrict__ M, uint32_t L, double* __restrict__ E,
+                                                    double* __restrict__ ET, double* __restrict__ mshift) {
+  __shared__ double tile[64 * 65];
+  __shared__ double wmax[4];
+  const uint32_t LL = L * L, tid = threadIdx.x, ts = L + 1 - (L & 1);   // odd stride >= L
+  const double* Mb = M + (size_t)blockIdx.x * LL;
+  double v[NE];
+  double mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    const uint32_t i = tid + k * 256;
+    v[k] = i < LL ? __builtin_nontemporal_load(Mb + i) : -INFINITY;
+    mx = fmax(mx, v[k]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+  if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+  double* Eb = E + (size_t)blockIdx.x * LL;
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    const uint32_t i = tid + k * 256;
+    if (i < LL) {
+      const double e = exp(v[k] - mx);
+      Eb[i] = e;
+      tile[(i / L) * ts + i % L] = e;
+    }
+  }
+  __syncthreads();
+  double* Tb = ET + (size_t)blockIdx.x * LL;
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    const uint32_t i = tid + k * 256;
+    if (i < LL) Tb[i] = tile[(i % L) * ts + i / L];   // ET[r][c] = E[c][r]
+  }
+  if (tid == 0) mshift[blockIdx.x] = mx;
+}
+
 void launch_exp_m(hipStream_t st, const double* M, uint32_t L, uint64_t n_mat, double* E, double* ET,
                   double* mshift) {
   if (n_mat == 0) return;
+  static const bool tile_off = getenv("SCRF_EXPM_TILE") && atoi(getenv("SCRF_EXPM_TILE")) == 0;   // A/B knob
+  const uint32_t ne = (L * L + 255) / 256;
+  if (L <= 64 && !tile_off) {
+    if (ne <= 4) hipLaunchKernelGGL(k_exp_m_tile<4>, dim3((uint32_t)n_mat), dim3(256), 0, st, M, L, E, ET, mshift);
+    else if (ne <= 9) hipLaunchKernelGGL(k_exp_m_tile<9>, dim3((uint32_t)n_mat), dim3(256), 0, st, M, L, E, ET, mshift);
+    else hipLaunchKernelGGL(k_exp_m_tile<16>, dim3((uint32_t)n_mat), dim3(256), 0, st, M, L, E, ET, mshift);
+    return;
+  }
   hipLaunchKernelGGL(k_exp_m, dim3((uint32_t)n_mat), dim3(256), 0, st, M, L, E, ET, mshift);
 }
 

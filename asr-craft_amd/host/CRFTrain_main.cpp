@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
     if (world > 1) {
       if (a.has("threads") && threads != 1 && threads != world) { std::cerr << "threads=" << threads << " but WORLD_SIZE=" << world << ": with one process per GPU every rank is one stream" << std::endl; return 1; }
       threads = world;
+      crf_amd::setProcessView(rank, world);   // the managers below keep this rank's child view of the training data only
     }
 
     // ---- Main.cpp:508-537: one manager per input file, joined

@@ -328,6 +328,22 @@ void CRF_MemoryFeatureStream::addUtterance(const std::vector<std::vector<float> 
   end_ = s.T.size();
 }
 
+void CRF_MemoryFeatureStream::addPlaceholder() {
+  Store& s = *store_;
+  s.T.push_back(0);
+  s.frames.push_back(std::vector<std::vector<float> >(s.recipes.size()));
+  s.seg_phone.push_back(std::vector<uint32_t>());
+  s.seg_start.push_back(std::vector<uint32_t>());
+  end_ = s.T.size();
+}
+
+static int g_view_rank = 0, g_view_world = 1;
+void crf_amd::setProcessView(int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world) throw runtime_error("crf_amd::setProcessView: rank outside [0, world)");
+  g_view_rank = rank;
+  g_view_world = world;
+}
+
 void CRF_MemoryFeatureStream::join(const CRF_MemoryFeatureStream& other) {
   Store& s = *store_;
   const Store& o = *other.store_;
@@ -505,18 +521,27 @@ CRF_FeatureStreamManager::CRF_FeatureStreamManager(int debug, const char* debug_
   r.right_ctx = (uint32_t)right_ctx_len;
   r.extract_seg_ftr = extract_seg_ftr ? 1 : 0;
   const QNUInt32 D = (QNUInt32)win_len;
-  auto fill = [&](const char* rng, std::unique_ptr<CRF_MemoryFeatureStream>* dst) {
+  auto fill = [&](const char* rng, std::unique_ptr<CRF_MemoryFeatureStream>* dst, bool my_view_only) {
     const std::vector<uint32_t> sents = qn::parse_range(rng ? rng : "all", (uint32_t)data.size());
     dst->reset(new CRF_MemoryFeatureStream(std::vector<scrf_stream_recipe>(1, r), D));
-    for (uint32_t u : sents) {
+    // crf_amd::setProcessView: this process is stream g_view_rank of nthreads -- the child view it walks (below)
+    size_t lo = 0, hi = sents.size();
+    if (my_view_only) {
+      const size_t per = sents.size() / nthreads;
+      lo = (size_t)g_view_rank * per;
+      hi = (size_t)g_view_rank == nthreads - 1 ? sents.size() : lo + per;
+    }
+    for (size_t i = 0; i < sents.size(); i++) {
+      const uint32_t u = sents[i];
+      if (i < lo || i >= hi) { (*dst)->addPlaceholder(); continue; }
       std::vector<std::vector<float> > fr(1, data.get(u));
       (*dst)->addUtterance(fr, u < labs.size() ? labs[u] : std::vector<uint32_t>());
     }
   };
   // the training stream reads the train range; the CV stream (built like the reference's, read by no SG
   // trainer) the CV range
-  fill(trn_rng, &trn);
-  if (cv_rng && *cv_rng && string(cv_rng) != "nil" && string(cv_rng) != "none") fill(cv_rng, &cv);
+  fill(trn_rng, &trn, g_view_world > 1 && (size_t)g_view_world == nthreads);
+  if (cv_rng && *cv_rng && string(cv_rng) != "nil" && string(cv_rng) != "none") fill(cv_rng, &cv, false);
   for (size_t u = 0; u < data.size(); u++) data.drop(u);
   if (ts != SEQUENTIAL) trn->setPresentation(ts, rseed);
   trn_stream = trn.get();

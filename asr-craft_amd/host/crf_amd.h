@@ -208,6 +208,10 @@ class CRF_MemoryFeatureStream : public CRF_FeatureStream {
     std::vector<std::vector<uint32_t> > seg_start;          // [utt][T] its first frame
   };
   void fetchWindows();   // read(): the current utterance's window vectors, synthesised on the GPU
+ public:
+  // an utterance this process never reads (another rank's share, crf_amd::setProcessView): keeps the numbering, holds no frames
+  void addPlaceholder();
+ private:
   std::shared_ptr<Store> store_;
   size_t begin_ = 0, end_ = 0, width_ = 0;
   long cur_ = -1;
@@ -269,6 +273,11 @@ class Engine {
 };
 
 scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision);
+// One process per GPU (CRFTrain under RANK / WORLD_SIZE): rank r only ever walks child view r of the training stream
+// (io/CRF_FeatureStreamManager.cpp:425-464: [r floor(n/N), ...)), so a CRF_FeatureStreamManager built afterwards with N
+// threads keeps the frames of that view alone and placeholders for the rest -- N ranks hold the training data once between
+// them instead of N times.  The file is still parsed by every rank (pfiles carry no per-sentence seek table worth trusting).
+void setProcessView(int rank, int world);
 
 // minimal FST recorder with the four calls buildLattice needs
 struct ArcListFst {

@@ -397,7 +397,8 @@ def main():
             out["parity_gate"] = "skipped (--no-cpu-baseline): finiteness of lambda only"
     batch.close()
     eng.close()
-    if rank == 0 and out is not None and not args.no_other_configs:
+    if rank == 0 and world == 1 and out is not None and not args.no_other_configs:
+        # (at N = 1 only, like the CPU baseline: the other ranks would sit in the barrier below meanwhile)
         # the north-star training shape and the stress shape on the same clock (general path: materialised windows,
         # dense fp64-MFMA contractions); parity cases elsewhere, throughput entries here.  After the config-2 engine
         # has released its arena.

@@ -343,7 +343,11 @@ def main():
                     "phase_ms": {k: round(v / N_INSTR, 3) for k, v in phase.items() if not k.startswith("k_")},
                     "step": {"ms": round(step_ms, 3), "mfma_floor_ms": round(floors_mfma, 3),
                              "hbm_floor_ms": round(hbm_floor, 3), "algorithmic_gb": round(b_alg / 1e9, 2),
-                             "frac_of_larger_floor": round(max(floors_mfma, hbm_floor) / step_ms, 4)}}
+                             "frac_of_larger_floor": round(max(floors_mfma, hbm_floor) / step_ms, 4),
+                             # SURVEY 8d's own bound for this config: the DENSE flops of scores + expected counts
+                             # (4 N_seg L F per utterance, 0.466 GFLOP) on the fp64 matrix pipe = 169 k utterances/s per GPU
+                             "survey_8d_dense_gflop_per_utt": round(4.0 * nseg * L * F / 1e9, 4),
+                             "frac_of_survey_8d_mfma_bound": round(4.0 * nseg * L * F * U / (mfma_peak * 1e12) * 1e3 / step_ms, 4)}}
         out = {
             "metric": "utterances/sec SCRF forward-backward (TIMIT-shape)",
             "value": round(U * world * args.steps / dt, 2),

@@ -346,7 +346,9 @@ static void launch_scores_mfma_f(hipStream_t st, const float* X, uint32_t F, con
   const uint32_t gx = (uint32_t)((n_rows + SM_ROWS - 1) / SM_ROWS);
   uint32_t o_base = 0;
   static const bool ws_off = getenv("SCRF_SCORES_MFMA_WS") && atoi(getenv("SCRF_SCORES_MFMA_WS")) == 0;   // A/B knob
-  if (!F32 && !ws_off && n_out >= SW_NO && sp.nfe > 0) {
+  // (from 192 features on: with only a few 32-feature chunks the role split is all prologue -- the 40-feature per-window
+  // transition scores of STDSEG_NO_DUR: 5.8 ms single-role, 6.1 split)
+  if (!F32 && !ws_off && n_out >= SW_NO && sp.nfe >= 192) {
     // the wave-specialised form: 16 T outputs as a tiles of 96 and b tiles of 112 (T = 6a + 7b, fewest masked outputs); when
     // the count does not split that way, the whole 96-output tiles go here and the rest to the single-role kernels below
     const uint32_t T = (n_out + 15) / 16;
@@ -391,11 +393,15 @@ void launch_scores_mfma(hipStream_t st, const float* X, uint32_t F, const uint64
 #ifndef EM_MTF
 #define EM_MTF 4
 #endif
-#define EM_MTW(F32) ((F32) ? 3 : EM_MTF)
+// (the narrow forms keep 3: with 1-4 wavefronts per workgroup a 64-wide posterior image means a third more staging
+// registers per thread -- the frame model's 40-column count contraction went from 0.58 to 1.54 ms with it)
+#define EM_MTW(F32, NW) (((F32) || (NW) < 8) ? 3 : EM_MTF)
 #define EM_SPLIT_NO 48        // outputs per wavefront of the split form (3 M-tiles)
 // row stride (doubles) of the posterior image [k][outputs]: == 16 (mod 32), so that the two k rows a 32-lane half of a
 // ds_read_b64 fragment read covers fall on disjoint bank halves (a stride of 64 or 192 doubles puts them on the same banks)
-constexpr int em_rss(int no) { return no % 32 == 16 ? no : no + 16; }
+// (only the 64-wide image of the wide form is padded: the split form's 192-wide image measured FASTER unpadded, 4.8 against
+// 6.6 ms at the per-window transition counts of STDSEG_NO_DUR)
+constexpr int em_rss(int no) { return no == 64 ? 80 : no; }
 
 // NW wavefronts per workgroup, each owning 48 feature columns (3 N-tiles): NW = 8 covers 384
 // columns (the full 338-wide state block of config 2 in one workgroup, so R is read once);
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   // Staging coordinates and tail masks are fixed per thread: computed once, outside the loop.
   f4u xr_[XIT];
   double ar_[AIT];
-  uint32_t xrw[XIT], xcl[XIT], xlds[XIT], arw[AIT], acol[AIT];
+  uint32_t xrw[XIT], xcl[XIT], xlds[XIT], arw[AIT], acol[AIT], alds[AIT];
   bool aok[AIT];
   float xfill[XIT][4];   // value for masked components: bias column or zero
   bool xkeep[XIT][4];
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
   for (int k = 0; k < AIT; k++) {
     const uint32_t idx = tid + k * NT;
     arw[k] = idx / NO;
+    alds[k] = arw[k] * RSS + idx % NO;   // where the element goes in the posterior image
     const uint32_t o = o0 + idx % NO;
     aok[k] = idx < EM_KC * NO && o < n_out;
     acol[k] = o < n_out ? o : n_out - 1;
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(64 * NW) void k_expf_mfma(const double* __restrict_
     }
 #pragma unroll
     for (int k = 0; k < AIT; k++)
-      if (tid + k * NT < EM_KC * NO) Rs[arw[k] * RSS + (tid + k * NT) % NO] = ar_[k];
+      if (tid + k * NT < EM_KC * NO) Rs[alds[k]] = ar_[k];
   };
 
   __builtin_amdgcn_s_setprio(MM_PRIO);
@@ -761,10 +768,10 @@ __global__ __launch_bounds__(768) void k_expf_mfma_ws(const double* __restrict__
 template <int HAS_XROW, int NW, int KC, int F32, int MT>
 static void launch_expf_mfma_one(hipStream_t st, dim3 grid, size_t sm, const double* A, uint32_t n_out, const float* X, uint32_t F,
                                  const uint64_t* xrow, uint64_t n_rows, const ScrfLayout& lay, const ScrfGemmSpec& sp,
-                                 uint64_t rows_per_chunk, double* slab, uint32_t o_base, uint32_t o_step = 16 * EM_MTW(F32)) {
+                                 uint64_t rows_per_chunk, double* slab, uint32_t o_base, uint32_t o_step = 16 * EM_MTW(F32, NW)) {
   constexpr int DB = NW == 8 ? 1 : 0;   // the 8-wave workgroup has its CU to itself: room for a second image pair
   static const bool db_off = getenv("SCRF_EXPF_DB") && atoi(getenv("SCRF_EXPF_DB")) == 0;   // A/B knob
-  constexpr int MTW = EM_MTW(F32);
+  constexpr int MTW = EM_MTW(F32, NW);
   static const bool ws_off = getenv("SCRF_EXPF_MFMA_WS") && atoi(getenv("SCRF_EXPF_MFMA_WS")) == 0;   // A/B knob
   if (NW == 8 && !F32 && KC == EW_KC && MTW * 16 == EW_NO && !ws_off) {
     constexpr int MTC = MT > 4 ? 4 : MT;
@@ -791,7 +798,7 @@ static void launch_expf_mfma_x(hipStream_t st, const double* A, uint32_t n_out, 
                                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
   const uint32_t nfun = sp.nfun();
   const uint32_t gx = (nfun + 48 * NW - 1) / (48 * NW);
-  constexpr int MTW = EM_MTW(F32);
+  constexpr int MTW = EM_MTW(F32, NW);
   constexpr uint32_t NO = 16 * MTW;
   const size_t sm = sizeof(double) * KC * em_rss((int)NO) + sizeof(float) * KC * (48 * NW + 16);
   const uint32_t n_full = n_out / NO, rem = n_out % NO;
@@ -834,7 +841,7 @@ uint32_t expf_mfma_wide_tiles(uint32_t n_out, uint32_t nfun, int f32) {
   const uint32_t tiles = (nfun + 47) / 48;
   if (tiles <= 4) return 0;   // split and narrow forms: several workgroups per CU, no round structure to fit
   const uint32_t gx = (nfun + 48 * 8 - 1) / (48 * 8);
-  const uint32_t NO = 16 * (uint32_t)EM_MTW(f32);
+  const uint32_t NO = 16 * (uint32_t)EM_MTW(f32, 8);
   return gx * ((n_out + NO - 1) / NO);
 }
 

@@ -781,7 +781,11 @@ static uint32_t transframe_chunks(uint64_t nfr, uint32_t n_out, uint32_t nfun, i
   const uint32_t cus = 256;
   uint32_t best = base;
   double best_fill = 0.0;
-  for (uint32_t n = base; n <= 16 && nfr / n >= 1024; n++) {
+  // every chunk owns a slab of partial sums [n_out][nfun]: no more chunks than keep the slabs within 1 GB (the TIMIT
+  // demo: 34.5 MB each)
+  const uint64_t slab_bytes = (uint64_t)n_out * nfun * sizeof(double);
+  const uint32_t n_max = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(base, (1ull << 30) / std::max<uint64_t>(1, slab_bytes)));
+  for (uint32_t n = base; n <= n_max && nfr / n >= 1024; n++) {
     const uint64_t wg = (uint64_t)tiles * n;
     const double fill = (double)wg / (double)(((wg + cus - 1) / cus) * cus);
     if (fill > best_fill + 1e-9) { best_fill = fill; best = n; }

@@ -77,6 +77,9 @@ int main(int argc, char** argv) {
     if (rank == 0) std::cout << "FEATURES: " << my_crf.getLambdaLen() << std::endl;
     my_crf.setDevice((int)a.num("crf_device", world > 1 ? local_rank : 0));
     my_crf.setTrainPrecision(parse_precision(a));
+    my_crf.setTrainingOnly(true);   // this process never builds lattices: the n-state frame model may take the dense kernels
+    if (rank == 0 && m.mtype == STDFRAME && m.fmap.numStates > 1 && parse_precision(a) != SCRF_PREC_EXACT)
+      std::cout << "NOTE: crf_states=" << m.fmap.numStates << " on the frame model trains through the dense kernels (as the n-state segmental model with maximum duration 1: the same function and weight layout); crf_precision=exact keeps the reference-order n-state kernels" << std::endl;
     if (world > 1 || a.num("crf_force_comm", 0) != 0) my_crf.setDistributed(rank, world, a.str("out_weight_file") + ".rccl_id");
 
     // ---- Main.cpp:599-631: resume flags, nested as there -- the average and AdaGrad accumulators are only

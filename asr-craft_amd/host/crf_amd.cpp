@@ -112,6 +112,9 @@ scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision) {
   g.trans_bias_val = c->transBiasVal;
   g.device_id = device;
   g.train_precision = precision;
+  // a training-only engine takes the n-state frame model through the masked dense layout (CRF_Model::setTrainingOnly)
+  if (crf->trainingOnly() && precision != SCRF_PREC_EXACT && g.model_type == SCRF_STDFRAME && g.num_states > 1 && g.lab_max_dur == 1)
+    g.model_type = SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR;
   return g;
 }
 

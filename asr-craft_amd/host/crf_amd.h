@@ -115,6 +115,15 @@ class CRF_Model {
   void setDevice(int d) { device = d; }
   int getDevice() const { return device; }
   void setTrainPrecision(uint32_t p) { precision = p; }   // scrf_precision; decode entry points stay EXACT
+  // This model's engine will only ever train (CRFTrain).  With FAST / FAST32 precision the n-state FRAME model
+  // (stdframe, crf_states > 1) is then run as the n-state segmental model with maximum duration 1 -- the same function
+  // (nodes/CRF_StdNStateNode.cpp against nodes/CRF_StdSegNStateNode_WithoutDurLab_WithoutSegTransFtr.cpp at one frame
+  // per segment: gradient, numerator and Zx agree to 1e-12 at the TIMIT shape, tools/experiments/r03_nstate_frame_vs_seg.py),
+  // the same weight layout, but on the dense MFMA kernels over the masked layout instead of the
+  // reference-order n-state kernels: 10.5 -> 3.7 ms per 256 utterances of 300 frames at 48 phones x 3 states.  Lattices
+  // and decoding keep the n-state kernels (their arc order is the frame lattice builder's), hence "training only".
+  void setTrainingOnly(bool on) { training_only = on; }
+  bool trainingOnly() const { return training_only; }
   // One process per GPU (RANK / WORLD_SIZE of the launcher): rank r is the reference's stream (thread) r.
   // The RCCL communicator is created together with the engine; its 128-byte unique id travels from rank 0
   // to the others through `id_file` (rank 0 writes it, the others poll; removed after the collective
@@ -134,6 +143,7 @@ class CRF_Model {
   modeltype model_type = STDFRAME;
   int device = 0;
   uint32_t precision = SCRF_PREC_FAST;
+  bool training_only = false;
   bool dist_on = false;
   int dist_rank = 0, dist_world = 1;
   std::string dist_id_file;

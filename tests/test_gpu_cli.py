@@ -1573,6 +1573,16 @@ def test_crftrain_and_fstdecode_with_three_states_per_label(tmp_path):
     w = np.loadtxt(out)
     assert np.abs(w).max() > 0
     np.testing.assert_allclose(w, np.array([float("%g" % v) for v in lam]), rtol=2e-5, atol=1e-12)
+    # the default precision took the dense kernels (the n-state segmental form with maximum duration 1); crf_precision=exact
+    # keeps the reference-order n-state kernels: the same weights
+    assert "trains through the dense kernels" in r.stdout
+    (tmp_path / "exact").mkdir()
+    out_x = str(tmp_path / "exact" / "w.out")
+    rx = subprocess.run([os.path.join(BIN, "CRFTrain")] + flags + ["hardtarget_file=" + os.path.join(G, "crftrain_test.lab.ascii"), "out_weight_file=" + out_x,
+                         "crf_epochs=%d" % epochs, "crf_lr=%g" % lr, "crf_bunch_size=1", "threads=1", "crf_train_order=seq", "crf_precision=exact"],
+                        capture_output=True, text=True, timeout=300)
+    assert rx.returncode == 0 and "trains through the dense kernels" not in rx.stdout, rx.stdout + rx.stderr
+    np.testing.assert_allclose(np.loadtxt(out_x), w, rtol=1e-5, atol=1e-12)
     dec = str(tmp_path / "labels.txt")
     r = subprocess.run([os.path.join(BIN, "CRFFstDecode")] + flags + ["weight_file=" + out, "crf_output_labelfile=" + dec], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

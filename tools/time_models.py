@@ -17,6 +17,7 @@ MODELS = [
     ("stdseg_no_dur (transition features = mean block of the window)", dict(model_type=scrf_amd.STDSEG_NO_DUR, L=P, D=D, F=Fs, use_trans_ftrs=True, tfs=0, tfe=W - 1), P, D),
     ("stdseg (labels carry the duration)", dict(model_type=scrf_amd.STDSEG, L=P * D, D=D, F=Fs), P, D),
     ("stdframe, 3 states per phone", dict(model_type=scrf_amd.STDFRAME, L=P * 3, D=1, F=W, num_states=3), P * 3, 1),
+    ("stdframe, 3 states per phone, as CRFTrain runs it (masked dense layout, maximum duration 1)", dict(model_type=scrf_amd.STDSEG_NO_DUR_NO_SEGTRANSFTR, L=P * 3, D=1, F=W, num_states=3), P * 3, 1),
     ("stdframe", dict(model_type=scrf_amd.STDFRAME, L=P, D=1, F=W), P, 1),
 ]
 for name, kw, L, Dm in MODELS:

@@ -152,8 +152,8 @@ struct scrf_batch_s {
   int* d_status = nullptr;
   // fused window synthesis: row tiles of the score kernel [0] and of the expected-count kernel [1]
   bool fused_ok = false;
-  std::vector<uint64_t> tile_off[2];
-  ScrfTileDesc* d_tiles[2] = {nullptr, nullptr};
+  std::vector<uint64_t> tile_off[3];   // 0: score tiles, 1: expected-count tiles (<= 76 rows), 2: <= 100 rows (FASTLIN)
+  ScrfTileDesc* d_tiles[3] = {nullptr, nullptr, nullptr};
   ScrfBatchView view() const {
     ScrfBatchView v;
     v.U = U; v.T = d_T; v.frame_off = d_frame_off; v.seg_off = d_seg_off; v.arc_off = d_arc_off;
@@ -545,7 +545,7 @@ extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_prev_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u); hipFree(b->d_xm_f);
   for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
   hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
-  hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]);
+  hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]); hipFree(b->d_tiles[2]);
   delete b;
   return SCRF_OK;
 }
@@ -694,7 +694,13 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     }
     // score tiles: the windows of TB whole frames; expected-count tiles: those of TBE whole frames (<= 64 windows)
     const uint32_t D = lay.D, TB = fused_scores_tb(recipes[0].in_width, D), TBE = fused_expf_frames(D);
-    for (int k = 0; k < 2; k++) {
+    // a third list when the engine trains with the linear window average and its count kernel walks taller tiles
+    uint32_t TBL = 0;
+    if (h->cfg.train_precision == SCRF_PREC_FASTLIN && fused_la_supported(lay, recipes[0].in_width)) {
+      const ScrfFusedExpfPlan plan = fused_expf_plan(lay, recipes[0].in_width, 0, 1);
+      if (plan.tile_list == 2) TBL = plan.frames;
+    }
+    for (int k = 0; k < (TBL ? 3 : 2); k++) {
       std::vector<ScrfTileDesc> td;
       b->tile_off[k].assign(n + 1, 0);
       for (uint32_t u = 0; u < n; u++) {
@@ -706,7 +712,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
           memset(&q, 0, sizeof(q));
           uint32_t t_end;   // one past the last frame touched
           uint64_t r1;
-          t_end = std::min(T, t + (k == 0 ? TB : TBE));
+          t_end = std::min(T, t + (k == 0 ? TB : k == 1 ? TBE : TBL));
           r1 = scrf_seg_base(t_end, D);
           q.r0 = (uint32_t)r0; q.t0 = t; q.back = (uint16_t)std::min(t, D - 1);
           q.nfr = (uint16_t)(t_end - t); q.nrows = (uint16_t)(r1 - r0);
@@ -854,9 +860,12 @@ struct ChunkBufs {
   double* slab_l = nullptr;
   uint32_t nch_l = 0;
   uint64_t rpc_l = 0;
+  bool la = false;           // SCRF_PREC_FASTLIN: linear window average (6 groups in P / Z, no avg group in the dense parts)
+  double* slab_d = nullptr;  // duration + bias counts of the wave-specialised count kernel (behind slab_s)
+  int expf_tiles = 1;        // tile list the fused count kernel walks
 };
 
-struct Need { bool fb, post, beta, vit; bool fused = false; bool vitfast = false; };
+struct Need { bool fb, post, beta, vit; bool fused = false; bool vitfast = false; bool la = false; };
 
 // entries the decode screen may list per chunk before the chunk falls back to the EXACT path
 static uint32_t decode_fix_cap(uint64_t nseg, uint32_t L) {
@@ -888,8 +897,9 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
   size_t tot = 0;
   const uint32_t W0 = b->mode == 1 ? b->recipe[0].in_width : 0;
   if (nd.fused) {
-    tot += pad256(nfr * 5 * l.L * sizeof(double));                // P (scores) / Z (counts)
-    if (nd.post) tot += pad256((size_t)512 * 5 * l.L * W0 * sizeof(double));
+    const size_t ng = nd.la ? 6 : 5;
+    tot += pad256(nfr * ng * l.L * sizeof(double));                // P (scores) / Z (counts)
+    if (nd.post) tot += pad256((size_t)512 * ng * l.L * W0 * sizeof(double));
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
   if (nd.vitfast) tot += pad256(nseg * l.L * sizeof(float)) + pad256((size_t)decode_fix_cap(nseg, l.L) * 8) + 256;  // Wn, list, count
   else tot += pad256(nseg * l.L * sizeof(double));                  // S
@@ -963,12 +973,14 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   if (nd.fused) {
     const uint32_t W0 = b->recipe[0].in_width;
     cb->X = nullptr;
-    cb->P = a.take<double>(nfr * 5 * l.L);
+    cb->la = nd.la;
+    const size_t ng = nd.la ? 6 : 5;
+    cb->P = a.take<double>(nfr * ng * l.L);
     cb->Z = cb->P;  // the projections are dead once the scores exist
     if (nd.post) {
       cb->rpc_l = ((nfr + 511) / 512 + 31) & ~31ull;   // <= 512 K-chunks of whole 4-frame groups
       cb->nch_l = (uint32_t)((nfr + cb->rpc_l - 1) / cb->rpc_l);
-      cb->slab_l = a.take<double>((size_t)512 * 5 * l.L * W0);
+      cb->slab_l = a.take<double>((size_t)512 * ng * l.L * W0);
     }
   } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
@@ -1051,8 +1063,16 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       }
       cb->rpc_s = expf_rows_per_chunk(nseg);
       cb->nch_s = (uint32_t)((nseg + cb->rpc_s - 1) / cb->rpc_s);
-      if (nd.fused) cb->nch_s = fused_expf_blocks(l, b->recipe[0].in_width, h->cfg.train_precision == SCRF_PREC_FAST32, b->tile_off[1][u1] - b->tile_off[1][u0]);
+      ScrfFusedExpfPlan plan;
+      if (nd.fused) {
+        plan = fused_expf_plan(l, b->recipe[0].in_width, h->cfg.train_precision == SCRF_PREC_FAST32, nd.la);
+        cb->expf_tiles = plan.tile_list;
+        cb->nch_s = fused_expf_blocks(l, b->recipe[0].in_width, h->cfg.train_precision == SCRF_PREC_FAST32,
+                                      b->tile_off[plan.tile_list][u1] - b->tile_off[plan.tile_list][u0], nd.la);
+      }
       cb->slab_s = a.take<double>((size_t)(nd.fused ? 512 : cb->nch_s) * l.L * l.nsf);
+      // dense columns + durations + bias <= nsf: the duration slab fits behind the dense one
+      if (nd.fused) cb->slab_d = cb->slab_s + (size_t)cb->nch_s * l.L * plan.ncol;
     }
   }
   if (nd.vit) {
@@ -1126,9 +1146,10 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     const uint32_t W0 = b->recipe[0].in_width;
     ScrfFusedArgs fa = fused_args(h, b, u0, 0);
     // per-frame projections of the five sampled blocks, then the dense part + gather
-    if (pframe_supported(W0))
-      KT_RUN("k_pframe", cb.st, launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, 5 * l.L, cb.P));
-    else
+    if (pframe_supported(W0)) {
+      KT_RUN("k_pframe", cb.st, launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, (cb.la ? 6 : 5) * l.L, cb.P));
+      if (cb.la) KT_RUN("k_avg_prefix", cb.st, launch_avg_prefix(cb.st, bv, u0, u1 - u0, l.L, cb.P));
+    } else
       KT_RUN("k_scores_mfma(samples)", cb.st, launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
                          spec_samples(W0), 5 * l.L, cb.P));
     if (cb.Wn) {
@@ -1155,7 +1176,7 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     {
       PhaseTimer tk(h, PH_K_SCORE, cb.st);
       KT_RUN("k_scores_fused", cb.st, launch_scores_fused(cb.st, fa, l, h->d_lambda, cb.P, b->tile_off[0][u1] - b->tile_off[0][u0], cb.S, f32,
-                          cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels));
+                          cb.es_ready ? cb.smax : nullptr, cb.s_true, b->d_labels, cb.la ? 1 : 0));
       tk.stop(1);
     }
     tm.stop(2);
@@ -1253,7 +1274,7 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
         // posterior pass and the per-frame sums of R in one walk (R is not read back for Z)
         if (l.L > 64) HIPCHK(h, hipMemsetAsync(cb.mass_s, 0, sizeof(double) * nfr, cb.st));   // summed over the 64-output groups
         KT_RUN("k_post_z", cb.st, launch_post_z(cb.st, l, bv, u0, (uint32_t)nutt, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S, cb.smax,
-                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z, cb.mass_s));
+                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z, cb.mass_s, cb.la ? 1 : 0));
         cb.z_ready = true;
       } else {
         KT_RUN("k_post_lin", cb.st, launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,
@@ -1524,6 +1545,10 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   const bool fast = h->cfg.train_precision >= SCRF_PREC_FAST;
   const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
   nd.fused = fast && b->fused_ok && h->fuse_windows;
+  // the linear window average needs the fused kernels, the linear-domain recursion (k_post_z builds Z_avg) and a
+  // shape its kernels take; anything else runs as FAST
+  nd.la = nd.fused && h->cfg.train_precision == SCRF_PREC_FASTLIN && h->lin_dp && !h->force_fb && wave_path(h, true) &&
+          fused_la_supported(l, b->recipe[0].in_width);
 
   // plan the chunks first: each must fit the scratch budget; with two lanes a batch is cut into
   // at least four chunks so that both streams always have work
@@ -1582,15 +1607,15 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
       uint32_t nl = 1;
       if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
-        ScrfFusedArgs fa = fused_args(h, b, u0, 1);
+        ScrfFusedArgs fa = fused_args(h, b, u0, cb.expf_tiles);
         {
           PhaseTimer tk(h, PH_K_EXPF, cb.st);
-          KT_RUN("k_expf_fused", cb.st, launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[1][u1] - b->tile_off[1][u0], cb.slab_s, f32));
+          KT_RUN("k_expf_fused", cb.st, launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[cb.expf_tiles][u1] - b->tile_off[cb.expf_tiles][u0], cb.slab_s, cb.slab_d, f32, cb.la ? 1 : 0));
           tk.stop(1);
         }
         if (!cb.z_ready) KT_RUN("k_lin_z", cb.st, launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z));
         if (pframe_supported(W0))
-          KT_RUN("k_ztf", cb.st, launch_ztf(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l));
+          KT_RUN("k_ztf", cb.st, launch_ztf(cb.st, cb.Z, (cb.la ? 6 : 5) * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l));
         else
           KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
                            spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l));
@@ -1619,8 +1644,13 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
       KernelTimer kt(h, "reductions (k_reduce_slabs, k_atb, k_batch_sums)", cb.st);
       if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
-        launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
-        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 5 * l.L, l, spec_samples(W0), cb.grad);
+        const ScrfFusedExpfPlan plan = fused_expf_plan(l, W0, f32, cb.la ? 1 : 0);
+        if (plan.ndur) {
+          // dense groups [avg |] max | min at columns (5 + g0) W ..; one-hot duration + bias counts from their own slab
+          launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, ScrfGemmSpec{0, 0, plan.ncol, 0, 0.0, (5 + plan.g0) * W0, 0}, cb.grad);
+          launch_reduce_slabs(cb.st, cb.slab_d, cb.nch_s, l.L, l, ScrfGemmSpec{0, 0, l.D, (uint32_t)l.use_sb, l.sbv, 8 * W0, 0}, cb.grad);
+        } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
+        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, (cb.la ? 6 : 5) * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
       if (l.use_tf || segtrans(h)) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
       else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad,
@@ -2138,6 +2168,9 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
 extern "C" int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused) {
   if (!h || !b || !fused) return SCRF_ERR_INVALID;
   *fused = b->fused_ok && h->fuse_windows ? 1 : 0;
+  // 2: training runs with the linear window average (SCRF_PREC_FASTLIN on a shape its kernels take)
+  if (*fused && h->cfg.train_precision == SCRF_PREC_FASTLIN && h->lin_dp && wave_path(h, true) &&
+      fused_la_supported(h->lay, b->recipe[0].in_width)) *fused = 2;
   return SCRF_OK;
 }
 

@@ -273,8 +273,16 @@ __host__ __device__ inline uint32_t fu_p_rows(uint32_t D, uint32_t TB) {
   return n;
 }
 #define FU_NPQ 12       // P rows per thread held in registers between their loads and their LDS stores (slot + 10 q)
+// LA (linear window average, SCRF_PREC_FASTLIN): the avg block leaves the dense contraction.  The average is linear in
+// the frames, so its share of the score is (C[t] - C[t-d]) / d with C the per-utterance prefix sum of the per-frame
+// projection Q[f][o] = F[f] . W_avg[o] (group 5 of k_pframe, summed in place by k_avg_prefix).  The reference rounds the
+// running float sum and the quotient to float (io/CRF_InFtrStream_SeqMultiWindow.cpp:609-646); this form does not, which
+// makes it a precision tier of its own (measured 3e-8 relative on the gradient against the reference arithmetic; contract 1e-4).
+// Block 5 of the staged P image holds C for the frames t0 - D .. t0 + nfr - 1 (zero rows before the utterance).
+__host__ __device__ inline uint32_t fu_p_rows_la(uint32_t D, uint32_t TB) { return fu_p_rows(D, TB) + TB + D; }
+#define FU_NPQ_LA 15
 
-template <int DMAX, int F32, int DEC>
+template <int DMAX, int F32, int DEC, int LA>
 __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, ScrfLayout lay,
                                                            const double* __restrict__ lambda,
                                                            const double* __restrict__ P, uint32_t n_out,
@@ -291,11 +299,11 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   float* fr = (float*)(Wg + FU_GC * FU_WS);                             // [nfmax][W]
   double* Pl = (double*)fsm;                                            // [fu_p_rows][FU_DS]: 48 used
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
-  const uint32_t nprmax = fu_p_rows(D, fa.TB);
+  const uint32_t nprmax = fu_p_rows_la(D, fa.TB);   // the tile size is planned for the larger (LA) image
   const size_t pb = sizeof(double) * nprmax * FU_DS;
   if (pb > opn) opn = pb;
   // outside the union (staged with the raw frames, read by the epilogue):
-  double* Dt = (double*)(fsm + ((opn + 15) & ~(size_t)15));             // [D][FU_DS] duration weight + bias term
+  double* Dt = (double*)(fsm + ((opn + 15) & ~(size_t)15));             // [D][FU_DS] duration weight + bias term; [.][48] = 1/d
   // per-row record (16 bytes, one ds_read_b128 in the epilogue): the five gather offsets into Pl (in doubles), the
   // duration, the frame inside the tile, and the output whose score is the labelled window's (0xffff: none)
   uint4* recs = (uint4*)(Dt + D * FU_DS);                               // [FU_ROWS]
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     }
   };
   FU_SETPRIO(1);
-  load_w(0);
+  load_w(LA ? cpg : 0);   // LA: the dense groups are max and min only
 #if FU_PROF
   asm volatile("" :: "v"(ft.t0));   // the descriptor has arrived
   FU_STAMP(5);
@@ -358,6 +366,8 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     prow0[k] = nprows;
     nprows += nf - pf0[k];
   }
+  const uint32_t crow0 = nprows;          // LA: block 5 = the prefix sums C of frames t0 - D .. t0 + nfr - 1
+  if (LA) nprows += ft.nfr + D;
   // stage raw frames f0 .. t0+nfr-1 and the duration weights (loads batched ahead of the LDS stores), decode rows
   {
     auto dur_w = [&](uint32_t i) {
@@ -385,6 +395,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
     for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * 48) Dt[((tid + FU_NT * q) / 48) * FU_DS + (tid + FU_NT * q) % 48] = dtv[q];
     for (uint32_t i = tid + 3 * FU_NT; i < D * 48; i += FU_NT) Dt[(i / 48) * FU_DS + i % 48] = dur_w(i);   // D > 32 only
+    if (LA && tid < D) Dt[tid * FU_DS + 48] = 1.0 / (double)(tid + 1);
     FU_STAMP(6);   // frames and duration weights in LDS
     const uint32_t mD = fu_magic(D);
     for (uint32_t i = tid; i < ft.nfr * D; i += FU_NT) {
@@ -408,14 +419,20 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     }
     FU_STAMP(7);   // row records
     for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) rbase[tl] = (uint16_t)(scrf_seg_base(ft.t0 + tl, D) - ft.r0);
+    // image row -> NG * (frame - f0 + 1) + k (LA: NG = 6 and frame t0 - D may lie one before f0; 0xffff: a zero row)
     for (uint32_t r = tid; r < nprows; r += FU_NT) {
+      if (LA && r >= crow0) {
+        const int32_t fq = (int32_t)ft.t0 - (int32_t)D + (int32_t)(r - crow0);   // frame inside the utterance
+        rowmap[r] = fq < 0 ? (uint16_t)0xffffu : (uint16_t)(6 * ((uint32_t)fq - ft.f0 + 1) + 5);
+        continue;
+      }
       uint32_t k = 0;
 #pragma unroll
       for (int kk = 1; kk < 5; kk++) k += r >= prow0[kk] ? 1u : 0u;
       uint32_t base = prow0[0], f0k = pf0[0];
 #pragma unroll
       for (int kk = 1; kk < 5; kk++) if (k == (uint32_t)kk) { base = prow0[kk]; f0k = pf0[kk]; }
-      rowmap[r] = (uint16_t)(5 * (f0k + r - base) + k);
+      rowmap[r] = (uint16_t)((LA ? 6 : 5) * (f0k + r - base + 1) + k);
     }
 #if FU_EXPTAB
     if (!DEC && smax && tid < FU_EXPT_N) etab[tid] = exp2((double)tid * (1.0 / FU_EXPT_N));
@@ -451,19 +468,23 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   // slot + 10 q, all loads of a batch in flight together.  (Requesting the batch BEFORE the last chunk's MFMAs hides
   // its latency -- the staging phase fell from 20 k to 4 k cycles per tile -- but the 24 registers it holds across
   // the loop spill the scans: 10.2 -> 11.7 ms.  Measured, not kept.)
-  double pr[FU_NPQ];
+  constexpr int NPQ = LA ? FU_NPQ_LA : FU_NPQ;
+  constexpr uint32_t NG = LA ? 6 : 5;   // groups per frame of P
+  double pr[NPQ];
   const uint32_t pslot = tid / 48, pol = tid % 48;
   const bool plive = tid < 480 && o0 + pol < n_out;
   auto p_load = [&](uint32_t r0) {
 #pragma unroll
-    for (int q = 0; q < FU_NPQ; q++) {
+    for (int q = 0; q < NPQ; q++) {
       const uint32_t r = r0 + pslot + 10 * q;
-      pr[q] = (FU_ABL < 1 && plive && r < nprows) ? P[(ft.fr0 * 5 + rowmap[r < nprows ? r : 0]) * (uint64_t)n_out + o0 + pol] : 0.0;
+      const uint32_t rm = rowmap[r < nprows ? r : 0];
+      // (frame f0 - 1 exists whenever a row refers to it: t0 >= D then)
+      pr[q] = (FU_ABL < 1 && plive && r < nprows && !(LA && rm == 0xffffu)) ? P[((ft.fr0 - 1) * NG + rm) * (uint64_t)n_out + o0 + pol] : 0.0;
     }
   };
   auto p_store = [&](uint32_t r0) {
 #pragma unroll
-    for (int q = 0; q < FU_NPQ; q++) {
+    for (int q = 0; q < NPQ; q++) {
       const uint32_t r = r0 + pslot + 10 * q;
       if (tid < 480 && r < nprows) Pl[r * FU_DS + pol] = pr[q];
     }
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
   const bool full = FU_FULLSCAN && (D == (uint32_t)DMAX) && ft.t0 + 1 >= D;
   const uint32_t ncw = min(W, (uint32_t)FU_GC), mncw = fu_magic(ncw);   // width of a full chunk
   const uint32_t nchunks = 3 * cpg;
-  for (uint32_t ci = 0; ci < nchunks; ci++) {
+  for (uint32_t ci = LA ? cpg : 0; ci < nchunks; ci++) {
     const uint32_t ty = ci / cpg, c0 = (ci % cpg) * FU_GC;   // 0 avg, 1 max, 2 min
     const uint32_t nc = min((uint32_t)FU_GC, W - c0);
     // a narrower last chunk of a group leaves stale columns behind: clear them
@@ -550,7 +571,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     FU_STAMP(2);   // MFMA loops (+ barrier)
   }
   // the P image over the dead operand images
-  for (uint32_t r0 = 0; r0 < nprows; r0 += 10 * FU_NPQ) {   // one batch unless the tile is wider than the registers hold
+  for (uint32_t r0 = 0; r0 < nprows; r0 += 10 * NPQ) {   // one batch unless the tile is wider than the registers hold
     p_load(r0);
     p_store(r0);
   }
@@ -614,18 +635,25 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
     const double* p3 = Pl + (rec.y >> 16);
     const double* p4 = Pl + (rec.z & 0xffffu);
     const double* dp = Dt + (d - 1) * FU_DS;
+    // LA: prefix sums at the window's last frame and at the frame before its first
+    const double* pct = Pl + (crow0 + D + tl) * FU_DS;
+    const double* pcb = pct - d * FU_DS;
+    const double invd = LA ? dp[48] : 0.0;
     double sv[12];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       const uint32_t ob = FU_OB(j);
       const v2f64 a0 = *(const v2f64*)(p0 + ob), a1 = *(const v2f64*)(p1 + ob), a2 = *(const v2f64*)(p2 + ob),
                   a3 = *(const v2f64*)(p3 + ob), a4 = *(const v2f64*)(p4 + ob), dw = *(const v2f64*)(dp + ob);
+      v2f64 ct = (v2f64){0.0, 0.0}, cb = (v2f64){0.0, 0.0};
+      if (LA) { ct = *(const v2f64*)(pct + ob); cb = *(const v2f64*)(pcb + ob); }
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int c = 2 * j + h, n = c >> 2, r = c & 3;
         const double lin = (((a0[h] + a1[h]) + a2[h]) + a3[h]) + a4[h];
         const double v = F32 ? (double)acc32[F32 ? m : 0][F32 ? n : 0][r] : acc[F32 ? 0 : m][F32 ? 0 : n][r];
         sv[c] = (v + lin) + dw[h];
+        if (LA) sv[c] = fma(ct[h] - cb[h], invd, sv[c]);
       }
     }
     const uint64_t grow = ft.row0 + rl;
@@ -704,7 +732,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 static size_t fused_scores_smem_tb(uint32_t W, uint32_t D, uint32_t TB) {
   const uint32_t nfmax = TB + D - 1;
   size_t opn = sizeof(float) * (FU_ROWS + 1) * FU_XS + sizeof(double) * FU_GC * FU_WS + sizeof(float) * nfmax * W;
-  const uint32_t npr = fu_p_rows(D, TB);
+  const uint32_t npr = fu_p_rows_la(D, TB);   // one tile plan for every form of the kernel
   const size_t pb = sizeof(double) * npr * FU_DS;
   if (pb > opn) opn = pb;
   opn = (opn + 15) & ~(size_t)15;
@@ -723,28 +751,30 @@ uint32_t fused_scores_tb(uint32_t W, uint32_t D) {
 }
 static size_t fused_scores_smem(uint32_t W, uint32_t D) { return fused_scores_smem_tb(W, D, fused_scores_tb(W, D)); }
 
-template <int DMAX, int F32, int DEC>
+template <int DMAX, int F32, int DEC, int LA>
 static void launch_scores_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                                   const double* P, uint64_t n_tiles, double* S, double* smax, double* s_true,
                                   const uint32_t* labels, const ScrfDecodeOut& dz) {
   const size_t sm = fused_scores_smem(fa.W, lay.D);
   dim3 grid((uint32_t)n_tiles, (lay.L + 47) / 48);
-  hipFuncSetAttribute((const void*)k_scores_fused<DMAX, F32, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL((k_scores_fused<DMAX, F32, DEC>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S, smax,
+  hipFuncSetAttribute((const void*)k_scores_fused<DMAX, F32, DEC, LA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL((k_scores_fused<DMAX, F32, DEC, LA>), grid, dim3(FU_NT), sm, st, fa, lay, lambda, P, lay.L, S, smax,
                      s_true, labels, dz);
 }
 
+// la (SCRF_PREC_FASTLIN, fp64 only): P carries 6 groups per frame, the sixth summed along the utterance (k_avg_prefix)
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                          const double* P, uint64_t n_tiles, double* S, int f32, double* smax, double* s_true,
-                         const uint32_t* labels) {
+                         const uint32_t* labels, int la) {
   if (n_tiles == 0) return;
   if (lay.L > 48) smax = nullptr;   // a row spans several workgroups: the caller runs k_exp_rows instead
   ScrfDecodeOut off;
   memset(&off, 0, sizeof(off));
 #define FS_GO(N)                                                                        \
   do {                                                                                  \
-    if (f32) launch_scores_fused_t<N, 1, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off);   \
-    else launch_scores_fused_t<N, 0, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off);       \
+    if (la) launch_scores_fused_t<N, 0, 0, 1>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off); \
+    else if (f32) launch_scores_fused_t<N, 1, 0, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off);   \
+    else launch_scores_fused_t<N, 0, 0, 0>(st, fa, lay, lambda, P, n_tiles, S, smax, s_true, labels, off);       \
   } while (0)
   if (lay.D <= 12) FS_GO(12);
   else if (lay.D <= 25) FS_GO(25);
@@ -755,9 +785,9 @@ void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayo
 void launch_scores_fused_decode(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                                 const double* P, uint64_t n_tiles, const ScrfDecodeOut& dz) {
   if (n_tiles == 0) return;
-  if (lay.D <= 12) launch_scores_fused_t<12, 0, 1>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
-  else if (lay.D <= 25) launch_scores_fused_t<25, 0, 1>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
-  else launch_scores_fused_t<40, 0, 1>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
+  if (lay.D <= 12) launch_scores_fused_t<12, 0, 1, 0>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
+  else if (lay.D <= 25) launch_scores_fused_t<25, 0, 1, 0>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
+  else launch_scores_fused_t<40, 0, 1, 0>(st, fa, lay, lambda, P, n_tiles, nullptr, nullptr, nullptr, nullptr, dz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -954,6 +984,32 @@ void launch_pframe(hipStream_t st, const float* F, uint32_t W, uint64_t n_frames
 }
 int pframe_supported(uint32_t W) { return W <= 80; }
 
+// k_avg_prefix (SCRF_PREC_FASTLIN): group 5 of P (the projection of every frame on the avg weights) summed in place along
+// each utterance, C[f][o] = sum_{f' <= f} Q[f'][o].  One wavefront per (utterance, 64 outputs), eight frames' loads in
+// flight per step; the additions run in frame order (fixed association).
+__global__ __launch_bounds__(64) void k_avg_prefix(ScrfBatchView bv, uint32_t u0, uint32_t L, double* __restrict__ P) {
+  const uint32_t u = u0 + blockIdx.x, o = blockIdx.y * 64 + threadIdx.x;
+  if (o >= L) return;
+  const uint32_t T = bv.T[u];
+  const size_t zs = (size_t)6 * L;
+  double* q = P + (bv.frame_off[u] - bv.frame_off[u0]) * zs + (size_t)5 * L + o;
+  double c = 0.0;
+  for (uint32_t t0 = 0; t0 < T; t0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (t0 + j < T) ? q[(size_t)(t0 + j) * zs] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      c += v[j];
+      if (t0 + j < T) q[(size_t)(t0 + j) * zs] = c;
+    }
+  }
+}
+void launch_avg_prefix(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint32_t L, double* P) {
+  if (n_utts == 0) return;
+  hipLaunchKernelGGL(k_avg_prefix, dim3(n_utts, (L + 63) / 64), dim3(64), 0, st, bv, u0, L, P);
+}
+
 #define ZT_MT 4     // output tiles per wavefront (64 outputs): leaves registers for a second prefetch stage
 template <int NT>   // column tiles: ceil(W / 16)
 __global__ __launch_bounds__(64) void k_ztf(const double* __restrict__ Zm, uint32_t n_out, const float* __restrict__ F,
@@ -1043,7 +1099,12 @@ void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F
 // scale factors of a frame are computed by lanes 0..D-1 and broadcast through LDS.
 // Also produces the per-frame numerator terms (gradbuilder :388-469).
 // ------------------------------------------------------------------------------------------
-template <int DMAX>
+// LA (SCRF_PREC_FASTLIN): a sixth group Z_avg[f][o] = sum over the windows (t, d) that contain frame f of R / d -- the
+// expected-count side of the linear window average (its counts are Z_avg^T F, one more group of k_ztf).  A window reaches
+// D - 1 frames back, so the open sums of the last D frames sit in an LDS ring (the register file is full of the five
+// sample windows): at frame t the suffix sums u_j = sum_{d > j} R(t, d) / d are added to the slots of frames t - j, and
+// frame t - D + 1 retires.  RW = lanes of the rings that exist (48 when L <= 48: 8 wavefronts per CU keep their LDS).
+template <int DMAX, int LA, int RW>
 __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0,
                                                   const uint32_t* __restrict__ next_lab,
                                                   const double* __restrict__ s_true, const double* __restrict__ M,
@@ -1052,8 +1113,9 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
                                                   const double* __restrict__ zx, double* __restrict__ numer_f,
                                                   int* __restrict__ status, double* __restrict__ Z,
                                                   double* __restrict__ mass_s) {
-  __shared__ double pring[DMAX * 64];
-  __shared__ double fsb[64];
+  __shared__ double pring[DMAX * RW];
+  __shared__ double zring[LA ? DMAX * RW : 1];
+  __shared__ double fsb[DMAX < 64 ? DMAX : 64];
   const uint32_t D = lay.D, L = lay.L;
   const uint32_t u = u0 + blockIdx.x;
   const int T = (int)bv.T[u];
@@ -1065,14 +1127,20 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
   const uint64_t gf0 = bv.frame_off[u];
   double* ESu = ES + s_base * L + oc;
   const double* smu = smax + s_base;
-  double* Zu = Z + f_base * (uint64_t)(5 * L) + oc;
+  const size_t zs = (size_t)(LA ? 6 : 5) * L;
+  double* Zu = Z + f_base * (uint64_t)zs + oc;
   const double Zx = zx[u];
   const double LN_MAX = 709.782712893384;
   LzWin<0, DMAX> w0; LzWin<1, DMAX> w1; LzWin<2, DMAX> w2; LzWin<3, DMAX> w3; LzWin<4, DMAX> w4;
   w0.clear(); w1.clear(); w2.clear(); w3.clear(); w4.clear();
-  const size_t zs = (size_t)5 * L;
+  const uint32_t rl = lane < (uint32_t)RW ? lane : RW - 1;   // ring column (lanes past RW are never active)
+  const bool rw_ok = lane < (uint32_t)RW;
+  if (LA) {
+#pragma unroll
+    for (int j = 0; j < DMAX; j++) if (rw_ok) zring[j * RW + lane] = 0.0;
+  }
   int err = 0;
-  int slot = 0;   // ring slot that will receive p[t]
+  int slot = 0;   // ring slot that will receive p[t] (= t mod D)
 #pragma unroll 1
   for (int t = 0; t < T; t++) {
     const uint32_t nd = scrf_node_max_dur((uint32_t)t, D), np = scrf_num_prev((uint32_t)t, D);
@@ -1090,7 +1158,7 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
         x = ((lane < np) ? o_.gp[f_base + t - 1 - lane] : 0.0) + smu[row0 + lane] + o_.gb[f_base + t] - Zx;
         if (x >= LN_MAX) err = SCRF_ERR_NUMERIC;
       }
-      fsb[lane] = (lane < nd) ? exp(x) : 0.0;
+      if (lane < (DMAX < 64 ? DMAX : 64)) fsb[lane] = (lane < nd) ? exp(x) : 0.0;
     }
     const uint32_t lab = bv.labels ? bv.labels[gf0 + t] : SCRF_LAB_BAD;
     uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD;
@@ -1104,7 +1172,7 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
     for (int d0 = 0; d0 < DMAX; d0++) {
       int ps = slot - 1 - d0;            // ring slot of p[t-1-d0]
       if (ps < 0) ps += (int)D;
-      const double pv = ((uint32_t)d0 < np) ? pring[(((uint32_t)d0 < np) ? ps : 0) * 64 + lane] : 1.0;
+      const double pv = ((uint32_t)d0 < np) ? pring[(((uint32_t)d0 < np) ? ps : 0) * RW + rl] : 1.0;
       const double g = (pv * r[d0]) * (b * fsb[d0]);
       const double y = (o == al && (uint32_t)d0 + 1 == ld) ? 1.0 : 0.0;
       const double rv = ((uint32_t)d0 < nd) ? y - g : 0.0;
@@ -1119,6 +1187,25 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
         else atomicAdd(&mass_s[f_base + t], m);   // L > 64: one partial sum per 64 outputs (buffer zeroed by the caller)
       }
     }
+    if (LA) {
+      // u runs over the suffix sums (durations descending); slot of frame t - d0 = (slot - d0) mod D
+      double usum = 0.0;
+#pragma unroll
+      for (int d0 = DMAX - 1; d0 >= 0; d0--) {
+        if ((uint32_t)d0 >= D) continue;
+        usum = fma(r[d0], 1.0 / (double)(d0 + 1), usum);   // r is 0 past the node's durations
+        int zsl = slot - d0;
+        if (zsl < 0) zsl += (int)D;
+        // LDS atomic without return (ds_add_f64): no read-add-write round trip in the frame's dependent chain; one
+        // wavefront owns the ring, so the additions still happen in program order
+        if (rw_ok) __hip_atomic_fetch_add(&zring[zsl * RW + lane], usum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      // frame t - D + 1 has seen its last window
+      int zf = slot + 1 == (int)D ? 0 : slot + 1;
+      const double zv = zring[zf * RW + rl];
+      if (act && t + 1 >= (int)D) __builtin_nontemporal_store(zv, &Zu[(size_t)(t + 1 - (int)D) * zs + 5 * (size_t)L]);
+      if (rw_ok) zring[zf * RW + lane] = 0.0;
+    }
     w0.add(r); w1.add(r); w2.add(r); w3.add(r); w4.add(r);
     if (act) {
       w0.retire(Zu, t, zs);
@@ -1130,7 +1217,7 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
       w0.retire(Zu, -1000000, zs); w1.retire(Zu, -1000000, zs); w2.retire(Zu, -1000000, zs);
       w3.retire(Zu, -1000000, zs); w4.retire(Zu, -1000000, zs);
     }
-    pring[slot * 64 + lane] = pnew;
+    if (rw_ok) pring[slot * RW + lane] = pnew;
     slot = (slot + 1 == (int)D) ? 0 : slot + 1;
     if (lane == 0 && blockIdx.y == 0) {
       double nodeLi = 0.0;
@@ -1154,6 +1241,13 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
     w2.flush(Zu + 2 * (size_t)L, T, zs);
     w3.flush(Zu + 3 * (size_t)L, T, zs);
     w4.flush(Zu + 4 * (size_t)L, T, zs);
+    if (LA) {
+      // frames T - D + 1 .. T - 1 are still open in the ring
+      for (int j = 1; j < (int)D && j <= T; j++) {
+        const int f = T - j;
+        Zu[(size_t)f * zs + 5 * (size_t)L] = zring[(f % (int)D) * RW + rl];
+      }
+    }
   }
   if (__any(err != 0) && lane == 0) atomicMax(&status[u], err > 0 ? err : SCRF_ERR_NUMERIC);
 }
@@ -1161,16 +1255,23 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
                    const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,
-                   double* mass_s) {
+                   double* mass_s, int la) {
   if (n_utts == 0) return;
   dim3 grid(n_utts, (lay.L + 63) / 64);
-#define PZ_GO(N) hipLaunchKernelGGL(k_post_z<N>, grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z, mass_s)
+#define PZ_GO3(N, A, R) hipLaunchKernelGGL((k_post_z<N, A, R>), grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z, mass_s)
+#define PZ_GO(N)                                              \
+  do {                                                        \
+    if (la && lay.L <= 48) PZ_GO3(N, 1, 48);                  \
+    else if (la) PZ_GO3(N, 1, 64);                            \
+    else PZ_GO3(N, 0, 64);                                    \
+  } while (0)
   if (lay.D <= 8) PZ_GO(8);
   else if (lay.D <= 16) PZ_GO(16);
   else if (lay.D <= 25) PZ_GO(25);
   else if (lay.D <= 32) PZ_GO(32);
   else PZ_GO(40);
 #undef PZ_GO
+#undef PZ_GO3
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1437,16 +1538,26 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
 // one-hot and bias columns -- and the two halves meet at ONE barrier per tile.
 // LDS: 2 x ([76+1][xs] floats + [76][48] doubles) = 147 KB at config 2.
 // ------------------------------------------------------------------------------------------
+// Round 4: the one-hot duration and bias columns are no longer multiplied.  Their counts are plain sums of R over the
+// rows of one duration, sum_t R[(t, d)][o]: producer thread (output ol, slot ds) reads the finished R image of the tile
+// the consumers are working on and keeps the sums of the durations ds + 1, ds + 6, ... in registers for the whole launch
+// (15 LDS reads per tile at config 2) -- an exact re-association, and 26 of the 143 dense columns less for the MFMAs.
+// G0 = first dense group: 0 = [avg | max | min], 1 = [max | min] (SCRF_PREC_FASTLIN: the average goes through Z_avg).
+// Outputs: slab[block][o][(3 - G0) W] and dslab[block][o][D + bias].
 #define FW_NT 512
-template <int NT, int DMAX, int NKS>
+#define FW_DSL 5        // duration slots: producer threads 0..239 = (ol = ptid % 48, ds = ptid / 48)
+// ROWS = window rows per tile (76, or 100 where the two image pairs still fit 160 KB: fewer tiles, fewer barriers and
+// producer round trips per row); NKS = ceil(rows used / 4).
+template <int NT, int DMAX, int NKS, int G0, int ROWS>
 __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R,
                                                             uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
-                                                            double* __restrict__ slab) {
+                                                            double* __restrict__ slab, double* __restrict__ dslab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const uint32_t W = fa.W, D = lay.D;
-  constexpr uint32_t xs = (NT == 4 ? 5 : NT == 7 ? 9 : 13) * 16;
-  constexpr uint32_t XB = (FE_ROWS + 1) * xs;   // floats per column image (row FE_ROWS: dump row)
-  constexpr uint32_t RB = FE_ROWS * FE_RS;      // doubles per R image
+  constexpr uint32_t xs = (NT == 4 ? 5 : NT <= 7 ? 9 : 13) * 16;
+  constexpr uint32_t XB = (ROWS + 1) * xs;   // floats per column image (row ROWS: dump row)
+  constexpr uint32_t RB = ROWS * FE_RS;
+  constexpr int NRP = (ROWS * 48 + 255) / 256;   // R elements per producer thread      // doubles per R image
   float* Xs0 = (float*)fsm;                     // [2][XB]
   double* Rs0 = (double*)(Xs0 + 2 * XB);        // [2][RB]
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1454,7 +1565,7 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
   const bool producer = wave >= 4;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t o0 = blockIdx.y * 48;
-  const uint32_t ncol = 3 * W + D + (lay.use_sb ? 1 : 0);
+  const uint32_t ncol = (3 - G0) * W;
   const uint32_t n_ot = 3 * n_ct;
   for (uint32_t i = tid; i < 2 * XB; i += FW_NT) Xs0[i] = 0.0f;
   for (uint32_t i = tid; i < 2 * RB; i += FW_NT) Rs0[i] = 0.0;
@@ -1469,9 +1580,28 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
   // ---- producer state
   const uint32_t ptid = tid - 256;
   const uint32_t mW = fu_magic(W);
-  uint32_t dur_prev0 = 0, dur_prev1 = 0;   // producer thread ptid < nrows: the one-hot column set in row ptid of image 0 / 1
   ScrfTileDesc dn;                         // descriptor of the tile the producers build next
   if (producer && first < n_tiles) dn = fa.tiles[fa.tile0 + first];
+  // per-duration sums of R (one-hot duration counts): durations dsl + 1 + FW_DSL q of output o0 + dol
+  constexpr int NDA = (DMAX + FW_DSL - 1) / FW_DSL;
+  double da[NDA];
+#pragma unroll
+  for (int q = 0; q < NDA; q++) da[q] = 0.0;
+  const uint32_t dol = ptid % 48, dsl = ptid / 48;
+  uint32_t ct0 = 0, cnfr = 0, cr0 = 0;     // frames and first row of the tile whose images the consumers hold
+  auto dur_sums = [&](uint32_t buf) {
+    if (ptid >= 48 * FW_DSL) return;
+    const double* Rs = Rs0 + buf * RB + dol;
+    for (uint32_t tl = 0; tl < cnfr; tl++) {
+      const uint32_t t = ct0 + tl, nd = scrf_node_max_dur(t, D);
+      const double* Rt = Rs + ((uint32_t)scrf_seg_base(t, D) - cr0) * FE_RS;
+#pragma unroll
+      for (int q = 0; q < NDA; q++) {
+        const uint32_t d0 = dsl + FW_DSL * q;
+        if (d0 < nd) da[q] += Rt[d0 * FE_RS];
+      }
+    }
+  };
   auto build = [&](uint32_t buf, uint64_t tile_next) {
     // fills image pair `buf` with the tile whose descriptor sits in dn; then fetches tile_next's descriptor
     float* Xs = Xs0 + buf * XB;
@@ -1490,26 +1620,13 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
       asm volatile("" : "+v"(ti));   // a vector load: a scalar one would wait with the LDS traffic below
       dn = fa.tiles[ti];
     }
-    double rp[FE_NRP];
+    double rp[NRP];
 #pragma unroll
-    for (int q = 0; q < FE_NRP; q++) {
+    for (int q = 0; q < NRP; q++) {
       const uint32_t e = ptid + 256 * q, row = e / 48, ol = e % 48;
       const double* Rt = R + ft.row0 * n_out + o0;   // uniform base, 32-bit lane offset
       const uint32_t offb = (row * n_out + ol) * 8u;
       rp[q] = (row < ft.nrows && o0 + ol < n_out) ? __builtin_nontemporal_load((const double*)((const char*)Rt + offb)) : 0.0;
-    }
-    // the rows' one-hot duration and bias columns (per image: each keeps what it set last time)
-    if (ptid < ft.nrows) {
-      const uint32_t r = ft.r0 + ptid;
-      uint32_t t = ft.t0;
-      while ((uint32_t)scrf_seg_base(t + 1, D) <= r) t++;
-      const uint32_t d = r - (uint32_t)scrf_seg_base(t, D) + 1;
-      float* xr = Xs + ptid * xs + 3 * W;
-      const uint32_t dp = buf ? dur_prev1 : dur_prev0;
-      if (dp) xr[dp - 1] = 0.0f;
-      xr[d - 1] = 1.0f;
-      if (buf) dur_prev1 = d; else dur_prev0 = d;
-      if (lay.use_sb) xr[D] = 1.0f;
     }
     // avg | max | min: task = (statistic, frame, column), values straight from the raw frames in memory.  A thread
     // takes tasks ptid and ptid + 256 together: both tasks' loads are in flight at once (one memory round trip per
@@ -1519,21 +1636,23 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
       const float* gfr = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
       const uint32_t nfW = ft.nfr * W, mfW = fu_magic(nfW);
       const bool full = FU_FULLSCAN && D == (uint32_t)DMAX && ft.t0 + 1 >= D;
-      float* dump = Xs + FE_ROWS * xs;
+      float* dump = Xs + ROWS * xs;
+      // st = statistic (0 avg, 1 max, 2 min); its columns start at (st - G0) W
       auto decode = [&](uint32_t i, uint32_t& st, uint32_t& tl, uint32_t& c) {
-        st = fu_div(i, mfW);
-        const uint32_t rem = i - st * nfW;
+        const uint32_t g = fu_div(i, mfW);
+        st = g + G0;
+        const uint32_t rem = i - g * nfW;
         tl = fu_div(rem, mW);
         c = rem - tl * W;
       };
       auto scan_full = [&](const float (&v)[DMAX], uint32_t st, float* o) {
-        if (st == 0) fu_scan_avg_full<DMAX, xs>(v, o);
+        if (G0 == 0 && st == 0) fu_scan_avg_full<DMAX, xs>(v, o);
         else if (st == 1) fu_scan_ext_full<DMAX, 1, xs>(v, o);
         else fu_scan_ext_full<DMAX, 0, xs>(v, o);
       };
-      for (uint32_t i0 = ptid; i0 < 3 * nfW; i0 += 512) {
+      for (uint32_t i0 = ptid; i0 < (3 - G0) * nfW; i0 += 512) {
         const uint32_t i1 = i0 + 256;
-        const bool two = i1 < 3 * nfW;
+        const bool two = i1 < (3 - G0) * nfW;
         uint32_t st0, tl0, c0, st1, tl1, c1;
         decode(i0, st0, tl0, c0);
         decode(two ? i1 : i0, st1, tl1, c1);
@@ -1541,8 +1660,8 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
           float v0[DMAX], v1[DMAX];
           fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl0 - ft.f0) * W + c0, W, v0);
           fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl1 - ft.f0) * W + c1, W, v1);
-          scan_full(v0, st0, Xs + tl0 * (DMAX * xs) + st0 * W + c0);
-          if (two) scan_full(v1, st1, Xs + tl1 * (DMAX * xs) + st1 * W + c1);
+          scan_full(v0, st0, Xs + tl0 * (DMAX * xs) + (st0 - G0) * W + c0);
+          if (two) scan_full(v1, st1, Xs + tl1 * (DMAX * xs) + (st1 - G0) * W + c1);
         } else {
           for (int h = 0; h < (two ? 2 : 1); h++) {
             const uint32_t st = h ? st1 : st0, tl = h ? tl1 : tl0, c = h ? c1 : c0;
@@ -1554,9 +1673,9 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
             const uint32_t d_lo = lbase < 0 ? (uint32_t)(1 - lbase) : 1u;
             const uint32_t d_hi = min(nd, (uint32_t)((int32_t)ft.nrows - lbase));
             fu_load_vals<DMAX>(gfr + at, W, nd, v);
-            float* o = Xs + lbase * (int32_t)xs + st * W + c;
-            float* dmp = dump + st * W + c;
-            if (st == 0) fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dmp);
+            float* o = Xs + lbase * (int32_t)xs + (st - G0) * W + c;
+            float* dmp = dump + (st - G0) * W + c;
+            if (G0 == 0 && st == 0) fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dmp);
             else if (st == 1) fu_scan_ext<DMAX, 1>(v, o, xs, d_lo, d_hi, dmp);
             else fu_scan_ext<DMAX, 0>(v, o, xs, d_lo, d_hi, dmp);
           }
@@ -1564,16 +1683,18 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
       }
     }
 #pragma unroll
-    for (int q = 0; q < FE_NRP; q++) {
+    for (int q = 0; q < NRP; q++) {
       const uint32_t e = ptid + 256 * q, row = e / 48, ol = e % 48;
-      if (row < FE_ROWS) Rs[row * FE_RS + ol] = rp[q];
+      if (row < ROWS) Rs[row * FE_RS + ol] = rp[q];
     }
+    return ft;
   };
 
   __syncthreads();   // the cleared images
+  uint32_t nt0 = 0, nnfr = 0, nr0 = 0;     // the tile built last (becomes the consumers' tile at the next barrier)
   if (producer) {
     FU_SETPRIO(1);
-    if (first < n_tiles) build(0, first + G);
+    if (first < n_tiles) { const FuTile b0 = build(0, first + G); nt0 = b0.t0; nnfr = b0.nfr; nr0 = b0.r0; }
   }
   __syncthreads();
   uint32_t k = 0;
@@ -1589,7 +1710,9 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
     if (threadIdx.x == 0) atomicAdd(&fu_prof[14], 1ull);
 #endif
     if (producer) {
-      if (FU_ABL != 4 && tile + G < n_tiles) build(cur ^ 1, tile + 2 * G);
+      ct0 = nt0; cnfr = nnfr; cr0 = nr0;
+      dur_sums(cur);
+      if (FU_ABL != 4 && tile + G < n_tiles) { const FuTile bn = build(cur ^ 1, tile + 2 * G); nt0 = bn.t0; nnfr = bn.nfr; nr0 = bn.r0; }
       FW_STAMP(256, 8);    // producers: building the next tile's images
     } else {
       if (FU_ABL != 3) fe_mfma_tile<NT, 0, xs, NKS>(Rs0 + cur * RB, Xs0 + cur * XB, wave, lk, li, n_ot, acc, acc32_unused);
@@ -1599,29 +1722,56 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
     FW_STAMP(256, 9);      // producers: waiting at the barrier
     FW_STAMP(0, 11);       // consumers: waiting at the barrier
   }
-  if (producer) return;
-  // slab[blockIdx.x][o][f]
-  double* out = slab + (uint64_t)blockIdx.x * n_out * ncol;
+  // dslab[blockIdx.x][o][d0]; the bias count is the sum over the durations (in duration order) times the bias value
+  const uint32_t nd1 = D + (lay.use_sb ? 1 : 0);
+  double* dout = dslab + (uint64_t)blockIdx.x * n_out * nd1;
+  double* dl = Rs0;   // [D][48], over the dead R images (the loop's last barrier is behind every wavefront)
+  if (producer) {
+    if (ptid < 48 * FW_DSL) {
 #pragma unroll
-  for (int j = 0; j < NT; j++) {
-    const uint32_t q = wave + 4 * j;
-    if (q >= n_ot) continue;
-    const uint32_t n = q % 3, ct = q / 3;
-    const uint32_t f = ct * 16 + li;
-    if (f >= ncol) continue;
-    const double sc = (lay.use_sb && f == 3 * W + D) ? lay.sbv : 1.0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint32_t o = o0 + n * 16 + lk + 4 * r;
-      if (o >= n_out) continue;
-      out[(uint64_t)o * ncol + f] = acc[j][r] * sc;
+      for (int q = 0; q < NDA; q++) {
+        const uint32_t d0 = dsl + FW_DSL * q;
+        if (d0 < D) {
+          dl[d0 * 48 + dol] = da[q];
+          if (o0 + dol < n_out) dout[(uint64_t)(o0 + dol) * nd1 + d0] = da[q];
+        }
+      }
     }
+  } else {
+    // slab[blockIdx.x][o][f]
+    double* out = slab + (uint64_t)blockIdx.x * n_out * ncol;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const uint32_t q = wave + 4 * j;
+      if (q >= n_ot) continue;
+      const uint32_t n = q % 3, ct = q / 3;
+      const uint32_t f = ct * 16 + li;
+      if (f >= ncol) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t o = o0 + n * 16 + lk + 4 * r;
+        if (o >= n_out) continue;
+        out[(uint64_t)o * ncol + f] = acc[j][r];
+      }
+    }
+  }
+  __syncthreads();
+  if (producer && lay.use_sb && ptid < 48 && o0 + ptid < n_out) {
+    double bsum = 0.0;
+    for (uint32_t d0 = 0; d0 < D; d0++) bsum += dl[d0 * 48 + ptid];
+    dout[(uint64_t)(o0 + ptid) * nd1 + D] = bsum * lay.sbv;
   }
 }
 
 // column tiles needed, and the row stride of the kernel instantiation that serves them (NCT * 16)
 static uint32_t fused_expf_xs(const ScrfLayout& lay, uint32_t W, uint32_t* n_ct) {
   const uint32_t ncol = 3 * W + lay.D + (lay.use_sb ? 1 : 0);
+  *n_ct = (ncol + 15) / 16;
+  return (*n_ct <= 5 ? 5 : *n_ct <= 9 ? 9 : 13) * 16;
+}
+// the wave-specialised kernel: dense groups only (g0 = 1: without the average)
+static uint32_t fused_expf_ws_xs(uint32_t W, int g0, uint32_t* n_ct) {
+  const uint32_t ncol = (3 - g0) * W;
   *n_ct = (ncol + 15) / 16;
   return (*n_ct <= 5 ? 5 : *n_ct <= 9 ? 9 : 13) * 16;
 }
@@ -1652,50 +1802,73 @@ int fused_supported(const ScrfLayout& lay, uint32_t W) {
 }
 
 // the wave-specialised kernel (one 512-thread workgroup per CU, two image pairs in LDS) serves the fp64 form whenever
-// its LDS fits; SCRF_EXPF_WS=0 switches it off (A/B measurements)
-static size_t fused_expf_ws_smem(const ScrfLayout& lay, uint32_t W) {
+// its LDS fits; SCRF_EXPF_WS=0 switches it off (A/B measurements).  Rows per tile: 100 when g0 = 1 and the narrower
+// column image lets two pairs of that height into 160 KB (its own tile list, built with the batch), else 76.
+#define FW_ROWS_BIG 100
+static size_t fused_expf_ws_smem_rows(uint32_t W, int g0, uint32_t rows) {
   uint32_t n_ct;
-  const uint32_t xs = fused_expf_xs(lay, W, &n_ct);
-  return 2 * (sizeof(float) * (FE_ROWS + 1) * xs + sizeof(double) * FE_ROWS * FE_RS);
+  const uint32_t xs = fused_expf_ws_xs(W, g0, &n_ct);
+  return 2 * (sizeof(float) * (rows + 1) * xs + sizeof(double) * rows * FE_RS);
 }
-static bool fused_expf_ws(const ScrfLayout& lay, uint32_t W, int f32) {
+static uint32_t fused_expf_ws_rows(uint32_t W, int g0) {
+  static const bool big = !(getenv("SCRF_EXPF_BIG") && atoi(getenv("SCRF_EXPF_BIG")) == 0);
+  uint32_t n_ct;
+  fused_expf_ws_xs(W, g0, &n_ct);
+  return (big && g0 == 1 && n_ct <= 5 && fused_expf_ws_smem_rows(W, g0, FW_ROWS_BIG) <= 160 * 1024) ? FW_ROWS_BIG : FE_ROWS;
+}
+static size_t fused_expf_ws_smem(uint32_t W, int g0) { return fused_expf_ws_smem_rows(W, g0, fused_expf_ws_rows(W, g0)); }
+static bool fused_expf_ws(const ScrfLayout& lay, uint32_t W, int f32, int g0) {
   static const bool on = !(getenv("SCRF_EXPF_WS") && atoi(getenv("SCRF_EXPF_WS")) == 0);
-  return on && !f32 && fused_expf_ws_smem(lay, W) <= 160 * 1024;
+  uint32_t n_ct;
+  fused_expf_ws_xs(W, g0, &n_ct);
+  return on && !f32 && n_ct <= 13 && fused_expf_ws_smem(W, g0) <= 160 * 1024;
 }
-uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles) {
+// SCRF_PREC_FASTLIN needs the wave-specialised count kernel (the only one without the avg group) and one 64-output
+// group in k_post_z; other shapes run the FAST kernels (the reference's float average) under that precision
+int fused_la_supported(const ScrfLayout& lay, uint32_t W) {
+  return fused_supported(lay, W) && lay.L <= 64 && pframe_supported(W) && fused_expf_ws(lay, W, 0, 1);
+}
+// layout of the count slabs: {dense columns, first dense group, separate duration slab?}, the tile list and its height
+ScrfFusedExpfPlan fused_expf_plan(const ScrfLayout& lay, uint32_t W, int f32, int la) {
+  ScrfFusedExpfPlan p;
+  p.ws = fused_expf_ws(lay, W, f32, la ? 1 : 0) ? 1 : 0;
+  p.g0 = (p.ws && la) ? 1 : 0;
+  p.ncol = p.ws ? (3 - p.g0) * W : 3 * W + lay.D + (lay.use_sb ? 1 : 0);
+  p.ndur = p.ws ? lay.D + (lay.use_sb ? 1 : 0) : 0;
+  p.rows = p.ws ? fused_expf_ws_rows(W, p.g0) : FE_ROWS;
+  p.tile_list = p.rows == FE_ROWS ? 1 : 2;
+  p.frames = lay.D >= p.rows ? 1u : p.rows / lay.D;
+  return p;
+}
+uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles, int la) {
   static const uint32_t nb = getenv("SCRF_EXPF_BLOCKS") ? (uint32_t)atoi(getenv("SCRF_EXPF_BLOCKS")) : 512u;  // experiment knob (<= 512)
-  const uint32_t cap = fused_expf_ws(lay, W, f32) ? std::min(nb, 256u) : nb;   // one workgroup per CU there
+  const uint32_t cap = fused_expf_ws(lay, W, f32, la ? 1 : 0) ? std::min(nb, 256u) : nb;   // one workgroup per CU there
   return (uint32_t)(n_tiles < cap ? n_tiles : cap);
+}
+
+template <int NT, int DMAX, int NKS, int G0, int ROWS>
+static void launch_expf_ws_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R, uint64_t n_tiles,
+                             uint32_t n_ct, double* slab, double* dslab) {
+  dim3 grid(fused_expf_blocks(lay, fa.W, 0, n_tiles, G0), (lay.L + 47) / 48);
+  const size_t smw = fused_expf_ws_smem_rows(fa.W, G0, ROWS);
+  hipFuncSetAttribute((const void*)k_expf_fused_ws<NT, DMAX, NKS, G0, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
+  hipLaunchKernelGGL((k_expf_fused_ws<NT, DMAX, NKS, G0, ROWS>), grid, dim3(FW_NT), smw, st, fa, lay, R, lay.L, n_tiles, n_ct, slab, dslab);
 }
 
 template <int NT, int DMAX, int F32, int NKS>
 static void launch_expf_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                                 uint64_t n_tiles, uint32_t n_ct, size_t sm, double* slab) {
-  dim3 grid(fused_expf_blocks(lay, fa.W, F32, n_tiles), (lay.L + 47) / 48);
-  if (!F32 && fused_expf_ws(lay, fa.W, F32)) {
-    const size_t smw = fused_expf_ws_smem(lay, fa.W);
-    hipFuncSetAttribute((const void*)k_expf_fused_ws<NT, DMAX, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
-    hipLaunchKernelGGL((k_expf_fused_ws<NT, DMAX, NKS>), grid, dim3(FW_NT), smw, st, fa, lay, R, lay.L, n_tiles, n_ct, slab);
-    return;
-  }
+  dim3 grid(fused_expf_blocks(lay, fa.W, F32, n_tiles, 0), (lay.L + 47) / 48);
   hipFuncSetAttribute((const void*)k_expf_fused<NT, DMAX, F32, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL((k_expf_fused<NT, DMAX, F32, NKS>), grid, dim3(FE_NT), sm, st, fa, lay, R, lay.L, n_tiles, n_ct,
                      fused_expf_nfmax(lay.D), slab);
 }
 
-// slab: [fused_expf_blocks(n_tiles)][L][3W + D + bias]
+// slab: [fused_expf_blocks(n_tiles)][L][plan.ncol]; dslab (plan.ndur > 0): [blocks][L][D + bias]
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
-                       uint64_t n_tiles, double* slab, int f32) {
+                       uint64_t n_tiles, double* slab, double* dslab, int f32, int la) {
   if (n_tiles == 0) return;
-  uint32_t n_ct;
-  fused_expf_xs(lay, fa.W, &n_ct);
-  const size_t sm = fused_expf_smem(lay, fa.W);
   const uint32_t nks = fused_expf_nks(lay.D);
-#define FE_GO3(N, DM, KS)                                                                             \
-  do {                                                                                                \
-    if (f32) launch_expf_fused_t<N, DM, 1, KS>(st, fa, lay, R, n_tiles, n_ct, sm, slab);              \
-    else launch_expf_fused_t<N, DM, 0, KS>(st, fa, lay, R, n_tiles, n_ct, sm, slab);                  \
-  } while (0)
   // the depths that occur per duration class: D <= 12 always fills more than 64 rows, 13..25 never stops at 52
 #define FE_GO(N)                                                   \
   do {                                                             \
@@ -1707,6 +1880,45 @@ void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout
       else if (nks == 16) FE_GO3(N, 40, 16);                       \
       else FE_GO3(N, 40, 19);                                      \
     }                                                              \
+  } while (0)
+  const ScrfFusedExpfPlan plan = fused_expf_plan(lay, fa.W, f32, la);
+  if (plan.ws) {
+    uint32_t n_ct;
+    fused_expf_ws_xs(fa.W, plan.g0, &n_ct);
+    if (plan.rows == FW_ROWS_BIG) {
+      // 100-row tiles (g0 = 1, n_ct <= 5): k-steps = ceil(frames * D / 4) rounded up to 21 or 25
+      const uint32_t used = plan.frames * lay.D;
+#define FB_GO(DM)                                                                                                 \
+  do {                                                                                                            \
+    if (used <= 84) launch_expf_ws_t<4, DM, 21, 1, FW_ROWS_BIG>(st, fa, lay, R, n_tiles, n_ct, slab, dslab);      \
+    else launch_expf_ws_t<4, DM, 25, 1, FW_ROWS_BIG>(st, fa, lay, R, n_tiles, n_ct, slab, dslab);                 \
+  } while (0)
+      if (lay.D <= 12) FB_GO(12);
+      else if (lay.D <= 25) FB_GO(25);
+      else FB_GO(40);
+#undef FB_GO
+      return;
+    }
+#define FE_GO3(N, DM, KS)                                                                                   \
+  do {                                                                                                      \
+    if (plan.g0) launch_expf_ws_t<N, DM, KS, 1, FE_ROWS>(st, fa, lay, R, n_tiles, n_ct, slab, dslab);       \
+    else launch_expf_ws_t<N, DM, KS, 0, FE_ROWS>(st, fa, lay, R, n_tiles, n_ct, slab, dslab);               \
+  } while (0)
+    // slots per consumer wavefront = ceil(3 n_ct / 4)
+    if (n_ct <= 5) FE_GO(4);
+    else if (n_ct <= 8) FE_GO(6);
+    else if (n_ct <= 9) FE_GO(7);
+    else FE_GO(10);
+#undef FE_GO3
+    return;
+  }
+  uint32_t n_ct;
+  fused_expf_xs(lay, fa.W, &n_ct);
+  const size_t sm = fused_expf_smem(lay, fa.W);
+#define FE_GO3(N, DM, KS)                                                                             \
+  do {                                                                                                \
+    if (f32) launch_expf_fused_t<N, DM, 1, KS>(st, fa, lay, R, n_tiles, n_ct, sm, slab);              \
+    else launch_expf_fused_t<N, DM, 0, KS>(st, fa, lay, R, n_tiles, n_ct, sm, slab);                  \
   } while (0)
   if (n_ct <= 5) FE_GO(4);
   else if (n_ct <= 9) FE_GO(7);

@@ -118,10 +118,20 @@ uint32_t fused_scores_tb(uint32_t W, uint32_t D);   // whole frames per score ti
 #define SCRF_FUSED_ROWS_EXPF 76
 uint32_t fused_expf_frames(uint32_t D);            // whole frames per expected-count tile (<= 76 rows)
 int fused_supported(const ScrfLayout& lay, uint32_t W);
-uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles);   // workgroups (= slabs) of launch_expf_fused, <= 512
+// SCRF_PREC_FASTLIN (`la`): the window average leaves both dense contractions (prefix sums of a sixth per-frame
+// projection / a sixth group of Z); shapes this returns 0 for run the FAST kernels under that precision
+int fused_la_supported(const ScrfLayout& lay, uint32_t W);
+// slabs of the fused expected-count kernel: slab [blocks][L][ncol] (dense groups from g0: 0 avg, 1 max) and, when
+// ndur > 0, a separate duration slab [blocks][L][ndur] (one-hot duration counts + bias; wave-specialised kernel)
+// rows / frames: height of the row tiles the kernel walks (whole frames); tile_list: which of the batch's tile lists
+// describes them (1: <= 76 rows, 2: <= 100 rows, built only for batches of an SCRF_PREC_FASTLIN engine)
+struct ScrfFusedExpfPlan { int ws; int g0; uint32_t ncol; uint32_t ndur; uint32_t rows; uint32_t frames; int tile_list; };
+ScrfFusedExpfPlan fused_expf_plan(const ScrfLayout& lay, uint32_t W, int f32, int la);
+uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles, int la);   // workgroups (= slabs) of launch_expf_fused, <= 512
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                          const double* P, uint64_t n_tiles, double* S, int f32, double* smax = nullptr,
-                         double* s_true = nullptr, const uint32_t* labels = nullptr);
+                         double* s_true = nullptr, const uint32_t* labels = nullptr, int la = 0);
+void launch_avg_prefix(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint32_t L, double* P);
 // k_viterbi on float arc weights with one wavefront per utterance (fast decode; L <= 64, constant M)
 int viterbi_fast_supported(const ScrfLayout& lay);
 void launch_viterbi_fast(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const float* Wn,
@@ -145,9 +155,9 @@ void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
                    const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,
-                   double* mass_s);
+                   double* mass_s, int la = 0);
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
-                       uint64_t n_tiles, double* slab, int f32);
+                       uint64_t n_tiles, double* slab, double* dslab, int f32, int la);
 
 // ---- STDSEG (scrf_stdseg.hip): lay is the layout over FULL labels (lay.L = nLabs), La = nActualLabs
 void launch_stdseg_rowinfo(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,

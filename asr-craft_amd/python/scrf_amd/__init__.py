@@ -6,5 +6,5 @@ There is no CPU fallback: loading fails loudly if the library is missing, and en
 creation fails with SCRF_ERR_NO_DEVICE without a GPU.
 """
 from .engine import (LAB_BAD, STDFRAME, STDSEG, STDSEG_NO_DUR, STDSEG_NO_DUR_NO_SEGTRANSFTR, STDSEG_NO_DUR_NO_TRANSFTR,  # noqa: F401
-                     STDSTATE, STDTRANS, ARC_DTYPE, Batch, Engine, ScrfError, StreamRecipe, lib_path,
+                     STDSTATE, STDTRANS, PREC_EXACT, PREC_FAST, PREC_FAST32, PREC_FASTLIN, ARC_DTYPE, Batch, Engine, ScrfError, StreamRecipe, lib_path,
                      load_library, make_config, window_width)

@@ -9,7 +9,7 @@ PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # asr-craft_amd/
 LAB_BAD = 0xFFFFFFFF
 STDFRAME, STDSEG, STDSEG_NO_DUR, STDSEG_NO_DUR_NO_TRANSFTR, STDSEG_NO_DUR_NO_SEGTRANSFTR = range(5)
 STDSTATE, STDTRANS = 0, 1
-PREC_EXACT, PREC_FAST, PREC_FAST32 = 0, 1, 2
+PREC_EXACT, PREC_FAST, PREC_FAST32, PREC_FASTLIN = 0, 1, 2, 3
 ABI_VERSION = 1
 MAX_STREAMS = 3
 N_PHASES = 10
@@ -315,6 +315,12 @@ class Engine:
         f = C.c_int()
         self._chk(self.lib.scrf_batch_is_fused(self.h, batch.handle, C.byref(f)))
         return bool(f.value)
+
+    def batch_fused_mode(self, batch):
+        """0: materialised windows; 1: fused window synthesis; 2: fused with the linear window average (FASTLIN)."""
+        f = C.c_int()
+        self._chk(self.lib.scrf_batch_is_fused(self.h, batch.handle, C.byref(f)))
+        return f.value
 
     def decode_stats(self):
         """(arc weights recomputed in reference order, chunks sent back to the EXACT path) since create."""

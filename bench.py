@@ -152,8 +152,10 @@ def main():
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the collective path)")
-    ap.add_argument("--precision", choices=["exact", "fast", "fast32"], default="fast",
-                    help="exact: reference-order unfused fp64; fast: fp64 MFMA, window synthesis fused into the contractions; fast32: f32 MFMA contractions (opt-in)")
+    ap.add_argument("--precision", choices=["exact", "fast", "fast32", "fastlin"], default="fastlin",
+                    help="exact: reference-order unfused fp64; fast: fp64 MFMA, window synthesis fused into the contractions; "
+                         "fastlin (default): fast with the window average taken as the exact mean, which is linear in the frames and "
+                         "leaves the dense contractions (fp64 throughout; 3e-8 on the gradient, contract 1e-4); fast32: f32 MFMA contractions (opt-in)")
     ap.add_argument("--scratch-gib", type=int, default=96, help="device scratch budget per chunk of utterances")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-3 / config-5 steps after the timed region")
     args = ap.parse_args()
@@ -186,7 +188,7 @@ def main():
     # synthetic data of the config-2 shape; every rank owns a different contiguous utterance range
     frames, labels, off = synth.make_batch(U, T_FRAMES, IN_W, L, D, seed=1234 + 100003 * rank)
     cfg = scrf_amd.make_config(L=L, D=D, F=F, device_id=local_rank, scratch_bytes=args.scratch_gib << 30,
-                               precision={"exact": 0, "fast": 1, "fast32": 2}[args.precision])
+                               precision={"exact": 0, "fast": 1, "fast32": 2, "fastlin": 3}[args.precision])
     eng = scrf_amd.Engine(cfg)
     lam = synth.make_lambda(eng.lambda_len)
     eng.set_lambda(lam)
@@ -263,9 +265,17 @@ def main():
         # sampled blocks are re-associated into the per-frame contractions k_pframe / k_ztf.
         SL = 8.0 * nseg * L          # one pass over the [N_seg][L] fp64 array
         VL = 8.0 * nfr * L           # one [T][L] fp64 vector array
+        # fastlin: a sixth per-frame group (the average) in k_pframe / k_ztf / k_post_z, two dense groups (max, min)
+        # instead of three in the fused kernels; the wave-specialised count kernel (fast, fastlin) sums the one-hot
+        # duration and bias columns instead of multiplying them
+        la = args.precision == "fastlin"
+        NG = 6 if la else 5
+        GD = 2 if la else 3
+        expf_cols = GD * IN_W if args.precision in ("fast", "fastlin") else 3 * IN_W + D + 1
         work = {
-            "k_pframe": (2.0 * nfr * 5 * L * IN_W, 4.0 * nfr * IN_W + 5 * VL),
-            "k_scores_fused": (2.0 * nseg * L * 3 * IN_W, SL + 8.0 * nseg + 5 * VL + 4.0 * nfr * IN_W),
+            "k_pframe": (2.0 * nfr * NG * L * IN_W, 4.0 * nfr * IN_W + NG * VL),
+            "k_avg_prefix": (0.0, 2 * VL),
+            "k_scores_fused": (2.0 * nseg * L * GD * IN_W, SL + 8.0 * nseg + NG * VL + 4.0 * nfr * IN_W),
             "k_windows": (0.0, 4.0 * nseg * F),
             "k_scores_exact(state)": (0.0, 4.0 * nseg * F + SL),      # fp64 VALU, unfused: priced by bytes only
             "k_scores_mfma(state)": (2.0 * nseg * L * F, 4.0 * nseg * F + SL),
@@ -273,15 +283,15 @@ def main():
             "k_exp_rows": (0.0, 2 * SL),
             "k_dp_lin": (0.0, 2 * SL + 4 * VL),                         # ES read by both sweeps, 4 vectors written
             "k_dp_wave": (0.0, 3 * SL + 3 * VL),
-            "k_post_z": (0.0, 2 * SL + 5 * VL + 2 * VL),                # ES -> R in place, Z written, p and b read
+            "k_post_z": (0.0, 2 * SL + NG * VL + 2 * VL),               # ES -> R in place, Z written, p and b read
             "k_post_lin": (0.0, 2 * SL + 2 * VL),
             "k_post_state": (0.0, 2 * SL + VL),
             "k_lin_z": (0.0, SL + 5 * VL),
             "k_mass_check": (0.0, 2 * VL),
-            "k_expf_fused": (2.0 * nseg * L * (3 * IN_W + D + 1), SL + 4.0 * nfr * IN_W),
+            "k_expf_fused": (2.0 * nseg * L * expf_cols, SL + 4.0 * nfr * IN_W),
             "k_expf_mfma(state)": (2.0 * nseg * L * F, 4.0 * nseg * F + SL),
             "k_expf_gemm(state)": (0.0, 4.0 * nseg * F + SL),
-            "k_ztf": (2.0 * nfr * 5 * L * IN_W, 5 * VL + 4.0 * nfr * IN_W),
+            "k_ztf": (2.0 * nfr * NG * L * IN_W, NG * VL + 4.0 * nfr * IN_W),
             "reductions (k_reduce_slabs, k_atb, k_batch_sums)": (2.0 * nfr * L * L, 2 * VL),
         }
         kernels = []
@@ -311,12 +321,12 @@ def main():
         # HBM bytes of the dominant kernel from separate rocprofv3 --pmc passes (profiles/README.md); the file names the
         # kernel sources it was measured on, and a figure from other sources is not reported
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("kernels_sha16") != kernels_fingerprint():
-                traffic_note = "profiles/r03_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("kernels_sha16")
+                traffic_note = "profiles/r04_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("kernels_sha16")
             else:
                 ent = tj.get(args.precision, {}).get(dom["name"])
                 if ent:

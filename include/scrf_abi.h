@@ -79,8 +79,17 @@ enum scrf_map_type { SCRF_STDSTATE = 0, SCRF_STDTRANS = 1 };
  *          f32 as operands, scores sum in f32 over the feature axis, expected counts sum in f32
  *          inside 32/64-row chunks and in f64 across chunks.  The DP recursion, log-partition and
  *          posteriors stay f64.  Measured deviation <= ~1e-6 relative on gradients (contract 1e-4).
- *          Not the default of anything; opt-in. */
-enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FAST32 = 2 };
+ *          Not the default of anything; opt-in.
+ *  FASTLIN : FAST (fp64 throughout), except that the window AVERAGE of the segment recipe is taken as the exact
+ *          mean (sum of the frames / length, linear in the frames) instead of the reference's float arithmetic
+ *          (running float sum, float division: io/CRF_InFtrStream_SeqMultiWindow.cpp:609-646).  Linear means the
+ *          average no longer has to be rebuilt and multiplied per window: its score share is a difference of
+ *          prefix sums of one more per-frame projection, its expected counts one more per-frame sum -- a third
+ *          of the dense matrix work of the fused kernels less.  The feature values differ from the reference's
+ *          by their float rounding (<= 2^-24 relative per addition): measured 3e-8 relative on the gradient,
+ *          1e-12 on the log-partition (contract 1e-4).  What bench.py runs.  Batches the fused kernels do not
+ *          take (several streams, transition features, L > 64) run as FAST.  Decode never uses it. */
+enum scrf_precision { SCRF_PREC_EXACT = 0, SCRF_PREC_FAST = 1, SCRF_PREC_FAST32 = 2, SCRF_PREC_FASTLIN = 3 };
 
 /* Mirrors CRF_FeatureMap_config (ftrmaps/CRF_FeatureMap.h:24-47) plus the model fields
  * CRFTrain sets on CRF_Model (CRFTrain/src/Main.cpp:539-597). */

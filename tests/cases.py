@@ -29,11 +29,18 @@ class Case:
 
     def __init__(self, L, D, in_w, Ts, trans_ctx=None, seed=0, lam_scale=0.3, frame_model=False,
                  scratch_bytes=0, precision=0, l1_norm=False, model_type=None, trans_share=None,
-                 num_states=1, conform_labels=True):
+                 num_states=1, conform_labels=True, exact_avg=False):
         self.L, self.D, self.in_w, self.Ts = L, D, in_w, list(Ts)
         self.trans_ctx = trans_ctx
         rng = np.random.RandomState(seed)
         self.frames = [rng.random_sample((T, in_w)).astype(np.float32) for T in Ts]
+        if exact_avg:
+            # frame values m * lcm(1..D) / 2^k, m in 0..4: every running float sum over <= D frames and its quotient by
+            # the length is exact in float, so the reference's float window average IS the exact mean (D <= 10)
+            assert D <= 10
+            lcm = int(np.lcm.reduce(np.arange(1, D + 1)))
+            scale = 2.0 ** -int(np.ceil(np.log2(5 * lcm)))
+            self.frames = [(rng.randint(0, 5, (T, in_w)) * (lcm * scale)).astype(np.float32) for T in Ts]
         if l1_norm:   # rows L1-normalised like softmax posteriors (SURVEY 8d, config 3/4 inputs)
             self.frames = [(f / f.sum(1, keepdims=True)).astype(np.float32) for f in self.frames]
         if frame_model:

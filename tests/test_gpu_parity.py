@@ -134,6 +134,79 @@ def test_fb_batch_gradient_fast32_precision(ci):
     b.close(); eng.close()
 
 
+FASTLIN_SHAPES = [
+    dict(L=48, D=25, in_w=39, Ts=[300, 57, 24, 1]),     # config-2 shape, utterances shorter than D
+    dict(L=3, D=3, in_w=2, Ts=[1, 2, 3, 4, 7]),
+    dict(L=7, D=10, in_w=5, Ts=[9, 10, 11, 30]),
+    dict(L=64, D=12, in_w=20, Ts=[40, 5]),              # the widest label set the tier takes
+    dict(L=20, D=40, in_w=9, Ts=[100, 41, 39]),         # the longest duration
+    dict(L=33, D=7, in_w=45, Ts=[50]),                  # two column chunks per dense group, odd label count
+]
+
+
+@pytest.mark.parametrize("si", range(len(FASTLIN_SHAPES)))
+def test_fb_batch_gradient_fastlin_precision(si):
+    """FASTLIN (what bench.py runs): FAST with the window average taken as the exact mean -- linear in the frames, so it
+    leaves both dense contractions (prefix sums of a per-frame projection; a sixth per-frame sum of R).  The feature
+    values differ from the reference's float arithmetic by its rounding, so this is a tolerance of its own: 1e-6
+    relative on the gradient against the oracle (the reference's floats), contract 1e-4."""
+    c = Case(seed=700 + si, precision=scrf_amd.PREC_FASTLIN, **FASTLIN_SHAPES[si])
+    eng = c.engine(); b = c.batch(eng)
+    assert eng.batch_fused_mode(b) == 2
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-6 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-8 * np.abs(ozx).max()
+    err = np.abs(g - og).max() / np.abs(og).max()
+    assert err <= REL_CONTRACT and err <= 1e-6, err
+    # a second call accumulates the same gradient again (slabs, rings and prefix sums are rebuilt per call)
+    eng.fb_batch(b)
+    assert np.abs(eng.get_grad() - 2 * g).max() <= 1e-12 * np.abs(g).max()
+    # decode entry points stay EXACT whatever the training precision
+    So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(0), c.Ts[0])
+    S, M = eng.scores(b, 0, c.Ts[0])
+    assert np.array_equal(bits(S), bits(So)) and np.array_equal(bits(M), bits(Mo))
+    labs, cost = eng.viterbi_batch(b)
+    for u, T in enumerate(c.Ts):
+        So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(u), T)
+        oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, T)
+        ol, oc = orc.best_path(oa, ons, ofin)
+        assert list(labs[u]) == list(ol)
+    b.close(); eng.close()
+
+
+@pytest.mark.parametrize("shape", [dict(L=5, D=4, in_w=3, Ts=[1, 2, 3, 4, 5, 9, 30]), dict(L=48, D=10, in_w=39, Ts=[120, 9, 10, 11]),
+                                   dict(L=13, D=8, in_w=45, Ts=[70, 3])])
+def test_fastlin_is_fast_when_the_float_average_is_exact(shape):
+    """Frame values on a grid where every float running sum and its quotient by the window length are exact: the
+    reference's float average equals the exact mean, and FASTLIN has to agree with the oracle as tightly as FAST does
+    (1e-9) -- which pins the prefix-sum gather of the score kernel and the ring sums of k_post_z, edges included."""
+    c = Case(seed=810, precision=scrf_amd.PREC_FASTLIN, exact_avg=True, **shape)
+    eng = c.engine(); b = c.batch(eng)
+    assert eng.batch_fused_mode(b) == 2
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, onumer, ozx = c.oracle_gradient()
+    assert np.abs(numer - onumer).max() <= 1e-11 * max(1, np.abs(onumer).max())
+    assert np.abs(zx - ozx).max() <= 1e-11 * np.abs(ozx).max()
+    assert np.abs(g - og).max() / np.abs(og).max() <= 1e-9
+    b.close(); eng.close()
+
+
+def test_fastlin_falls_back_to_fast_where_its_kernels_do_not_apply():
+    """Transition features, several streams or L > 64: the batch runs the FAST kernels under FASTLIN (same contract)."""
+    for kw in (dict(L=70, D=3, in_w=4, Ts=[5, 9, 14]), dict(L=6, D=4, in_w=5, Ts=[9, 14], trans_ctx=1)):
+        c = Case(seed=820, precision=scrf_amd.PREC_FASTLIN, **kw)
+        eng = c.engine(); b = c.batch(eng)
+        assert eng.batch_fused_mode(b) in (0, 1)
+        numer, zx = eng.fb_batch(b)
+        og, on, oz = c.oracle_gradient()
+        assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
+        assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() <= 1e-9
+        b.close(); eng.close()
+
+
 FUSED_SHAPES = [
     dict(L=3, D=3, in_w=2, Ts=[1, 2, 3, 4, 7]),
     dict(L=50, D=5, in_w=45, Ts=[1, 13, 40, 77]),       # two output groups, two column chunks per group

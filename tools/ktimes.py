@@ -21,7 +21,7 @@ def main():
     L, D, IN_W, T = 48, 25, 39, 300
     frames, labels, off = synth.make_batch(args.utts, T, IN_W, L, D, seed=1234)
     cfg = scrf_amd.make_config(L=L, D=D, F=8 * IN_W + D, device_id=0, scratch_bytes=96 << 30,
-                               precision={"exact": 0, "fast": 1, "fast32": 2}[args.precision])
+                               precision={"exact": 0, "fast": 1, "fast32": 2, "fastlin": 3}[args.precision])
     eng = scrf_amd.Engine(cfg)
     eng.set_lambda(synth.make_lambda(eng.lambda_len))
     stream = torch.cuda.Stream()

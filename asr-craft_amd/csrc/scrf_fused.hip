@@ -249,7 +249,8 @@ __device__ __forceinline__ void fu_scan_ext_full(const float (&v)[DMAX], float* 
 #define FU_SETPRIO(p) do {} while (0)
 #endif
 #ifndef FU_ABL
-#define FU_ABL 0        // ablations (wrong results): 1 = no global loads in the P staging, 2 = nor in the frame staging
+#define FU_ABL 0        // ablations (wrong results): 1 = no global loads in the P staging, 2 = nor in the frame staging;
+                        // count kernel: 3 = no consumer MFMAs, 4 = no producer builds, 5 = no R loads, 6 = no window scans
 #endif
 #define FU_DS 50        // double row stride of the P image and of the duration-weight table: 25 16-byte slots, odd, so
                         // that the rows of consecutive frames / durations a ds_read_b128 lane group gathers start on
@@ -1602,7 +1603,7 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
       }
     }
   };
-  auto build = [&](uint32_t buf, uint64_t tile_next) {
+  auto build = [&](uint32_t buf, uint64_t tile_next, uint32_t sum_buf) {
     // fills image pair `buf` with the tile whose descriptor sits in dn; then fetches tile_next's descriptor
     float* Xs = Xs0 + buf * XB;
     double* Rs = Rs0 + buf * RB;
@@ -1626,8 +1627,10 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
       const uint32_t e = ptid + 256 * q, row = e / 48, ol = e % 48;
       const double* Rt = R + ft.row0 * n_out + o0;   // uniform base, 32-bit lane offset
       const uint32_t offb = (row * n_out + ol) * 8u;
-      rp[q] = (row < ft.nrows && o0 + ol < n_out) ? __builtin_nontemporal_load((const double*)((const char*)Rt + offb)) : 0.0;
+      rp[q] = (FU_ABL != 5 && row < ft.nrows && o0 + ol < n_out) ? __builtin_nontemporal_load((const double*)((const char*)Rt + offb)) : 0.0;
     }
+    // the duration sums of the tile the consumers hold run under the loads just requested
+    if (sum_buf < 2) dur_sums(sum_buf);
     // avg | max | min: task = (statistic, frame, column), values straight from the raw frames in memory.  A thread
     // takes tasks ptid and ptid + 256 together: both tasks' loads are in flight at once (one memory round trip per
     // tile instead of two).  (Interleaving the two scan chains by hand, so that the wave always has a second
@@ -1650,6 +1653,30 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
         else if (st == 1) fu_scan_ext_full<DMAX, 1, xs>(v, o);
         else fu_scan_ext_full<DMAX, 0, xs>(v, o);
       };
+      if (FU_ABL == 6) {
+      } else if (G0 == 1 && full) {
+        // max and min of a (frame, column) from ONE set of loads; the tile's nfr W tasks are dealt evenly to the four
+        // producer wavefronts (a 100-row tile has 156 of them: 39 lanes of every wavefront, one pass each, instead of
+        // 312 single-statistic tasks that gave the first wavefront two passes)
+        const uint32_t per = (nfW + 3) >> 2, pw = ptid >> 6, pl = ptid & 63;
+        for (uint32_t j = pl; j < per; j += 64) {
+          const uint32_t i = pw * per + j;
+          if (i < nfW) {
+            const uint32_t tl = fu_div(i, mW), c = i - tl * W;
+            float v[DMAX];
+            fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl - ft.f0) * W + c, W, v);
+            float* o = Xs + tl * (DMAX * xs) + c;
+            float amx = v[0], amn = v[0];
+#pragma unroll
+            for (int jj = 0; jj < DMAX; jj++) {
+              amx = fu_vmax(amx, v[jj]);
+              amn = fu_vmin(amn, v[jj]);
+              o[jj * xs] = amx;
+              o[jj * xs + W] = amn;
+            }
+          }
+        }
+      } else
       for (uint32_t i0 = ptid; i0 < (3 - G0) * nfW; i0 += 512) {
         const uint32_t i1 = i0 + 256;
         const bool two = i1 < (3 - G0) * nfW;
@@ -1694,7 +1721,7 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
   uint32_t nt0 = 0, nnfr = 0, nr0 = 0;     // the tile built last (becomes the consumers' tile at the next barrier)
   if (producer) {
     FU_SETPRIO(1);
-    if (first < n_tiles) { const FuTile b0 = build(0, first + G); nt0 = b0.t0; nnfr = b0.nfr; nr0 = b0.r0; }
+    if (first < n_tiles) { const FuTile b0 = build(0, first + G, 2); nt0 = b0.t0; nnfr = b0.nfr; nr0 = b0.r0; }
   }
   __syncthreads();
   uint32_t k = 0;
@@ -1711,8 +1738,8 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
 #endif
     if (producer) {
       ct0 = nt0; cnfr = nnfr; cr0 = nr0;
-      dur_sums(cur);
-      if (FU_ABL != 4 && tile + G < n_tiles) { const FuTile bn = build(cur ^ 1, tile + 2 * G); nt0 = bn.t0; nnfr = bn.nfr; nr0 = bn.r0; }
+      if (FU_ABL != 4 && tile + G < n_tiles) { const FuTile bn = build(cur ^ 1, tile + 2 * G, cur); nt0 = bn.t0; nnfr = bn.nfr; nr0 = bn.r0; }
+      else dur_sums(cur);
       FW_STAMP(256, 8);    // producers: building the next tile's images
     } else {
       if (FU_ABL != 3) fe_mfma_tile<NT, 0, xs, NKS>(Rs0 + cur * RB, Xs0 + cur * XB, wave, lk, li, n_ot, acc, acc32_unused);

@@ -43,10 +43,33 @@ def host_topology():
         return None
 
 
-def cpu_baseline(frames, labels, off, lam):
+def one_socket_cpus():
+    """One logical CPU per physical core of the socket this process may use most of (`lscpu -p`), restricted to the
+    CPUs this process is allowed on: the list the CPU baseline pins its workers to.  None if it cannot be read."""
+    import subprocess
+    try:
+        allowed = os.sched_getaffinity(0)
+        txt = subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, timeout=10).stdout
+        per = {}
+        for ln in txt.splitlines():
+            if ln.startswith("#") or not ln.strip():
+                continue
+            cpu, core, sock = (int(x) if x else 0 for x in ln.split(",")[:3])
+            if cpu in allowed:
+                per.setdefault(sock, {}).setdefault(core, cpu)   # first hardware thread of each core
+        if not per:
+            return None
+        best = max(per.values(), key=len)
+        return sorted(best.values())
+    except Exception:
+        return None
+
+
+def cpu_baseline(frames, labels, off, lam, cfg_kw=None, in_w=IN_W, frames2=None, in_w2=0, ctx2=0, utts_per_core=24):
     """The oracle (CPU restatement of the reference path, `port`) timed on this box's host cores
     over a bounded sample of the same workload: one worker thread per physical core of ONE socket,
-    capped by what this process may use.  Reported beside the GPU number, never shipped."""
+    each PINNED to its core and keeping its arrays across utterances as the reference's threads keep their node
+    vector (nodes/CRF_StateVector.cpp:37-67).  Reported beside the GPU number, never shipped."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     try:
@@ -54,23 +77,37 @@ def cpu_baseline(frames, labels, off, lam):
     except AttributeError:
         allowed = os.cpu_count() or 1
     topo = host_topology()
-    cores = max(1, min(allowed, topo[0] if topo else allowed, 128))
-    n = min(len(off) - 1, cores * 24)
-    cfg = orc.config(L=L, D=D, F=F)
+    cpus = one_socket_cpus()
+    cores = max(1, min(len(cpus) if cpus else allowed, topo[0] if topo else allowed, 128))
+    orc.bench_set_cpus(cpus[:cores] if cpus else [])
+    n = min(len(off) - 1, cores * utts_per_core)
+    cfg = orc.config(**(cfg_kw or dict(L=L, D=D, F=F)))
     o = np.asarray(off[:n + 1])
-    rc, g, numer, zx, sec = orc.bench_fb(cfg, lam, frames[:int(o[-1])], labels[:int(o[-1])], o, IN_W, cores)
+
+    def run(nu, nthreads):
+        oo = o[:nu + 1]
+        if frames2 is None:
+            return orc.bench_fb(cfg, lam, frames[:int(oo[-1])], labels[:int(oo[-1])], oo, in_w, nthreads)
+        return orc.bench_fb2(cfg, lam, frames[:int(oo[-1])], frames2[:int(oo[-1]) + 2 * ctx2 * nu], in_w2, ctx2,
+                             labels[:int(oo[-1])], oo, in_w, nthreads)
+    rc, g, numer, zx, sec = run(n, cores)
     assert rc == 0
     ph = orc.bench_phases()
     tot = sum(ph.values()) or 1.0
-    rc1, _, _, _, sec1 = orc.bench_fb(cfg, lam, frames[:int(o[2])], labels[:int(o[2])], o[:3], IN_W, 1)
+    n1 = min(n, 2)
+    rc1, _, _, _, sec1 = run(n1, 1)
+    orc.bench_set_cpus([])
+    single = n1 / sec1
     return {"value": round(n / sec, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "pinned": bool(cpus), "cpu_list": (cpus[:cores] if cpus else None),
             "host": {"physical_cores_per_socket": topo[0] if topo else None, "sockets": topo[1] if topo else None,
                      "threads_per_core": topo[2] if topo else None, "cpus_allowed": allowed},
             # the reference's own phase timers (gradbuilder :155-157, :481-488), microseconds per utterance and share
             "phase_us_per_utt": {k: round(v / n, 1) for k, v in ph.items()},
             "phase_share": {k: round(v / tot, 4) for k, v in ph.items()},
-            "single_thread_utt_per_s": round(2 / sec1, 3),
-            "sample": "%d utterances of the same batch, %d threads (one per physical core of one socket), %.1f s"
+            "single_thread_utt_per_s": round(single, 3),
+            "parallel_efficiency": round((n / sec) / (cores * single), 3),
+            "sample": "%d utterances of the same batch, %d threads (one per physical core of one socket, pinned), %.1f s"
                       % (n, cores, sec)}, (g, numer, zx, n)
 
 
@@ -85,7 +122,19 @@ def kernels_fingerprint():
     return h.hexdigest()[:16]
 
 
-def other_config(eng_mod, name, device_id, scratch_gib):
+def measured_traffic(section):
+    """profiles/r04_traffic.json[section] if the file was measured on the kernel sources of this tree, else (None, why)"""
+    tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/r04_traffic.json absent"
+    with open(tpath) as fh:
+        tj = json.load(fh)
+    if tj.get("kernels_sha16") != kernels_fingerprint():
+        return None, "profiles/r04_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("kernels_sha16")
+    return tj.get(section), None
+
+
+def other_config(eng_mod, name, device_id, scratch_gib, with_cpu=True):
     """One forward-backward + gradient step at another BASELINE shape (after the timed region): BASELINE config 3
     (TIMIT demo: 48 labels, D = 10, 144-dim segment stream + +-6-frame context stream, `stdtrans`, 4 371 216 weights,
     demo/segmental-timit-demo.cfg.in:13-33) at 256 utterances of 304 frames, or the forward-backward half of config 5
@@ -110,8 +159,9 @@ def other_config(eng_mod, name, device_id, scratch_gib):
         kw = dict(L=Lc, D=Dc, F=Fs + Ft, sfe=Fs - 1, use_trans_ftrs=True, tfs=Fs)
         recipes.append(eng_mod.StreamRecipe(W, ctx, ctx, 0))
         streams2 = [[np.concatenate([np.repeat(f[:1], ctx, 0), f, np.repeat(f[-1:], ctx, 0)]) for f in frames]]
-    eng = eng_mod.Engine(eng_mod.make_config(device_id=device_id, scratch_bytes=scratch_gib << 30, precision=1, **kw))
-    eng.set_lambda(rng.normal(0, 0.01, eng.lambda_len))
+    eng = eng_mod.Engine(eng_mod.make_config(device_id=device_id, scratch_bytes=scratch_gib << 30, precision=3, **kw))
+    lam = rng.normal(0, 0.01, eng.lambda_len)
+    eng.set_lambda(lam)
     b = eng.batch_from_frames(frames, labels, recipes, streams2)
     eng.zero_grad(); eng.fb_batch(b, want_scalars=False); eng.synchronize()      # untimed first pass
     reps = 3
@@ -140,6 +190,34 @@ def other_config(eng_mod, name, device_id, scratch_gib):
            "dominant_kernel": {"name": dom_name, "ms": round(dom_ms, 3),
                                "frac_executed": round(dom_flops * U / (dom_ms * 1e-3) / (PEAK["mfma_f64_tflops"] * 1e12), 4) if dom_flops else None},
            "kernels_ms": {nm: round(m_, 3) for nm, m_, _ in kt[:8]}}
+    # HBM bytes per step of this shape from the separate rocprofv3 --pmc passes (tools/collect_profiles.sh)
+    tr, why = measured_traffic(name)
+    ent["roofline"] = {"kernel": dom_name, "bound": "mfma" if dom_flops else "hbm",
+                       "frac": ent["dominant_kernel"]["frac_executed"],
+                       "traffic": round(tr["step_bytes"]) if tr else None,
+                       "traffic_dominant_kernel": round(tr["kernels"].get(dom_name, {}).get("bytes", 0)) if tr else None,
+                       "traffic_note": why,
+                       # B_alg = 4 T W_in + 3*8 (N_seg L + M_elems) + 2*8 (N_seg L + 2 T L) per utterance
+                       "algorithmic_gb_per_step": round(U * (4.0 * T * (2 * W if ctx else W) + 24.0 * (nseg * Lc + (T * Lc * Lc if ctx else Lc * Lc))
+                                                             + 16.0 * (nseg * Lc + 2 * T * Lc)) / 1e9, 2)}
+    if with_cpu and name == "config3":
+        # the north-star claim (>= 50x the reference's single-socket CPU rate on TIMIT-shape SCRF forward-backward) is
+        # stated on THIS shape: the oracle's threaded path on a bounded sample, and the 1e-4 gate on the same sample
+        fr = np.concatenate(frames); lb = np.concatenate(labels)
+        off = np.concatenate([[0], np.cumsum([T] * U)]).astype(np.uint64)
+        cb, (og, on, oz, n_cb) = cpu_baseline(fr, lb, off, lam, cfg_kw=kw, in_w=W, frames2=np.concatenate(streams2[0]), in_w2=W, ctx2=ctx,
+                                              utts_per_core=2)
+        ent["cpu_baseline"] = cb
+        ent["speedup_vs_cpu_baseline"] = round(ent["utt_per_s"] / cb["value"], 1)
+        eng.zero_grad()
+        gb = eng.batch_from_frames(frames[:n_cb], labels[:n_cb], recipes, [streams2[0][:n_cb]])
+        gn, gz = eng.fb_batch(gb)
+        gg = eng.get_grad() / cb["cores"]
+        gb.close()
+        ent["parity_gate"] = {"utterances": int(n_cb), "tolerance": 1e-4,
+                              "grad_rel": float(np.abs(gg - og).max() / np.abs(og).max()),
+                              "numer_rel": float(np.abs(gn - on[:n_cb]).max() / max(1.0, np.abs(on[:n_cb]).max())),
+                              "zx_rel": float(np.abs(gz - oz[:n_cb]).max() / np.abs(oz[:n_cb]).max())}
     b.close(); eng.close()
     return ent
 
@@ -320,17 +398,10 @@ def main():
             per_launch = dom["gbyte"] / per_step
         # HBM bytes of the dominant kernel from separate rocprofv3 --pmc passes (profiles/README.md); the file names the
         # kernel sources it was measured on, and a figure from other sources is not reported
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("kernels_sha16") != kernels_fingerprint():
-                traffic_note = "profiles/r04_traffic.json was measured on other kernel sources (%s): not reported" % tj.get("kernels_sha16")
-            else:
-                ent = tj.get(args.precision, {}).get(dom["name"])
-                if ent:
-                    traffic = round(ent["bytes_per_utt"] * U / per_step)
+        traffic = None
+        tsec, traffic_note = measured_traffic(args.precision)
+        if tsec and tsec.get(dom["name"]):
+            traffic = round(tsec[dom["name"]]["bytes_per_utt"] * U / per_step)
         frac = achieved / peak
         # SURVEY 8d's DENSE figure for the same kernel next to the executed one: the fused kernels contract only the
         # avg | max | min (+ one-hot, bias) columns and leave the five sampled blocks to k_pframe / k_ztf, so the dense
@@ -416,7 +487,12 @@ def main():
         # the north-star training shape and the stress shape on the same clock (general path: materialised windows,
         # dense fp64-MFMA contractions); parity cases elsewhere, throughput entries here.  After the config-2 engine
         # has released its arena.
-        out["configs"] = [other_config(scrf_amd, nm, local_rank, max(args.scratch_gib, 160)) for nm in ("config3", "config5")]
+        out["configs"] = [other_config(scrf_amd, nm, local_rank, max(args.scratch_gib, 160), with_cpu=not args.no_cpu_baseline)
+                          for nm in ("config3", "config5")]
+        for ent in out["configs"]:
+            pg = ent.get("parity_gate")
+            if pg and not (pg["grad_rel"] <= 1e-4 and pg["numer_rel"] <= 1e-4 and pg["zx_rel"] <= 1e-4):
+                gate_err = "%s: engine vs oracle grad %.3g numer %.3g zx %.3g (tolerance 1e-4)" % (ent["name"], pg["grad_rel"], pg["numer_rel"], pg["zx_rel"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

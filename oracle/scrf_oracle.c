@@ -529,24 +529,52 @@ static double phase_now_us(void) {
 #define PHASE_BEGIN() double ph_t0_ = orc_phase_us ? phase_now_us() : 0.0
 #define PHASE_END(i) do { if (orc_phase_us) { const double n_ = phase_now_us(); orc_phase_us[i] += n_ - ph_t0_; ph_t0_ = n_; } } while (0)
 
+/* A worker's arrays, kept across utterances the way the reference keeps its node vector (nodes/CRF_StateVector.cpp:37-67:
+ * set() resets an existing node and only constructs one when the utterance is longer than any before) and its builder
+ * keeps ExpF (gradbuilder ctor :30-34, zeroed per utterance :99-101). */
+static void* ws_take(void** p, size_t* cap, size_t need) {
+  if (need > *cap) {
+    free(*p);
+    *p = malloc(need);
+    *cap = *p ? need : 0;
+  }
+  return *p;
+}
+void orc_workspace_free(orc_workspace* w) {
+  if (!w) return;
+  for (int i = 0; i < ORC_WS_SLOTS; i++) { free(w->p[i]); w->p[i] = NULL; w->cap[i] = 0; }
+}
+
 int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
                            const float* segftrs, const uint32_t* labels, uint32_t T,
                            double* grad, double* numer, double* Zx_out) {
+  orc_workspace w;
+  memset(&w, 0, sizeof(w));
+  const int rc = orc_seg_build_gradient_ws(cfg, lay, lambda, segftrs, labels, T, grad, numer, Zx_out, &w);
+  orc_workspace_free(&w);
+  return rc;
+}
+
+int orc_seg_build_gradient_ws(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                              const float* segftrs, const uint32_t* labels, uint32_t T,
+                              double* grad, double* numer, double* Zx_out, orc_workspace* w) {
   const uint32_t L = cfg->num_labs, D = cfg->lab_max_dur, F = cfg->num_feas;
   if (T == 0) return ORC_ERR_EMPTY;
   const uint64_t nseg = orc_num_segs(T, D);
   int err = ORC_OK;
-  double* ExpF = (double*)calloc(lay->lambda_len, sizeof(double)); /* :99-101 */
-  double* S = (double*)malloc(sizeof(double) * nseg * L);
-  double* M = (double*)malloc(sizeof(double) * (size_t)T * L * L);
-  double* ad = (double*)malloc(sizeof(double) * nseg * L);
-  double* alpha = (double*)malloc(sizeof(double) * (size_t)T * L);
-  double* apt = (double*)malloc(sizeof(double) * (size_t)T * L);
-  double* beta = (double*)malloc(sizeof(double) * (size_t)T * L);
-  double* sd = (double*)malloc(sizeof(double) * (size_t)T * L);
   uint32_t accn = (L > D ? L : D) + 2;
-  double* tmp = (double*)malloc(sizeof(double) * accn);
-  uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (L + 2));
+  double* ExpF = (double*)ws_take(&w->p[0], &w->cap[0], sizeof(double) * lay->lambda_len);
+  double* S = (double*)ws_take(&w->p[1], &w->cap[1], sizeof(double) * nseg * L);
+  double* M = (double*)ws_take(&w->p[2], &w->cap[2], sizeof(double) * (size_t)T * L * L);
+  double* ad = (double*)ws_take(&w->p[3], &w->cap[3], sizeof(double) * nseg * L);
+  double* alpha = (double*)ws_take(&w->p[4], &w->cap[4], sizeof(double) * (size_t)T * L);
+  double* apt = (double*)ws_take(&w->p[5], &w->cap[5], sizeof(double) * (size_t)T * L);
+  double* beta = (double*)ws_take(&w->p[6], &w->cap[6], sizeof(double) * (size_t)T * L);
+  double* sd = (double*)ws_take(&w->p[7], &w->cap[7], sizeof(double) * (size_t)T * L);
+  double* tmp = (double*)ws_take(&w->p[8], &w->cap[8], sizeof(double) * accn);
+  uint32_t* plist = (uint32_t*)ws_take(&w->p[9], &w->cap[9], sizeof(uint32_t) * (L + 2));
+  if (!ExpF || !S || !M || !ad || !alpha || !apt || !beta || !sd || !tmp || !plist) return ORC_ERR_EMPTY;
+  memset(ExpF, 0, sizeof(double) * lay->lambda_len); /* :99-101 */
   double logLi = 0.0, Zx = 0.0;
 
   PHASE_BEGIN();
@@ -623,7 +651,6 @@ int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const d
   for (uint32_t i = 0; i < lay->lambda_len; i++) grad[i] -= ExpF[i]; /* :471-473 */
   *Zx_out = Zx;
   *numer = logLi;
-  free(ExpF); free(S); free(M); free(ad); free(alpha); free(apt); free(beta); free(sd); free(tmp); free(plist);
   return err;
 }
 

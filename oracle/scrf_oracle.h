@@ -146,6 +146,14 @@ int orc_seg_backward(const orc_config* cfg, const double* S, const double* M, ui
 int orc_seg_build_gradient(const orc_config* cfg, const orc_layout* lay, const double* lambda,
                            const float* segftrs, const uint32_t* labels, uint32_t T,
                            double* grad, double* numer, double* Zx);
+/* the same with the worker's arrays kept across utterances (bench_cpu.c: one workspace per thread, like the reference's
+ * per-thread CRF_StateVector and builder, nodes/CRF_StateVector.cpp:37-67); a zeroed struct is an empty workspace */
+#define ORC_WS_SLOTS 10
+typedef struct { void* p[ORC_WS_SLOTS]; size_t cap[ORC_WS_SLOTS]; } orc_workspace;
+void orc_workspace_free(orc_workspace* w);
+int orc_seg_build_gradient_ws(const orc_config* cfg, const orc_layout* lay, const double* lambda,
+                              const float* segftrs, const uint32_t* labels, uint32_t T,
+                              double* grad, double* numer, double* Zx_out, orc_workspace* w);
 /* posteriors for tests: gamma [N_seg][L], xi [T][L*L] (row T-1 unused) */
 int orc_seg_posteriors(const orc_config* cfg, const double* S, const double* M, uint32_t T,
                        double* gamma, double* xi, double* Zx);
@@ -268,4 +276,16 @@ int orc_free_phone_decode(const orc_config* cfg, const double* S, const double* 
 #ifdef __cplusplus
 }
 #endif
+/* ---- bench_cpu.c: the reference's threaded accumulator as the CPU baseline (a13; bench.py's cpu_baseline leg) ---- */
+void orc_bench_set_cpus(const int* cpus, int n);   /* worker s is pinned to cpus[s % n]; n = 0: not pinned */
+void orc_bench_phases(double* out5);               /* featLoad, transMat, alpha, beta, expF of the last call, us over all workers */
+int orc_bench_fb(const orc_config* cfg, const double* lambda, const float* frames, const uint32_t* labels,
+                 const uint64_t* frame_off, uint32_t U, uint32_t in_width, uint32_t n_threads, double* grad_out,
+                 double* numer, double* zx, double* seconds);
+/* with a second stream of in_width2-wide frames padded by ctx2 frames each side (no segment recipe: its window is the
+ * 2 ctx2 + 1 frames around the node), joined behind the first stream's columns */
+int orc_bench_fb2(const orc_config* cfg, const double* lambda, const float* frames, const float* frames2,
+                  uint32_t in_width2, uint32_t ctx2, const uint32_t* labels, const uint64_t* frame_off, uint32_t U,
+                  uint32_t in_width, uint32_t n_threads, double* grad_out, double* numer, double* zx, double* seconds);
+
 #endif /* SCRF_ORACLE_H_ */

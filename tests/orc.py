@@ -565,6 +565,30 @@ def bench_fb(cfg, lam, frames, labels, frame_off, in_width, n_threads):
     return rc, grad, numer, zx, sec.value
 
 
+def bench_fb2(cfg, lam, frames, frames2, in_width2, ctx2, labels, frame_off, in_width, n_threads):
+    """bench_fb with a second, context-padded stream (frames2: [sum_u (T_u + 2 ctx2)][in_width2]) joined behind the
+    first stream's window columns: BASELINE config 3's input."""
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    frames = np.ascontiguousarray(frames, dtype=np.float32)
+    frames2 = np.ascontiguousarray(frames2, dtype=np.float32)
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    U = frame_off.shape[0] - 1
+    lay = Layout(cfg)
+    grad = np.zeros(lay.lambda_len); numer = np.zeros(U); zx = np.zeros(U)
+    sec = C.c_double()
+    rc = lib().orc_bench_fb2(C.byref(cfg), _p(lam), _p(frames), _p(frames2), C.c_uint32(in_width2), C.c_uint32(ctx2),
+                             _p(labels), _p(frame_off), C.c_uint32(U), C.c_uint32(in_width), C.c_uint32(n_threads),
+                             _p(grad), _p(numer), _p(zx), C.byref(sec))
+    return rc, grad, numer, zx, sec.value
+
+
+def bench_set_cpus(cpus):
+    """pin the workers of the following bench_fb calls: worker s -> cpus[s % len(cpus)]; [] = floating threads"""
+    arr = (C.c_int * max(1, len(cpus)))(*cpus)
+    lib().orc_bench_set_cpus(arr, C.c_int(len(cpus)))
+
+
 def bench_phases():
     """the reference's five phase timers (featLoad, transMat, alpha, beta, expF) of the last bench_fb call:
     microseconds summed over the worker threads"""

@@ -275,6 +275,41 @@ def test_threaded_cpu_path_matches_serial_and_is_thread_count_invariant():
     assert (tot == g1).all()
 
 
+def test_threaded_cpu_path_with_a_context_stream_pinned_workers_and_reused_workspaces():
+    """bench.py's config-3 baseline: a second stream of context frames joined behind the segment-recipe windows (the
+    demo's transition features), workers pinned to a CPU list, one workspace per worker reused over utterances of
+    different lengths -- against the serial builder on windows joined here."""
+    import os
+    L, D, in_w, ctx = 3, 3, 2, 2
+    Ts = [7, 3, 12, 5, 9]
+    rng = np.random.RandomState(5)
+    frames = [rng.random_sample((T, in_w)).astype(np.float32) for T in Ts]
+    labels = [synth.group_labels(synth.frame_labels(rng, T, L, D), D, L) for T in Ts]
+    frames2 = [np.concatenate([np.repeat(f[:1], ctx, 0), f, np.repeat(f[-1:], ctx, 0)]) for f in frames]
+    Fs, Ft = orc.window_width(in_w, D, 0, 0, True), orc.window_width(in_w, D, ctx, ctx, False)
+    cfg = orc.config(L=L, D=D, F=Fs + Ft, sfe=Fs - 1, use_trans_ftrs=True, tfs=Fs)
+    lay = orc.Layout(cfg)
+    lam = rng.normal(0, 0.3, lay.lambda_len)
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.uint64)
+    tot = np.zeros(lay.lambda_len); ns, zs = [], []
+    for u, T in enumerate(Ts):
+        X = np.zeros((orc.num_segs(T, D), Fs + Ft), dtype=np.float32)
+        orc.windows(frames[u], D, 0, 0, True, out=X, out_col=0)
+        orc.windows(frames2[u], D, ctx, ctx, False, out=X, out_col=Fs)
+        rc, tot, n, z = orc.seg_build_gradient(cfg, lay, lam, X, labels[u], T, grad=tot)
+        assert rc == 0
+        ns.append(n); zs.append(z)
+    try:
+        orc.bench_set_cpus(sorted(os.sched_getaffinity(0))[:2])
+        for nt in (1, 2):
+            rc, g, n, z, _ = orc.bench_fb2(cfg, lam, np.concatenate(frames), np.concatenate(frames2), in_w, ctx,
+                                           np.concatenate(labels), off, in_w, nt)
+            assert rc == 0 and (n == np.array(ns)).all() and (z == np.array(zs)).all()
+            np.testing.assert_allclose(g * nt, tot, rtol=1e-12, atol=1e-12)
+    finally:
+        orc.bench_set_cpus([])
+
+
 @pytest.mark.parametrize("L,D,T,trans", [(2, 2, 1, True), (3, 3, 2, True), (3, 2, 6, True), (2, 4, 7, True), (4, 3, 6, False), (5, 1, 5, True)])
 def test_free_phone_decoder_against_enumeration_and_lattice_best_path(L, D, T, trans):
     """a19: the push-form restatement of CRFDecode's decoder (free phone loop) finds the path the

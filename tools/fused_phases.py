@@ -14,7 +14,7 @@ from scrf_amd import synth
 
 L, D, IN_W, T, U = 48, 25, 39, 300, 4096
 frames, labels, off = synth.make_batch(U, T, IN_W, L, D, seed=1234)
-eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=8 * IN_W + D, device_id=0, scratch_bytes=96 << 30, precision=1))
+eng = scrf_amd.Engine(scrf_amd.make_config(L=L, D=D, F=8 * IN_W + D, device_id=0, scratch_bytes=96 << 30, precision=int(os.environ.get("PREC", "3"))))
 eng.set_lambda(synth.make_lambda(eng.lambda_len))
 batch = eng.batch_from_frames([frames[int(off[u]):int(off[u + 1])] for u in range(U)],
                               [labels[int(off[u]):int(off[u + 1])] for u in range(U)])

@@ -9,7 +9,7 @@ SHAPES = {"cfg3x64": dict(L=48, D=10, in_w=144, Ts=[304] * 64, trans_ctx=6, seed
           "cfg5x32": dict(L=200, D=40, in_w=123, Ts=[2000] * 32, seed=6, lam_scale=0.01),
           "cfg5x128": dict(L=200, D=40, in_w=123, Ts=[2000] * 128, seed=6, lam_scale=0.01)}
 name = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-c = Case(precision=1, scratch_bytes=160 << 30, **SHAPES[name])
+c = Case(precision=int(os.environ.get("PREC", "3")), scratch_bytes=160 << 30, **SHAPES[name])
 eng = c.engine(); b = c.batch(eng)
 eng.fb_batch(b)
 eng.enable_timing(True)

@@ -43,6 +43,23 @@ def host_topology():
         return None
 
 
+def cpu_quota():
+    """CPUs' worth of time the container's cgroup grants this process (cpu.max / cfs quota), or None when unlimited.
+    The GPU boxes expose all 256 hardware threads but cap the cgroup at 16 CPUs: more runnable threads than that are
+    throttled, not run (64 pinned workers measured 11.5x one worker there, with 439 of 870 periods throttled)."""
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p_)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p_
+    except Exception:
+        return None
+
+
 def one_socket_cpus():
     """One logical CPU per physical core of the socket this process may use most of (`lscpu -p`), restricted to the
     CPUs this process is allowed on: the list the CPU baseline pins its workers to.  None if it cannot be read."""
@@ -65,7 +82,7 @@ def one_socket_cpus():
         return None
 
 
-def cpu_baseline(frames, labels, off, lam, cfg_kw=None, in_w=IN_W, frames2=None, in_w2=0, ctx2=0, utts_per_core=24):
+def cpu_baseline(frames, labels, off, lam, cfg_kw=None, in_w=IN_W, frames2=None, in_w2=0, ctx2=0, utts_per_core=96):
     """The oracle (CPU restatement of the reference path, `port`) timed on this box's host cores
     over a bounded sample of the same workload: one worker thread per physical core of ONE socket,
     each PINNED to its core and keeping its arrays across utterances as the reference's threads keep their node
@@ -78,9 +95,12 @@ def cpu_baseline(frames, labels, off, lam, cfg_kw=None, in_w=IN_W, frames2=None,
         allowed = os.cpu_count() or 1
     topo = host_topology()
     cpus = one_socket_cpus()
+    quota = cpu_quota()
     cores = max(1, min(len(cpus) if cpus else allowed, topo[0] if topo else allowed, 128))
+    if quota is not None:   # more workers than the cgroup's CPU quota would be throttled, not run
+        cores = max(1, min(cores, int(quota)))
     orc.bench_set_cpus(cpus[:cores] if cpus else [])
-    n = min(len(off) - 1, cores * utts_per_core)
+    n = min(len(off) - 1, cores * utts_per_core)   # about 10-20 s of CPU work
     cfg = orc.config(**(cfg_kw or dict(L=L, D=D, F=F)))
     o = np.asarray(off[:n + 1])
 
@@ -101,14 +121,17 @@ def cpu_baseline(frames, labels, off, lam, cfg_kw=None, in_w=IN_W, frames2=None,
     return {"value": round(n / sec, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
             "pinned": bool(cpus), "cpu_list": (cpus[:cores] if cpus else None),
             "host": {"physical_cores_per_socket": topo[0] if topo else None, "sockets": topo[1] if topo else None,
-                     "threads_per_core": topo[2] if topo else None, "cpus_allowed": allowed},
+                     "threads_per_core": topo[2] if topo else None, "cpus_allowed": allowed, "cgroup_cpu_quota": quota},
+            # what a whole socket could reach at perfect scaling of the single-thread rate: an upper bound for the CPU
+            # path on this host, extrapolated (the cgroup does not let this process measure it)
+            "full_socket_upper_bound_utt_per_s": round(single * topo[0], 2) if topo else None,
             # the reference's own phase timers (gradbuilder :155-157, :481-488), microseconds per utterance and share
             "phase_us_per_utt": {k: round(v / n, 1) for k, v in ph.items()},
             "phase_share": {k: round(v / tot, 4) for k, v in ph.items()},
             "single_thread_utt_per_s": round(single, 3),
             "parallel_efficiency": round((n / sec) / (cores * single), 3),
-            "sample": "%d utterances of the same batch, %d threads (one per physical core of one socket, pinned), %.1f s"
-                      % (n, cores, sec)}, (g, numer, zx, n)
+            "sample": "%d utterances of the same batch, %d threads (one per physical core of one socket, pinned%s), %.1f s"
+                      % (n, cores, "; the cgroup grants %.0f CPUs" % quota if quota is not None else "", sec)}, (g, numer, zx, n)
 
 
 def kernels_fingerprint():
@@ -206,9 +229,11 @@ def other_config(eng_mod, name, device_id, scratch_gib, with_cpu=True):
         fr = np.concatenate(frames); lb = np.concatenate(labels)
         off = np.concatenate([[0], np.cumsum([T] * U)]).astype(np.uint64)
         cb, (og, on, oz, n_cb) = cpu_baseline(fr, lb, off, lam, cfg_kw=kw, in_w=W, frames2=np.concatenate(streams2[0]), in_w2=W, ctx2=ctx,
-                                              utts_per_core=2)
+                                              utts_per_core=8)
         ent["cpu_baseline"] = cb
         ent["speedup_vs_cpu_baseline"] = round(ent["utt_per_s"] / cb["value"], 1)
+        if cb.get("full_socket_upper_bound_utt_per_s"):   # the north-star target (>= 50x one socket) against the most a socket could do
+            ent["speedup_vs_full_socket_upper_bound"] = round(ent["utt_per_s"] / cb["full_socket_upper_bound_utt_per_s"], 1)
         eng.zero_grad()
         gb = eng.batch_from_frames(frames[:n_cb], labels[:n_cb], recipes, [streams2[0][:n_cb]])
         gn, gz = eng.fb_batch(gb)
@@ -462,6 +487,8 @@ def main():
             cb, (og, on, oz, n_cb) = cpu_baseline(frames, labels, off, lam)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(out["value"] / cb["value"], 1)
+            if cb.get("full_socket_upper_bound_utt_per_s"):
+                out["speedup_vs_full_socket_upper_bound"] = round(out["value"] / cb["full_socket_upper_bound_utt_per_s"], 1)
             # ---- correctness gate, part 2 (north_star: log-likelihood and gradients within 1e-4 relative): the
             # engine's gradient, numerators and log-partitions on the cpu_baseline sample against the oracle's.
             # The oracle's minibatch gradient is the sum over its worker streams / active streams

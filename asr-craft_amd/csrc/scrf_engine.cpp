@@ -3,6 +3,8 @@
 // single device arena carved per chunk of utterances.  There is NO CPU compute path here:
 // without a HIP device scrf_create fails with SCRF_ERR_NO_DEVICE.
 #include <dlfcn.h>
+#include <time.h>
+#include <unistd.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +28,8 @@ struct RcclApi {
   int (*CommInitRank)(scrf_nccl_comm*, int, scrf_nccl_uid, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, scrf_nccl_comm, hipStream_t) = nullptr;
   int (*CommDestroy)(scrf_nccl_comm) = nullptr;
+  int (*CommAbort)(scrf_nccl_comm) = nullptr;
+  int (*CommGetAsyncError)(scrf_nccl_comm, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -44,6 +48,8 @@ static bool rccl_load(std::string* why) {
   g_rccl.CommInitRank = (int (*)(scrf_nccl_comm*, int, scrf_nccl_uid, int))dlsym(g_rccl.lib, "ncclCommInitRank");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, scrf_nccl_comm, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(scrf_nccl_comm))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.CommAbort = (int (*)(scrf_nccl_comm))dlsym(g_rccl.lib, "ncclCommAbort");
+  g_rccl.CommGetAsyncError = (int (*)(scrf_nccl_comm, int*))dlsym(g_rccl.lib, "ncclCommGetAsyncError");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) {
     *why = "RCCL symbols missing";
@@ -101,6 +107,7 @@ struct scrf_engine_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
+  bool frame_mass = false;   // posterior-mass self-checks with the frame model's bounds (scrf_set_frame_mass_check)
   bool lin_dp = true;
   // the workgroup-per-utterance log-domain recursion (k_fb: column-wise max-shifted log-sum-exp, the
   // reference's LogMath) instead of the wavefront kernels, whose transition step works on exp(M - max M):
@@ -1237,7 +1244,8 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
 static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBufs& cb, bool post, uint32_t* nl_out) {
   const ScrfLayout& l = h->lay;
   const uint64_t nutt = u1 - u0, nfr = b->frame_off[u1] - b->frame_off[u0];
-  const int frame_model = h->cfg.model_type == SCRF_STDFRAME;
+  // (only the posterior-mass self-checks look at it in the recursion kernels)
+  const int frame_model = h->cfg.model_type == SCRF_STDFRAME || h->frame_mass;
   ScrfBatchView bv = b->view();
   uint32_t nl = 0;
   if (segtrans(h)) {
@@ -2174,6 +2182,12 @@ extern "C" int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused) {
   return SCRF_OK;
 }
 
+extern "C" int scrf_set_frame_mass_check(scrf_handle h, int on) {
+  if (!h) return SCRF_ERR_INVALID;
+  h->frame_mass = on != 0;
+  return SCRF_OK;
+}
+
 extern "C" int scrf_decode_stats(scrf_handle h, uint64_t* n_recomputed, uint64_t* n_fallback_chunks) {
   if (!h) return SCRF_ERR_INVALID;
   if (n_recomputed) *n_recomputed = h->n_decode_fix;
@@ -2223,28 +2237,85 @@ __global__ void k_gauss_prior(double* __restrict__ g, uint32_t n, double inv) {
   if (i < n) g[i] = __dsub_rn(g[i], __dmul_rn(g[i], inv));   // grad[i] -= grad[i] * invSquareVar
 }
 
+// ncclCommAbort: frees the communicator without waiting for outstanding collectives and makes the PEERS' pending
+// operations fail (their watchdog below sees the asynchronous error) instead of leaving them in RCCL for ever.  The host
+// calls it when a rank cannot enter or finish the per-step collective, then exits non-zero (a restart is a fresh process).
+extern "C" int scrf_comm_abort(scrf_handle h) {
+  if (!h) return SCRF_ERR_INVALID;
+  if (h->comm) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort(h->comm);
+    h->comm = nullptr;
+  }
+  return SCRF_OK;
+}
+
+// Bounded wait for the engine stream while a collective is on it: polls the stream and the communicator's asynchronous
+// error state; after SCRF_COMM_TIMEOUT_S seconds (default 300) without completion, or on an asynchronous error (a peer
+// aborted or died), the communicator is aborted and SCRF_ERR_COMM returned -- the caller ends the process.
+static int wait_collective(scrf_handle h, const char* what) {
+  const char* ts = getenv("SCRF_COMM_TIMEOUT_S");
+  const double limit = ts && atof(ts) > 0 ? atof(ts) : 300.0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) return SCRF_OK;
+    if (q != hipErrorNotReady) { scrf_comm_abort(h); return fail(h, SCRF_ERR_HIP, "%s: %s", what, hipGetErrorString(q)); }
+    if (h->comm && g_rccl.CommGetAsyncError) {
+      int ae = 0;
+      if (g_rccl.CommGetAsyncError(h->comm, &ae) == 0 && ae != 0) {
+        scrf_comm_abort(h);
+        return fail(h, SCRF_ERR_COMM, "%s: rank %d: the communicator reports an asynchronous error (%s): a peer failed or aborted", what,
+                    h->rank, g_rccl.GetErrorString ? g_rccl.GetErrorString(ae) : "?");
+      }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit) {
+      scrf_comm_abort(h);
+      return fail(h, SCRF_ERR_COMM, "%s: rank %d: the collective did not complete within %.0f s (SCRF_COMM_TIMEOUT_S): a peer died or never "
+                  "joined; communicator aborted", what, h->rank, limit);
+    }
+    usleep(200);
+  }
+}
+
 extern "C" int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4,
                                       double* extra_out) {
   if (!h || n_extra > 4 || (n_extra && !extra_in)) return SCRF_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  // a rank that fails on its way into or out of the collective must not leave the others waiting in RCCL: every error
+  // path below aborts the communicator first (the peers' wait_collective then ends with an error, not a hang)
+#define ARCHK(call)                                                                                        \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) { scrf_comm_abort(h); return fail(h, SCRF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } \
+  } while (0)
+  ARCHK(hipSetDevice(h->device));
   const uint32_t n = h->lay.lambda_len;
   double e[4] = {0, 0, 0, 0};
   for (uint32_t i = 0; i < n_extra; i++) e[i] = extra_in[i];
   hipLaunchKernelGGL(k_set_tail, dim3(1), dim3(1), 0, h->stream, h->d_sums, active ? 1 : 0, e[0], e[1], e[2], e[3]);
+  ARCHK(hipGetLastError());
   if (h->comm) {
     int r = g_rccl.AllReduce(h->d_grad, h->d_grad, n, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
     if (r == 0) r = g_rccl.AllReduce(h->d_sums, h->d_sums, 8, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
-    if (r != 0) return fail(h, SCRF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    if (r != 0) {
+      scrf_comm_abort(h);
+      return fail(h, SCRF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
   }
   hipLaunchKernelGGL(k_div_by_active, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_grad, n, h->d_sums);
-  HIPCHK(h, hipGetLastError());
-  if (sums4 || extra_out) {
+  ARCHK(hipGetLastError());
+  if (sums4 || extra_out || h->comm) {
     double s8[8];
-    HIPCHK(h, hipMemcpyAsync(s8, h->d_sums, sizeof(double) * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ARCHK(hipMemcpyAsync(s8, h->d_sums, sizeof(double) * 8, hipMemcpyDeviceToHost, h->stream));
+    if (h->comm) {
+      const int rc = wait_collective(h, "scrf_allreduce_grad");
+      if (rc != SCRF_OK) return rc;
+    } else ARCHK(hipStreamSynchronize(h->stream));
     if (sums4) memcpy(sums4, s8, sizeof(double) * 4);
     if (extra_out) memcpy(extra_out, s8 + 4, sizeof(double) * n_extra);
   }
+#undef ARCHK
   return SCRF_OK;
 }
 extern "C" int scrf_allreduce_grad(scrf_handle h, int active, double* sums4) {

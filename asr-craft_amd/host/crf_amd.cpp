@@ -87,6 +87,12 @@ void Engine::check(int rc, const char* what) {
   if (rc != SCRF_OK) throw runtime_error(string(what) + " caught exception: " + scrf_last_error(h));
 }
 
+// a training-only engine takes the n-state frame model through the masked dense layout (CRF_Model::setTrainingOnly)
+bool frameAsSegmental(CRF_Model* crf, uint32_t precision) {
+  const CRF_FeatureMap_config* c = crf->getFeatureMap()->getConfig();
+  return crf->trainingOnly() && precision != SCRF_PREC_EXACT && crf->getModelType() == STDFRAME && c->numStates > 1 && crf->getLabMaxDur() == 1;
+}
+
 scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision) {
   CRF_FeatureMap* fm = crf->getFeatureMap();
   if (!fm) throw runtime_error("CRF_Model has no feature map");
@@ -112,9 +118,7 @@ scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision) {
   g.trans_bias_val = c->transBiasVal;
   g.device_id = device;
   g.train_precision = precision;
-  // a training-only engine takes the n-state frame model through the masked dense layout (CRF_Model::setTrainingOnly)
-  if (crf->trainingOnly() && precision != SCRF_PREC_EXACT && g.model_type == SCRF_STDFRAME && g.num_states > 1 && g.lab_max_dur == 1)
-    g.model_type = SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR;
+  if (frameAsSegmental(crf, precision)) g.model_type = SCRF_STDSEG_NO_DUR_NO_SEGTRANSFTR;
   return g;
 }
 
@@ -185,7 +189,9 @@ bool CRF_Model::readGradSqrAccFromFile(const char* fname) { return read_vec(fnam
 // token: a leftover of an earlier run is never mistaken for this launch's id, whatever the clocks say and however far
 // apart the ranks start.  The token is SCRF_LAUNCH_TOKEN when the launcher provides one, else what one launch's
 // processes share on a node: MASTER_ADDR, MASTER_PORT, TORCHELASTIC_RUN_ID, TORCHELASTIC_RESTART_COUNT and the
-// launcher's process id (the parent of every rank).  Waiting time: SCRF_COMM_TIMEOUT_S seconds (120).
+// launcher's process id (the parent of every rank) -- the parent only when none of the launcher variables is set: ranks
+// started by per-node daemons, wrapper scripts or on several nodes do not share a parent (there, MASTER_PORT / the run
+// id identify the launch, or SCRF_LAUNCH_TOKEN must be given).  Waiting time: SCRF_COMM_TIMEOUT_S seconds (120).
 namespace {
 double wall_now() {
   struct timespec ts;
@@ -195,11 +201,13 @@ double wall_now() {
 string launch_token() {
   if (const char* t = getenv("SCRF_LAUNCH_TOKEN")) return string("token:") + t;
   string t = "launch";
+  bool named = false;
   for (const char* k : {"MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) {
     const char* v = getenv(k);
     t += string(":") + (v ? v : "-");
+    if (v && (string(k) == "MASTER_PORT" || string(k) == "TORCHELASTIC_RUN_ID")) named = true;
   }
-  return t + ":ppid" + std::to_string((long)getppid());
+  return named ? t : t + ":ppid" + std::to_string((long)getppid());
 }
 
 void exchange_comm_id(int rank, const string& path, unsigned char id[128]) {
@@ -217,6 +225,7 @@ void exchange_comm_id(int rank, const string& path, unsigned char id[128]) {
   const char* to = getenv("SCRF_COMM_TIMEOUT_S");
   const double deadline = wall_now() + (to && atof(to) > 0 ? atof(to) : 120.0);
   std::vector<char> buf(128 + token.size() + 1);
+  string seen;   // the token of the last file that did not match (for the message)
   while (wall_now() < deadline) {
     FILE* f = fopen(path.c_str(), "rb");
     if (f) {
@@ -226,10 +235,13 @@ void exchange_comm_id(int rank, const string& path, unsigned char id[128]) {
         memcpy(id, buf.data(), 128);
         return;
       }
+      if (n > 128) seen.assign(buf.data() + 128, n - 128);
     }
     usleep(20000);
   }
-  throw runtime_error("timed out waiting for rank 0's communicator id file " + path + " (launch token " + token + ")");
+  throw runtime_error("timed out waiting for rank 0's communicator id file " + path + " (this rank's launch token: " + token +
+                      (seen.empty() ? "; no file with a token was found" : "; the file there carries: " + seen + (seen.size() > token.size() ? "..." : "")) +
+                      "; set SCRF_LAUNCH_TOKEN to the same value on every rank when the ranks do not share MASTER_PORT / TORCHELASTIC_RUN_ID or a parent process)");
 }
 }  // namespace
 
@@ -246,6 +258,8 @@ void CRF_Model::setDistributed(int rank, int world, const string& id_file) {
 crf_amd::Engine* CRF_Model::engine() {
   if (!eng) {
     eng.reset(new crf_amd::Engine(crf_amd::makeConfig(this, device, precision)));
+    // the recast frame model keeps the frame node's posterior-mass bounds (CRF_StdStateNode.cpp:252-275)
+    if (crf_amd::frameAsSegmental(this, precision)) eng->check(scrf_set_frame_mass_check(eng->h, 1), "scrf_set_frame_mass_check");
     if (dist_on) {
       unsigned char id[128];
       exchange_comm_id(dist_rank, dist_id_file, id);
@@ -739,6 +753,16 @@ extern "C" void crf_amd_view_range(uint32_t n_utts, uint32_t n_streams, uint32_t
   *hi = s == n_streams - 1 ? n_utts : (s + 1) * per;
 }
 
+// The per-step collective itself failed on this rank (a device error around it, the watchdog's timeout, a peer's abort):
+// the communicator is aborted -- which ends the peers' wait with an error instead of a hang -- and the exception takes
+// the process down with a non-zero exit (mains catch, print and exit(-1)); a restart is a fresh process.
+static void collective(crf_amd::Engine* e, int rc, const char* what) {
+  if (rc == SCRF_OK) return;
+  const string msg = string(what) + ": " + scrf_last_error(e->h);
+  scrf_comm_abort(e->h);
+  throw runtime_error(msg + " [communicator aborted; this rank exits]");
+}
+
 // One process: grad != nullptr -- per-stream gradients come to the host and are summed there in stream
 // order, like the reference's join; grad == nullptr -- the streams accumulate into the device gradient
 // one after the other (same order) and it is divided there.
@@ -752,15 +776,21 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
   const bool dist = crf->distributed();
   if (dist && (QNUInt32)crf->distWorld() != N)
     throw runtime_error("CRF_Minibatch_GradAccumulator: " + std::to_string(N) + " streams but " + std::to_string(crf->distWorld()) + " ranks (threads must equal WORLD_SIZE)");
-  if (grad && !dist) for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
-  else e->check(scrf_zero_grad(e->h), "accumulateGradient");
+  string local_failure;   // distributed: a rank that fails must still meet its peers in the collective (below)
+  try {   // (inside the net as well: a device error here would otherwise skip the collective the peers are entering)
+    if (grad && !dist) for (QNUInt32 i = 0; i < n; i++) grad[i] = 0.0;
+    else e->check(scrf_zero_grad(e->h), "accumulateGradient");
+  } catch (const std::exception& ex) {
+    if (!dist) throw;
+    local_failure = ex.what();
+  }
   int nEnd = 0, nActive = 0;
   for (QNUInt32 s = 0; s < N; s++) if (segids[s] == QN_SEGID_BAD) ++nEnd;
   if (nEnd == (int)N) throw runtime_error("All feature streams are at the end! You don't have any utterances or you forget to rewind all the streams.");
   double totNumer = 0.0;
   std::vector<double> sgrad(grad && !dist ? n : 0);
-  string local_failure;   // distributed: a rank that fails must still meet its peers in the collective (below)
   for (QNUInt32 s = 0; s < N; s++) try {  // stream order == the reference's join/sum order
+    if (!local_failure.empty()) break;
     if (dist && (int)s != crf->distRank()) continue;
     if (segids[s] == QN_SEGID_BAD) continue;
     const QNUInt32 share = crf_amd_minibatch_share(minibatch, N, s);
@@ -798,7 +828,7 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     const int r = crf->distRank();
     const double flags_in[2] = {segids[r] == QN_SEGID_BAD ? 1.0 : 0.0, local_failure.empty() ? 0.0 : 1.0};
     double sums4[4] = {0, 0, 0, 0}, flags_out[2] = {0.0, 0.0};
-    e->check(scrf_allreduce_grad_ex(e->h, nActive, flags_in, 2, sums4, flags_out), "accumulateGradient (all-reduce)");
+    collective(e, scrf_allreduce_grad_ex(e->h, nActive, flags_in, 2, sums4, flags_out), "accumulateGradient (all-reduce)");
     if (flags_out[1] > 0.5) {
       if (!local_failure.empty()) throw runtime_error(local_failure);
       throw runtime_error("CRF_Minibatch_GradAccumulator: " + std::to_string((int)(flags_out[1] + 0.5)) + " other rank(s) failed in this minibatch; rank " + std::to_string(r) + " stops with them");
@@ -956,10 +986,16 @@ double CRF_GradAccumulator::accumulateGradient(CRF_FeatureStreamManager* mgr, in
   const bool dist = crf->distributed();
   if (dist && crf->distWorld() != nStreams)
     throw runtime_error("CRF_GradAccumulator: " + std::to_string(nStreams) + " streams but " + std::to_string(crf->distWorld()) + " ranks");
-  crf->pushLambda();
-  e->check(scrf_zero_grad(e->h), "accumulateGradient");
   string local_failure;
+  try {
+    crf->pushLambda();
+    e->check(scrf_zero_grad(e->h), "accumulateGradient");
+  } catch (const std::exception& ex) {
+    if (!dist) throw;
+    local_failure = ex.what();
+  }
   for (int s = 0; s < nStreams; s++) try {
+    if (!local_failure.empty()) break;
     if (dist && s != crf->distRank()) continue;
     CRF_FeatureStream* strm = nStreams == 1 ? mgr->trn_stream : mgr->getChild((size_t)s)->trn_stream;
     strm->rewind();
@@ -986,7 +1022,7 @@ double CRF_GradAccumulator::accumulateGradient(CRF_FeatureStreamManager* mgr, in
     // still joins, with a flag, so that every rank stops in the same evaluation (see the minibatch accumulator).
     const double failed_in = local_failure.empty() ? 0.0 : 1.0;
     double failed_out = 0.0;
-    e->check(scrf_allreduce_grad_ex(e->h, 1, &failed_in, 1, sums, &failed_out), "accumulateGradient (all-reduce)");
+    collective(e, scrf_allreduce_grad_ex(e->h, 1, &failed_in, 1, sums, &failed_out), "accumulateGradient (all-reduce)");
     if (failed_out > 0.5) throw runtime_error(!local_failure.empty() ? local_failure : "CRF_GradAccumulator: another rank failed in this evaluation; rank " + std::to_string(crf->distRank()) + " stops with it");
     e->check(scrf_scale_grad(e->h, sums[3]), "accumulateGradient");
   } else {

@@ -283,6 +283,7 @@ class Engine {
 };
 
 scrf_config makeConfig(CRF_Model* crf, int device, uint32_t precision);
+bool frameAsSegmental(CRF_Model* crf, uint32_t precision);   // the n-state frame model recast as the n-state segmental model with maximum duration 1
 // One process per GPU (CRFTrain under RANK / WORLD_SIZE): rank r only ever walks child view r of the training stream
 // (io/CRF_FeatureStreamManager.cpp:425-464: [r floor(n/N), ...)), so a CRF_FeatureStreamManager built afterwards with N
 // threads keeps the frames of that view alone and placeholders for the rest -- N ranks hold the training data once between

@@ -322,6 +322,10 @@ class Engine:
         self._chk(self.lib.scrf_batch_is_fused(self.h, batch.handle, C.byref(f)))
         return f.value
 
+    def set_frame_mass_check(self, on=True):
+        """posterior-mass self-checks with the frame model's bounds on a segmental engine (scrf_set_frame_mass_check)"""
+        self._chk(self.lib.scrf_set_frame_mass_check(self.h, C.c_int(int(on))))
+
     def decode_stats(self):
         """(arc weights recomputed in reference order, chunks sent back to the EXACT path) since create."""
         a = C.c_uint64(); b = C.c_uint64()

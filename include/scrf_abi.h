@@ -255,6 +255,11 @@ int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_labels, uint64
  * the EXACT path's bit for bit.  Counters since scrf_create: weights recomputed, chunks whose
  * list overflowed and went through the EXACT path.  SCRF_FAST_DECODE=0 disables the fast path. */
 int scrf_decode_stats(scrf_handle h, uint64_t* n_recomputed, uint64_t* n_fallback_chunks);
+/* Posterior-mass self-checks of the training path with the FRAME model's bounds ([0.9, 1.1], nodes/CRF_StdStateNode.cpp
+ * :252-275) on an engine whose model type is segmental (1e-6, ...WithoutSegTransFtr.cpp:917-947).  For a host that runs
+ * the n-state frame model as the n-state segmental model with maximum duration 1 (the same function): an
+ * utterance the reference's frame node accepts must not abort training because the stricter segmental check is applied. */
+int scrf_set_frame_mass_check(scrf_handle h, int on);
 
 /* ---- minibatch reduce + optimizer ------------------------------------------------------------ */
 /* replaces the join/sum/average of CRF_Minibatch_GradAccumulator::accumulateGradient
@@ -270,6 +275,14 @@ int scrf_allreduce_grad(scrf_handle h, int active, double* sums4);
  * extra_out (host, n_extra doubles) and sums4 are read back together; either may be NULL. */
 int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4,
                            double* extra_out);
+/* Failure behaviour of the collective (the reference's join is a pthread_join and cannot hang on a dead peer; a
+ * collective can).  With a communicator, scrf_allreduce_grad[_ex] waits for completion under a watchdog: it polls the
+ * stream and ncclCommGetAsyncError and gives up after SCRF_COMM_TIMEOUT_S seconds (default 300) -- in both cases, and
+ * on any error of its own on the way into the collective, it aborts the communicator (ncclCommAbort) and returns
+ * SCRF_ERR_COMM / SCRF_ERR_HIP.  scrf_comm_abort does the same on request: a host whose rank cannot enter the
+ * collective calls it before exiting non-zero, so that its peers fail fast instead of waiting for the timeout.  After
+ * an abort the handle has no communicator; a restart is a fresh process. */
+int scrf_comm_abort(scrf_handle h);
 /* the reference's Gaussian-prior step as written (trainers/CRF_SGTrainer.cpp:300-303): grad[i] -= grad[i] *
  * inv_square_var on the device gradient (it scales the gradient, not lambda -- kept as is) */
 int scrf_gauss_prior(scrf_handle h, float inv_square_var);

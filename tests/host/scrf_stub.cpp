@@ -9,6 +9,11 @@
 // order.  tests/test_host_multirank.py holds the same function in Python and replays the reference's protocol
 // (trainers/accumulators/CRF_Minibatch_GradAccumulator.cpp:229-241, 296-312) to predict the weight files.
 //   SCRF_STUB_FAIL_RANK / SCRF_STUB_FAIL_AT: rank and 1-based scrf_fb_batch call that fails with SCRF_ERR_NUMERIC.
+//   SCRF_STUB_COLL_FAIL_RANK / SCRF_STUB_COLL_FAIL_AT: rank and 1-based all-reduce call that itself returns an error
+//     WITHOUT publishing (what a HIP error around ncclAllReduce looks like to the host); SCRF_STUB_COLL_DIE=1 makes
+//     that rank _exit(9) there instead (a process that is killed).  The collective waits under the same watchdog
+//     contract as the engine's: SCRF_COMM_TIMEOUT_S seconds (default 60 here), and a peer's scrf_comm_abort (a marker
+//     file, standing in for the asynchronous error ncclCommAbort raises on the peers) ends the wait at once.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -158,8 +163,29 @@ int scrf_comm_init(scrf_handle h, const void* id128, int rank, int n_ranks) {
   }
   return SCRF_OK;
 }
+int scrf_comm_abort(scrf_handle h) {
+  if (h && h->comm) {
+    FILE* f = fopen((h->comm_dir + "/abort." + std::to_string(h->rank)).c_str(), "wb");
+    if (f) fclose(f);
+    h->comm = false;
+  }
+  return SCRF_OK;
+}
+static bool peer_aborted(scrf_handle h, int* who) {
+  for (int r = 0; r < h->world; r++) {
+    struct stat st;
+    if (r != h->rank && stat((h->comm_dir + "/abort." + std::to_string(r)).c_str(), &st) == 0) { *who = r; return true; }
+  }
+  return false;
+}
 int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4, double* extra_out) {
   if (!h->comm) { h->err = "stub: all-reduce without a communicator"; return SCRF_ERR_COMM; }
+  if (getenv("SCRF_STUB_COLL_FAIL_RANK") && atoi(getenv("SCRF_STUB_COLL_FAIL_RANK")) == h->rank &&
+      h->round + 1 == atoi(getenv("SCRF_STUB_COLL_FAIL_AT") ? getenv("SCRF_STUB_COLL_FAIL_AT") : "1")) {
+    if (getenv("SCRF_STUB_COLL_DIE")) _exit(9);
+    h->err = "stub: injected failure inside the collective";
+    return SCRF_ERR_HIP;
+  }
   const size_t len = h->n + 4 + n_extra;
   std::vector<double> mine(len);
   memcpy(mine.data(), h->grad.data(), sizeof(double) * h->n);
@@ -171,7 +197,8 @@ int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, ui
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f || fwrite(mine.data(), sizeof(double), len, f) != len || fclose(f) != 0 || rename(tmp.c_str(), fin.c_str()) != 0) { h->err = "stub: cannot publish " + fin; return SCRF_ERR_COMM; }
   std::vector<double> tot(len, 0.0), part(len);
-  const time_t deadline = time(nullptr) + 60;
+  const char* ts = getenv("SCRF_COMM_TIMEOUT_S");
+  const time_t deadline = time(nullptr) + (ts && atoi(ts) > 0 ? atoi(ts) : 60);
   for (int r = 0; r < h->world; r++) {
     snprintf(name, sizeof(name), "/r%06d.%d", h->round, r);
     const std::string p = h->comm_dir + name;
@@ -182,7 +209,9 @@ int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, ui
         fclose(g);
         if (got == len) break;
       }
-      if (time(nullptr) > deadline) { h->err = "stub: rank " + std::to_string(r) + " never joined round " + std::to_string(h->round); return SCRF_ERR_COMM; }
+      int who = -1;
+      if (peer_aborted(h, &who)) { h->err = "stub: rank " + std::to_string(who) + " aborted the communicator (asynchronous error)"; h->comm = false; return SCRF_ERR_COMM; }
+      if (time(nullptr) > deadline) { h->err = "stub: the collective did not complete within SCRF_COMM_TIMEOUT_S: rank " + std::to_string(r) + " never joined round " + std::to_string(h->round); h->comm = false; return SCRF_ERR_COMM; }
       usleep(500);
     }
     for (size_t i = 0; i < len; i++) tot[i] += part[i];
@@ -195,6 +224,7 @@ int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, ui
   return SCRF_OK;
 }
 
+int scrf_set_frame_mass_check(scrf_handle, int) { return SCRF_OK; }
 // the rest of the ABI the host layer references: not part of the training control flow
 #define NOT_HERE(sig) int sig { return SCRF_ERR_INVALID; }
 NOT_HERE(scrf_scores(scrf_handle, scrf_batch, uint32_t, double*, double*))

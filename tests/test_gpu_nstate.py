@@ -110,3 +110,36 @@ def test_chunks_and_refusals():
         scrf_amd.Engine(scrf_amd.make_config(model_type=orc.STDFRAME, L=7, D=1, F=3, num_states=2))
     with pytest.raises(scrf_amd.ScrfError):      # the reference has no n-state node for this model type (tests/test_gpu_segnstate.py has the one it has)
         scrf_amd.Engine(scrf_amd.make_config(model_type=orc.STDSEG_NO_DUR, L=6, D=3, F=8 * 2 + 3, num_states=2))
+
+
+@pytest.mark.parametrize("prec,tol", [(scrf_amd.PREC_FAST, 1e-9), (scrf_amd.PREC_FAST32, 1e-5), (scrf_amd.PREC_FASTLIN, 1e-9)])
+def test_frame_model_recast_as_segmental_with_transition_features(prec, tol):
+    """CRFTrain (FAST / FAST32 / FASTLIN, training only) runs the n-state FRAME model as the n-state segmental model
+    with maximum duration 1 over the masked dense layout (host/crf_amd.cpp frameAsSegmental): the same function, here with
+    transition features (stdtrans), against the oracle's n-state frame gradient; and the recast engine keeps the frame
+    node's posterior-mass bounds (scrf_set_frame_mass_check)."""
+    c = NCase(P=16, K=3, F=6, Ts=[20, 7, 33], seed=77, trans_ftrs=True, scale=0.1)
+    for T, labs in zip(c.Ts, c.labels):   # the segmental node wants an utterance to end in an end state
+        labs[T - 1] = (labs[T - 1] // c.K) * c.K + c.K - 1
+        for t in range(T - 2, -1, -1):    # and the label sequence to follow the topology back from there
+            nxt, cur = int(labs[t + 1]), int(labs[t])
+            ok = cur == nxt or (nxt % c.K != 0 and cur == nxt - 1) or (nxt % c.K == 0 and (cur + 1) % c.K == 0)
+            if not ok:
+                labs[t] = nxt if nxt % c.K == 0 else nxt - 1
+    kw = dict(model_type=orc.STDSEG_NO_DUR_NO_SEGTRANSFTR, L=c.L, D=1, F=c.F, use_trans_ftrs=True, tfs=0, tfe=c.F - 1, num_states=c.K)
+    eng = scrf_amd.Engine(scrf_amd.make_config(precision=prec, **kw))
+    eng.set_frame_mass_check(True)
+    assert eng.lambda_len == c.olay.lambda_len
+    eng.set_lambda(c.lam)
+    b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og = np.zeros(c.olay.lambda_len); on, oz = [], []
+    for u, T in enumerate(c.Ts):
+        rc, og, n, z = orc.nstate_build_gradient(c.ocfg, c.olay, c.lam, c.frames[u], c.labels[u], T, grad=og)
+        assert rc == 0
+        on.append(n); oz.append(z)
+    assert np.abs(numer - np.array(on)).max() <= tol * max(1, np.abs(on).max())
+    assert np.abs(zx - np.array(oz)).max() <= tol * np.abs(oz).max()
+    assert np.abs(g - og).max() <= 10 * tol * max(1.0, np.abs(og).max())
+    b.close(); eng.close()

@@ -175,6 +175,33 @@ def test_a_failing_rank_stops_every_rank(exe, data, tmp_path):
     assert not os.path.exists(str(tmp_path / "fail" / "w.out"))
 
 
+def test_a_rank_whose_collective_itself_fails_aborts_and_the_peers_stop(exe, data, tmp_path):
+    """The failure-flag protocol covers a rank that fails in its SHARE.  A rank whose all-reduce call itself errors (a
+    device error around the collective) cannot send a flag: it aborts the communicator and exits non-zero, and its
+    peers' bounded wait ends with the asynchronous error -- nobody hangs, nobody writes a weight file."""
+    d, _ = data
+    t0 = time.time()
+    res = launch(exe, d, str(tmp_path / "cfail"), 3, crf_bunch_size=3,
+                 env_extra={"SCRF_STUB_COLL_FAIL_RANK": "1", "SCRF_STUB_COLL_FAIL_AT": "2", "SCRF_COMM_TIMEOUT_S": "30"})
+    assert time.time() - t0 < 25                       # the abort ended the peers' wait, not the 30 s watchdog
+    assert all(rc != 0 for rc, _, _ in res)
+    assert "injected failure inside the collective" in res[1][2] and "communicator aborted" in res[1][2]
+    assert "aborted the communicator" in res[0][2] and "aborted the communicator" in res[2][2]
+    assert not os.path.exists(str(tmp_path / "cfail" / "w.out"))
+
+
+def test_a_rank_that_dies_inside_the_collective_is_found_by_the_watchdog(exe, data, tmp_path):
+    """a killed rank sends nothing at all: the peers' wait is bounded by SCRF_COMM_TIMEOUT_S and ends non-zero"""
+    d, _ = data
+    t0 = time.time()
+    res = launch(exe, d, str(tmp_path / "cdie"), 2, crf_bunch_size=2,
+                 env_extra={"SCRF_STUB_COLL_FAIL_RANK": "1", "SCRF_STUB_COLL_FAIL_AT": "2", "SCRF_STUB_COLL_DIE": "1", "SCRF_COMM_TIMEOUT_S": "3"})
+    assert 2.5 < time.time() - t0 < 40
+    assert res[1][0] != 0 and res[0][0] != 0
+    assert "did not complete within SCRF_COMM_TIMEOUT_S" in res[0][2]
+    assert not os.path.exists(str(tmp_path / "cdie" / "w.out"))
+
+
 def test_stale_id_file_and_a_late_rank(exe, data, tmp_path):
     """a leftover id file of another launch (other token) is ignored, and a rank that starts seconds after rank 0
     published the id still joins -- the handshake compares launch tokens, not clocks"""

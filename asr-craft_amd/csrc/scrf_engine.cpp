@@ -107,6 +107,7 @@ struct scrf_engine_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
+  double* d_sl_tab = nullptr;   // STDSEG, bias-only transitions: E, E^T (nLabs^2 each) and max M (scrf_stdseg_lin.hip)
   bool frame_mass = false;   // posterior-mass self-checks with the frame model's bounds (scrf_set_frame_mass_check)
   bool lin_dp = true;
   // the workgroup-per-utterance log-domain recursion (k_fb: column-wise max-shifted log-sum-exp, the
@@ -310,6 +311,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_grad, nb));
   CRCHK(hipMalloc((void**)&h->d_m0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_w1, sizeof(double) * lay.L));
+  if (cfg->model_type == SCRF_STDSEG && !lay.use_tf) CRCHK(hipMalloc((void**)&h->d_sl_tab, sizeof(double) * (2 * (size_t)lay.L * lay.L + 8)));
   CRCHK(hipMalloc((void**)&h->d_e0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_msh0, sizeof(double)));
@@ -363,7 +365,7 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  hipFree(h->d_w1); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
+  hipFree(h->d_w1); hipFree(h->d_sl_tab); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1404,8 +1406,95 @@ static size_t stdseg_chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nfr, uint
   if (post) tot += pad256(nseg * La * sizeof(double)) + pad256(nseg * (size_t)l.L * La * sizeof(double)) + 2 * pad256(nfr * sizeof(double));
   return tot;
 }
+// ---- STDSEG, bias-only transitions, FAST precisions, training path: scrf_stdseg_lin.hip
+static bool stdseg_lin(scrf_handle h) {
+  static const bool on = !(getenv("SCRF_STDSEG_LIN") && atoi(getenv("SCRF_STDSEG_LIN")) == 0);
+  return on && h->cfg.train_precision != SCRF_PREC_EXACT && h->lay.use_sf && stdseg_lin_supported(h->lay, stdseg_La(h));
+}
+static uint64_t sl_rows_per_chunk(uint64_t nfr) {   // K-chunks of the count contractions: <= 256 of them, multiples of 32 frames
+  uint64_t rpc = ((nfr + 255) / 256 + 31) & ~31ull;
+  return rpc < 64 ? 64 : rpc;
+}
+static size_t stdseg_lin_chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nfr, uint64_t nseg) {
+  const ScrfLayout& l = h->lay;
+  const uint32_t La = stdseg_La(h);
+  const size_t node = pad256((size_t)l.D * nfr * La * sizeof(double));
+  const uint64_t nch = (nfr + sl_rows_per_chunk(nfr) - 1) / sl_rows_per_chunk(nfr);
+  size_t tot = 0;
+  if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
+  tot += pad256((size_t)l.D * nfr * sizeof(uint64_t));                // xrow
+  tot += 5 * node;                                                    // Sd, Ad, Bd, Rd, Bp
+  tot += pad256(nfr * (size_t)l.L * sizeof(double)) + 2 * pad256(nfr * sizeof(double));   // Am, ga, numer_f
+  tot += pad256(nch * (size_t)La * l.nsf * sizeof(double));           // state-count slabs (one duration at a time)
+  tot += pad256(nch * (size_t)l.L * l.L * sizeof(double)) + pad256((size_t)l.L * l.L * sizeof(double));   // transition slabs, observed
+  return tot + 4096;
+}
+static int stdseg_lin_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, double* grad) {
+  const ScrfLayout& l = h->lay;
+  const uint32_t La = stdseg_La(h);
+  const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
+  int rc = ensure_scratch(h, stdseg_lin_chunk_bytes(h, b, nfr, nseg));
+  if (rc != SCRF_OK) return rc;
+  Arena a{h->scratch, h->scratch_cap, 0};
+  ScrfBatchView bv = b->view();
+  hipStream_t st = h->stream;
+  const int f32 = h->cfg.train_precision == SCRF_PREC_FAST32;
+  float* X;
+  if (b->mode == 1) {
+    X = a.take<float>(nseg * l.F);
+    uint32_t col = 0;
+    for (uint32_t s = 0; s < b->n_streams; s++) {
+      const scrf_stream_recipe& r = b->recipe[s];
+      KT_RUN("k_windows", st, launch_windows(st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx, r.right_ctx,
+                                             r.extract_seg_ftr, X, l.F, col));
+      col += b->width[s];
+    }
+  } else X = b->d_windows + b->seg_off[u0] * l.F;
+  const size_t nn = (size_t)l.D * nfr * La;
+  uint64_t* xrow = a.take<uint64_t>((size_t)l.D * nfr);
+  double* Sd = a.take<double>(nn); double* Ad = a.take<double>(nn); double* Bd = a.take<double>(nn);
+  double* Rd = a.take<double>(nn); double* Bp = a.take<double>(nn);
+  double* Am = a.take<double>(nfr * (size_t)l.L);
+  double* ga = a.take<double>(nfr); double* numer_f = a.take<double>(nfr);
+  const uint64_t rpc = sl_rows_per_chunk(nfr);
+  const uint32_t nch = (uint32_t)((nfr + rpc - 1) / rpc);
+  double* slab_s = a.take<double>((size_t)nch * La * l.nsf);
+  double* slab_t = a.take<double>((size_t)nch * l.L * l.L);
+  double* obs = a.take<double>((size_t)l.L * l.L);
+  if (a.off > a.cap) return fail(h, SCRF_ERR_INVALID, "internal: scratch arena overflow");
+  // the transition table and its exponential (once per call: lambda may have changed)
+  double* E = h->d_sl_tab; double* ET = E + (size_t)l.L * l.L; double* mmax = ET + (size_t)l.L * l.L;
+  launch_sl_tables(st, l, h->d_lambda, E, ET, mmax);
+  launch_sl_rows(st, bv, b->d_frame_u, u0, nfr, l.D, xrow);
+  {
+    KernelTimer kt(h, "k_scores_mfma(state, per duration)", st);
+    for (uint32_t d0 = 0; d0 < l.D; d0++) {
+      const ScrfGemmSpec sp{0, l.sfs, l.nsfe, (uint32_t)l.use_sb, l.sbv, d0 * La * l.stride, 0};
+      launch_scores_mfma(st, X, l.F, xrow + (size_t)d0 * nfr, nfr, h->d_lambda, l, sp, La, Sd + (size_t)d0 * nfr * La, f32);
+    }
+    kt.stop(l.D);
+  }
+  KT_RUN("k_sl_fb", st, launch_sl_fb(st, l, La, bv, u0, u1 - u0, nfr, Sd, E, ET, mmax, Ad, Bd, Am, ga, b->d_zx, b->d_status));
+  KT_RUN("k_sl_post", st, launch_sl_post(st, l, La, bv, b->d_frame_u, u0, u1 - u0, nfr, b->d_prev_lab, h->d_lambda, Sd, Ad, Bd, ga, b->d_zx, Rd, Bp,
+                                         numer_f, b->d_numer, b->d_status));
+  {
+    KernelTimer kt(h, "k_expf_mfma(state, per duration)", st);
+    for (uint32_t d0 = 0; d0 < l.D; d0++) {
+      const ScrfGemmSpec sp{0, l.sfs, l.nsfe, (uint32_t)l.use_sb, l.sbv, d0 * La * l.stride, 0};
+      launch_expf_mfma(st, Rd + (size_t)d0 * nfr * La, La, X, l.F, xrow + (size_t)d0 * nfr, nfr, l, sp, rpc, nch, slab_s, f32);
+      launch_reduce_slabs(st, slab_s, nch, La, l, sp, grad);
+    }
+    kt.stop(2 * l.D);
+  }
+  HIPCHK(h, hipMemsetAsync(obs, 0, sizeof(double) * l.L * l.L, st));
+  KT_RUN("k_sl_atb", st, launch_sl_trans_counts(st, l, La, bv, b->d_frame_u, u0, nfr, b->d_prev_lab, rpc, nch, Am, Bp, E, mmax, slab_t, obs, grad));
+  HIPCHK(h, hipGetLastError());
+  return SCRF_OK;
+}
+
 // chunk [u0, u1): scores and recursion (and, with post, posteriors, numerators, the gradient into `grad`)
 static int stdseg_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, bool post, double* grad, StdsegBufs* out) {
+  if (post && !out && stdseg_lin(h)) return stdseg_lin_run_chunk(h, b, u0, u1, grad);
   const ScrfLayout& l = h->lay;
   const uint32_t La = stdseg_La(h);
   const uint64_t nfr = b->frame_off[u1] - b->frame_off[u0], nseg = b->seg_off[u1] - b->seg_off[u0];
@@ -1450,6 +1539,11 @@ static int stdseg_run_chunk(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u
 }
 static uint32_t stdseg_plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, bool post) {
   uint32_t u1 = u0 + 1;
+  if (post && stdseg_lin(h)) {
+    while (u1 < b->U && u1 - u0 < 32767 &&
+           stdseg_lin_chunk_bytes(h, b, b->frame_off[u1 + 1] - b->frame_off[u0], b->seg_off[u1 + 1] - b->seg_off[u0]) <= h->cfg.scratch_bytes) u1++;
+    return u1;
+  }
   while (u1 < b->U && stdseg_chunk_bytes(h, b, b->frame_off[u1 + 1] - b->frame_off[u0], b->seg_off[u1 + 1] - b->seg_off[u0], post) <= h->cfg.scratch_bytes) u1++;
   return u1;
 }

@@ -173,6 +173,22 @@ void launch_stdseg_post(hipStream_t st, const ScrfLayout& lay, uint32_t La, Scrf
 void launch_stdseg_expf(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint64_t n_rows,
                         const uint32_t* row_t, const uint32_t* row_d, const uint32_t* row_u, const uint32_t* prev_lab,
                         const float* X, const double* G, const double* XI, double* grad);
+// scrf_stdseg_lin.hip: STDSEG with bias-only transitions on the training path: linear-domain recursion against one
+// exp(M) table, node arrays duration-major [D][frames][La], transition counts as E o (A^T B) on the MFMA
+int stdseg_lin_supported(const ScrfLayout& lay, uint32_t La);
+void launch_sl_tables(hipStream_t st, const ScrfLayout& lay, const double* lambda, double* E, double* ET, double* mmax);
+void launch_sl_rows(hipStream_t st, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames, uint32_t D, uint64_t* xrow);
+void launch_sl_fb(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint64_t n_frames,
+                  const double* Sd, const double* E, const double* ET, const double* mmax, double* Ad, double* Bd, double* Am,
+                  double* ga, double* zx, int* status);
+void launch_sl_post(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                    uint32_t n_utts, uint64_t n_frames, const uint32_t* prev_lab, const double* lambda, const double* Sd,
+                    const double* Ad, const double* Bd, const double* ga, const double* zx, double* Rd, double* Bp,
+                    double* numer_f, double* numer, int* status);
+void launch_sl_trans_counts(hipStream_t st, const ScrfLayout& lay, uint32_t La, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,
+                            uint64_t n_frames, const uint32_t* prev_lab, uint64_t rows_per_chunk, uint32_t n_chunks,
+                            const double* Am, const double* Bp, const double* E, const double* mmax, double* slab, double* obs,
+                            double* grad);
 void launch_stdseg_sums(hipStream_t st, const double* numer, const double* zx, uint32_t u0, uint32_t n, double* sums);
 uint64_t stdseg_num_arcs(uint32_t T, uint32_t La, uint32_t D);
 void stdseg_row_arc_offsets(uint32_t T, uint32_t La, uint32_t D, std::vector<uint64_t>* off);

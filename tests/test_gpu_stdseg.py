@@ -68,6 +68,81 @@ def test_fb_batch_gradient(ci):
     b.close(); eng.close()
 
 
+LIN_CASES = [
+    dict(L=4, D=5, in_w=3, Ts=[4, 5, 6, 15, 1, 2]),          # T = 1, 2, D-1, D, D+1, 3D
+    dict(L=12, D=4, in_w=4, Ts=[20, 9], lam_scale=0.1),      # 48 full labels
+    dict(L=48, D=10, in_w=5, Ts=[40, 9, 10, 11], lam_scale=0.05),   # the TIMIT label space: 480 full labels (one thread each)
+    dict(L=3, D=3, in_w=2, Ts=[7, 3, 5, 8, 2, 9, 4]),
+    dict(L=9, D=12, in_w=2, Ts=[30, 13], lam_scale=0.1),
+]
+
+
+@pytest.mark.parametrize("prec,tol", [(scrf_amd.PREC_FAST, 1e-9), (scrf_amd.PREC_FASTLIN, 1e-9), (scrf_amd.PREC_FAST32, 1e-5)])
+@pytest.mark.parametrize("ci", range(len(LIN_CASES)))
+def test_bias_only_transitions_linear_domain_path(ci, prec, tol, monkeypatch):
+    """FAST precisions with bias-only transitions (`stdstate`): scrf_stdseg_lin.hip -- one exp(M) table, mantissa
+    recursion as a matrix-vector product per node, duration-major node arrays through the dense MFMA contractions,
+    transition counts as E o (A^T B).  Against the oracle (the reference's log-domain order), and against the
+    reference-order kernels of the same engine (SCRF_STDSEG_LIN=0)."""
+    c = Case(seed=940 + ci, model_type=orc.STDSEG, precision=prec, **LIN_CASES[ci])
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    g = eng.get_grad()
+    og, on, oz = c.oracle_gradient()
+    assert np.abs(numer - on).max() <= tol * max(1, np.abs(on).max())
+    assert np.abs(zx - oz).max() <= tol * np.abs(oz).max()
+    assert np.abs(g - og).max() <= 10 * tol * max(1.0, np.abs(og).max())
+    numer2, zx2 = eng.fb_batch(b)   # accumulates
+    np.testing.assert_allclose(eng.get_grad(), 2 * g, rtol=1e-12, atol=1e-13)
+    assert eng.batch_sums()[2] == 2 * len(c.Ts)
+    # which kernels ran
+    eng.enable_timing(True); eng.zero_grad(); eng.fb_batch(b)
+    names = [k[0] for k in eng.kernel_timing()]
+    eng.enable_timing(False)
+    assert "k_sl_fb" in names and "k_stdseg_fb" not in names
+    b.close(); eng.close()
+    if prec == scrf_amd.PREC_FAST:
+        monkeypatch.setenv("SCRF_STDSEG_LIN", "0")
+        eng = c.engine(); b = c.batch(eng)
+        n0, z0 = eng.fb_batch(b)
+        np.testing.assert_allclose(numer, n0, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(zx, z0, rtol=1e-11)
+        assert np.abs(eng.get_grad() - g).max() <= 1e-9 * max(1.0, np.abs(g).max())
+        b.close(); eng.close()
+
+
+def test_linear_domain_path_chunks_errors_and_extreme_weights():
+    kw = dict(L=3, D=3, in_w=2, Ts=[5, 7, 3, 9, 4, 8])
+    out = []
+    for sb in (0, 1 << 16):     # one chunk / a few utterances per chunk
+        c = Case(seed=78, model_type=orc.STDSEG, precision=1, scratch_bytes=sb, **kw)
+        eng = c.engine(); b = c.batch(eng)
+        numer, zx = eng.fb_batch(b)
+        out.append((numer.copy(), zx.copy(), eng.get_grad().copy()))
+        b.close(); eng.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12, atol=1e-13)
+    # a label outside nLabs: the batch fails and contributes nothing
+    c = Case(seed=5, model_type=orc.STDSEG, precision=1, L=3, D=3, in_w=2, Ts=[6, 5])
+    eng = c.engine()
+    bad = [l.copy() for l in c.labels]
+    bad[1][-1] = 3 * 3 + 2
+    b = eng.batch_from_frames(c.frames, bad, c.recipes, None)
+    with pytest.raises(scrf_amd.ScrfError) as ei:
+        eng.fb_batch(b)
+    assert "label" in str(ei.value).lower() and np.all(eng.get_grad() == 0.0)
+    b.close(); eng.close()
+    # weights two orders of magnitude larger (scores in the hundreds): the per-node log-scales carry the range
+    c = Case(seed=6, model_type=orc.STDSEG, precision=1, L=4, D=4, in_w=3, Ts=[25, 8], lam_scale=30.0)
+    eng = c.engine(); b = c.batch(eng)
+    numer, zx = eng.fb_batch(b)
+    og, on, oz = c.oracle_gradient()
+    assert np.abs(zx - oz).max() <= 1e-10 * np.abs(oz).max()
+    assert np.abs(eng.get_grad() - og).max() <= 1e-8 * max(1.0, np.abs(og).max())
+    b.close(); eng.close()
+
+
 def test_chunked_batches_equal_one_chunk():
     kw = dict(L=3, D=3, in_w=2, Ts=[5, 7, 3, 9, 4, 8], trans_share=(0, 1))
     c1 = Case(seed=77, model_type=orc.STDSEG, **kw)

@@ -1331,8 +1331,15 @@ void crf_amd::readFstBinary(const char* fname, crf_amd::ArcListFst* fst) {
   if (seen != n_arcs || r.at != r.d.size()) throw runtime_error(r.name + ": the file does not end where its header says" + hint);
 }
 
-bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd::ArcListFst& lm, crf_amd::ArcListFst* best, float* total) {
+// With `group` and a positive `beam` the search is pruned time-synchronously the way the reference's decoder prunes
+// (decoders/CRF_ViterbiDecoder_StdSeg_NoSegTransFtr.cpp pruning() :976-1060 and its reads at :573, :760: a hypothesis of
+// a node is kept, and expanded into the next nodes, iff its weight is < the node's minimum + beam): group[s] >= 0 names
+// the node whose hypotheses lattice state s carries (the states of one group have consecutive ids and no arcs among
+// themselves, so all of them are final when the first is reached); states with group -1 are never pruned.
+bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd::ArcListFst& lm, crf_amd::ArcListFst* best, float* total,
+                                  const std::vector<int>* group, double beam, uint64_t* n_expanded) {
   const int S = lat.n_states, Q = lm.n_states;
+  if (group && (int)group->size() != S) throw runtime_error("composeShortestPath: one group entry per lattice state");
   if (S <= 0 || Q <= 0 || lat.start < 0 || lm.start < 0) throw runtime_error("composeShortestPath: a machine has no start state");
   if ((size_t)S * (size_t)Q > ((size_t)1 << 28)) throw runtime_error("composeShortestPath: lattice x LM too large for the dense product search");
   const float INF = std::numeric_limits<float>::infinity();
@@ -1360,8 +1367,24 @@ bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd:
   std::vector<int> work;
   float best_w = INF;
   long best_at = -1;
+  int cur_group = -1;
+  uint64_t n_exp = 0;
   for (int s = 0; s < S; s++) {
     float* ds = &dist[(size_t)s * Q];
+    if (group && beam > 0 && (*group)[s] >= 0 && (*group)[s] != cur_group) {
+      // first state of a node: its hypotheses are final; keep those below the node's minimum + beam
+      cur_group = (*group)[s];
+      int s1 = s;
+      float gmin = INF;
+      for (; s1 < S && (*group)[s1] == cur_group; s1++)
+        for (int q = 0; q < Q; q++) gmin = std::min(gmin, dist[(size_t)s1 * Q + q]);
+      for (int x = s; x < s1; x++)
+        for (int q = 0; q < Q; q++) {
+          float& dq = dist[(size_t)x * Q + q];
+          if (dq < INF && !(dq < gmin + (float)beam)) dq = INF;
+        }
+    }
+    for (int q = 0; q < Q; q++) if (ds[q] < INF) n_exp++;
     // epsilon-input closure of the LM at this lattice state
     work.clear();
     for (int q = 0; q < Q; q++) if (ds[q] < INF) work.push_back(q);
@@ -1434,6 +1457,7 @@ bool crf_amd::composeShortestPath(const crf_amd::ArcListFst& lat, const crf_amd:
     const int sf = (int)(best_at / Q), qf = (int)(best_at % Q);
     best->SetFinal(cur, carry + (lfin[sf] + mfin[qf]));
   }
+  if (n_expanded) *n_expanded = n_exp;
   return true;
 }
 
@@ -1760,7 +1784,7 @@ void crf_amd::writeFstBinary(const char* fname, const crf_amd::ArcListFst& fst, 
   }
 }
 
-int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeNState(const crf_amd::ArcListFst* lm, crf_amd::ArcListFst* result_fst) {
+int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeNState(const crf_amd::ArcListFst* lm, double beam, crf_amd::ArcListFst* result_fst) {
   const modeltype mt = crf->getModelType();
   if (mt != STDFRAME && mt != STDSEG_NO_DUR_NO_TRANSFTR && mt != STDSEG_NO_DUR_NO_SEGTRANSFTR)
     throw runtime_error("nStateDecode: crf_states > 1 is built for stdframe and stdseg_no_dur_no_segtransftr");
@@ -1815,8 +1839,28 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeNState(const crf_amd::ArcList
     loop.SetFinal(s0, 0.0f);
     lm = &loop;
   }
+  // The reference's time-synchronous beam (pruning() :976-1060): the hypotheses of a node are its states a segment can
+  // END in -- every state of a frame in the frame lattice (1 + t L + c), the second run of L states of a node in the
+  // segmental one (boundary states first: decoders/...WithoutSegTransFtr.h:248-330) -- kept iff below the node's
+  // minimum + beam.  beam <= 0: exhaustive.
+  std::vector<int> group;
+  if (beam > 0) {
+    group.assign(n_states, -1);
+    if (mt == STDFRAME) {
+      for (uint32_t t = 0; t < T; t++) for (uint32_t c = 0; c < L; c++) group[1 + t * L + c] = (int)t;
+    } else {
+      for (uint32_t c = 0; c < L; c++) group[1 + c] = 0;
+      for (uint32_t t = 1; t < T; t++) {
+        const uint32_t s0 = 1 + L + (t - 1) * 2 * L;
+        for (uint32_t c = 0; c < L; c++) group[s0 + L + c] = (int)t;
+      }
+    }
+  }
   float total = 0.0f;
-  if (!crf_amd::composeShortestPath(lat, *lm, result_fst, &total)) {   // "Could not reach end of utterance" (:2141-2147)
+  uint64_t nexp = 0;
+  const bool found = crf_amd::composeShortestPath(lat, *lm, result_fst, &total, beam > 0 ? &group : nullptr, beam, &nexp);
+  n_hyps = nexp;
+  if (!found) {   // "Could not reach end of utterance" (:2141-2147)
     *result_fst = crf_amd::ArcListFst();
     const int s0 = result_fst->AddState(), s1 = result_fst->AddState();
     result_fst->SetStart(s0);
@@ -2044,7 +2088,7 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst&
       float best_last = INF;
       if (beam > 0) for (size_t i = 0; i < QL; i++) best_last = std::min(best_last, Fl[i]);
       for (size_t idx = 0; idx < QL; idx++) {
-        if (Fl[idx] >= INF || (beam > 0 && !(Fl[idx] < best_last + beam))) continue;
+        if (Fl[idx] >= INF || (beam > 0 && Fl[idx] > best_last + beam)) continue;   // pruneFinal :947-970 erases weight > min + beam
         if (sid[(size_t)(T - 1) * QL + idx] >= 0) full.SetFinal(sid[(size_t)(T - 1) * QL + idx], (float)zx);
       }
     }

@@ -327,7 +327,8 @@ void readFstBinary(const char* fname, ArcListFst* fst);
 // either side (ilabel = the lattice arc's ilabel, olabel = the LM arc's olabel); the weights of label-free
 // arcs are folded into the next arc (the final weight at the end), as RmEpsilon does on a linear path.
 // Returns false when no path reaches a final state of both machines.
-bool composeShortestPath(const ArcListFst& lat, const ArcListFst& lm, ArcListFst* best, float* total);
+bool composeShortestPath(const ArcListFst& lat, const ArcListFst& lm, ArcListFst* best, float* total,
+                         const std::vector<int>* group = nullptr, double beam = 0.0, uint64_t* n_expanded = nullptr);
 // Compose(a, b) on the tropical semiring (CRFFstDecode/src/Main.cpp:898-955 chains ComposeFst over the phone lattice,
 // the dictionary, the alignment acceptor and the LM): states are the reachable pairs, numbered in discovery order
 // (breadth first from the start pair); a pair of arcs with a.olabel == b.ilabel != 0 moves both machines (ilabel of a,
@@ -647,7 +648,7 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
         throw std::runtime_error("CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::nStateDecode: the full output lattice is built for crf_states = 1 only");
       return decodeFull(lm_fst, input_beam, result_fst, out_full_fst);
     }
-    if (crf->getFeatureMap() && crf->getFeatureMap()->getNumStates() > 1) return decodeNState(lm_fst, result_fst);
+    if (crf->getFeatureMap() && crf->getFeatureMap()->getNumStates() > 1) return decodeNState(lm_fst, input_beam, result_fst);
     if (lm_fst != nullptr) return decodeLm(*lm_fst, input_beam, result_fst);
     const int T = decode();
     typedef typename Fst::Arc Arc;
@@ -709,10 +710,12 @@ class CRF_ViterbiDecoder_StdSeg_NoSegTransFtr {
   // prune it (ties: unpinned).  Result: one arc per lattice arc that carries a label and per LM word, StdArc(state
   // label + 1 [+ nLabs*(dur-1) for a segmental model], word where a phone starts else 0, weight, next); final weight
   // Zx + the LM's final weight.
-  template <class Fst> int decodeNState(const Fst*, Fst*) {
+  // `beam` > 0: the reference's time-synchronous pruning over the n-state lattice's nodes (kept iff below the node's
+  // minimum + beam, pruning() :976-1060); <= 0: exhaustive.
+  template <class Fst> int decodeNState(const Fst*, double, Fst*) {
     throw std::runtime_error("nStateDecode: with crf_states > 1 the result and LM FSTs must be crf_amd::ArcListFst");
   }
-  int decodeNState(const crf_amd::ArcListFst* lm, crf_amd::ArcListFst* result_fst);
+  int decodeNState(const crf_amd::ArcListFst* lm, double beam, crf_amd::ArcListFst* result_fst);
   size_t lastNumHyps() const { return n_hyps; }   // hypotheses kept, summed over frames (beam diagnostics)
 
  protected:

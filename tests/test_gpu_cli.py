@@ -1711,6 +1711,42 @@ def test_crftrain_and_fstdecode_segmental_model_with_states_per_phone(tmp_path):
                         best = (tot, [l + L * (d - 1) for (_, d, l) in segs], [10 + ph for ph in phones])
                 assert abs(gcost + float(got[-1][1]) - float(np.float32(ozx_of(cfg, S, M, T))) - best[0]) <= 1e-3 * max(1.0, abs(best[0]))
                 assert glabs == best[1] and gwords == best[2]
+    # the reference's time-synchronous beam over the n-state search (pruning(): a node's hypotheses survive iff below the
+    # node's minimum + beam): a beam wider than any score difference changes nothing; a narrow one returns a path of the
+    # same search space (labels tile the utterance, follow the topology, cost = that path's own cost) that is never cheaper
+    # than the exhaustive best
+    def run_beam(beam, tag):
+        latdir = tmp_path / ("latb" + tag); latdir.mkdir()
+        r = subprocess.run([os.path.join(BIN, "CRFDecode")] + model + ["weight_file=" + wf, "crf_olist=" + olist, "crf_lat_outdir=" + str(latdir),
+                            "crf_output_mlffile=" + str(tmp_path / ("ob%s.mlf" % tag)), "crf_lm_txt=" + lmf, "crf_decode_beam=" + beam],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return latdir
+    wide, narrow = run_beam("1000", "w"), run_beam("0.5", "n")
+    for u, T in enumerate(Ts):
+        full = open(str(tmp_path / "lat1" / ("u%d.fst.txt" % u))).read()
+        assert open(str(wide / ("u%d.fst.txt" % u))).read() == full
+        got = [x.split() for x in open(str(narrow / ("u%d.fst.txt" % u))).read().strip().split("\n")]
+        ref = [x.split() for x in full.strip().split("\n")]
+        if len(got) == 2 and int(got[0][2]) == 0:     # the beam lost every complete path: the decoder's error arc
+            continue
+        labs = [int(g[2]) - 1 for g in got[:-1] if int(g[2]) != 0]
+        assert sum(l // L + 1 for l in labs) == T
+        seq = [l % L for l in labs]
+        assert seq[0] % K == 0 and (seq[-1] + 1) % K == 0 and all(orc.ns_allowed(K, a, b) for a, b in zip(seq, seq[1:]))
+        assert sum(float(g[4]) for g in got[:-1]) >= sum(float(g[4]) for g in ref[:-1]) - 1e-3
+        if T <= 7:   # its cost is the enumerated cost of that very path
+            S, M = orc.seg_scores(cfg, lay, w, orc.windows(utts[u], D), T)
+            bf = orc.brute_force(S, M, T, L, D, K=K)
+            mine = [sc for sc, segs in bf["paths"] if [l + L * (d - 1) for (_, d, l) in segs] == labs]
+            assert len(mine) == 1
+            phones = [seq[0] // K] + [b // K for a, b in zip(seq, seq[1:]) if a != b and b % K == 0]
+            q, lw = 0, 0.0
+            for ph in phones:
+                lw += lmw[q, ph]; q = 1 + ph
+            want = -mine[0] + lw + 0.25 * q
+            gcost = sum(float(g[4]) for g in got[:-1])
+            assert abs(gcost + float(got[-1][1]) - float(np.float32(ozx_of(cfg, S, M, T))) - want) <= 1e-3 * max(1.0, abs(want))
 
 
 def ozx_of(cfg, S, M, T):

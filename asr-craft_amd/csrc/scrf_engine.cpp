@@ -107,6 +107,7 @@ struct scrf_engine_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
+  bool side_stream = true;    // k_ztf + transition counts on the second stream under k_expf_fused_ws (SCRF_SIDE=0: off)
   double* d_sl_tab = nullptr;   // STDSEG, bias-only transitions: E, E^T (nLabs^2 each) and max M (scrf_stdseg_lin.hip)
   bool frame_mass = false;   // posterior-mass self-checks with the frame model's bounds (scrf_set_frame_mass_check)
   bool lin_dp = true;
@@ -287,6 +288,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (h->cfg.scratch_bytes == 0) h->cfg.scratch_bytes = 8ull << 30;
   if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knobs
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_SIDE")) h->side_stream = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
   if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = std::max(1.0, atof(e));   // widening only: < 1 would void the bound
@@ -1704,19 +1706,36 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
       rc = queue_status(h, b);
       if (rc != SCRF_OK) return rc;
     }
+    bool side = false;   // part of the count work runs on the second stream (below)
     {
       PhaseTimer tm(h, PH_EXPF, cb.st);
       uint32_t nl = 1;
       if (cb.fused) {
         const uint32_t W0 = b->recipe[0].in_width;
         ScrfFusedArgs fa = fused_args(h, b, u0, cb.expf_tiles);
+        // Side stream (round 4): the per-frame count contraction k_ztf, its reduction and the transition counts A^T B
+        // need Z / the recursion's vectors, not R's contraction -- they run on the engine's second stream UNDER
+        // k_expf_fused_ws, whose one workgroup per CU leaves 80 registers per SIMD lane and the wave slots for a narrow
+        // k_ztf (one output tile per wavefront).  The two sides add into disjoint weights; the streams join before the
+        // commit.  Off while kernels are timed one by one (scrf_enable_timing) and with SCRF_SIDE=0.
+        side = h->side_stream && !use2 && !h->timing && cb.z_ready && pframe_supported(W0) && !l.use_tf && !segtrans(h) && cb.wave &&
+               fused_expf_plan(l, W0, f32, cb.la ? 1 : 0).ws;
+        if (side) {
+          HIPCHK(h, hipEventRecord(h->ev_fork, cb.st));
+          HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+          launch_ztf(h->stream2, cb.Z, (cb.la ? 6 : 5) * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l, 1);
+          launch_reduce_slabs(h->stream2, cb.slab_l, cb.nch_l, (cb.la ? 6 : 5) * l.L, l, spec_samples(W0), cb.grad);
+          launch_atb(h->stream2, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad, cb.lin ? cb.dl.gsd : nullptr);
+          HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+        }
         {
           PhaseTimer tk(h, PH_K_EXPF, cb.st);
           KT_RUN("k_expf_fused", cb.st, launch_expf_fused(cb.st, fa, l, cb.R, b->tile_off[cb.expf_tiles][u1] - b->tile_off[cb.expf_tiles][u0], cb.slab_s, cb.slab_d, f32, cb.la ? 1 : 0));
           tk.stop(1);
         }
         if (!cb.z_ready) KT_RUN("k_lin_z", cb.st, launch_lin_z(cb.st, l, bv, u0, (uint32_t)nutt, cb.R, cb.Z));
-        if (pframe_supported(W0))
+        if (side) {
+        } else if (pframe_supported(W0))
           KT_RUN("k_ztf", cb.st, launch_ztf(cb.st, cb.Z, (cb.la ? 6 : 5) * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l));
         else
           KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
@@ -1752,9 +1771,10 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
           launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, ScrfGemmSpec{0, 0, plan.ncol, 0, 0.0, (5 + plan.g0) * W0, 0}, cb.grad);
           launch_reduce_slabs(cb.st, cb.slab_d, cb.nch_s, l.L, l, ScrfGemmSpec{0, 0, l.D, (uint32_t)l.use_sb, l.sbv, 8 * W0, 0}, cb.grad);
         } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
-        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, (cb.la ? 6 : 5) * l.L, l, spec_samples(W0), cb.grad);
+        if (!side) launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, (cb.la ? 6 : 5) * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
-      if (l.use_tf || segtrans(h)) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
+      if (side) HIPCHK(h, hipStreamWaitEvent(cb.st, h->ev_join, 0));   // the side stream's weights are in
+      else if (l.use_tf || segtrans(h)) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
       else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad,
                                    cb.lin ? cb.dl.gsd : nullptr);
       else launch_reduce_xiacc(cb.st, cb.xi_acc, (uint32_t)nutt, l, cb.grad);

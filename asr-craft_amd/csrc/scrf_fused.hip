@@ -1011,8 +1011,10 @@ void launch_avg_prefix(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n
   hipLaunchKernelGGL(k_avg_prefix, dim3(n_utts, (L + 63) / 64), dim3(64), 0, st, bv, u0, L, P);
 }
 
-#define ZT_MT 4     // output tiles per wavefront (64 outputs): leaves registers for a second prefetch stage
-template <int NT>   // column tiles: ceil(W / 16)
+// ZT_MT = output tiles per wavefront: 4 (64 outputs; leaves registers for a second prefetch stage) when the kernel has
+// the chip to itself, 1 (74 registers: fits beside the two 216-register wavefronts per SIMD of k_expf_fused_ws) when it
+// runs on the side stream under the expected-count kernel
+template <int NT, int ZT_MT>   // NT = column tiles: ceil(W / 16)
 __global__ __launch_bounds__(64) void k_ztf(const double* __restrict__ Zm, uint32_t n_out, const float* __restrict__ F,
                                             uint32_t W, uint64_t n_frames, uint64_t rows_per_chunk,
                                             double* __restrict__ slab) {
@@ -1078,11 +1080,16 @@ __global__ __launch_bounds__(64) void k_ztf(const double* __restrict__ Zm, uint3
 
 // slab: [n_chunks][n_out][W]
 void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F, uint32_t W, uint64_t n_frames,
-                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab) {
+                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int narrow) {
   if (n_frames == 0 || n_chunks == 0) return;
-  dim3 grid(n_chunks, (n_out + 16 * ZT_MT - 1) / (16 * ZT_MT));
+  const uint32_t mt = narrow ? 1 : 4;
+  dim3 grid(n_chunks, (n_out + 16 * mt - 1) / (16 * mt));
   const uint32_t nt = (W + 15) / 16;
-#define ZT_GO(N) hipLaunchKernelGGL(k_ztf<N>, grid, dim3(64), 0, st, Zm, n_out, F, W, n_frames, rows_per_chunk, slab)
+#define ZT_GO(N)                                                                                                           \
+  do {                                                                                                                     \
+    if (narrow) hipLaunchKernelGGL((k_ztf<N, 1>), grid, dim3(64), 0, st, Zm, n_out, F, W, n_frames, rows_per_chunk, slab);  \
+    else hipLaunchKernelGGL((k_ztf<N, 4>), grid, dim3(64), 0, st, Zm, n_out, F, W, n_frames, rows_per_chunk, slab);         \
+  } while (0)
   if (nt <= 1) ZT_GO(1);
   else if (nt == 2) ZT_GO(2);
   else if (nt == 3) ZT_GO(3);
@@ -1549,10 +1556,12 @@ __global__ __launch_bounds__(FE_NT, 2) void k_expf_fused(ScrfFusedArgs fa, ScrfL
 #define FW_DSL 5        // duration slots: producer threads 0..239 = (ol = ptid % 48, ds = ptid / 48)
 // ROWS = window rows per tile (76, or 100 where the two image pairs still fit 160 KB: fewer tiles, fewer barriers and
 // producer round trips per row); NKS = ceil(rows used / 4).
+// (register cap 208 for the narrow forms: two such wavefronts per SIMD leave 96 registers per lane, which is what lets
+// the narrow k_ztf of the side stream -- 64 registers -- be resident on the same SIMD)
 template <int NT, int DMAX, int NKS, int G0, int ROWS>
-__global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R,
-                                                            uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
-                                                            double* __restrict__ slab, double* __restrict__ dslab) {
+__device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* __restrict__ R,
+                                                   uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
+                                                   double* __restrict__ slab, double* __restrict__ dslab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const uint32_t W = fa.W, D = lay.D;
   constexpr uint32_t xs = (NT == 4 ? 5 : NT <= 7 ? 9 : 13) * 16;
@@ -1790,6 +1799,22 @@ __global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, Sc
   }
 }
 
+template <int NT, int DMAX, int NKS, int G0, int ROWS>
+__global__ __launch_bounds__(FW_NT, 2) void k_expf_fused_ws(ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R, uint32_t n_out,
+                                                            uint64_t n_tiles, uint32_t n_ct, double* __restrict__ slab,
+                                                            double* __restrict__ dslab) {
+  expf_fused_ws_body<NT, DMAX, NKS, G0, ROWS>(fa, lay, R, n_out, n_tiles, n_ct, slab, dslab);
+}
+// the same with 208 registers per wavefront (the attribute wants a literal, hence the second entry point): two such
+// wavefronts per SIMD leave 96 registers per lane, which lets the narrow k_ztf of the side stream (64) be resident on
+// the same SIMD while this kernel owns the CU
+template <int NT, int DMAX, int NKS, int G0, int ROWS>
+__global__ __launch_bounds__(FW_NT) __attribute__((amdgpu_num_vgpr(208))) void k_expf_fused_ws_n(
+    ScrfFusedArgs fa, ScrfLayout lay, const double* __restrict__ R, uint32_t n_out, uint64_t n_tiles, uint32_t n_ct,
+    double* __restrict__ slab, double* __restrict__ dslab) {
+  expf_fused_ws_body<NT, DMAX, NKS, G0, ROWS>(fa, lay, R, n_out, n_tiles, n_ct, slab, dslab);
+}
+
 // column tiles needed, and the row stride of the kernel instantiation that serves them (NCT * 16)
 static uint32_t fused_expf_xs(const ScrfLayout& lay, uint32_t W, uint32_t* n_ct) {
   const uint32_t ncol = 3 * W + lay.D + (lay.use_sb ? 1 : 0);
@@ -1838,7 +1863,11 @@ static size_t fused_expf_ws_smem_rows(uint32_t W, int g0, uint32_t rows) {
   return 2 * (sizeof(float) * (rows + 1) * xs + sizeof(double) * rows * FE_RS);
 }
 static uint32_t fused_expf_ws_rows(uint32_t W, int g0) {
-  static const bool big = !(getenv("SCRF_EXPF_BIG") && atoi(getenv("SCRF_EXPF_BIG")) == 0);
+  // 100-row tiles take 232 registers per wavefront, 76-row tiles 212: only the latter leaves room on a SIMD for the
+  // side stream's narrow k_ztf (64), and with that overlap the 76-row form is the faster step (29.22 against 29.46 ms;
+  // without the side stream 29.54 against 29.43).  So: tall tiles only when the side stream is off.
+  static const bool side = !(getenv("SCRF_SIDE") && atoi(getenv("SCRF_SIDE")) == 0);
+  static const bool big = getenv("SCRF_EXPF_BIG") ? atoi(getenv("SCRF_EXPF_BIG")) != 0 : !side;
   uint32_t n_ct;
   fused_expf_ws_xs(W, g0, &n_ct);
   return (big && g0 == 1 && n_ct <= 5 && fused_expf_ws_smem_rows(W, g0, FW_ROWS_BIG) <= 160 * 1024) ? FW_ROWS_BIG : FE_ROWS;
@@ -1878,6 +1907,11 @@ static void launch_expf_ws_t(hipStream_t st, const ScrfFusedArgs& fa, const Scrf
                              uint32_t n_ct, double* slab, double* dslab) {
   dim3 grid(fused_expf_blocks(lay, fa.W, 0, n_tiles, G0), (lay.L + 47) / 48);
   const size_t smw = fused_expf_ws_smem_rows(fa.W, G0, ROWS);
+  if (NT <= 4) {   // the narrow forms leave room for the side stream's kernels
+    hipFuncSetAttribute((const void*)k_expf_fused_ws_n<NT, DMAX, NKS, G0, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
+    hipLaunchKernelGGL((k_expf_fused_ws_n<NT, DMAX, NKS, G0, ROWS>), grid, dim3(FW_NT), smw, st, fa, lay, R, lay.L, n_tiles, n_ct, slab, dslab);
+    return;
+  }
   hipFuncSetAttribute((const void*)k_expf_fused_ws<NT, DMAX, NKS, G0, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
   hipLaunchKernelGGL((k_expf_fused_ws<NT, DMAX, NKS, G0, ROWS>), grid, dim3(FW_NT), smw, st, fa, lay, R, lay.L, n_tiles, n_ct, slab, dslab);
 }

@@ -151,7 +151,7 @@ int pframe_supported(uint32_t W);
 void launch_pframe(hipStream_t st, const float* F, uint32_t W, uint64_t n_frames, const double* lambda,
                    const ScrfLayout& lay, uint32_t n_out, double* P);
 void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F, uint32_t W, uint64_t n_frames,
-                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab);
+                uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int narrow = 0);
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
                    const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,

@@ -11,7 +11,7 @@
 //     RCCL/xGMI every SGD step (scrf_allreduce_grad_ex) -- the reference's join / sum / average.  Rank 0
 //     hands the RCCL unique id to the others through <out_weight_file>.rccl_id and is the only writer of
 //     weight files, markers and progress lines.  crf_force_comm=1 initialises the communicator for one rank.
-// crf_precision=exact|fast|fast32 selects the arithmetic of the training contractions (default fast).
+// crf_precision=exact|fast|fastlin|fast32 selects the arithmetic of the training contractions (default fast).
 #include "cli_common.h"
 
 int main(int argc, char** argv) {

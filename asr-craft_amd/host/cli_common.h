@@ -105,15 +105,18 @@ inline void set_fmap_config(const Args& a, CliModel* m) {
   c.nActualLabs = (QNUInt32)a.num("num_actual_labs", m->L);
 }
 
-// crf_precision=exact|fast|fast32: arithmetic of the training contractions (scrf_precision, scrf_abi.h).
+// crf_precision=exact|fast|fastlin|fast32: arithmetic of the training contractions (scrf_precision, scrf_abi.h).
 // fast (default): fp64 MFMA, sums re-associated (<= 1e-9 relative on gradients; the contract is 1e-4);
-// exact: the reference's operation order everywhere.  Decode entry points are always exact.
+// fastlin: fast with the segment recipe's window average taken as the exact mean (linear in the frames: it leaves the dense
+// contractions; <= 1e-6, measured 3e-8; what bench.py runs); exact: the reference's operation order everywhere.
+// Decode entry points are always exact.
 inline uint32_t parse_precision(const Args& a) {
   const std::string p = a.str("crf_precision", "fast");
   if (p == "exact") return SCRF_PREC_EXACT;
   if (p == "fast") return SCRF_PREC_FAST;
+  if (p == "fastlin") return SCRF_PREC_FASTLIN;
   if (p == "fast32") return SCRF_PREC_FAST32;
-  std::cerr << "crf_precision=" << p << " (exact|fast|fast32)" << std::endl;
+  std::cerr << "crf_precision=" << p << " (exact|fast|fastlin|fast32)" << std::endl;
   exit(1);
 }
 inline long env_num(const char* name, long d) { const char* v = getenv(name); return v && *v ? atol(v) : d; }

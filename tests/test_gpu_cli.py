@@ -120,6 +120,35 @@ def test_segmental_gradbuilder_via_read_protocol(tmp_path):
     np.testing.assert_allclose(np.loadtxt(out), np.array([float("%g" % v) for v in ref]), rtol=2e-5, atol=1e-9)
 
 
+def test_crftrain_precision_fastlin_on_a_segmental_model(tmp_path):
+    """crf_precision=fastlin (the linear window average) through CRFTrain on a segmental model: two
+    epochs of SGD end in the weights of crf_precision=exact to the weight file's digits (the tier differs by the float
+    rounding of the average: ~1e-7 on the features, far below the 6 digits the file keeps)."""
+    rng = np.random.RandomState(3)
+    L, D, W = 6, 4, 5
+    f = str(tmp_path / "f.ascii"); l = str(tmp_path / "l.ascii")
+    with open(f, "w") as ff, open(l, "w") as lf:
+        for u, T in enumerate([17, 9, 3, 26]):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 3)[:T].astype(np.uint32)
+            for t in range(T):
+                ff.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    ws = {}
+    for prec in ("exact", "fastlin"):
+        (tmp_path / prec).mkdir()
+        out = str(tmp_path / prec / "w.out")
+        r = subprocess.run([os.path.join(BIN, "CRFTrain"), "ftr1_file=" + f, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1",
+                            "hardtarget_file=" + l, "out_weight_file=" + out, "crf_label_size=%d" % L,
+                            "crf_model_type=stdseg_no_dur_no_segtransftr", "label_maximum_duration=%d" % D,
+                            "crf_epochs=2", "crf_lr=0.05", "crf_bunch_size=2", "threads=1", "crf_precision=" + prec],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ws[prec] = np.loadtxt(out)
+    assert np.abs(ws["exact"]).max() > 0
+    np.testing.assert_allclose(ws["fastlin"], ws["exact"], rtol=2e-5, atol=1e-9)
+
+
 def test_crftrain_and_fstdecode_on_pfile_and_ilab_inputs(tmp_path):
     """the same runs from binary pfile features + ILAB labels (the reference's
     default formats) give the same weight files and labels, byte for byte, as from the ascii

@@ -146,6 +146,8 @@ struct ScrfFusedArgs {
   uint64_t row_base;          // seg_off[u0], frame_off[u0] of the chunk
   uint64_t frame_base;
   uint32_t TB, W;
+  const double* dtab;         // k_dur_table's output ([output block][D][50]), or nullptr: the score kernel builds it per tile
+  const void* rtab;           // k_tile_tables' output (records, row bases, rowmap of a steady-state tile), or nullptr
 };
 
 // Decode mode of the fused score kernel: instead of the fp64 scores it writes the float arc

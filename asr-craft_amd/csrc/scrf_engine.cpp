@@ -107,7 +107,11 @@ struct scrf_engine_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
+  bool dur_table = true;      // the score kernel copies its duration-weight table instead of building it per tile (SCRF_DTAB=0: off)
   bool side_stream = true;    // k_ztf + transition counts on the second stream under k_expf_fused_ws (SCRF_SIDE=0: off)
+  void* d_rtab = nullptr;       // k_tile_tables: row records / row bases / rowmap of a steady-state score tile
+  size_t rtab_bytes = 0;
+  double* d_dtab = nullptr;     // k_dur_table: duration weight + bias per output block, for the fused score kernel
   double* d_sl_tab = nullptr;   // STDSEG, bias-only transitions: E, E^T (nLabs^2 each) and max M (scrf_stdseg_lin.hip)
   bool frame_mass = false;   // posterior-mass self-checks with the frame model's bounds (scrf_set_frame_mass_check)
   bool lin_dp = true;
@@ -289,6 +293,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_LANES")) h->n_lanes = atoi(e) > 1 ? 2 : 1;  // experiment knobs
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
   if (const char* e = getenv("SCRF_SIDE")) h->side_stream = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_DTAB")) h->dur_table = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
   if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = std::max(1.0, atof(e));   // widening only: < 1 would void the bound
@@ -313,6 +318,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_grad, nb));
   CRCHK(hipMalloc((void**)&h->d_m0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_w1, sizeof(double) * lay.L));
+  if (lay.D <= 40) CRCHK(hipMalloc((void**)&h->d_dtab, sizeof(double) * fused_dur_table_doubles(lay)));
   if (cfg->model_type == SCRF_STDSEG && !lay.use_tf) CRCHK(hipMalloc((void**)&h->d_sl_tab, sizeof(double) * (2 * (size_t)lay.L * lay.L + 8)));
   CRCHK(hipMalloc((void**)&h->d_e0, sizeof(double) * lay.L * lay.L));
   CRCHK(hipMalloc((void**)&h->d_et0, sizeof(double) * lay.L * lay.L));
@@ -367,7 +373,7 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  hipFree(h->d_w1); hipFree(h->d_sl_tab); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
+  hipFree(h->d_w1); hipFree(h->d_dtab); hipFree(h->d_rtab); hipFree(h->d_sl_tab); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1156,6 +1162,19 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     PhaseTimer tm(h, PH_SCORE, cb.st);
     const uint32_t W0 = b->recipe[0].in_width;
     ScrfFusedArgs fa = fused_args(h, b, u0, 0);
+    if (h->d_dtab && h->dur_table) {
+      launch_dur_table(cb.st, l, W0, h->d_lambda, h->d_dtab);
+      fa.dtab = h->d_dtab;
+      const size_t nb = fused_tile_table_bytes(l.D, fa.TB);
+      if (nb > h->rtab_bytes) {
+        hipFree(h->d_rtab); h->d_rtab = nullptr; h->rtab_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->d_rtab, nb));
+        h->rtab_bytes = nb;
+      }
+      launch_tile_tables(cb.st, l.D, fa.TB, (cb.la && !cb.Wn) ? 1 : 0, h->d_rtab);
+      static const bool rtab_on = !(getenv("SCRF_RTAB") && atoi(getenv("SCRF_RTAB")) == 0);   // A/B knob
+      if (rtab_on) fa.rtab = h->d_rtab;
+    }
     // per-frame projections of the five sampled blocks, then the dense part + gather
     if (pframe_supported(W0)) {
       KT_RUN("k_pframe", cb.st, launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, (cb.la ? 6 : 5) * l.L, cb.P));

@@ -381,9 +381,15 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
       }
       return v;
     };
+    // fa.dtab (k_dur_table, once per launch): the [D][FU_DS] table of this output block, copied with coalesced loads --
+    // built per tile it costs two loads per element from 48 different weight rows (lambda[state(o) + 8W + d] and the bias)
+    const double* dtab = fa.dtab ? fa.dtab + (size_t)blockIdx.y * D * FU_DS : nullptr;
     double dtv[3];
 #pragma unroll
-    for (int q = 0; q < 3; q++) dtv[q] = (tid + FU_NT * q < D * 48) ? dur_w(tid + FU_NT * q) : 0.0;
+    for (int q = 0; q < 3; q++) {
+      const uint32_t i = tid + FU_NT * q;
+      dtv[q] = dtab ? (i < D * FU_DS ? dtab[i] : 0.0) : (i < D * 48 ? dur_w(i) : 0.0);
+    }
     const float* src = fa.frames + (fa.frame_base + ft.fr0) * (uint64_t)W;
     const uint32_t n = nf * W;
     for (uint32_t i0 = 0; i0 < n; i0 += 4 * FU_NT) {
@@ -393,11 +399,37 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
       for (int q = 0; q < 4; q++) if (i0 + tid + FU_NT * q < n) fr[i0 + tid + FU_NT * q] = tmp[q];
     }
+    if (dtab) {
 #pragma unroll
-    for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * 48) Dt[((tid + FU_NT * q) / 48) * FU_DS + (tid + FU_NT * q) % 48] = dtv[q];
-    for (uint32_t i = tid + 3 * FU_NT; i < D * 48; i += FU_NT) Dt[(i / 48) * FU_DS + i % 48] = dur_w(i);   // D > 32 only
-    if (LA && tid < D) Dt[tid * FU_DS + 48] = 1.0 / (double)(tid + 1);
+      for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * FU_DS) Dt[tid + FU_NT * q] = dtv[q];
+      for (uint32_t i = tid + 3 * FU_NT; i < D * FU_DS; i += FU_NT) Dt[i] = dtab[i];   // D > 30 only
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; q++) if (tid + FU_NT * q < D * 48) Dt[((tid + FU_NT * q) / 48) * FU_DS + (tid + FU_NT * q) % 48] = dtv[q];
+      for (uint32_t i = tid + 3 * FU_NT; i < D * 48; i += FU_NT) Dt[(i / 48) * FU_DS + i % 48] = dur_w(i);   // D > 32 only
+      if (LA && tid < D) Dt[tid * FU_DS + 48] = 1.0 / (double)(tid + 1);
+    }
     FU_STAMP(6);   // frames and duration weights in LDS
+    // steady-state tiles (every frame has all D durations, TB frames) share their row records, row bases and rowmap:
+    // copied from fa.rtab (k_tile_tables, once per launch), only the label slot is the tile's own
+    const bool std_tile = fa.rtab && ft.t0 >= D && ft.nfr == fa.TB;
+    if (std_tile) {
+      const uint4* rg = (const uint4*)fa.rtab;
+      const uint16_t* bg = (const uint16_t*)(rg + FU_ROWS);
+      const uint16_t* mg = bg + ((fa.TB + 7) & ~7u);
+      for (uint32_t i = tid; i < ft.nfr * D; i += FU_NT) {
+        uint4 rec = rg[i];
+        if (labels) {
+          const uint32_t d = (rec.z >> 16) & 0xffu, tl = rec.z >> 24;
+          const uint32_t lab = labels[fa.frame_base + ft.fr0 + back + tl];
+          const uint32_t rel = lab - (d - 1) * n_out;
+          if (lab != SCRF_LAB_BAD && rel < n_out) rec.w = rel;
+        }
+        recs[i] = rec;
+      }
+      for (uint32_t tl = tid; tl < ft.nfr; tl += FU_NT) rbase[tl] = bg[tl];
+      for (uint32_t r = tid; r < nprows; r += FU_NT) rowmap[r] = mg[r];
+    } else {
     const uint32_t mD = fu_magic(D);
     for (uint32_t i = tid; i < ft.nfr * D; i += FU_NT) {
       const uint32_t tl = fu_div(i, mD), d = i - tl * D + 1;
@@ -434,6 +466,7 @@ __global__ __launch_bounds__(FU_NT, 4) void k_scores_fused(ScrfFusedArgs fa, Scr
 #pragma unroll
       for (int kk = 1; kk < 5; kk++) if (k == (uint32_t)kk) { base = prow0[kk]; f0k = pf0[kk]; }
       rowmap[r] = (uint16_t)((LA ? 6 : 5) * (f0k + r - base + 1) + k);
+    }
     }
 #if FU_EXPTAB
     if (!DEC && smax && tid < FU_EXPT_N) etab[tid] = exp2((double)tid * (1.0 / FU_EXPT_N));
@@ -751,6 +784,71 @@ uint32_t fused_scores_tb(uint32_t W, uint32_t D) {
   return 0;
 }
 static size_t fused_scores_smem(uint32_t W, uint32_t D) { return fused_scores_smem_tb(W, D, fused_scores_tb(W, D)); }
+
+// dtab[y][d][FU_DS]: one-hot duration weight + bias term of output 48 y + o (slots 0..47; -1e300 past n_out), 1/(d+1) in
+// slot 48 -- what k_scores_fused stages per tile, built once per launch
+__global__ void k_dur_table(ScrfLayout lay, uint32_t W, const double* __restrict__ lambda, double* __restrict__ dtab) {
+  const uint32_t D = lay.D, n_out = lay.L;
+  const uint32_t o0 = blockIdx.x * 48;
+  for (uint32_t i = threadIdx.x; i < D * FU_DS; i += blockDim.x) {
+    const uint32_t dd = i / FU_DS, oo = i % FU_DS;
+    double v = 0.0;
+    if (oo == 48) v = 1.0 / (double)(dd + 1);
+    else if (oo < 48) {
+      v = -1e300;
+      if (o0 + oo < n_out) {
+        const uint32_t base = lay.state_idx(o0 + oo) + 8 * W;
+        v = lambda[base + dd];
+        if (lay.use_sb) v += lambda[base + D] * lay.sbv;
+      }
+    }
+    dtab[(size_t)blockIdx.x * D * FU_DS + i] = v;
+  }
+}
+// rtab: the row records (label slot 0xffff), row bases and rowmap of a steady-state score tile (t0 >= D, TB whole frames):
+// [FU_ROWS] uint4 | [(TB + 7) & ~7] uint16 | [fu_p_rows_la] uint16 -- the same arithmetic as the kernel's own (edge) path
+__global__ void k_tile_tables(uint32_t D, uint32_t TB, int la, unsigned char* __restrict__ rtab) {
+  uint4* rg = (uint4*)rtab;
+  uint16_t* bg = (uint16_t*)(rg + FU_ROWS);
+  uint16_t* mg = bg + ((TB + 7) & ~7u);
+  const uint32_t back = D - 1, nf = back + TB;
+  uint32_t prow0[5], pf0[5], nprows = 0;
+  for (int k = 0; k < 5; k++) {
+    const uint32_t reach = D - 1 - fu_sample_step(D, k);
+    pf0[k] = back > reach ? back - reach : 0;
+    prow0[k] = nprows;
+    nprows += nf - pf0[k];
+  }
+  const uint32_t crow0 = nprows;
+  if (la) nprows += TB + D;
+  for (uint32_t i = threadIdx.x; i < TB * D; i += blockDim.x) {
+    const uint32_t tl = i / D, d = i - tl * D + 1;
+    const uint32_t b0 = tl + D - d;   // t - d + 1 - f0 with f0 = t0 - (D - 1)
+    uint32_t q[5];
+    for (int k = 0; k < 5; k++) q[k] = (prow0[k] - pf0[k] + b0 + fu_sample_step(d, k)) * FU_DS;
+    rg[i] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (d << 16) | (tl << 24), 0xffffu);
+  }
+  for (uint32_t tl = threadIdx.x; tl < TB; tl += blockDim.x) bg[tl] = (uint16_t)(tl * D);
+  for (uint32_t r = threadIdx.x; r < nprows; r += blockDim.x) {
+    if (la && r >= crow0) {   // frame t0 - D + (r - crow0), one before f0 at most: 6 * (frame - f0 + 1) + 5
+      mg[r] = (uint16_t)(6 * (r - crow0) + 5);
+      continue;
+    }
+    uint32_t k = 0;
+    for (int kk = 1; kk < 5; kk++) k += r >= prow0[kk] ? 1u : 0u;
+    mg[r] = (uint16_t)((la ? 6 : 5) * (pf0[k] + r - prow0[k] + 1) + k);
+  }
+}
+size_t fused_tile_table_bytes(uint32_t D, uint32_t TB) {
+  return sizeof(uint4) * FU_ROWS + sizeof(uint16_t) * (((TB + 7) & ~7u) + ((fu_p_rows_la(D, TB) + 7) & ~7u)) + 64;
+}
+void launch_tile_tables(hipStream_t st, uint32_t D, uint32_t TB, int la, void* rtab) {
+  hipLaunchKernelGGL(k_tile_tables, dim3(1), dim3(256), 0, st, D, TB, la, (unsigned char*)rtab);
+}
+size_t fused_dur_table_doubles(const ScrfLayout& lay) { return (size_t)((lay.L + 47) / 48) * lay.D * FU_DS; }
+void launch_dur_table(hipStream_t st, const ScrfLayout& lay, uint32_t W, const double* lambda, double* dtab) {
+  hipLaunchKernelGGL(k_dur_table, dim3((lay.L + 47) / 48), dim3(256), 0, st, lay, W, lambda, dtab);
+}
 
 template <int DMAX, int F32, int DEC, int LA>
 static void launch_scores_fused_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,

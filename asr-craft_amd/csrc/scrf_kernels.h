@@ -131,6 +131,10 @@ uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t 
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,
                          const double* P, uint64_t n_tiles, double* S, int f32, double* smax = nullptr,
                          double* s_true = nullptr, const uint32_t* labels = nullptr, int la = 0);
+size_t fused_tile_table_bytes(uint32_t D, uint32_t TB);
+void launch_tile_tables(hipStream_t st, uint32_t D, uint32_t TB, int la, void* rtab);
+size_t fused_dur_table_doubles(const ScrfLayout& lay);
+void launch_dur_table(hipStream_t st, const ScrfLayout& lay, uint32_t W, const double* lambda, double* dtab);
 void launch_avg_prefix(hipStream_t st, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint32_t L, double* P);
 // k_viterbi on float arc weights with one wavefront per utterance (fast decode; L <= 64, constant M)
 int viterbi_fast_supported(const ScrfLayout& lay);

@@ -28,6 +28,8 @@ struct RcclApi {
   int (*CommInitRank)(scrf_nccl_comm*, int, scrf_nccl_uid, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, scrf_nccl_comm, hipStream_t) = nullptr;
   int (*CommDestroy)(scrf_nccl_comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   int (*CommAbort)(scrf_nccl_comm) = nullptr;
   int (*CommGetAsyncError)(scrf_nccl_comm, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -48,6 +50,8 @@ static bool rccl_load(std::string* why) {
   g_rccl.CommInitRank = (int (*)(scrf_nccl_comm*, int, scrf_nccl_uid, int))dlsym(g_rccl.lib, "ncclCommInitRank");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, scrf_nccl_comm, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(scrf_nccl_comm))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.GroupStart = (int (*)())dlsym(g_rccl.lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(g_rccl.lib, "ncclGroupEnd");
   g_rccl.CommAbort = (int (*)(scrf_nccl_comm))dlsym(g_rccl.lib, "ncclCommAbort");
   g_rccl.CommGetAsyncError = (int (*)(scrf_nccl_comm, int*))dlsym(g_rccl.lib, "ncclCommGetAsyncError");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
@@ -107,6 +111,14 @@ struct scrf_engine_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_lanes = 1;  // SCRF_LANES=2: alternate chunks on two streams (worth ~3 % at config 2; off by default)
   bool fuse_windows = true;
+  // all-reduce / compute overlap (scrf_fb_batch_allreduce): inside the fused call the transition
+  // contraction runs first and the all-reduce of the transition weights (98.7 % of the TIMIT-demo gradient) is issued on
+  // the second stream as soon as they are committed, under the state contraction
+  bool overlap_comm = false;  // set for the duration of a scrf_fb_batch_allreduce call
+  bool early_done = false;    // the transition block of this step has been all-reduced already
+  uint64_t n_collectives = 0, n_overlapped = 0;   // scrf_comm_stats
+  bool comm_overlap_on = true;   // SCRF_COMM_OVERLAP=0: the fused call issues both blocks after the batch (same results)
+  double* d_pack = nullptr;   // [L * nsf + 8]: the state weights of every label + the 8 scalars, one small message
   bool dur_table = true;      // the score kernel copies its duration-weight table instead of building it per tile (SCRF_DTAB=0: off)
   bool side_stream = true;    // k_ztf + transition counts on the second stream under k_expf_fused_ws (SCRF_SIDE=0: off)
   void* d_rtab = nullptr;       // k_tile_tables: row records / row bases / rowmap of a steady-state score tile
@@ -294,6 +306,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
   if (const char* e = getenv("SCRF_SIDE")) h->side_stream = atoi(e) != 0;
   if (const char* e = getenv("SCRF_DTAB")) h->dur_table = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_COMM_OVERLAP")) h->comm_overlap_on = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
   if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = std::max(1.0, atof(e));   // widening only: < 1 would void the bound
@@ -373,7 +386,7 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  hipFree(h->d_w1); hipFree(h->d_dtab); hipFree(h->d_rtab); hipFree(h->d_sl_tab); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
+  hipFree(h->d_w1); hipFree(h->d_dtab); hipFree(h->d_rtab); hipFree(h->d_pack); hipFree(h->d_sl_tab); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1392,6 +1405,17 @@ __global__ void k_commit(double* __restrict__ grad, const double* __restrict__ s
   if (i < 3) sums[i] += sums_stage[i];
 }
 
+// the same for one block of the weight vector: part 1 = the transition weights of every label ([nsf, stride) of its
+// block), part 0 = the state weights ([0, nsf)) and the batch sums
+__global__ void k_commit_part(double* __restrict__ grad, const double* __restrict__ stage, uint32_t n, uint32_t stride, uint32_t nsf,
+                              int part, double* __restrict__ sums, const double* __restrict__ sums_stage,
+                              const int* __restrict__ latch) {
+  if (latch[0] != 0) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ((i % stride >= nsf) ? 1 : 0) == part) grad[i] += stage[i];
+  if (part == 0 && i < 3) sums[i] += sums_stage[i];
+}
+
 static const char* status_text(int code) {
   return code == SCRF_ERR_BAD_LABEL ? "the label is larger than nActualLabs*labMaxDur"
          : code == SCRF_ERR_EMPTY   ? "No features read from this sentence."
@@ -1639,6 +1663,9 @@ static uint32_t nstate_plan_chunk(scrf_handle h, scrf_batch b, uint32_t u0, bool
 // One pass of the forward-backward pipeline over the batch into the staging gradient.  latch[2] receives
 // {status code, utterance} of the first failed utterance (0 = clean, gradient committed); *used_lin tells
 // whether any chunk ran the linear-domain recursion.
+static int allreduce_block(scrf_handle h, hipStream_t st, int part);
+static bool two_block_reduce(scrf_handle h) { return h->comm && h->lay.use_tf && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && h->lay.K <= 1 && !h->shadow; }
+
 static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   const ScrfLayout& l = h->lay;
   HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));
@@ -1724,6 +1751,38 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
     if (!use2 && ci + 1 == n_chunks) {
       rc = queue_status(h, b);
       if (rc != SCRF_OK) return rc;
+    }
+    // all-reduce / compute overlap (fused call only): transition counts first; once the last chunk's are reduced they
+    // are committed and their all-reduce goes to the second stream, under the state contraction.  A NUMERIC failure of
+    // the recursion is retried with the log-domain kernels by the caller: that has to be known BEFORE a collective is
+    // issued (the peers issue theirs exactly once), so the host waits for the status here.
+    const bool ov = h->overlap_comm && h->comm_overlap_on && two_block_reduce(h) && !use2 && !h->timing && !cb.fused;
+    if (ov) {
+      if (ci + 1 == n_chunks) {
+        HIPCHK(h, hipEventSynchronize(h->ev_status));
+        latch_decode(h->h_latch, latch);
+        if (latch[0] == SCRF_ERR_NUMERIC && wave_path(h, true)) return SCRF_OK;   // the caller reruns; nothing committed, nothing sent
+      }
+      launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
+      if (fast) launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32);
+      else launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t);
+      launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
+      if (ci + 1 == n_chunks) {
+        hipLaunchKernelGGL(k_commit_part, dim3((l.lambda_len + 255) / 256), dim3(256), 0, h->stream, h->d_grad, h->d_stage, l.lambda_len,
+                           l.stride, l.nsf, 1, h->d_sums, h->d_sums_stage, h->d_latch);
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        rc = allreduce_block(h, h->stream2, 1);
+        if (rc != SCRF_OK) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+        h->early_done = true;
+      }
+      if (fast) launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
+      else launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
+      launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
+      launch_batch_sums(cb.st, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, cb.sums);
+      HIPCHK(h, hipGetLastError());
+      continue;
     }
     bool side = false;   // part of the count work runs on the second stream (below)
     {
@@ -1813,6 +1872,10 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
     if (rc != SCRF_OK) return rc;
   }
   if (!l.use_tf && wave_path(h, true)) launch_add_trans_counts(h->stream, b->d_trans_counts, l, h->d_stage);
+  if (h->early_done)   // the transition block was committed (and sent) before the state contraction
+    hipLaunchKernelGGL(k_commit_part, dim3((l.lambda_len + 255) / 256), dim3(256), 0, h->stream, h->d_grad, h->d_stage, l.lambda_len,
+                       l.stride, l.nsf, 0, h->d_sums, h->d_sums_stage, h->d_latch);
+  else
   hipLaunchKernelGGL(k_commit, dim3((l.lambda_len + 255) / 256), dim3(256), 0, h->stream, h->d_grad, h->d_stage, l.lambda_len,
                      h->d_sums, h->d_sums_stage, h->d_latch);
   HIPCHK(h, hipGetLastError());
@@ -2315,6 +2378,13 @@ extern "C" int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused) {
   return SCRF_OK;
 }
 
+extern "C" int scrf_comm_stats(scrf_handle h, uint64_t* n_collectives, uint64_t* n_overlapped) {
+  if (!h) return SCRF_ERR_INVALID;
+  if (n_collectives) *n_collectives = h->n_collectives;
+  if (n_overlapped) *n_overlapped = h->n_overlapped;
+  return SCRF_OK;
+}
+
 extern "C" int scrf_set_frame_mass_check(scrf_handle h, int on) {
   if (!h) return SCRF_ERR_INVALID;
   h->frame_mass = on != 0;
@@ -2412,6 +2482,48 @@ static int wait_collective(scrf_handle h, const char* what) {
   }
 }
 
+// ---- the per-step collective in two blocks (models with transition features, e.g. the TIMIT demo: 4.37 M weights) ----
+// The weight vector interleaves, per label, [nsf state weights | L * ntf transition weights]; 98.7 % of the TIMIT-demo
+// gradient are transition weights.  Block 1 = the transition weights of every label (L contiguous pieces, one RCCL
+// group), block 0 = the state weights of every label packed with the 8 scalars into one small message.  Every rank
+// issues block 1 then block 0, whatever it did before (active, exhausted or failed): the sequence is part of the protocol.
+// Inside scrf_fb_batch_allreduce block 1 is issued early, on the second stream, under the state contraction.
+__global__ void k_pack_state(const double* __restrict__ grad, const double* __restrict__ sums8, uint32_t L, uint32_t stride,
+                             uint32_t nsf, double* __restrict__ pack) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < L * nsf) pack[i] = grad[(size_t)(i / nsf) * stride + i % nsf];
+  else if (i < L * nsf + 8) pack[i] = sums8[i - L * nsf];
+}
+__global__ void k_unpack_state(const double* __restrict__ pack, uint32_t L, uint32_t stride, uint32_t nsf, double* __restrict__ grad,
+                               double* __restrict__ sums8) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < L * nsf) grad[(size_t)(i / nsf) * stride + i % nsf] = pack[i];
+  else if (i < L * nsf + 8) sums8[i - L * nsf] = pack[i];
+}
+static int allreduce_block(scrf_handle h, hipStream_t st, int part) {
+  const ScrfLayout& l = h->lay;
+  int r = 0;
+  if (part == 1) {
+    if (g_rccl.GroupStart && g_rccl.GroupEnd) r = g_rccl.GroupStart();
+    for (uint32_t c = 0; c < l.L && r == 0; c++) {
+      double* p = h->d_grad + (size_t)c * l.stride + l.nsf;
+      r = g_rccl.AllReduce(p, p, (size_t)l.L * l.ntf, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, st);
+    }
+    if (g_rccl.GroupStart && g_rccl.GroupEnd) { const int r2 = g_rccl.GroupEnd(); if (r == 0) r = r2; }
+  } else {
+    const uint32_t n = l.L * l.nsf + 8;
+    if (!h->d_pack && hipMalloc((void**)&h->d_pack, sizeof(double) * n) != hipSuccess) { scrf_comm_abort(h); return fail(h, SCRF_ERR_HIP, "hipMalloc of the pack buffer failed"); }
+    hipLaunchKernelGGL(k_pack_state, dim3((n + 255) / 256), dim3(256), 0, st, h->d_grad, h->d_sums, l.L, l.stride, l.nsf, h->d_pack);
+    r = g_rccl.AllReduce(h->d_pack, h->d_pack, n, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, st);
+    hipLaunchKernelGGL(k_unpack_state, dim3((n + 255) / 256), dim3(256), 0, st, h->d_pack, l.L, l.stride, l.nsf, h->d_grad, h->d_sums);
+  }
+  if (r != 0) {
+    scrf_comm_abort(h);
+    return fail(h, SCRF_ERR_COMM, "ncclAllReduce (block %d) failed: %s", part, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  }
+  return SCRF_OK;
+}
+
 extern "C" int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4,
                                       double* extra_out) {
   if (!h || n_extra > 4 || (n_extra && !extra_in)) return SCRF_ERR_INVALID;
@@ -2420,7 +2532,7 @@ extern "C" int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* e
 #define ARCHK(call)                                                                                        \
   do {                                                                                                     \
     hipError_t e_ = (call);                                                                                \
-    if (e_ != hipSuccess) { scrf_comm_abort(h); return fail(h, SCRF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } \
+    if (e_ != hipSuccess) { scrf_comm_abort(h); h->early_done = false; return fail(h, SCRF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } \
   } while (0)
   ARCHK(hipSetDevice(h->device));
   const uint32_t n = h->lay.lambda_len;
@@ -2429,11 +2541,22 @@ extern "C" int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* e
   hipLaunchKernelGGL(k_set_tail, dim3(1), dim3(1), 0, h->stream, h->d_sums, active ? 1 : 0, e[0], e[1], e[2], e[3]);
   ARCHK(hipGetLastError());
   if (h->comm) {
-    int r = g_rccl.AllReduce(h->d_grad, h->d_grad, n, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
-    if (r == 0) r = g_rccl.AllReduce(h->d_sums, h->d_sums, 8, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
-    if (r != 0) {
-      scrf_comm_abort(h);
-      return fail(h, SCRF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    h->n_collectives++;
+    if (two_block_reduce(h)) {
+      const bool early = h->early_done;
+      h->early_done = false;
+      if (early) h->n_overlapped++;
+      if (early) ARCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // block 1 went out on the second stream already
+      else { const int rc = allreduce_block(h, h->stream, 1); if (rc != SCRF_OK) return rc; }
+      const int rc = allreduce_block(h, h->stream, 0);
+      if (rc != SCRF_OK) return rc;
+    } else {
+      int r = g_rccl.AllReduce(h->d_grad, h->d_grad, n, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
+      if (r == 0) r = g_rccl.AllReduce(h->d_sums, h->d_sums, 8, SCRF_NCCL_DOUBLE, SCRF_NCCL_SUM, h->comm, h->stream);
+      if (r != 0) {
+        scrf_comm_abort(h);
+        return fail(h, SCRF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+      }
     }
   }
   hipLaunchKernelGGL(k_div_by_active, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_grad, n, h->d_sums);
@@ -2450,6 +2573,32 @@ extern "C" int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* e
   }
 #undef ARCHK
   return SCRF_OK;
+}
+
+// scrf_fb_batch + scrf_allreduce_grad_ex in one call, for a host whose rank runs exactly one batch per step (the
+// distributed minibatch accumulator): the all-reduce of the transition block overlaps the state contraction (above).
+// The batch's own failure is reported through *fb_status (and extra[fail_slot] is raised, `active` cleared) while the
+// collective still runs -- the peers learn it from the summed flag; the return value is the collective's.
+extern "C" int scrf_fb_batch_allreduce(scrf_handle h, scrf_batch b, int active, const double* extra_in, uint32_t n_extra,
+                                       uint32_t fail_slot, double* sums4, double* extra_out, int* fb_status) {
+  if (!h || !b || n_extra > 4 || (n_extra && !extra_in) || (n_extra && fail_slot >= n_extra)) return SCRF_ERR_INVALID;
+  h->overlap_comm = true;
+  h->early_done = false;
+  const int frc = scrf_fb_batch(h, b, nullptr, nullptr);
+  h->overlap_comm = false;
+  if (fb_status) *fb_status = frc;
+  if (frc == SCRF_ERR_HIP || frc == SCRF_ERR_COMM) {   // the device or the communicator is gone: no collective can follow
+    scrf_comm_abort(h);
+    h->early_done = false;
+    return frc;
+  }
+  const std::string batch_err = h->err;
+  double e[4] = {0, 0, 0, 0};
+  for (uint32_t i = 0; i < n_extra; i++) e[i] = extra_in[i];
+  if (frc != SCRF_OK && n_extra) e[fail_slot] = 1.0;
+  const int rc = scrf_allreduce_grad_ex(h, frc == SCRF_OK ? active : 0, e, n_extra, sums4, extra_out);
+  if (rc == SCRF_OK && frc != SCRF_OK) h->err = batch_err;   // scrf_last_error keeps the batch's message
+  return rc;
 }
 extern "C" int scrf_allreduce_grad(scrf_handle h, int active, double* sums4) {
   return scrf_allreduce_grad_ex(h, active, nullptr, 0, sums4, nullptr);

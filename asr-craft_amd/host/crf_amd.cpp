@@ -756,11 +756,14 @@ extern "C" void crf_amd_view_range(uint32_t n_utts, uint32_t n_streams, uint32_t
 // The per-step collective itself failed on this rank (a device error around it, the watchdog's timeout, a peer's abort):
 // the communicator is aborted -- which ends the peers' wait with an error instead of a hang -- and the exception takes
 // the process down with a non-zero exit (mains catch, print and exit(-1)); a restart is a fresh process.
+struct CollectiveFailure : public runtime_error {
+  explicit CollectiveFailure(const string& m) : runtime_error(m) {}
+};
 static void collective(crf_amd::Engine* e, int rc, const char* what) {
   if (rc == SCRF_OK) return;
   const string msg = string(what) + ": " + scrf_last_error(e->h);
   scrf_comm_abort(e->h);
-  throw runtime_error(msg + " [communicator aborted; this rank exits]");
+  throw CollectiveFailure(msg + " [communicator aborted; this rank exits]");
 }
 
 // One process: grad != nullptr -- per-stream gradients come to the host and are summed there in stream
@@ -789,6 +792,8 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
   if (nEnd == (int)N) throw runtime_error("All feature streams are at the end! You don't have any utterances or you forget to rewind all the streams.");
   double totNumer = 0.0;
   std::vector<double> sgrad(grad && !dist ? n : 0);
+  bool collective_done = false;              // distributed: the fused batch + all-reduce call has run
+  double dist_sums4[4] = {0, 0, 0, 0}, dist_flags[2] = {0.0, 0.0};
   for (QNUInt32 s = 0; s < N; s++) try {  // stream order == the reference's join/sum order
     if (!local_failure.empty()) break;
     if (dist && (int)s != crf->distRank()) continue;
@@ -803,6 +808,17 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     BatchGuard g{e};
     make_batch(e, ftrStrms[s], utts, &g);
     if (grad && !dist) e->check(scrf_zero_grad(e->h), "accumulateGradient");
+    if (dist) {
+      // this rank's one batch of the step and the collective in one call: the engine reduces the transition block
+      // under the state contraction (scrf_fb_batch_allreduce).  The batch's own failure travels as the flag.
+      const double fl[2] = {segids[s] == QN_SEGID_BAD ? 1.0 : 0.0, 0.0};
+      int fb_rc = SCRF_OK;
+      collective(e, scrf_fb_batch_allreduce(e->h, g.b, 1, fl, 2, 1, dist_sums4, dist_flags, &fb_rc), "accumulateGradient (all-reduce)");
+      collective_done = true;
+      *uttCount += (QNUInt32)utts.size();
+      if (fb_rc != SCRF_OK) local_failure = string("CRF_Minibatch_GradAccumulator::accumulateGradient() caught exception: ") + scrf_last_error(e->h);
+      continue;
+    }
     e->check(scrf_fb_batch(e->h, g.b, nullptr, nullptr), "CRF_Minibatch_GradAccumulator::accumulateGradient()");
     if (grad && !dist) {   // per-stream gradient and sums to the host (they restart with every scrf_zero_grad)
       double sums[3] = {0, 0, 0};
@@ -815,6 +831,8 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     *uttCount += (QNUInt32)utts.size();
     if (segids[s] == QN_SEGID_BAD) ++nEnd;
     if (grad && !dist) for (QNUInt32 i = 0; i < n; i++) grad[i] += sgrad[i];
+  } catch (const CollectiveFailure&) {
+    throw;   // the collective itself failed (the fused call): not a failure of the share -- no second collective can follow
   } catch (const std::exception& ex) {
     if (!dist) throw;
     local_failure = ex.what();
@@ -828,7 +846,11 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     const int r = crf->distRank();
     const double flags_in[2] = {segids[r] == QN_SEGID_BAD ? 1.0 : 0.0, local_failure.empty() ? 0.0 : 1.0};
     double sums4[4] = {0, 0, 0, 0}, flags_out[2] = {0.0, 0.0};
-    collective(e, scrf_allreduce_grad_ex(e->h, nActive, flags_in, 2, sums4, flags_out), "accumulateGradient (all-reduce)");
+    if (collective_done) {
+      for (int i = 0; i < 4; i++) sums4[i] = dist_sums4[i];
+      flags_out[0] = dist_flags[0]; flags_out[1] = dist_flags[1];
+    } else   // no batch on this rank (exhausted view, or it failed before one existed): the same block sequence
+      collective(e, scrf_allreduce_grad_ex(e->h, nActive, flags_in, 2, sums4, flags_out), "accumulateGradient (all-reduce)");
     if (flags_out[1] > 0.5) {
       if (!local_failure.empty()) throw runtime_error(local_failure);
       throw runtime_error("CRF_Minibatch_GradAccumulator: " + std::to_string((int)(flags_out[1] + 0.5)) + " other rank(s) failed in this minibatch; rank " + std::to_string(r) + " stops with them");
@@ -970,6 +992,11 @@ void CRF_SGTrainer::sgtrainMinibatch() {
     crf_ptr->writeToFile(weight_fname.c_str());
     crf_ptr->writeToFile((weight_fname + ".avg.out").c_str(), lambdaAvg.data(), n);
     touchDoneFileFinal();
+    if (crf_ptr->distributed()) {
+      uint64_t nc = 0, no = 0;
+      if (scrf_comm_stats(crf_ptr->engine()->h, &nc, &no) == SCRF_OK)
+        std::cout << "Gradient all-reduces: " << nc << " (transition block overlapped with the state contraction in " << no << ")" << std::endl;
+    }
   }
 }
 

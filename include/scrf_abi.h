@@ -275,6 +275,17 @@ int scrf_allreduce_grad(scrf_handle h, int active, double* sums4);
  * extra_out (host, n_extra doubles) and sums4 are read back together; either may be NULL. */
 int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4,
                            double* extra_out);
+/* scrf_fb_batch followed by scrf_allreduce_grad_ex, as ONE call -- for a host whose rank runs exactly one batch per step
+ * (rank r = stream r of CRF_Minibatch_GradAccumulator).  With transition features (the TIMIT demo: 4.37 M weights, 98.7 % of
+ * them transition weights) the collective runs in two blocks, transition weights then state weights + scalars, and inside
+ * this call the transition contraction comes first so that its block is all-reduced on a second stream UNDER the state
+ * contraction (SCRF_COMM_OVERLAP=0: after it; results identical).  The block sequence is the same in
+ * scrf_allreduce_grad[_ex], so ranks that call either (an exhausted rank has no batch) still match.
+ * A failure of the batch itself does not stop the collective: *fb_status gets scrf_fb_batch's code, extra[fail_slot] is
+ * raised and `active` cleared before the scalars are reduced (the peers see the summed flag), scrf_last_error keeps the
+ * batch's message.  The return value is the collective's (errors as described below). */
+int scrf_fb_batch_allreduce(scrf_handle h, scrf_batch b, int active, const double* extra_in, uint32_t n_extra,
+                            uint32_t fail_slot, double* sums4, double* extra_out, int* fb_status);
 /* Failure behaviour of the collective (the reference's join is a pthread_join and cannot hang on a dead peer; a
  * collective can).  With a communicator, scrf_allreduce_grad[_ex] waits for completion under a watchdog: it polls the
  * stream and ncclCommGetAsyncError and gives up after SCRF_COMM_TIMEOUT_S seconds (default 300) -- in both cases, and
@@ -283,6 +294,9 @@ int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, ui
  * collective calls it before exiting non-zero, so that its peers fail fast instead of waiting for the timeout.  After
  * an abort the handle has no communicator; a restart is a fresh process. */
 int scrf_comm_abort(scrf_handle h);
+/* per-step collectives run under a communicator since scrf_create, and how many of them had their transition block
+ * all-reduced early, under the state contraction (scrf_fb_batch_allreduce) */
+int scrf_comm_stats(scrf_handle h, uint64_t* n_collectives, uint64_t* n_overlapped);
 /* the reference's Gaussian-prior step as written (trainers/CRF_SGTrainer.cpp:300-303): grad[i] -= grad[i] *
  * inv_square_var on the device gradient (it scales the gradient, not lambda -- kept as is) */
 int scrf_gauss_prior(scrf_handle h, float inv_square_var);

@@ -36,7 +36,7 @@ struct scrf_engine_s {
   uint32_t n = 0;
   std::vector<double> lambda, acc, gsa, grad;
   double sums[3] = {0, 0, 0};
-  int rank = 0, world = 1, round = 0, fb_calls = 0;
+  int rank = 0, world = 1, round = 0, step = 0, fb_calls = 0;
   bool comm = false;
   std::string comm_dir, err;
 };
@@ -178,25 +178,16 @@ static bool peer_aborted(scrf_handle h, int* who) {
   }
   return false;
 }
-int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4, double* extra_out) {
-  if (!h->comm) { h->err = "stub: all-reduce without a communicator"; return SCRF_ERR_COMM; }
-  if (getenv("SCRF_STUB_COLL_FAIL_RANK") && atoi(getenv("SCRF_STUB_COLL_FAIL_RANK")) == h->rank &&
-      h->round + 1 == atoi(getenv("SCRF_STUB_COLL_FAIL_AT") ? getenv("SCRF_STUB_COLL_FAIL_AT") : "1")) {
-    if (getenv("SCRF_STUB_COLL_DIE")) _exit(9);
-    h->err = "stub: injected failure inside the collective";
-    return SCRF_ERR_HIP;
-  }
-  const size_t len = h->n + 4 + n_extra;
-  std::vector<double> mine(len);
-  memcpy(mine.data(), h->grad.data(), sizeof(double) * h->n);
-  mine[h->n] = h->sums[0]; mine[h->n + 1] = h->sums[1]; mine[h->n + 2] = h->sums[2]; mine[h->n + 3] = active ? 1.0 : 0.0;
-  for (uint32_t i = 0; i < n_extra; i++) mine[h->n + 4 + i] = extra_in[i];
+// one exchange: every rank publishes `mine` for the current round and sums all ranks' vectors in rank order
+static int stub_exchange(scrf_handle h, const std::vector<double>& mine, std::vector<double>* tot) {
+  const size_t len = mine.size();
   char name[64];
   snprintf(name, sizeof(name), "/r%06d.%d", h->round, h->rank);
   const std::string fin = h->comm_dir + name, tmp = fin + ".tmp";
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f || fwrite(mine.data(), sizeof(double), len, f) != len || fclose(f) != 0 || rename(tmp.c_str(), fin.c_str()) != 0) { h->err = "stub: cannot publish " + fin; return SCRF_ERR_COMM; }
-  std::vector<double> tot(len, 0.0), part(len);
+  tot->assign(len, 0.0);
+  std::vector<double> part(len);
   const char* ts = getenv("SCRF_COMM_TIMEOUT_S");
   const time_t deadline = time(nullptr) + (ts && atoi(ts) > 0 ? atoi(ts) : 60);
   for (int r = 0; r < h->world; r++) {
@@ -214,17 +205,75 @@ int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, ui
       if (time(nullptr) > deadline) { h->err = "stub: the collective did not complete within SCRF_COMM_TIMEOUT_S: rank " + std::to_string(r) + " never joined round " + std::to_string(h->round); h->comm = false; return SCRF_ERR_COMM; }
       usleep(500);
     }
-    for (size_t i = 0; i < len; i++) tot[i] += part[i];
+    for (size_t i = 0; i < len; i++) (*tot)[i] += part[i];
   }
   h->round++;
+  return SCRF_OK;
+}
+// The engine's protocol: with transition features two blocks per step -- the transition weights of every label, then
+// the state weights + the scalars -- in that order on every rank, whichever entry point it uses (scrf_stub_layout tells
+// the blocks apart the way ScrfLayout does); otherwise one block.
+int scrf_allreduce_grad_ex(scrf_handle h, int active, const double* extra_in, uint32_t n_extra, double* sums4, double* extra_out) {
+  if (!h->comm) { h->err = "stub: all-reduce without a communicator"; return SCRF_ERR_COMM; }
+  if (getenv("SCRF_STUB_COLL_FAIL_RANK") && atoi(getenv("SCRF_STUB_COLL_FAIL_RANK")) == h->rank &&
+      h->step + 1 == atoi(getenv("SCRF_STUB_COLL_FAIL_AT") ? getenv("SCRF_STUB_COLL_FAIL_AT") : "1")) {
+    if (getenv("SCRF_STUB_COLL_DIE")) _exit(9);
+    h->err = "stub: injected failure inside the collective";
+    return SCRF_ERR_HIP;
+  }
+  h->step++;
+  const scrf_config& c = h->cfg;
+  const uint32_t nsf = (c.use_state_ftrs ? c.state_fidx_end - c.state_fidx_start + 1 : 0) + (c.use_state_bias ? 1 : 0);
+  const uint32_t ntf = (c.use_trans_ftrs ? c.trans_fidx_end - c.trans_fidx_start + 1 : 0) + (c.use_trans_bias ? 1 : 0);
+  const uint32_t stride = nsf + c.num_labs * ntf;
+  std::vector<double> tot(h->n + 4 + n_extra, 0.0);
+  std::vector<double> tail(4 + n_extra);
+  tail[0] = h->sums[0]; tail[1] = h->sums[1]; tail[2] = h->sums[2]; tail[3] = active ? 1.0 : 0.0;
+  for (uint32_t i = 0; i < n_extra; i++) tail[4 + i] = extra_in[i];
+  if (c.use_trans_ftrs) {
+    std::vector<double> blk, got;
+    for (uint32_t i = 0; i < h->n; i++) if (i % stride >= nsf) blk.push_back(h->grad[i]);     // block 1: transition weights
+    int rc = stub_exchange(h, blk, &got);
+    if (rc != SCRF_OK) return rc;
+    size_t k = 0;
+    for (uint32_t i = 0; i < h->n; i++) if (i % stride >= nsf) tot[i] = got[k++];
+    blk.clear();
+    for (uint32_t i = 0; i < h->n; i++) if (i % stride < nsf) blk.push_back(h->grad[i]);      // block 0: state weights + scalars
+    blk.insert(blk.end(), tail.begin(), tail.end());
+    rc = stub_exchange(h, blk, &got);
+    if (rc != SCRF_OK) return rc;
+    k = 0;
+    for (uint32_t i = 0; i < h->n; i++) if (i % stride < nsf) tot[i] = got[k++];
+    for (size_t j = 0; j < tail.size(); j++) tot[h->n + j] = got[k++];
+  } else {
+    std::vector<double> mine(h->grad.begin(), h->grad.end()), got;
+    mine.insert(mine.end(), tail.begin(), tail.end());
+    const int rc = stub_exchange(h, mine, &got);
+    if (rc != SCRF_OK) return rc;
+    tot = got;
+  }
   const double n_active = tot[h->n + 3];
   for (uint32_t i = 0; i < h->n; i++) h->grad[i] = n_active > 0 ? tot[i] / n_active : tot[i];
   for (int i = 0; i < 4; i++) sums4[i] = tot[h->n + i];
   for (uint32_t i = 0; i < n_extra; i++) extra_out[i] = tot[h->n + 4 + i];
   return SCRF_OK;
 }
+// the fused call: the batch, then the collective; the batch's failure travels as extra[fail_slot]
+int scrf_fb_batch_allreduce(scrf_handle h, scrf_batch b, int active, const double* extra_in, uint32_t n_extra, uint32_t fail_slot,
+                            double* sums4, double* extra_out, int* fb_status) {
+  const int frc = scrf_fb_batch(h, b, nullptr, nullptr);
+  if (fb_status) *fb_status = frc;
+  const std::string batch_err = h->err;
+  double e[4] = {0, 0, 0, 0};
+  for (uint32_t i = 0; i < n_extra; i++) e[i] = extra_in[i];
+  if (frc != SCRF_OK && n_extra) e[fail_slot] = 1.0;
+  const int rc = scrf_allreduce_grad_ex(h, frc == SCRF_OK ? active : 0, e, n_extra, sums4, extra_out);
+  if (rc == SCRF_OK && frc != SCRF_OK) h->err = batch_err;
+  return rc;
+}
 
 int scrf_set_frame_mass_check(scrf_handle, int) { return SCRF_OK; }
+int scrf_comm_stats(scrf_handle h, uint64_t* a, uint64_t* b) { if (a) *a = (uint64_t)h->step; if (b) *b = 0; return SCRF_OK; }
 // the rest of the ABI the host layer references: not part of the training control flow
 #define NOT_HERE(sig) int sig { return SCRF_ERR_INVALID; }
 NOT_HERE(scrf_scores(scrf_handle, scrf_batch, uint32_t, double*, double*))

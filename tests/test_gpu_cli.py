@@ -1025,6 +1025,47 @@ def test_crftrain_world_size_one_with_the_communicator_is_byte_identical(tmp_pat
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def test_two_block_all_reduce_with_and_without_the_overlap_is_byte_identical(tmp_path):
+    """A model with transition features (the TIMIT-demo kind: a segment-recipe stream for the state features, a context
+    stream for the transition features): under a communicator the per-step collective runs in two blocks, and inside
+    scrf_fb_batch_allreduce the transition contraction comes first so that its block is all-reduced on the second
+    stream under the state contraction.  One rank with the communicator -- overlap on and off -- writes the bytes of the
+    plain run (the reordering touches disjoint weights; RCCL over one rank is the identity)."""
+    rng = np.random.RandomState(11)
+    L, D, W = 5, 3, 4
+    f1 = str(tmp_path / "f1.ascii"); f2 = str(tmp_path / "f2.ascii"); l = str(tmp_path / "l.ascii")
+    with open(f1, "w") as a, open(f2, "w") as b, open(l, "w") as lf:
+        for u, T in enumerate([9, 14, 4, 11, 7]):
+            X = rng.random_sample((T, W)).astype(np.float32)
+            lab = np.repeat(rng.randint(0, L, T), 2)[:T].astype(np.uint32)
+            for t in range(T):
+                a.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t])))
+                b.write("%d %d %s\n" % (u, t, " ".join("%.9g" % v for v in X[t][:2])))
+                lf.write("%d %d %d\n" % (u, t, lab[t]))
+    base = ["ftr1_file=" + f1, "ftr1_format=ascii", "ftr1_extract_seg_ftr=1", "ftr2_file=" + f2, "ftr2_format=ascii",
+            "hardtarget_file=" + l, "crf_label_size=%d" % L, "crf_model_type=stdseg_no_dur_no_segtransftr",
+            "label_maximum_duration=%d" % D, "crf_featuremap=stdtrans", "crf_stateftr_start=0", "crf_stateftr_end=%d" % (8 * W + D - 1),
+            "crf_transftr_start=%d" % (8 * W + D), "crf_transftr_end=%d" % (8 * W + D + 1),
+            "crf_epochs=2", "crf_lr=0.05", "crf_bunch_size=2", "threads=1", "crf_train_order=seq"]
+    outs = {}
+    comm = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+    for tag, env, extra in [("plain", {}, []), ("overlap", comm, ["crf_force_comm=1"]), ("serial", dict(comm, SCRF_COMM_OVERLAP="0"), ["crf_force_comm=1"])]:
+        d = tmp_path / tag
+        d.mkdir()
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([os.path.join(BIN, "CRFTrain")] + base + ["out_weight_file=" + str(d / "w.out")] + extra,
+                           capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = _files(str(d))
+        if tag != "plain":   # 5 utterances, bunch 2, 2 epochs: 6 steps; all of them overlapped unless switched off
+            import re as _re
+            m = _re.search(r"Gradient all-reduces: (\d+) \(transition block overlapped with the state contraction in (\d+)\)", r.stdout)
+            assert m and int(m.group(1)) == 6 and int(m.group(2)) == (6 if tag == "overlap" else 0), r.stdout[-400:]
+    assert np.abs(np.loadtxt(str(tmp_path / "plain" / "w.out"))).max() > 0
+    for tag in ("overlap", "serial"):
+        assert sorted(outs["plain"]) == sorted(outs[tag]) and all(outs["plain"][k] == outs[tag][k] for k in outs["plain"]), tag
+
+
 def test_crftrain_refuses_stdtrans_for_stdseg_no_dur_no_transftr(tmp_path):
     """CRFTrain/src/Main.cpp:465-468: crf_featuremap must be "stdstate" for that model type"""
     r = subprocess.run([os.path.join(BIN, "CRFTrain")] + [f for f in _train_flags(str(tmp_path / "w.out")) if not f.startswith(("crf_model_type", "crf_featuremap", "label_maximum_duration"))] +

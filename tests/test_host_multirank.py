@@ -48,10 +48,10 @@ def data(tmp_path_factory):
 
 
 def flags(d, out, **kw):
-    f = dict(crf_epochs=3, crf_lr=0.1, crf_bunch_size=3, threads=1, crf_utt_rpt=1, crf_train_order="seq")
+    f = dict(crf_epochs=3, crf_lr=0.1, crf_bunch_size=3, threads=1, crf_utt_rpt=1, crf_train_order="seq", crf_featuremap="stdstate")
     f.update(kw)
     return ["ftr1_file=" + os.path.join(d, "f.ascii"), "ftr1_format=ascii", "hardtarget_file=" + os.path.join(d, "l.ascii"),
-            "crf_label_size=%d" % L, "crf_model_type=stdframe", "label_maximum_duration=1", "crf_featuremap=stdstate",
+            "crf_label_size=%d" % L, "crf_model_type=stdframe", "label_maximum_duration=1",
             "out_weight_file=" + out] + ["%s=%s" % kv for kv in f.items()]
 
 
@@ -147,6 +147,30 @@ def test_n_ranks_equal_one_process_with_n_streams_and_the_replayed_protocol(exe,
     lam, avg = replay(utts, world, bunch, 3)
     assert dist["w.out"] == as_file(lam)
     assert dist["w.out.avg.out"] == as_file(avg)
+
+
+@pytest.mark.parametrize("world,bunch", [(2, 3), (4, 5)])
+def test_two_block_collective_with_transition_features(exe, data, tmp_path, world, bunch):
+    """With transition features the per-step collective runs in two blocks (transition weights, then state weights +
+    scalars; the engine issues the first under the state contraction inside scrf_fb_batch_allreduce).  The block
+    sequence is part of the protocol: ranks that go through the fused call and ranks whose view is exhausted (plain
+    scrf_allreduce_grad_ex, world = 4 has views of 2, 2, 2 and 5 utterances) must still meet, and N processes must
+    write the bytes one process with N streams writes."""
+    d, utts = data
+    res = launch(exe, d, str(tmp_path / "dist"), world, crf_bunch_size=bunch, crf_featuremap="stdtrans")
+    for r, (rc, o, er) in enumerate(res):
+        assert rc == 0, "rank %d: %s %s" % (r, o[-400:], er[-400:])
+    dist = weight_files(str(tmp_path / "dist"))
+    # two rounds of the file collective per step: more rounds than steps
+    rounds = len([n for n in os.listdir(os.path.join(str(tmp_path / "dist"), "comm", os.listdir(os.path.join(str(tmp_path / "dist"), "comm"))[0]))
+                  if n.startswith("r") and n.endswith(".0")])
+    os.makedirs(str(tmp_path / "one"))
+    r1 = subprocess.run([exe] + flags(d, str(tmp_path / "one" / "w.out"), crf_bunch_size=bunch, threads=world, crf_featuremap="stdtrans"),
+                        capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0, r1.stderr
+    one = weight_files(str(tmp_path / "one"))
+    assert sorted(one) == sorted(dist) and all(one[k] == dist[k] for k in one)
+    assert rounds % 2 == 0 and rounds >= 2 * 3     # two blocks per step, at least one step per epoch
 
 
 def test_more_ranks_than_utterances_leaves_empty_views_inactive(exe, tmp_path):

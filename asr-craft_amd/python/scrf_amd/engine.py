@@ -346,6 +346,19 @@ class Engine:
             raise ScrfError(rc, self.lib.scrf_last_error(None).decode())
         self._chk(self.lib.scrf_comm_init(self.h, uid, 0, 1))
 
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 calls it and hands the bytes to the other ranks)"""
+        uid = (C.c_char * 128)()
+        rc = self.lib.scrf_comm_unique_id(uid)
+        if rc != 0:
+            raise ScrfError(rc, self.lib.scrf_last_error(None).decode())
+        return bytes(uid.raw)
+
+    def comm_init(self, uid, rank, world):
+        """collective: every rank of the communicator calls it with rank 0's id"""
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        self._chk(self.lib.scrf_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))
+
     def scale_grad(self, s): self._chk(self.lib.scrf_scale_grad(self.h, C.c_double(s)))
 
     def sgd_step(self, lr_or_eta, use_adagrad=False, eps=1e-12):

@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--utts", type=int, default=4096, help="utterances per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the collective path)")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="reduce the gradient through the ENGINE's own RCCL communicator (scrf_comm_init / scrf_allreduce_grad: what bin/CRFTrain "
+                         "uses) instead of torch.distributed; the id travels by a torch broadcast")
     ap.add_argument("--precision", choices=["exact", "fast", "fast32", "fastlin"], default="fastlin",
                     help="exact: reference-order unfused fp64; fast: fp64 MFMA, window synthesis fused into the contractions; "
                          "fastlin (default): fast with the window average taken as the exact mean, which is linear in the frames and "
@@ -300,9 +303,18 @@ def main():
     eng.set_stream(stream.cuda_stream)
     from scrf_amd.dist import MinibatchReducer
     # gradient + {numer, zx, n_utts, active} in one device buffer: one RCCL all-reduce per step
-    red = MinibatchReducer(eng.lambda_len, "cuda") if dist is not None else None
-    grad = red.grad if red is not None else torch.zeros(eng.lambda_len, dtype=torch.float64, device="cuda")
-    eng.set_grad_buffer(grad.data_ptr())
+    native = bool(args.native_comm and dist is not None)
+    red = MinibatchReducer(eng.lambda_len, "cuda") if (dist is not None and not native) else None
+    if native:
+        # the engine's communicator: rank 0's id to every rank, then the collective init; the gradient stays in the engine
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        eng.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+    else:
+        grad = red.grad if red is not None else torch.zeros(eng.lambda_len, dtype=torch.float64, device="cuda")
+        eng.set_grad_buffer(grad.data_ptr())
     fl = [frames[int(off[u]):int(off[u + 1])] for u in range(U)]
     ll = [labels[int(off[u]):int(off[u + 1])] for u in range(U)]
     batch = eng.batch_from_frames(fl, ll)  # inputs resident in HBM from here on
@@ -311,7 +323,9 @@ def main():
     def step():
         eng.zero_grad()
         eng.fb_batch(batch, want_scalars=False)  # returns once the recursion's status is known; contractions in flight
-        if red is not None:
+        if native:
+            eng.allreduce_grad(True)   # scrf_allreduce_grad: RCCL sum + / active on the engine's stream
+        elif red is not None:
             # RCCL all-reduce (sum) of the weight gradient over xGMI, then / active ranks
             # (Minibatch_GradAccumulator.cpp:296-308); every rank is active in this bench
             red.reduce()
@@ -467,6 +481,7 @@ def main():
                        "utts_per_rank_per_step": U, "global_minibatch": U * world, "precision": args.precision,
                        "parallelism": "dp%d" % world,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+                       "collective": ("engine RCCL communicator (scrf_allreduce_grad)" if native else "torch.distributed all_reduce (nccl = RCCL)") if dist is not None else None,
                        "step_sync": "scrf_fb_batch returns once the recursion's status is known (one event wait per step)"},
             "roofline": roofline,
         }

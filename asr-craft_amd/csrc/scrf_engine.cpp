@@ -119,6 +119,7 @@ struct scrf_engine_s {
   uint64_t n_collectives = 0, n_overlapped = 0;   // scrf_comm_stats
   bool comm_overlap_on = true;   // SCRF_COMM_OVERLAP=0: the fused call issues both blocks after the batch (same results)
   double* d_pack = nullptr;   // [L * nsf + 8]: the state weights of every label + the 8 scalars, one small message
+  bool fuse_mixed = true;     // SCRF_FUSE_MIXED=0: two-stream batches keep the general path for the state part too
   bool dur_table = true;      // the score kernel copies its duration-weight table instead of building it per tile (SCRF_DTAB=0: off)
   bool side_stream = true;    // k_ztf + transition counts on the second stream under k_expf_fused_ws (SCRF_SIDE=0: off)
   void* d_rtab = nullptr;       // k_tile_tables: row records / row bases / rowmap of a steady-state score tile
@@ -177,6 +178,7 @@ struct scrf_batch_s {
   int* d_status = nullptr;
   // fused window synthesis: row tiles of the score kernel [0] and of the expected-count kernel [1]
   bool fused_ok = false;
+  bool mixed = false;   // fused state part (stream 0) + materialised transition-feature streams (config 3's shape)
   std::vector<uint64_t> tile_off[3];   // 0: score tiles, 1: expected-count tiles (<= 76 rows), 2: <= 100 rows (FASTLIN)
   ScrfTileDesc* d_tiles[3] = {nullptr, nullptr, nullptr};
   ScrfBatchView view() const {
@@ -306,6 +308,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_FUSE")) h->fuse_windows = atoi(e) != 0;
   if (const char* e = getenv("SCRF_SIDE")) h->side_stream = atoi(e) != 0;
   if (const char* e = getenv("SCRF_DTAB")) h->dur_table = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_FUSE_MIXED")) h->fuse_mixed = atoi(e) != 0;
   if (const char* e = getenv("SCRF_COMM_OVERLAP")) h->comm_overlap_on = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
@@ -705,10 +708,17 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   }
   // fused window synthesis: one segment-recipe stream without context whose window is exactly
   // the state feature range, no transition features
-  if (!by_windows && n_streams == 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && !lay.use_tf && lay.use_sf && recipes[0].extract_seg_ftr &&
-      !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 && lay.nsfe == 8 * recipes[0].in_width + lay.D &&
-      lay.nsfe == lay.F && fused_supported(lay, recipes[0].in_width)) {
+  const int f32_cfg = h->cfg.train_precision == SCRF_PREC_FAST32;
+  const bool seg_stream0 = !by_windows && n_streams >= 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && lay.use_sf &&
+                           recipes[0].extract_seg_ftr && !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 &&
+                           lay.nsfe == 8 * recipes[0].in_width + lay.D && fused_supported(lay, recipes[0].in_width, f32_cfg);
+  // "mixed" (round 4, BASELINE config 3's shape): the state features are exactly stream 0's segment-recipe window and the
+  // transition features live in the other streams' columns -- the state part takes the fused kernels, the transition
+  // part keeps the materialised first-row windows and the dense contractions
+  const bool mixed_ok = seg_stream0 && n_streams >= 2 && lay.use_tf && lay.tfs >= lay.nsfe && h->fuse_mixed;
+  if ((seg_stream0 && n_streams == 1 && !lay.use_tf && lay.nsfe == lay.F) || mixed_ok) {
     b->fused_ok = true;
+    b->mixed = mixed_ok;
     {
       std::vector<float> xm(NF);
       const uint32_t W0 = recipes[0].in_width;
@@ -930,6 +940,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
     const size_t ng = nd.la ? 6 : 5;
     tot += pad256(nfr * ng * l.L * sizeof(double));                // P (scores) / Z (counts)
     if (nd.post) tot += pad256((size_t)512 * ng * l.L * W0 * sizeof(double));
+    if (b->mixed) tot += pad256(nseg * l.F * sizeof(float));     // the transition streams' windows
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
   if (nd.vitfast) tot += pad256(nseg * l.L * sizeof(float)) + pad256((size_t)decode_fix_cap(nseg, l.L) * 8) + 256;  // Wn, list, count
   else tot += pad256(nseg * l.L * sizeof(double));                  // S
@@ -1002,7 +1013,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
   cb->sums = lane ? h->d_sums2 : h->d_sums;
   if (nd.fused) {
     const uint32_t W0 = b->recipe[0].in_width;
-    cb->X = nullptr;
+    cb->X = b->mixed ? a.take<float>(nseg * l.F) : nullptr;
     cb->la = nd.la;
     const size_t ng = nd.la ? 6 : 5;
     cb->P = a.take<double>(nfr * ng * l.L);
@@ -1192,9 +1203,11 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     if (pframe_supported(W0)) {
       KT_RUN("k_pframe", cb.st, launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, (cb.la ? 6 : 5) * l.L, cb.P));
       if (cb.la) KT_RUN("k_avg_prefix", cb.st, launch_avg_prefix(cb.st, bv, u0, u1 - u0, l.L, cb.P));
-    } else
+    } else {
       KT_RUN("k_scores_mfma(samples)", cb.st, launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
-                         spec_samples(W0), 5 * l.L, cb.P));
+                         spec_samples(W0), (cb.la ? 6 : 5) * l.L, cb.P));
+      if (cb.la) KT_RUN("k_avg_prefix", cb.st, launch_avg_prefix(cb.st, bv, u0, u1 - u0, l.L, cb.P));
+    }
     if (cb.Wn) {
       // decode: float arc weights + the rounding screen
       launch_state_l1(cb.st, h->d_lambda, l, h->d_w1);
@@ -1224,13 +1237,15 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     }
     tm.stop(2);
     HIPCHK(h, hipGetLastError());
-    return SCRF_OK;
+    if (!b->mixed) return SCRF_OK;
+    // mixed: the transition part below (windows of the other streams, per-frame transition scores)
   }
   if (b->mode == 1) {
     PhaseTimer tm(h, PH_WIN, cb.st);
     uint32_t col = 0;
     for (uint32_t s = 0; s < b->n_streams; s++) {
       const scrf_stream_recipe& r = b->recipe[s];
+      if (cb.fused && s == 0) { col += b->width[s]; continue; }   // stream 0 is synthesised inside the fused kernels
       // FAST training path with per-frame transition features: a stream whose columns hold no state feature is read through
       // the frame rows (k_frame_rows: the node's first window) only -- its other window rows are not written (the TIMIT
       // demo's +-6-frame context stream: 5.8 GB of the 9.3 GB window image).  The window hook (scrf_windows) and EXACT
@@ -1244,7 +1259,7 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
   }
   PhaseTimer tm(h, PH_SCORE, cb.st);
   uint32_t nl = 1;
-  {
+  if (!cb.fused) {
     PhaseTimer tk(h, PH_K_SCORE, cb.st);
     if (fast) KT_RUN("k_scores_mfma(state)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32));
     else KT_RUN("k_scores_exact(state)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S));
@@ -1756,7 +1771,8 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
     // are committed and their all-reduce goes to the second stream, under the state contraction.  A NUMERIC failure of
     // the recursion is retried with the log-domain kernels by the caller: that has to be known BEFORE a collective is
     // issued (the peers issue theirs exactly once), so the host waits for the status here.
-    const bool ov = h->overlap_comm && h->comm_overlap_on && two_block_reduce(h) && !use2 && !h->timing && !cb.fused;
+    const bool ov = h->overlap_comm && h->comm_overlap_on && two_block_reduce(h) && !use2 && !h->timing;
+    bool trans_done = false;   // the transition counts of this chunk are already in the staged gradient
     if (ov) {
       if (ci + 1 == n_chunks) {
         HIPCHK(h, hipEventSynchronize(h->ev_status));
@@ -1777,12 +1793,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
         HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
         h->early_done = true;
       }
-      if (fast) launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32);
-      else launch_expf_gemm(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, 0, cb.rpc_s, cb.nch_s, cb.slab_s);
-      launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
-      launch_batch_sums(cb.st, b->d_numer + u0, b->d_zx + u0, (uint32_t)nutt, cb.sums);
-      HIPCHK(h, hipGetLastError());
-      continue;
+      trans_done = true;   // the state part (fused or dense) follows below, under the transition block's all-reduce
     }
     bool side = false;   // part of the count work runs on the second stream (below)
     {
@@ -1816,7 +1827,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
         } else if (pframe_supported(W0))
           KT_RUN("k_ztf", cb.st, launch_ztf(cb.st, cb.Z, (cb.la ? 6 : 5) * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l));
         else
-          KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
+          KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, (cb.la ? 6 : 5) * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
                            spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l));
         nl += 2;
       } else {
@@ -1830,7 +1841,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
         if (fast) KT_RUN("k_expf_mfma(trans)", cb.st, launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32));
         else KT_RUN("k_expf_gemm(trans)", cb.st, launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, nullptr, nseg, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t));
         nl += 1;
-      } else if (l.use_tf) {
+      } else if (l.use_tf && !trans_done) {
         launch_frame_rows(cb.st, bv, u0, u1, l.D, nfr, cb.xrow_next, 1);
         if (fast) KT_RUN("k_expf_mfma(trans)", cb.st, launch_expf_mfma(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, scrf_spec_trans(l), cb.rpc_t, cb.nch_t, cb.slab_t, f32));
         else KT_RUN("k_expf_gemm(trans)", cb.st, launch_expf_gemm(cb.st, cb.XI, l.L * l.L, cb.X, l.F, cb.xrow_next, nfr, l, 1, cb.rpc_t, cb.nch_t, cb.slab_t));
@@ -1852,6 +1863,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
         if (!side) launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, (cb.la ? 6 : 5) * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
       if (side) HIPCHK(h, hipStreamWaitEvent(cb.st, h->ev_join, 0));   // the side stream's weights are in
+      else if (trans_done) {}
       else if (l.use_tf || segtrans(h)) launch_reduce_slabs(cb.st, cb.slab_t, cb.nch_t, l.L * l.L, l, scrf_spec_trans(l), cb.grad);
       else if (cb.wave) launch_atb(cb.st, l, cb.fA, cb.fB, nfr, cb.rpc_atb, cb.nch_atb, cb.slab_atb, h->d_m0, cb.grad,
                                    cb.lin ? cb.dl.gsd : nullptr);
@@ -2248,7 +2260,7 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   // overflows (pathological cancellation) goes through the EXACT path instead.
   Need ndf = nd;
   ndf.fused = ndf.vitfast = true;
-  const bool fast = h->fast_decode && b->fused_ok && h->fuse_windows && !frame_model && l.L <= 0xffff;
+  const bool fast = h->fast_decode && b->fused_ok && !b->mixed && h->fuse_windows && !frame_model && l.L <= 0xffff;
   int rc = SCRF_OK;
   if (nstate(h)) {
     HIPCHK(h, hipMemsetAsync(b->d_status, 0, sizeof(int) * b->U, h->stream));

@@ -1673,7 +1673,12 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
   const bool producer = wave >= 4;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t o0 = blockIdx.y * 48;
-  const uint32_t ncol = (3 - G0) * W;
+  // gridDim.z > 1: one dense statistic per workgroup column (wide streams: (3 - G0) W columns do not fit one LDS image
+  // pair / 13 column tiles) -- this workgroup builds and contracts statistic st0 only and writes columns
+  // [blockIdx.z W, (blockIdx.z + 1) W) of the slab rows; the duration sums are taken by the z = 0 column
+  const uint32_t st0 = G0 + (gridDim.z > 1 ? blockIdx.z : 0u);
+  const uint32_t ngrp = gridDim.z > 1 ? 1u : (uint32_t)(3 - G0);
+  const uint32_t ncol = ngrp * W, ncol_all = (3 - G0) * W, zoff = gridDim.z > 1 ? blockIdx.z * W : 0u;
   const uint32_t n_ot = 3 * n_ct;
   for (uint32_t i = tid; i < 2 * XB; i += FW_NT) Xs0[i] = 0.0f;
   for (uint32_t i = tid; i < 2 * RB; i += FW_NT) Rs0[i] = 0.0;
@@ -1683,7 +1688,7 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
 #pragma unroll
   for (int j = 0; j < NT; j++) acc[j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-  const uint64_t first = gridDim.y == 1 ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint64_t first = (gridDim.y == 1 && gridDim.z == 1) ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   const uint64_t G = gridDim.x;
   // ---- producer state
   const uint32_t ptid = tid - 256;
@@ -1698,7 +1703,7 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
   const uint32_t dol = ptid % 48, dsl = ptid / 48;
   uint32_t ct0 = 0, cnfr = 0, cr0 = 0;     // frames and first row of the tile whose images the consumers hold
   auto dur_sums = [&](uint32_t buf) {
-    if (ptid >= 48 * FW_DSL) return;
+    if (ptid >= 48 * FW_DSL || blockIdx.z != 0) return;
     const double* Rs = Rs0 + buf * RB + dol;
     for (uint32_t tl = 0; tl < cnfr; tl++) {
       const uint32_t t = ct0 + tl, nd = scrf_node_max_dur(t, D);
@@ -1750,7 +1755,7 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
       // st = statistic (0 avg, 1 max, 2 min); its columns start at (st - G0) W
       auto decode = [&](uint32_t i, uint32_t& st, uint32_t& tl, uint32_t& c) {
         const uint32_t g = fu_div(i, mfW);
-        st = g + G0;
+        st = g + st0;
         const uint32_t rem = i - g * nfW;
         tl = fu_div(rem, mW);
         c = rem - tl * W;
@@ -1761,7 +1766,7 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
         else fu_scan_ext_full<DMAX, 0, xs>(v, o);
       };
       if (FU_ABL == 6) {
-      } else if (G0 == 1 && full) {
+      } else if (G0 == 1 && ngrp == 2 && full) {
         // max and min of a (frame, column) from ONE set of loads; the tile's nfr W tasks are dealt evenly to the four
         // producer wavefronts (a 100-row tile has 156 of them: 39 lanes of every wavefront, one pass each, instead of
         // 312 single-statistic tasks that gave the first wavefront two passes)
@@ -1784,21 +1789,21 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
           }
         }
       } else
-      for (uint32_t i0 = ptid; i0 < (3 - G0) * nfW; i0 += 512) {
+      for (uint32_t i0 = ptid; i0 < ngrp * nfW; i0 += 512) {
         const uint32_t i1 = i0 + 256;
-        const bool two = i1 < (3 - G0) * nfW;
-        uint32_t st0, tl0, c0, st1, tl1, c1;
-        decode(i0, st0, tl0, c0);
+        const bool two = i1 < ngrp * nfW;
+        uint32_t st0_, tl0, c0, st1, tl1, c1;
+        decode(i0, st0_, tl0, c0);
         decode(two ? i1 : i0, st1, tl1, c1);
         if (full) {
           float v0[DMAX], v1[DMAX];
           fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl0 - ft.f0) * W + c0, W, v0);
           fu_load_vals_full<DMAX>(gfr, (ft.t0 + tl1 - ft.f0) * W + c1, W, v1);
-          scan_full(v0, st0, Xs + tl0 * (DMAX * xs) + (st0 - G0) * W + c0);
-          if (two) scan_full(v1, st1, Xs + tl1 * (DMAX * xs) + (st1 - G0) * W + c1);
+          scan_full(v0, st0_, Xs + tl0 * (DMAX * xs) + (st0_ - st0) * W + c0);
+          if (two) scan_full(v1, st1, Xs + tl1 * (DMAX * xs) + (st1 - st0) * W + c1);
         } else {
           for (int h = 0; h < (two ? 2 : 1); h++) {
-            const uint32_t st = h ? st1 : st0, tl = h ? tl1 : tl0, c = h ? c1 : c0;
+            const uint32_t st = h ? st1 : st0_, tl = h ? tl1 : tl0, c = h ? c1 : c0;
             const uint32_t t = ft.t0 + tl;
             const uint32_t at = (t - ft.f0) * W + c;
             float v[DMAX];
@@ -1807,8 +1812,8 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
             const uint32_t d_lo = lbase < 0 ? (uint32_t)(1 - lbase) : 1u;
             const uint32_t d_hi = min(nd, (uint32_t)((int32_t)ft.nrows - lbase));
             fu_load_vals<DMAX>(gfr + at, W, nd, v);
-            float* o = Xs + lbase * (int32_t)xs + (st - G0) * W + c;
-            float* dmp = dump + (st - G0) * W + c;
+            float* o = Xs + lbase * (int32_t)xs + (st - st0) * W + c;
+            float* dmp = dump + (st - st0) * W + c;
             if (G0 == 0 && st == 0) fu_scan_avg<DMAX>(v, o, xs, d_lo, d_hi, dmp);
             else if (st == 1) fu_scan_ext<DMAX, 1>(v, o, xs, d_lo, d_hi, dmp);
             else fu_scan_ext<DMAX, 0>(v, o, xs, d_lo, d_hi, dmp);
@@ -1861,7 +1866,7 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
   double* dout = dslab + (uint64_t)blockIdx.x * n_out * nd1;
   double* dl = Rs0;   // [D][48], over the dead R images (the loop's last barrier is behind every wavefront)
   if (producer) {
-    if (ptid < 48 * FW_DSL) {
+    if (ptid < 48 * FW_DSL && blockIdx.z == 0) {
 #pragma unroll
       for (int q = 0; q < NDA; q++) {
         const uint32_t d0 = dsl + FW_DSL * q;
@@ -1873,7 +1878,7 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
     }
   } else {
     // slab[blockIdx.x][o][f]
-    double* out = slab + (uint64_t)blockIdx.x * n_out * ncol;
+    double* out = slab + (uint64_t)blockIdx.x * n_out * ncol_all + zoff;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const uint32_t q = wave + 4 * j;
@@ -1885,12 +1890,12 @@ __device__ __forceinline__ void expf_fused_ws_body(const ScrfFusedArgs& fa, cons
       for (int r = 0; r < 4; r++) {
         const uint32_t o = o0 + n * 16 + lk + 4 * r;
         if (o >= n_out) continue;
-        out[(uint64_t)o * ncol + f] = acc[j][r];
+        out[(uint64_t)o * ncol_all + f] = acc[j][r];
       }
     }
   }
   __syncthreads();
-  if (producer && lay.use_sb && ptid < 48 && o0 + ptid < n_out) {
+  if (producer && blockIdx.z == 0 && lay.use_sb && ptid < 48 && o0 + ptid < n_out) {
     double bsum = 0.0;
     for (uint32_t d0 = 0; d0 < D; d0++) bsum += dl[d0 * 48 + ptid];
     dout[(uint64_t)(o0 + ptid) * nd1 + D] = bsum * lay.sbv;
@@ -1919,9 +1924,9 @@ static uint32_t fused_expf_xs(const ScrfLayout& lay, uint32_t W, uint32_t* n_ct)
   *n_ct = (ncol + 15) / 16;
   return (*n_ct <= 5 ? 5 : *n_ct <= 9 ? 9 : 13) * 16;
 }
-// the wave-specialised kernel: dense groups only (g0 = 1: without the average)
-static uint32_t fused_expf_ws_xs(uint32_t W, int g0, uint32_t* n_ct) {
-  const uint32_t ncol = (3 - g0) * W;
+// the wave-specialised kernel: dense groups only (g0 = 1: without the average); zb: one statistic per workgroup column
+static uint32_t fused_expf_ws_xs(uint32_t W, int g0, int zb, uint32_t* n_ct) {
+  const uint32_t ncol = zb ? W : (3 - g0) * W;
   *n_ct = (ncol + 15) / 16;
   return (*n_ct <= 5 ? 5 : *n_ct <= 9 ? 9 : 13) * 16;
 }
@@ -1942,24 +1947,30 @@ static size_t fused_expf_smem(const ScrfLayout& lay, uint32_t W) {
   return sizeof(float) * (FE_ROWS + 1) * xs + sizeof(double) * FE_ROWS * FE_RS +
          sizeof(float) * fused_expf_nfmax(lay.D) * W + 64;
 }
-
-int fused_supported(const ScrfLayout& lay, uint32_t W) {
+// the single-role count kernel (all dense columns + one-hot + bias in one image; FAST32, SCRF_EXPF_WS=0)
+static bool fused_expf_plain_fits(const ScrfLayout& lay, uint32_t W) {
   uint32_t n_ct;
   fused_expf_xs(lay, W, &n_ct);
-  if (lay.D < 2 || lay.D > 40 || W < 1 || n_ct > 13) return 0;
-  if (fused_expf_smem(lay, W) > 156 * 1024) return 0;   // above 80 KB: one workgroup per CU instead of two
-  return fused_scores_tb(W, lay.D) >= 1;
+  return n_ct <= 13 && fused_expf_smem(lay, W) <= 156 * 1024;   // above 80 KB: one workgroup per CU instead of two
 }
 
 // the wave-specialised kernel (one 512-thread workgroup per CU, two image pairs in LDS) serves the fp64 form whenever
 // its LDS fits; SCRF_EXPF_WS=0 switches it off (A/B measurements).  Rows per tile: 100 when g0 = 1 and the narrower
 // column image lets two pairs of that height into 160 KB (its own tile list, built with the batch), else 76.
+// Wide streams (config 3: W = 144, config 5: W = 123) do not fit (3 - g0) W columns into 13 column tiles / 160 KB: the
+// launch is then z-blocked, one statistic per workgroup column (W <= 208).
 #define FW_ROWS_BIG 100
-static size_t fused_expf_ws_smem_rows(uint32_t W, int g0, uint32_t rows) {
+static size_t fused_expf_ws_smem_rows(uint32_t W, int g0, int zb, uint32_t rows) {
   uint32_t n_ct;
-  const uint32_t xs = fused_expf_ws_xs(W, g0, &n_ct);
+  const uint32_t xs = fused_expf_ws_xs(W, g0, zb, &n_ct);
   return 2 * (sizeof(float) * (rows + 1) * xs + sizeof(double) * rows * FE_RS);
 }
+static bool fused_expf_ws_fits(uint32_t W, int g0, int zb) {
+  uint32_t n_ct;
+  fused_expf_ws_xs(W, g0, zb, &n_ct);
+  return n_ct <= 13 && fused_expf_ws_smem_rows(W, g0, zb, FE_ROWS) <= 160 * 1024;
+}
+static int fused_expf_ws_zb(uint32_t W, int g0) { return !fused_expf_ws_fits(W, g0, 0) && fused_expf_ws_fits(W, g0, 1) ? 1 : 0; }
 static uint32_t fused_expf_ws_rows(uint32_t W, int g0) {
   // 100-row tiles take 232 registers per wavefront, 76-row tiles 212: only the latter leaves room on a SIMD for the
   // side stream's narrow k_ztf (64), and with that overlap the 76-row form is the faster step (29.22 against 29.46 ms;
@@ -1967,20 +1978,30 @@ static uint32_t fused_expf_ws_rows(uint32_t W, int g0) {
   static const bool side = !(getenv("SCRF_SIDE") && atoi(getenv("SCRF_SIDE")) == 0);
   static const bool big = getenv("SCRF_EXPF_BIG") ? atoi(getenv("SCRF_EXPF_BIG")) != 0 : !side;
   uint32_t n_ct;
-  fused_expf_ws_xs(W, g0, &n_ct);
-  return (big && g0 == 1 && n_ct <= 5 && fused_expf_ws_smem_rows(W, g0, FW_ROWS_BIG) <= 160 * 1024) ? FW_ROWS_BIG : FE_ROWS;
+  fused_expf_ws_xs(W, g0, 0, &n_ct);
+  return (big && g0 == 1 && n_ct <= 5 && !fused_expf_ws_zb(W, g0) && fused_expf_ws_smem_rows(W, g0, 0, FW_ROWS_BIG) <= 160 * 1024) ? FW_ROWS_BIG : FE_ROWS;
 }
-static size_t fused_expf_ws_smem(uint32_t W, int g0) { return fused_expf_ws_smem_rows(W, g0, fused_expf_ws_rows(W, g0)); }
 static bool fused_expf_ws(const ScrfLayout& lay, uint32_t W, int f32, int g0) {
   static const bool on = !(getenv("SCRF_EXPF_WS") && atoi(getenv("SCRF_EXPF_WS")) == 0);
-  uint32_t n_ct;
-  fused_expf_ws_xs(W, g0, &n_ct);
-  return on && !f32 && n_ct <= 13 && fused_expf_ws_smem(W, g0) <= 160 * 1024;
+  return on && !f32 && (fused_expf_ws_fits(W, g0, 0) || fused_expf_ws_fits(W, g0, 1));
 }
-// SCRF_PREC_FASTLIN needs the wave-specialised count kernel (the only one without the avg group) and one 64-output
-// group in k_post_z; other shapes run the FAST kernels (the reference's float average) under that precision
+
+// f32: FAST32 runs the single-role count kernel only
+int fused_supported(const ScrfLayout& lay, uint32_t W, int f32) {
+  if (lay.D < 2 || lay.D > 40 || W < 1) return 0;
+  if (!fused_expf_plain_fits(lay, W) && !fused_expf_ws(lay, W, f32, 0)) return 0;
+  // wide streams with many labels (config 5: W = 123, L = 200, D = 40) are served better by the general path: every
+  // 48-output block of the fused kernels repeats the window scans, the D = 40 forms spill, k_post_z walks four label
+  // groups (measured 253.6 ms fused against 206.4 ms materialised per 128 utterances).  The z-blocked count kernel is for
+  // one label group.
+  if (!fused_expf_plain_fits(lay, W) && lay.L > 64) return 0;
+  return fused_scores_tb(W, lay.D) >= 1;
+}
+// SCRF_PREC_FASTLIN needs the wave-specialised count kernel (the only one without the avg group); other shapes run the
+// FAST kernels (the reference's float average) under that precision.  (L > 64: k_post_z keeps one Z_avg ring per
+// 64-output group, which its LDS no longer holds two of per SIMD -- left to FAST.)
 int fused_la_supported(const ScrfLayout& lay, uint32_t W) {
-  return fused_supported(lay, W) && lay.L <= 64 && pframe_supported(W) && fused_expf_ws(lay, W, 0, 1);
+  return fused_supported(lay, W, 0) && lay.L <= 64 && fused_expf_ws(lay, W, 0, 1);
 }
 // layout of the count slabs: {dense columns, first dense group, separate duration slab?}, the tile list and its height
 ScrfFusedExpfPlan fused_expf_plan(const ScrfLayout& lay, uint32_t W, int f32, int la) {
@@ -1992,6 +2013,7 @@ ScrfFusedExpfPlan fused_expf_plan(const ScrfLayout& lay, uint32_t W, int f32, in
   p.rows = p.ws ? fused_expf_ws_rows(W, p.g0) : FE_ROWS;
   p.tile_list = p.rows == FE_ROWS ? 1 : 2;
   p.frames = lay.D >= p.rows ? 1u : p.rows / lay.D;
+  p.nz = (p.ws && fused_expf_ws_zb(W, p.g0)) ? (uint32_t)(3 - p.g0) : 1u;
   return p;
 }
 uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles, int la) {
@@ -2003,8 +2025,9 @@ uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t 
 template <int NT, int DMAX, int NKS, int G0, int ROWS>
 static void launch_expf_ws_t(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R, uint64_t n_tiles,
                              uint32_t n_ct, double* slab, double* dslab) {
-  dim3 grid(fused_expf_blocks(lay, fa.W, 0, n_tiles, G0), (lay.L + 47) / 48);
-  const size_t smw = fused_expf_ws_smem_rows(fa.W, G0, ROWS);
+  const int zb = fused_expf_ws_zb(fa.W, G0);
+  dim3 grid(fused_expf_blocks(lay, fa.W, 0, n_tiles, G0), (lay.L + 47) / 48, zb ? 3 - G0 : 1);
+  const size_t smw = fused_expf_ws_smem_rows(fa.W, G0, zb, ROWS);
   if (NT <= 4) {   // the narrow forms leave room for the side stream's kernels
     hipFuncSetAttribute((const void*)k_expf_fused_ws_n<NT, DMAX, NKS, G0, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw);
     hipLaunchKernelGGL((k_expf_fused_ws_n<NT, DMAX, NKS, G0, ROWS>), grid, dim3(FW_NT), smw, st, fa, lay, R, lay.L, n_tiles, n_ct, slab, dslab);
@@ -2043,7 +2066,7 @@ void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout
   const ScrfFusedExpfPlan plan = fused_expf_plan(lay, fa.W, f32, la);
   if (plan.ws) {
     uint32_t n_ct;
-    fused_expf_ws_xs(fa.W, plan.g0, &n_ct);
+    fused_expf_ws_xs(fa.W, plan.g0, plan.nz > 1 ? 1 : 0, &n_ct);
     if (plan.rows == FW_ROWS_BIG) {
       // 100-row tiles (g0 = 1, n_ct <= 5): k-steps = ceil(frames * D / 4) rounded up to 21 or 25
       const uint32_t used = plan.frames * lay.D;

@@ -117,7 +117,7 @@ void launch_lin_to_log(hipStream_t st, uint64_t n_frames, uint32_t L, const doub
 uint32_t fused_scores_tb(uint32_t W, uint32_t D);   // whole frames per score tile (0: shape not supported)
 #define SCRF_FUSED_ROWS_EXPF 76
 uint32_t fused_expf_frames(uint32_t D);            // whole frames per expected-count tile (<= 76 rows)
-int fused_supported(const ScrfLayout& lay, uint32_t W);
+int fused_supported(const ScrfLayout& lay, uint32_t W, int f32 = 0);
 // SCRF_PREC_FASTLIN (`la`): the window average leaves both dense contractions (prefix sums of a sixth per-frame
 // projection / a sixth group of Z); shapes this returns 0 for run the FAST kernels under that precision
 int fused_la_supported(const ScrfLayout& lay, uint32_t W);
@@ -125,7 +125,7 @@ int fused_la_supported(const ScrfLayout& lay, uint32_t W);
 // ndur > 0, a separate duration slab [blocks][L][ndur] (one-hot duration counts + bias; wave-specialised kernel)
 // rows / frames: height of the row tiles the kernel walks (whole frames); tile_list: which of the batch's tile lists
 // describes them (1: <= 76 rows, 2: <= 100 rows, built only for batches of an SCRF_PREC_FASTLIN engine)
-struct ScrfFusedExpfPlan { int ws; int g0; uint32_t ncol; uint32_t ndur; uint32_t rows; uint32_t frames; int tile_list; };
+struct ScrfFusedExpfPlan { int ws; int g0; uint32_t ncol; uint32_t ndur; uint32_t rows; uint32_t frames; int tile_list; uint32_t nz; };   // nz: workgroup columns of the launch (one dense statistic each when > 1)
 ScrfFusedExpfPlan fused_expf_plan(const ScrfLayout& lay, uint32_t W, int f32, int la);
 uint32_t fused_expf_blocks(const ScrfLayout& lay, uint32_t W, int f32, uint64_t n_tiles, int la);   // workgroups (= slabs) of launch_expf_fused, <= 512
 void launch_scores_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* lambda,

@@ -195,16 +195,54 @@ def test_fastlin_is_fast_when_the_float_average_is_exact(shape):
 
 
 def test_fastlin_falls_back_to_fast_where_its_kernels_do_not_apply():
-    """Transition features, several streams or L > 64: the batch runs the FAST kernels under FASTLIN (same contract)."""
-    for kw in (dict(L=70, D=3, in_w=4, Ts=[5, 9, 14]), dict(L=6, D=4, in_w=5, Ts=[9, 14], trans_ctx=1)):
-        c = Case(seed=820, precision=scrf_amd.PREC_FASTLIN, **kw)
-        eng = c.engine(); b = c.batch(eng)
-        assert eng.batch_fused_mode(b) in (0, 1)
-        numer, zx = eng.fb_batch(b)
-        og, on, oz = c.oracle_gradient()
-        assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
-        assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() <= 1e-9
-        b.close(); eng.close()
+    """L > 64: the batch runs the FAST kernels under FASTLIN (same contract)."""
+    c = Case(seed=820, precision=scrf_amd.PREC_FASTLIN, L=70, D=3, in_w=4, Ts=[5, 9, 14])
+    eng = c.engine(); b = c.batch(eng)
+    assert eng.batch_fused_mode(b) == 1
+    numer, zx = eng.fb_batch(b)
+    og, on, oz = c.oracle_gradient()
+    assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
+    assert np.abs(eng.get_grad() - og).max() / np.abs(og).max() <= 1e-9
+    b.close(); eng.close()
+
+
+MIXED_SHAPES = [
+    dict(L=6, D=4, in_w=5, Ts=[9, 14, 3, 1], trans_ctx=1),
+    dict(L=48, D=10, in_w=8, Ts=[40, 25], trans_ctx=1, lam_scale=0.05),          # TIMIT-like label space
+    dict(L=5, D=3, in_w=90, Ts=[12, 7], trans_ctx=1, lam_scale=0.05),            # wide stream: no k_pframe / k_ztf (W > 80), z-blocked count kernel under FAST
+    dict(L=48, D=10, in_w=144, Ts=[30, 11], trans_ctx=2, lam_scale=0.02),        # config 3's widths: z-blocked under FASTLIN too
+]
+
+
+@pytest.mark.parametrize("si", range(len(MIXED_SHAPES)))
+def test_fused_state_part_with_materialised_transition_streams(si, monkeypatch):
+    """BASELINE config 3's structure (round 4): the state features are stream 0's segment-recipe window, the transition
+    features a second (context) stream.  FAST / FASTLIN fuse the window synthesis of the STATE part into its two
+    contractions and keep the first-row windows + dense contractions for the transition part; SCRF_FUSE_MIXED=0 keeps the
+    general path for everything.  Both against the oracle; FAST also against each other (summation order only)."""
+    res = {}
+    for prec, tol in ((scrf_amd.PREC_FAST, 1e-9), (scrf_amd.PREC_FASTLIN, 1e-6)):
+        for mixed in ("1", "0"):
+            monkeypatch.setenv("SCRF_FUSE_MIXED", mixed)
+            c = Case(seed=830 + si, precision=prec, **MIXED_SHAPES[si])
+            eng = c.engine(); b = c.batch(eng)
+            assert eng.batch_fused_mode(b) == (0 if mixed == "0" else (2 if prec == scrf_amd.PREC_FASTLIN else 1))
+            numer, zx = eng.fb_batch(b)
+            g = eng.get_grad()
+            og, on, oz = c.oracle_gradient()
+            assert np.abs(numer - on).max() <= tol * max(1, np.abs(on).max())
+            assert np.abs(zx - oz).max() <= max(1e-11, tol * 1e-2) * np.abs(oz).max()
+            assert np.abs(g - og).max() / np.abs(og).max() <= tol
+            res[(prec, mixed)] = g.copy()
+            # decode of such a batch keeps the EXACT path
+            labs, cost = eng.viterbi_batch(b)
+            So, Mo = orc.seg_scores(c.ocfg, c.olay, c.lam, c.windows(0), c.Ts[0])
+            oa, ons, ofin = orc.seg_lattice_arcs(c.ocfg, So, Mo, c.Ts[0])
+            ol, _ = orc.best_path(oa, ons, ofin)
+            assert list(labs[0]) == list(ol)
+            b.close(); eng.close()
+    a, bb = res[(scrf_amd.PREC_FAST, "1")], res[(scrf_amd.PREC_FAST, "0")]
+    assert np.abs(a - bb).max() <= 1e-10 * np.abs(bb).max()
 
 
 FUSED_SHAPES = [

@@ -2061,10 +2061,34 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst&
     crf_amd::ArcListFst full;
     const int fs0 = full.AddState();
     full.SetStart(fs0);
-    std::vector<int32_t> sid((size_t)T * QL, -1);
+    // Lattice states are hypotheses (end frame, LM state, phone).  The reference's output_full_fst keys its states by
+    // (end frame, LM state) (stateValueUpdate_onOutputFullFst): the same state set whenever an LM state is entered on
+    // one phone only (its own free phone loop, phone-history LMs).  An LM with a state entered on several phones (a
+    // unigram / back-off state) gives more states and arcs here than there: said once per run.
+    {
+      static bool noted = false;
+      if (!noted) {
+        std::vector<int> in_label(Q, 0);
+        bool multi = false;
+        for (const scrf_arc& a : lm.arcs)
+          if (a.ilabel > 0 && a.ilabel <= (int)L) {
+            if (in_label[a.dst] != 0 && in_label[a.dst] != a.ilabel) multi = true;
+            in_label[a.dst] = a.ilabel;
+          }
+        if (multi) std::cerr << "NOTE: crf_if_output_full_lat: the LM has states that are entered on several phones; the full lattice keeps one state per "
+                                "(end frame, LM state, phone) where the reference keeps one per (end frame, LM state): its state and arc counts differ "
+                                "from the reference's for this LM (the paths and their weights are those of the search)" << std::endl;
+        noted = true;
+      }
+    }
+    // (a hash map: the dense T x Q x L table would be gigabytes for a large LM)
+    std::unordered_map<uint64_t, int32_t> sid;
     auto state_of = [&](uint32_t t, size_t idx) -> int {
-      int32_t& s_ = sid[(size_t)t * QL + idx];
-      if (s_ < 0) s_ = full.AddState();
+      const uint64_t key = (uint64_t)t * QL + idx;
+      auto it = sid.find(key);
+      if (it != sid.end()) return it->second;
+      const int32_t s_ = full.AddState();
+      sid.emplace(key, s_);
       return s_;
     };
     auto word_of = [&](const Eps& c, const scrf_arc& a) -> int {   // one word per arc, as the reference's wrdId: the phone arc's, else the last on the epsilon path
@@ -2116,7 +2140,7 @@ int CRF_ViterbiDecoder_StdSeg_NoSegTransFtr::decodeLm(const crf_amd::ArcListFst&
       if (beam > 0) for (size_t i = 0; i < QL; i++) best_last = std::min(best_last, Fl[i]);
       for (size_t idx = 0; idx < QL; idx++) {
         if (Fl[idx] >= INF || (beam > 0 && Fl[idx] > best_last + beam)) continue;   // pruneFinal :947-970 erases weight > min + beam
-        if (sid[(size_t)(T - 1) * QL + idx] >= 0) full.SetFinal(sid[(size_t)(T - 1) * QL + idx], (float)zx);
+        { auto it = sid.find((uint64_t)(T - 1) * QL + idx); if (it != sid.end()) full.SetFinal(it->second, (float)zx); }
       }
     }
     // Connect: keep the states that lie on a path from the start state to a final state

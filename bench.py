@@ -218,7 +218,10 @@ def other_config(eng_mod, name, device_id, scratch_gib, with_cpu=True):
     ent["roofline"] = {"kernel": dom_name, "bound": "mfma" if dom_flops else "hbm",
                        "frac": ent["dominant_kernel"]["frac_executed"],
                        "traffic": round(tr["step_bytes"]) if tr else None,
-                       "traffic_dominant_kernel": round(tr["kernels"].get(dom_name, {}).get("bytes", 0)) if tr else None,
+                       # the trace names kernels by function (k_expf_mfma_ws + the single-role k_expf_mfma of remainder
+                       # launches), the event table by launch site (k_expf_mfma(trans)): both forms of the dominant kernel
+                       "traffic_dominant_kernel": round(sum(tr["kernels"].get(dom_name.split("(")[0] + sfx, {}).get("bytes", 0)
+                                                            for sfx in ("", "_ws"))) if tr else None,
                        "traffic_note": why,
                        # B_alg = 4 T W_in + 3*8 (N_seg L + M_elems) + 2*8 (N_seg L + 2 T L) per utterance
                        "algorithmic_gb_per_step": round(U * (4.0 * T * (2 * W if ctx else W) + 24.0 * (nseg * Lc + (T * Lc * Lc if ctx else Lc * Lc))

@@ -365,9 +365,12 @@ __global__ __launch_bounds__(DP_WPB * 64, 3) void k_dp_lin(
 // s_waitcnt vmcnt(<= 9) ahead of each step, and the code grows to 100 KB); capping the kernel at 128 VGPRs with the
 // third set spills into the loop (16 ms).  Hence opt-in: SCRF_DPLIN_MV=1 (the parity tests cover it that way).
 // ------------------------------------------------------------------------------------------
+// Round 4: MPF = 1 takes per-frame transition matrices (each wavefront's quarter of the frame's matrix is requested a step
+// ahead into a second register set: 148-182 registers), and the launcher picks that form BY ITSELF when the launch has too
+// few sweeps to fill the chip (launch_dp_lin).
 #define DPV_NW 4
-template <int DMAX>
-__global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
+template <int DMAX, int MPF>
+__global__ __launch_bounds__(64 * DPV_NW, MPF ? 2 : 4) void k_dp_lin_mv(
     ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
     const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
     const double* __restrict__ mshift, double* __restrict__ a_g, double* __restrict__ ga_g,
@@ -397,17 +400,18 @@ __global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
   const bool act = lane < L;
   const int lc = act ? lane : L - 1;
   const bool w0 = wave == 0;
-  const double sh0 = mshift[0];
+  const double sh0 = MPF ? 0.0 : mshift[0];
+  const size_t LL = (size_t)L * L;
   int err = 0;
   double gslot = 0.0;   // lane j: log-scale of the vector in ring slot j (every wavefront keeps the same copy)
   // this wavefront's rows c0 .. c0 + CQ - 1 of the transition matrix, column lc
   const int c0 = wave * CQ;
-  double er[CQ];
-  {
-    const double* Em = dir ? ET : E;
+  double er[CQ], er_n[CQ];
+  auto load_rows = [&](const double* Em, double (&e)[CQ]) {
 #pragma unroll
-    for (int i = 0; i < CQ; i++) er[i] = (c0 + i < L) ? Em[(size_t)(c0 + i) * L + lc] : 0.0;
-  }
+    for (int i = 0; i < CQ; i++) e[i] = (c0 + i < L) ? Em[(size_t)(c0 + i) * L + lc] : 0.0;
+  };
+  if (!MPF) load_rows(dir ? ET : E, er);
   // sum over all rows of v[c] * Em[c][lc]: this wavefront's share, then the four shares in wavefront order
   auto matvec = [&](const double v) {
     abuf[lane] = v;
@@ -458,6 +462,8 @@ __global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
     };
     double es_n[NDW], smx_n;
     load_windows(1, es_n, smx_n);
+    double sh_n = sh0;
+    if (MPF && T > 1) { load_rows(E + (f_base + 1) * LL, er_n); sh_n = mshift[f_base + 1]; }
     for (int t = 1; t < T; t++) {
       rpos = (rpos + 1 == D) ? 0 : rpos + 1;  // ring slot of node t-1
       const int np = (int)scrf_num_prev(t, D), nd = (int)scrf_node_max_dur(t, D);
@@ -465,11 +471,20 @@ __global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
 #pragma unroll
       for (int i = 0; i < NDW; i++) es[i] = es_n[i];
       load_windows(t + 1, es_n, smx_n);   // the next step's rows: a step of latency cover
+      double sh = sh0;
+      if (MPF) {   // node t's matrix (requested a step ago), then node t+1's
+#pragma unroll
+        for (int i = 0; i < CQ; i++) er[i] = er_n[i];
+        sh = sh_n;
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+        load_rows(E + (f_base + tn) * LL, er_n);
+        sh_n = mshift[f_base + tn];
+      }
       // transition out of node t-1: p = 2^-k * (a . E)
       const double usum = matvec(a);
       const int k = hi_exp(wave_max_hi(act ? usum : 0.0), &err);
       const double p = ldexp(usum, -k);
-      const double gp = ga + sh0 + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      const double gp = ga + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
       if (w0) {
         ring[rpos * L + lc] = p;   // read by the others from the next step on (two barriers away)
         if (act) __builtin_nontemporal_store(p, &pu[(size_t)(t - 1) * L + lane]);
@@ -565,6 +580,8 @@ __global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
     };
     double es_n[NDW], smx_n;
     load_windows(T - 2, es_n, smx_n);
+    double sh_n = sh0;
+    if (MPF) { load_rows(ET + (f_base + T - 1) * LL, er_n); sh_n = mshift[f_base + T - 1]; }
     for (int t = T - 2; t >= 0; t--) {
       const int nn = (T - 1 - t <= D) ? T - 1 - t : D;
       tpos = (tpos == 0) ? D - 1 : tpos - 1;  // ring slot of node t
@@ -572,6 +589,14 @@ __global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
 #pragma unroll
       for (int i = 0; i < NDW; i++) es[i] = es_n[i];
       load_windows(t - 1, es_n, smx_n);
+      double sh = sh0;
+      if (MPF) {   // node t+1's matrix (requested a step ago), then node t's
+#pragma unroll
+        for (int i = 0; i < CQ; i++) er[i] = er_n[i];
+        sh = sh_n;
+        load_rows(ET + (f_base + t) * LL, er_n);
+        sh_n = mshift[f_base + t];
+      }
       int myslot = tpos + lane + 1;  // node t + d0 + 1
       if (myslot >= D) myslot -= D;
       const double gnext = shfl_f64(gslot, (lane < nn) ? myslot : 0);
@@ -594,7 +619,7 @@ __global__ __launch_bounds__(64 * DPV_NW, 4) void k_dp_lin_mv(
       const double wsum = matvec(sd);
       const int k = hi_exp(wave_max_hi(act ? wsum : 0.0), &err);
       const double b = ldexp(wsum, -k);
-      const double gb = G + sh0 + fma((double)k, LN2_HI, (double)k * LN2_LO);
+      const double gb = G + sh + fma((double)k, LN2_HI, (double)k * LN2_LO);
       if (lane == tpos) gslot = gb;
       if (w0) {
         ring[tpos * L + lc] = b;
@@ -819,6 +844,16 @@ void launch_exp_rows(hipStream_t st, double* S, uint64_t n_rows, uint32_t L, dou
   hipLaunchKernelGGL(k_exp_rows, dim3((uint32_t)((n_rows + 15) / 16)), dim3(256), 0, st, S, n_rows, L, smax);
 }
 
+static int dp_cu_count() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
 void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const double* ES, const double* smax, const double* E, const double* ET, const double* mshift,
                    int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
@@ -830,22 +865,31 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
     return;
   }
   // opt-in (SCRF_DPLIN_MV=1): parity-green, but measured no faster than one wavefront per sweep -- see the kernel's header
-  static const bool use_mv = getenv("SCRF_DPLIN_MV") && atoi(getenv("SCRF_DPLIN_MV")) != 0;
-  if (use_mv && !m_per_frame && lay.D >= 2) {
+  // k_dp_lin_mv (four wavefronts per sweep): SCRF_DPLIN_MV=1 always, =0 never; unset: with per-frame transition matrices
+  // when the launch has at most SCRF_DPLIN_MV_SWEEPS (default 3: the kernel's occupancy) sweeps per CU -- there the
+  // single-wavefront kernel's step is the latency of one wavefront fetching an L x L matrix, and four fetch it in
+  // parallel (config 3, 256 utterances: 1.86 -> 1.03 ms).  With time-invariant transitions it measured no faster at any
+  // batch size (64 .. 4096 utterances), so it stays opt-in there.
+  static const int mv_mode = getenv("SCRF_DPLIN_MV") ? (atoi(getenv("SCRF_DPLIN_MV")) != 0 ? 1 : 0) : -1;
+  static const int mv_sweeps = getenv("SCRF_DPLIN_MV_SWEEPS") ? atoi(getenv("SCRF_DPLIN_MV_SWEEPS")) : 3;
+  const bool use_mv = mv_mode == 1 || (mv_mode < 0 && m_per_frame && 2 * (uint64_t)n_utts <= (uint64_t)mv_sweeps * dp_cu_count());
+  if (use_mv && lay.D >= 2) {
     // several wavefronts per sweep (k_dp_lin_mv): one workgroup of 4 per (utterance, direction)
     const size_t smv = sizeof(double) * ((((size_t)lay.D * lay.L + 1) & ~(size_t)1) + 4 * DPV_NW * 64);
-#define DV_LAUNCH(DM)                                                                                             \
-  do {                                                                                                            \
-    hipFuncSetAttribute((const void*)k_dp_lin_mv<DM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smv);      \
-    hipLaunchKernelGGL((k_dp_lin_mv<DM>), dim3(2 * n_utts), dim3(64 * DPV_NW), smv, st, lay, bv, u0, n_utts, ES,  \
-                       smax, E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);            \
+#define DV_LAUNCH2(DM, MPF)                                                                                            \
+  do {                                                                                                                 \
+    hipFuncSetAttribute((const void*)k_dp_lin_mv<DM, MPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smv);      \
+    hipLaunchKernelGGL((k_dp_lin_mv<DM, MPF>), dim3(2 * n_utts), dim3(64 * DPV_NW), smv, st, lay, bv, u0, n_utts, ES,  \
+                       smax, E, ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);                 \
   } while (0)
+#define DV_LAUNCH(DM) do { if (m_per_frame) DV_LAUNCH2(DM, 1); else DV_LAUNCH2(DM, 0); } while (0)
     if (lay.D <= 10) DV_LAUNCH(10);
     else if (lay.D <= 16) DV_LAUNCH(16);
     else if (lay.D <= 25) DV_LAUNCH(25);
     else if (lay.D <= 32) DV_LAUNCH(32);
     else DV_LAUNCH(40);
 #undef DV_LAUNCH
+#undef DV_LAUNCH2
     return;
   }
   uint32_t wpb = dp_waves_per_block(sizeof(double) * (m_per_frame ? 0 : (size_t)lay.L * lay.L), sizeof(double) * ((size_t)lay.D * lay.L + 128));
@@ -854,12 +898,7 @@ void launch_dp_lin(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint
     // and a step costs a fixed latency plus a share per resident wavefront (measured on MI355X at config 2:
     // 3.4 us + 0.31 us per wavefront).  8192 sweeps on 256 CUs: 12 wavefronts per workgroup are
     // 2.67 -> 3 rounds of 7.1 us steps, 11 are 2.91 -> 3 rounds of 6.8 us steps.
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-    }
+    const int n_cu = dp_cu_count();
     uint32_t best = wpb;
     double best_cost = 1e300;
     for (uint32_t w = wpb; w >= 8; w--) {

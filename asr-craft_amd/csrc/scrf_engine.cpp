@@ -1332,8 +1332,10 @@ static int run_dp(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, ChunkBu
       if (cb.fused) {
         // posterior pass and the per-frame sums of R in one walk (R is not read back for Z)
         if (l.L > 64) HIPCHK(h, hipMemsetAsync(cb.mass_s, 0, sizeof(double) * nfr, cb.st));   // summed over the 64-output groups
+        uint32_t t_max = 0;   // the longest utterance of the chunk: a launch of few utterances splits each into segments
+        for (uint64_t u = u0; u < u1; u++) t_max = std::max(t_max, b->T[u]);
         KT_RUN("k_post_z", cb.st, launch_post_z(cb.st, l, bv, u0, (uint32_t)nutt, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S, cb.smax,
-                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z, cb.mass_s, cb.la ? 1 : 0));
+                      cb.dl, b->d_zx, cb.numer_f, b->d_status, cb.Z, cb.mass_s, cb.la ? 1 : 0, t_max, nfr));
         cb.z_ready = true;
       } else {
         KT_RUN("k_post_lin", cb.st, launch_post_lin(cb.st, l, bv, b->d_frame_u, u0, nfr, b->d_next_lab, cb.s_true, cb.M, cb.m_per_frame, cb.S,

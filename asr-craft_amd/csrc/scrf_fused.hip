@@ -930,6 +930,28 @@ struct LzWin {
     for (int j = 1; j <= MO; j++)
       if (T - j >= 0) __builtin_nontemporal_store(v[j], &Zk[(size_t)(T - j) * zstride]);
   }
+  // The same for a walk over the frame range of ONE SEGMENT of the utterance (k_post_z's split form): frames lo <= f < hi
+  // get windows from this segment only and are stored; the others are shared with the neighbouring segment and added
+  // into the zeroed array (two contributions at most: the sum does not depend on their order).
+  __device__ __forceinline__ void retire_seg(double* Zk, int t, size_t zstride, int lo, int hi) {
+    if (t >= MO) {
+      const int f = t - MO;
+      if (f >= lo && f < hi) __builtin_nontemporal_store(v[MO], &Zk[(size_t)f * zstride]);
+      else unsafeAtomicAdd(&Zk[(size_t)f * zstride], v[MO]);
+    }
+#pragma unroll
+    for (int j = MO; j >= 1; j--) v[j] = v[j - 1];
+    v[0] = 0.0;
+  }
+  __device__ __forceinline__ void flush_seg(double* Zk, int fb, size_t zstride, int lo, int hi) {
+#pragma unroll
+    for (int j = 1; j <= MO; j++) {
+      const int f = fb - j;
+      if (f < 0) continue;
+      if (f >= lo && f < hi) __builtin_nontemporal_store(v[j], &Zk[(size_t)f * zstride]);
+      else unsafeAtomicAdd(&Zk[(size_t)f * zstride], v[j]);
+    }
+  }
 };
 
 template <int DMAX>
@@ -1210,7 +1232,11 @@ void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F
 // D - 1 frames back, so the open sums of the last D frames sit in an LDS ring (the register file is full of the five
 // sample windows): at frame t the suffix sums u_j = sum_{d > j} R(t, d) / d are added to the slots of frames t - j, and
 // frame t - D + 1 retires.  RW = lanes of the rings that exist (48 when L <= 48: 8 wavefronts per CU keep their LDS).
-template <int DMAX, int LA, int RW>
+// SPLIT: gridDim.z wavefronts per (utterance, 64 outputs), each walking `seg_len` frames (>= 2 D): a launch of few
+// utterances is a handful of wavefronts whose frame step is bare load latency (BASELINE config 3, 256 utterances: one
+// wavefront per CU, 4 us per frame).  A segment warms its ring of alpha-plus-trans vectors from the stored ones; the
+// per-frame sums of frames near a segment boundary get windows from both sides and are ADDED into the zeroed Z (LzWin).
+template <int DMAX, int LA, int RW, int SPLIT>
 __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView bv, uint32_t u0,
                                                   const uint32_t* __restrict__ next_lab,
                                                   const double* __restrict__ s_true, const double* __restrict__ M,
@@ -1218,7 +1244,7 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
                                                   const double* __restrict__ smax, ScrfDpLin o_,
                                                   const double* __restrict__ zx, double* __restrict__ numer_f,
                                                   int* __restrict__ status, double* __restrict__ Z,
-                                                  double* __restrict__ mass_s) {
+                                                  double* __restrict__ mass_s, int seg_len) {
   __shared__ double pring[DMAX * RW];
   __shared__ double zring[LA ? DMAX * RW : 1];
   __shared__ double fsb[DMAX < 64 ? DMAX : 64];
@@ -1246,9 +1272,18 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
     for (int j = 0; j < DMAX; j++) if (rw_ok) zring[j * RW + lane] = 0.0;
   }
   int err = 0;
-  int slot = 0;   // ring slot that will receive p[t] (= t mod D)
+  const int fa = SPLIT ? (int)blockIdx.z * seg_len : 0;           // this wavefront's frames: fa .. fb - 1
+  if (SPLIT && fa >= T) return;
+  const int fb = SPLIT ? (fa + seg_len < T ? fa + seg_len : T) : T;
+  // frames whose sums this segment owns alone: from fa on, and (unless it is the last one) D frames short of its end
+  const int own_lo = fa, own_hi = (fb == T) ? 0x7fffffff : fb - (int)D + 1;
+  int slot = SPLIT ? fa % (int)D : 0;   // ring slot that will receive p[t] (= t mod D)
+  if (SPLIT && fa > 0) {
+    for (int j = 1; j <= (int)D && j <= fa; j++)
+      if (rw_ok) pring[((fa - j) % (int)D) * RW + lane] = o_.p[(f_base + fa - j) * L + oc];
+  }
 #pragma unroll 1
-  for (int t = 0; t < T; t++) {
+  for (int t = fa; t < fb; t++) {
     const uint32_t nd = scrf_node_max_dur((uint32_t)t, D), np = scrf_num_prev((uint32_t)t, D);
     const uint64_t row0 = scrf_seg_base((uint32_t)t, D);
     double r[DMAX];
@@ -1309,11 +1344,22 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
       // frame t - D + 1 has seen its last window
       int zf = slot + 1 == (int)D ? 0 : slot + 1;
       const double zv = zring[zf * RW + rl];
-      if (act && t + 1 >= (int)D) __builtin_nontemporal_store(zv, &Zu[(size_t)(t + 1 - (int)D) * zs + 5 * (size_t)L]);
+      if (act && t + 1 >= (int)D) {
+        const int f = t + 1 - (int)D;
+        double* q = &Zu[(size_t)f * zs + 5 * (size_t)L];
+        if (!SPLIT || (f >= own_lo && f < own_hi)) __builtin_nontemporal_store(zv, q);
+        else unsafeAtomicAdd(q, zv);
+      }
       if (rw_ok) zring[zf * RW + lane] = 0.0;
     }
     w0.add(r); w1.add(r); w2.add(r); w3.add(r); w4.add(r);
-    if (act) {
+    if (act && SPLIT) {
+      w0.retire_seg(Zu, t, zs, own_lo, own_hi);
+      w1.retire_seg(Zu + L, t, zs, own_lo, own_hi);
+      w2.retire_seg(Zu + 2 * (size_t)L, t, zs, own_lo, own_hi);
+      w3.retire_seg(Zu + 3 * (size_t)L, t, zs, own_lo, own_hi);
+      w4.retire_seg(Zu + 4 * (size_t)L, t, zs, own_lo, own_hi);
+    } else if (act) {
       w0.retire(Zu, t, zs);
       w1.retire(Zu + L, t, zs);
       w2.retire(Zu + 2 * (size_t)L, t, zs);
@@ -1341,7 +1387,22 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
       numer_f[f_base + t] = nodeLi;
     }
   }
-  if (act) {
+  if (act && SPLIT) {
+    w0.flush_seg(Zu, fb, zs, own_lo, own_hi);
+    w1.flush_seg(Zu + L, fb, zs, own_lo, own_hi);
+    w2.flush_seg(Zu + 2 * (size_t)L, fb, zs, own_lo, own_hi);
+    w3.flush_seg(Zu + 3 * (size_t)L, fb, zs, own_lo, own_hi);
+    w4.flush_seg(Zu + 4 * (size_t)L, fb, zs, own_lo, own_hi);
+    if (LA) {
+      for (int j = 1; j < (int)D && j <= fb; j++) {
+        const int f = fb - j;
+        double* q = &Zu[(size_t)f * zs + 5 * (size_t)L];
+        const double zv = zring[(f % (int)D) * RW + rl];
+        if (f >= own_lo && f < own_hi) *q = zv;
+        else unsafeAtomicAdd(q, zv);
+      }
+    }
+  } else if (act) {
     w0.flush(Zu, T, zs);
     w1.flush(Zu + L, T, zs);
     w2.flush(Zu + 2 * (size_t)L, T, zs);
@@ -1361,10 +1422,31 @@ __global__ __launch_bounds__(64, 2) void k_post_z(ScrfLayout lay, ScrfBatchView 
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
                    const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,
-                   double* mass_s, int la) {
+                   double* mass_s, int la, uint32_t t_max, uint64_t n_frames) {
   if (n_utts == 0) return;
   dim3 grid(n_utts, (lay.L + 63) / 64);
-#define PZ_GO3(N, A, R) hipLaunchKernelGGL((k_post_z<N, A, R>), grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z, mass_s)
+  // few wavefronts (a small minibatch): several segments per utterance, about four wavefronts per CU in all (half the
+  // kernel's occupancy), no segment shorter than 2 D frames (SCRF_POSTZ_SPLIT=0: never).  Config 3, 256 utterances:
+  // 1.21 -> 0.50 ms; config 2's shape at 64 utterances: 1.90 -> 0.38 ms
+  static const bool split_ok = !(getenv("SCRF_POSTZ_SPLIT") && atoi(getenv("SCRF_POSTZ_SPLIT")) == 0);
+  int seg_len = 0;
+  uint32_t nz = 1;
+  const uint64_t waves = (uint64_t)grid.x * grid.y;
+  if (split_ok && waves <= 2 * 256 && t_max >= 4 * lay.D) {
+    const uint32_t want = (uint32_t)((4 * 256 + waves - 1) / waves);
+    seg_len = (int)((t_max + want - 1) / want);
+    if (seg_len < (int)(2 * lay.D)) seg_len = (int)(2 * lay.D);
+    nz = (uint32_t)((t_max + seg_len - 1) / seg_len);
+  }
+  if (nz > 1) {
+    grid.z = nz;
+    hipMemsetAsync(Z, 0, sizeof(double) * n_frames * (size_t)(la ? 6 : 5) * lay.L, st);
+  }
+#define PZ_GO3(N, A, R)                                                                                                           \
+  do {                                                                                                                            \
+    if (nz > 1) hipLaunchKernelGGL((k_post_z<N, A, R, 1>), grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z, mass_s, seg_len); \
+    else hipLaunchKernelGGL((k_post_z<N, A, R, 0>), grid, dim3(64), 0, st, lay, bv, u0, next_lab, s_true, M, m_per_frame, ES, smax, o, zx, numer_f, status, Z, mass_s, 0); \
+  } while (0)
 #define PZ_GO(N)                                              \
   do {                                                        \
     if (la && lay.L <= 48) PZ_GO3(N, 1, 48);                  \

@@ -159,7 +159,7 @@ void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
                    const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,
-                   double* mass_s, int la = 0);
+                   double* mass_s, int la = 0, uint32_t t_max = 0, uint64_t n_frames = 0);
 void launch_expf_fused(hipStream_t st, const ScrfFusedArgs& fa, const ScrfLayout& lay, const double* R,
                        uint64_t n_tiles, double* slab, double* dslab, int f32, int la);
 

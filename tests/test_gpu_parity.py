@@ -604,6 +604,34 @@ def test_several_wavefronts_per_sweep_kernel_through_the_same_sweep():
     assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") == 30
 
 
+@pytest.mark.parametrize("prec,split", [("1", "1"), ("3", "1"), ("3", "0")])
+def test_posterior_walk_in_segments_and_in_one_piece(prec, split):
+    """A launch of few utterances walks each utterance's posterior pass in several segments (k_post_z<., ., ., 1>: rings
+    warmed from the stored vectors, boundary frames' sums added from both sides); large batches walk it in one piece.
+    Both forms through 24 random shapes with a 260-frame utterance appended, FAST and FASTLIN, against the
+    materialised-window kernels and the oracle (SCRF_POSTZ_SPLIT=0 forces the one-piece form, SCRF_DPLIN_MV=0 the
+    one-wavefront recursion)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SWEEP_PREC=prec, SWEEP_LONG="1")
+    if split == "0":
+        env.update(SCRF_POSTZ_SPLIT="0", SCRF_DPLIN_MV="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fused_shape_sweep.py"), "24", "11"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") == 24
+
+
+def test_one_wavefront_per_sweep_kernel_with_per_frame_matrices_at_small_batches():
+    """With per-frame transition matrices the launcher takes k_dp_lin_mv<., 1> for launches of few sweeps -- every
+    stdtrans case of this suite.  SCRF_DPLIN_MV=0 forces the single-wavefront k_dp_lin<., 1, .> (what large batches run)
+    through the same 30 random cases."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRF_DPLIN_MV="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "general_shape_sweep.py"), "30", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("L,D,W", [(64, 25, 3), (64, 32, 2), (3, 5, 1)])
 def test_regressions_found_by_the_shape_sweep(L, D, W, monkeypatch):
     """L = 64, D >= 17: twelve wavefronts' rings do not fit the LDS (the launch used to fail);

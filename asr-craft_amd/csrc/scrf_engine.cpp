@@ -138,6 +138,11 @@ struct scrf_engine_s {
   double decode_bound_factor = 1.0;   // SCRF_DECODE_BOUND_SCALE (tests widen the screen with it)
   double* d_w1 = nullptr;
   uint64_t n_decode_fix = 0, n_decode_fallback = 0;   // entries recomputed / chunks sent back to the EXACT path
+  // result buffers of scrf_viterbi_batch, kept across calls (a hipMalloc / hipFree pair per call is a device-wide
+  // synchronisation each) and their pinned host images (the labels come back in one asynchronous copy)
+  uint32_t *dec_lab = nullptr, *dec_n = nullptr, *dec_hlab = nullptr, *dec_hn = nullptr;
+  float *dec_cost = nullptr, *dec_hcost = nullptr;
+  uint64_t dec_cap_f = 0, dec_cap_u = 0;
   std::string err;
   // per-kernel HIP-event times of the last timed call (scrf_kernel_timing)
   struct KTime { std::string name; double ms; uint32_t n; };
@@ -389,6 +394,10 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
+  hipFree(h->dec_lab); hipFree(h->dec_n); hipFree(h->dec_cost);
+  if (h->dec_hlab) hipHostFree(h->dec_hlab);
+  if (h->dec_hn) hipHostFree(h->dec_hn);
+  if (h->dec_hcost) hipHostFree(h->dec_hcost);
   hipFree(h->d_w1); hipFree(h->d_dtab); hipFree(h->d_rtab); hipFree(h->d_pack); hipFree(h->d_sl_tab); hipFree(h->d_m0); hipFree(h->d_e0); hipFree(h->d_et0); hipFree(h->d_msh0); hipFree(h->d_sums); hipFree(h->scratch);
   if (h->ev_ok)
     for (int i = 0; i <= SCRF_N_PHASES; i++) { hipEventDestroy(h->ev[i][0]); hipEventDestroy(h->ev[i][1]); }
@@ -2246,16 +2255,27 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
   const bool frame_model = h->cfg.model_type == SCRF_STDFRAME;
   if (h->timing) { memset(h->ms, 0, sizeof(h->ms)); memset(h->nlaunch, 0, sizeof(h->nlaunch)); h->ktimes.clear(); hipEventRecord(h->ev[SCRF_N_PHASES][0], h->stream); }
   const uint64_t NF = b->frame_off[b->U];
-  uint32_t *d_lab = nullptr, *d_n = nullptr;
-  float* d_cost = nullptr;
-  struct Release {   // the result buffers go away on every exit path, error returns included
-    uint32_t **a, **b;
-    float** c;
-    ~Release() { hipFree(*a); hipFree(*b); hipFree(*c); }
-  } release{&d_lab, &d_n, &d_cost};
-  HIPCHK(h, hipMalloc((void**)&d_lab, sizeof(uint32_t) * NF));
-  HIPCHK(h, hipMalloc((void**)&d_n, sizeof(uint32_t) * b->U));
-  HIPCHK(h, hipMalloc((void**)&d_cost, sizeof(float) * b->U));
+  if (NF > h->dec_cap_f) {
+    hipFree(h->dec_lab); h->dec_lab = nullptr;
+    if (h->dec_hlab) hipHostFree(h->dec_hlab);
+    h->dec_hlab = nullptr; h->dec_cap_f = 0;
+    HIPCHK(h, hipMalloc((void**)&h->dec_lab, sizeof(uint32_t) * NF));
+    HIPCHK(h, hipHostMalloc((void**)&h->dec_hlab, sizeof(uint32_t) * NF, hipHostMallocDefault));
+    h->dec_cap_f = NF;
+  }
+  if (b->U > h->dec_cap_u) {
+    hipFree(h->dec_n); hipFree(h->dec_cost); h->dec_n = nullptr; h->dec_cost = nullptr;
+    if (h->dec_hn) hipHostFree(h->dec_hn);
+    if (h->dec_hcost) hipHostFree(h->dec_hcost);
+    h->dec_hn = nullptr; h->dec_hcost = nullptr; h->dec_cap_u = 0;
+    HIPCHK(h, hipMalloc((void**)&h->dec_n, sizeof(uint32_t) * b->U));
+    HIPCHK(h, hipMalloc((void**)&h->dec_cost, sizeof(float) * b->U));
+    HIPCHK(h, hipHostMalloc((void**)&h->dec_hn, sizeof(uint32_t) * b->U, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&h->dec_hcost, sizeof(float) * b->U, hipHostMallocDefault));
+    h->dec_cap_u = b->U;
+  }
+  uint32_t *d_lab = h->dec_lab, *d_n = h->dec_n;
+  float* d_cost = h->dec_cost;
   Need nd{false, false, false, true};
   // fast decode: the fused score kernel writes the float arc weights and lists the entries whose
   // rounding it cannot guarantee; those are recomputed in reference order.  A chunk whose list
@@ -2357,14 +2377,14 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
       u0 = u1;
     } while (fast && u0 < u_end && rc == SCRF_OK);
   }
-  std::vector<uint32_t> lab, cnt(b->U);
+  const uint32_t *lab = h->dec_hlab, *cnt = h->dec_hn;
   if (rc == SCRF_OK) {
-    lab.resize(NF);
-    hipError_t e = hipMemcpyAsync(lab.data(), d_lab, sizeof(uint32_t) * NF, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_n, sizeof(uint32_t) * b->U, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess && best_cost) e = hipMemcpyAsync(best_cost, d_cost, sizeof(float) * b->U, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipMemcpyAsync(h->dec_hlab, d_lab, sizeof(uint32_t) * NF, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->dec_hn, d_n, sizeof(uint32_t) * b->U, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && best_cost) e = hipMemcpyAsync(h->dec_hcost, d_cost, sizeof(float) * b->U, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) rc = fail(h, SCRF_ERR_HIP, "scrf_viterbi_batch: %s", hipGetErrorString(e));
+    else if (best_cost) memcpy(best_cost, h->dec_hcost, sizeof(float) * b->U);
   }
   if (rc != SCRF_OK) return rc;
   if (h->timing) {

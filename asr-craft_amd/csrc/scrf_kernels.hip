@@ -841,26 +841,48 @@ void launch_state_l1(hipStream_t st, const double* lambda, const ScrfLayout& lay
 // frames with k_windows' arithmetic -- lanes over the raw column: float running sum from the LAST
 // frame backwards / length, running max / min, sampled frames; one-hot duration -- into LDS in
 // feature order.  The contraction keeps the reference's order with unfused multiply and add
-// (k_scores_exact): the products of 64 consecutive features are formed in parallel (each is
-// rounded on its own, so that is the same number), then added one after the other in feature
-// order through readlane; bias last.  The arc weight is float(-1 * score).
+// (k_scores_exact): the products are formed in parallel (each is rounded on its own, so that is the
+// same number) and parked in LDS, then added one after the other in feature order -- every lane
+// runs the same chain over broadcast reads, which the compiler requests ahead of the adds; bias
+// last.  The arc weight is float(-1 * score).
+// Round 4: the utterance of a row is found by a 64-way search (each lane probes one offset, two
+// rounds for 4096 utterances) instead of twelve dependent loads, and the chain reads its terms
+// from LDS instead of two v_readlane per term: 1.26 -> see DESIGN 4.5 (212 k entries per 4096
+// utterances of config 2).
 #define FX_WAVES 4
 #define FX_MAXF 1024
+__device__ __forceinline__ uint32_t find_utt_wave(const uint64_t* __restrict__ off, uint32_t u0, uint32_t u1, uint64_t x,
+                                                  uint32_t lane) {
+  // largest u in [u0, u1) with off[u] <= x (off[u0] <= x < off[u1]); every lane gets the answer
+  uint32_t lo = u0, n = u1 - u0;
+  while (n > 1) {
+    const uint32_t step = (n + 63) / 64;            // probes lo + i * step, i = 0 .. 63
+    const uint32_t pu = lo + lane * step;
+    const bool le = pu < lo + n && off[pu] <= x;
+    const unsigned long long m = __ballot(le);      // a prefix of ones (off is non-decreasing), bit 0 set
+    const uint32_t i = (uint32_t)__popcll(m) - 1;
+    const uint32_t nlo = lo + i * step;
+    const uint32_t nn = min(step, lo + n - nlo);
+    lo = nlo;
+    n = nn;
+  }
+  return lo;
+}
 __global__ __launch_bounds__(64 * FX_WAVES) void k_decode_fixup(const float* __restrict__ frames, uint32_t W, ScrfBatchView bv,
                                                                 uint32_t u0, uint32_t u1, const double* __restrict__ lambda,
                                                                 ScrfLayout lay, const uint32_t* __restrict__ cnt,
                                                                 const uint64_t* __restrict__ list, uint32_t cap,
                                                                 float* __restrict__ wneg) {
-  __shared__ float xs_all[FX_WAVES][FX_MAXF];
+  __shared__ double pr_all[FX_WAVES][FX_MAXF];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* xs = xs_all[wave];
+  double* pr = pr_all[wave];
   const uint32_t n = min(*cnt, cap), D = lay.D, L = lay.L, F = 8 * W + D;
   const uint64_t tri = (uint64_t)D * (D + 1) / 2;
   for (uint32_t i = blockIdx.x * FX_WAVES + wave; i < n; i += gridDim.x * FX_WAVES) {
     const uint64_t row = list[i] >> 16;
     const uint32_t o = (uint32_t)(list[i] & 0xffff);
     const uint64_t arow = row + bv.seg_off[u0];
-    const uint32_t u = find_utt(bv.seg_off, u0, u1, arow);
+    const uint32_t u = find_utt_wave(bv.seg_off, u0, u1, arow, lane);
     const uint64_t r = arow - bv.seg_off[u];
     uint32_t t, d;
     if (r < tri) {
@@ -874,12 +896,13 @@ __global__ __launch_bounds__(64 * FX_WAVES) void k_decode_fixup(const float* __r
     const float* last = frames + (bv.frame_off[u] + t) * (uint64_t)W;
     const float* first = last - (uint64_t)(d - 1) * W;
     const float ot = (float)((double)d * 0.1);
+    const double* wp = lambda + lay.state_idx(o);
     for (uint32_t c = lane; c < W; c += 64) {
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const float prod = ot * (float)(2 * k + 1);
         const uint32_t step = (uint32_t)ceilf(prod) - 1u;
-        xs[k * W + c] = first[(uint64_t)step * W + c];
+        pr[k * W + c] = __dmul_rn((double)first[(uint64_t)step * W + c], wp[k * W + c]);
       }
       float acc = 0.0f, mx = last[c], mn = last[c];
       for (uint32_t w = 0; w < d; w++) {
@@ -888,31 +911,22 @@ __global__ __launch_bounds__(64 * FX_WAVES) void k_decode_fixup(const float* __r
         if (v > mx) mx = v;
         if (v < mn) mn = v;
       }
-      xs[5 * W + c] = __fdiv_rn(acc, (float)d);
-      xs[6 * W + c] = mx;
-      xs[7 * W + c] = mn;
+      pr[5 * W + c] = __dmul_rn((double)__fdiv_rn(acc, (float)d), wp[5 * W + c]);
+      pr[6 * W + c] = __dmul_rn((double)mx, wp[6 * W + c]);
+      pr[7 * W + c] = __dmul_rn((double)mn, wp[7 * W + c]);
     }
-    for (uint32_t k = lane; k < D; k += 64) xs[8 * W + k] = (k + 1 == d) ? 1.0f : 0.0f;
+    for (uint32_t k = lane; k < D; k += 64) pr[8 * W + k] = __dmul_rn((k + 1 == d) ? 1.0 : 0.0, wp[8 * W + k]);
     __builtin_amdgcn_wave_barrier();
-    const double* wp = lambda + lay.state_idx(o);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wavefront's own LDS stores have landed
     double s = 0.0;
-    for (uint32_t f0 = 0; f0 < F; f0 += 64) {
-      const uint32_t f = f0 + lane;
-      const double p = f < F ? __dmul_rn((double)xs[f], wp[f]) : 0.0;
-      const uint32_t m = min(64u, F - f0);
-      if (m == 64) {
-#pragma unroll
-        for (int j = 0; j < 64; j++) {
-          const double pj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), j), __builtin_amdgcn_readlane(__double2loint(p), j));
-          s = __dadd_rn(s, pj);
-        }
-      } else {
-        for (uint32_t j = 0; j < m; j++) {
-          const double pj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), j), __builtin_amdgcn_readlane(__double2loint(p), j));
-          s = __dadd_rn(s, pj);
-        }
-      }
+    uint32_t f = 0;
+    for (; f + 8 <= F; f += 8) {
+      const double2 a = *(const double2*)(pr + f), b = *(const double2*)(pr + f + 2);
+      const double2 c2 = *(const double2*)(pr + f + 4), e = *(const double2*)(pr + f + 6);
+      s = __dadd_rn(s, a.x); s = __dadd_rn(s, a.y); s = __dadd_rn(s, b.x); s = __dadd_rn(s, b.y);
+      s = __dadd_rn(s, c2.x); s = __dadd_rn(s, c2.y); s = __dadd_rn(s, e.x); s = __dadd_rn(s, e.y);
     }
+    for (; f < F; f++) s = __dadd_rn(s, pr[f]);
     if (lay.use_sb) s = __dadd_rn(s, __dmul_rn(wp[lay.nsfe], lay.sbv));
     if (lane == 0) wneg[row * L + o] = (float)(-1 * s);
     __builtin_amdgcn_wave_barrier();

@@ -873,10 +873,10 @@ __global__ __launch_bounds__(64 * FX_WAVES) void k_decode_fixup(const float* __r
                                                                 ScrfLayout lay, const uint32_t* __restrict__ cnt,
                                                                 const uint64_t* __restrict__ list, uint32_t cap,
                                                                 float* __restrict__ wneg) {
-  __shared__ double pr_all[FX_WAVES][FX_MAXF];
+  extern __shared__ double pr_all[];   // [FX_WAVES][F rounded up to 2]: sized by the launch, so that narrow streams keep 8 workgroups per CU
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* pr = pr_all[wave];
   const uint32_t n = min(*cnt, cap), D = lay.D, L = lay.L, F = 8 * W + D;
+  double* pr = pr_all + (size_t)wave * ((F + 1) & ~1u);
   const uint64_t tri = (uint64_t)D * (D + 1) / 2;
   for (uint32_t i = blockIdx.x * FX_WAVES + wave; i < n; i += gridDim.x * FX_WAVES) {
     const uint64_t row = list[i] >> 16;
@@ -937,8 +937,9 @@ void launch_decode_fixup(hipStream_t st, const float* frames, uint32_t W, ScrfBa
                          uint32_t cap, float* wneg) {
   if (cap == 0) return;
   const uint32_t blocks = std::min<uint32_t>((cap + FX_WAVES - 1) / FX_WAVES, 4096);
-  hipLaunchKernelGGL(k_decode_fixup, dim3(blocks), dim3(64 * FX_WAVES), 0, st, frames, W, bv, u0, u1, lambda, lay, cnt,
-                     list, cap, wneg);
+  const uint32_t F = 8 * W + lay.D;   // <= FX_MAXF (fused_supported)
+  hipLaunchKernelGGL(k_decode_fixup, dim3(blocks), dim3(64 * FX_WAVES), sizeof(double) * FX_WAVES * ((F + 1) & ~1u), st, frames, W, bv, u0, u1,
+                     lambda, lay, cnt, list, cap, wneg);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -134,6 +134,8 @@ struct scrf_engine_s {
   bool force_fb = false;
   // decode from the fused score kernel's float arc weights + reference-order fix-ups (bit-identical
   // to the EXACT path by a rounding-error bound, ScrfDecodeOut); SCRF_FAST_DECODE=0 turns it off
+  bool hybrid = true;   // SCRF_HYBRID=0: the general path contracts all 8 W + D columns of X
+  bool hybrid_first = false;   // SCRF_HYBRID=2 (A/B runs): L > 64 takes the hybrid path even where the fused kernels fit
   bool fast_decode = true;
   double decode_bound_factor = 1.0;   // SCRF_DECODE_BOUND_SCALE (tests widen the screen with it)
   double* d_w1 = nullptr;
@@ -183,6 +185,7 @@ struct scrf_batch_s {
   int* d_status = nullptr;
   // fused window synthesis: row tiles of the score kernel [0] and of the expected-count kernel [1]
   bool fused_ok = false;
+  bool hybrid_ok = false;   // one segment-recipe stream the fused kernels do not take (L > 64): sampled blocks through P / Z, dense statistics materialised
   bool mixed = false;   // fused state part (stream 0) + materialised transition-feature streams (config 3's shape)
   std::vector<uint64_t> tile_off[3];   // 0: score tiles, 1: expected-count tiles (<= 76 rows), 2: <= 100 rows (FASTLIN)
   ScrfTileDesc* d_tiles[3] = {nullptr, nullptr, nullptr};
@@ -317,6 +320,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_COMM_OVERLAP")) h->comm_overlap_on = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_HYBRID")) { h->hybrid = atoi(e) != 0; h->hybrid_first = atoi(e) == 2; }
   if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = std::max(1.0, atof(e));   // widening only: < 1 would void the bound
   memset(h->ms, 0, sizeof(h->ms));
   memset(h->nlaunch, 0, sizeof(h->nlaunch));
@@ -718,12 +722,20 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   // fused window synthesis: one segment-recipe stream without context whose window is exactly
   // the state feature range, no transition features
   const int f32_cfg = h->cfg.train_precision == SCRF_PREC_FAST32;
-  const bool seg_stream0 = !by_windows && n_streams >= 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && lay.use_sf &&
+  const bool hybrid_first = h->hybrid_first && lay.L > 64 && n_streams == 1 && !lay.use_tf;
+  const bool seg_stream0 = !hybrid_first && !by_windows && n_streams >= 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && lay.use_sf &&
                            recipes[0].extract_seg_ftr && !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 &&
                            lay.nsfe == 8 * recipes[0].in_width + lay.D && fused_supported(lay, recipes[0].in_width, f32_cfg);
   // "mixed" (round 4, BASELINE config 3's shape): the state features are exactly stream 0's segment-recipe window and the
   // transition features live in the other streams' columns -- the state part takes the fused kernels, the transition
   // part keeps the materialised first-row windows and the dense contractions
+  // "hybrid" (round 4, BASELINE config 5's shape): the same stream structure where the fused kernels' LDS images do not
+  // fit (L > 64).  The window vectors stay materialised, but the five sampled blocks -- 5 W of the 8 W + D columns, copies
+  // of raw frames -- leave the two dense contractions: scores get their share from the per-frame projections P (k_add_p),
+  // counts through the per-frame sums Z (k_lin_z, Z^T F), exactly as on the fused path.
+  b->hybrid_ok = !by_windows && n_streams == 1 && h->cfg.model_type != SCRF_STDSEG_NO_DUR && h->cfg.model_type != SCRF_STDSEG && lay.use_sf &&
+                 !lay.use_tf && recipes[0].extract_seg_ftr && !recipes[0].left_ctx && !recipes[0].right_ctx && lay.sfs == 0 && lay.D >= 2 &&
+                 lay.nsfe == 8 * recipes[0].in_width + lay.D && (hybrid_first || !fused_supported(lay, recipes[0].in_width, f32_cfg));
   const bool mixed_ok = seg_stream0 && n_streams >= 2 && lay.use_tf && lay.tfs >= lay.nsfe && h->fuse_mixed;
   if ((seg_stream0 && n_streams == 1 && !lay.use_tf && lay.nsfe == lay.F) || mixed_ok) {
     b->fused_ok = true;
@@ -909,12 +921,13 @@ struct ChunkBufs {
   double* slab_l = nullptr;
   uint32_t nch_l = 0;
   uint64_t rpc_l = 0;
+  bool hybrid = false;       // materialised X, but the sampled blocks through P / Z (scrf_batch::hybrid_ok)
   bool la = false;           // SCRF_PREC_FASTLIN: linear window average (6 groups in P / Z, no avg group in the dense parts)
   double* slab_d = nullptr;  // duration + bias counts of the wave-specialised count kernel (behind slab_s)
   int expf_tiles = 1;        // tile list the fused count kernel walks
 };
 
-struct Need { bool fb, post, beta, vit; bool fused = false; bool vitfast = false; bool la = false; };
+struct Need { bool fb, post, beta, vit; bool fused = false; bool vitfast = false; bool la = false; bool hybrid = false; };
 
 // entries the decode screen may list per chunk before the chunk falls back to the EXACT path
 static uint32_t decode_fix_cap(uint64_t nseg, uint32_t L) {
@@ -939,6 +952,13 @@ static ScrfGemmSpec spec_samples(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0
 static ScrfGemmSpec spec_dense(const ScrfLayout& l, uint32_t W) {
   return ScrfGemmSpec{0, 0, 3 * W + l.D, (uint32_t)l.use_sb, l.sbv, 5 * W, 0};
 }
+static ScrfGemmSpec spec_stats_x(const ScrfLayout& l, uint32_t W) {   // [avg | max | min] of a materialised window vector
+  return ScrfGemmSpec{0, l.sfs + 5 * W, 3 * W, 0, 0.0, 5 * W, 0};
+}
+// the same column groups read from a materialised window vector (hybrid path): X columns 5 W .. 8 W + D - 1
+static ScrfGemmSpec spec_dense_x(const ScrfLayout& l, uint32_t W) {
+  return ScrfGemmSpec{0, l.sfs + 5 * W, 3 * W + l.D, (uint32_t)l.use_sb, l.sbv, 5 * W, 0};
+}
 
 static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t nfr, uint64_t nseg, const Need& nd) {
   const ScrfLayout& l = h->lay;
@@ -951,6 +971,8 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
     if (nd.post) tot += pad256((size_t)512 * ng * l.L * W0 * sizeof(double));
     if (b->mixed) tot += pad256(nseg * l.F * sizeof(float));     // the transition streams' windows
   } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
+  if (nd.hybrid) tot += pad256(nfr * 5 * l.L * sizeof(double)) + pad256((size_t)512 * 5 * l.L * W0 * sizeof(double)) +   // P / Z, slab_l
+                        pad256((size_t)(nutt + 1024) * l.L * (l.D + 1) * sizeof(double));                                 // per-duration sums
   if (nd.vitfast) tot += pad256(nseg * l.L * sizeof(float)) + pad256((size_t)decode_fix_cap(nseg, l.L) * 8) + 256;  // Wn, list, count
   else tot += pad256(nseg * l.L * sizeof(double));                  // S
   if (segtrans(h)) tot += pad256(nseg * LL * sizeof(double));               // M2: one matrix per window
@@ -1034,6 +1056,15 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
     }
   } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
+  if (nd.hybrid) {
+    cb->hybrid = true;
+    cb->P = a.take<double>(nfr * 5 * l.L);
+    cb->Z = cb->P;  // the projections are dead once they are added to the scores
+    cb->rpc_l = ((nfr + 511) / 512 + 31) & ~31ull;
+    cb->nch_l = (uint32_t)((nfr + cb->rpc_l - 1) / cb->rpc_l);
+    cb->slab_l = a.take<double>((size_t)512 * 5 * l.L * b->recipe[0].in_width);
+    cb->slab_d = a.take<double>((size_t)(nutt + 1024) * l.L * (l.D + 1));
+  }
   cb->fused = nd.fused;
   if (nd.vitfast) {
     cb->Wn = a.take<float>(nseg * l.L);
@@ -1261,14 +1292,28 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
       // precision materialise every row.
       const bool first_only = fast && l.use_tf && !segtrans(h) && l.D > 1 && (col > l.sfe || col + b->width[s] <= l.sfs);
       KT_RUN("k_windows", cb.st, launch_windows(cb.st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
-                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col, first_only ? 1 : 0));
+                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col, (first_only ? 1 : 0) | (cb.hybrid ? 2 : 0)));
       col += b->width[s];
     }
     tm.stop(b->n_streams);
   }
   PhaseTimer tm(h, PH_SCORE, cb.st);
   uint32_t nl = 1;
-  if (!cb.fused) {
+  if (!cb.fused && cb.hybrid) {
+    // dense statistics [avg | max | min | onehot(d)] + bias from X (3 W + D of its 8 W + D columns), the five sampled blocks
+    // as per-frame projections added by row
+    const uint32_t W0 = b->recipe[0].in_width;
+    if (pframe_supported(W0)) KT_RUN("k_pframe", cb.st, launch_pframe(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, h->d_lambda, l, 5 * l.L, cb.P));
+    else KT_RUN("k_scores_mfma(samples)", cb.st, launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
+                                                                     spec_samples(W0), 5 * l.L, cb.P, f32));
+    PhaseTimer tk(h, PH_K_SCORE, cb.st);
+    KT_RUN("k_scores_mfma(state)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, spec_dense_x(l, W0), l.L, cb.S, f32));
+    // + the labelled windows' scores, the row maxima and exp(S - smax) for the linear-domain recursion (cb.lin)
+    KT_RUN("k_add_p_exp", cb.st, launch_add_p_exp(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.P, cb.S, cb.smax, cb.s_true));
+    cb.es_ready = true;
+    tk.stop(2);
+    nl += 2;
+  } else if (!cb.fused) {
     PhaseTimer tk(h, PH_K_SCORE, cb.st);
     if (fast) KT_RUN("k_scores_mfma(state)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, scrf_spec_state(l), l.L, cb.S, f32));
     else KT_RUN("k_scores_exact(state)", cb.st, launch_scores_exact(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, 0, l.L, cb.S));
@@ -1723,6 +1768,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
   nd.fused = fast && b->fused_ok && h->fuse_windows;
   // the linear window average needs the fused kernels, the linear-domain recursion (k_post_z builds Z_avg) and a
   // shape its kernels take; anything else runs as FAST
+  nd.hybrid = fast && !nd.fused && b->hybrid_ok && h->hybrid && h->fuse_windows && h->lin_dp && !h->force_fb && wave_path(h, true) && !f32;
   nd.la = nd.fused && h->cfg.train_precision == SCRF_PREC_FASTLIN && h->lin_dp && !h->force_fb && wave_path(h, true) &&
           fused_la_supported(l, b->recipe[0].in_width);
 
@@ -1841,6 +1887,24 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
           KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, (cb.la ? 6 : 5) * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
                            spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l));
         nl += 2;
+      } else if (cb.hybrid) {
+        const uint32_t W0 = b->recipe[0].in_width;
+        {
+          PhaseTimer tk(h, PH_K_EXPF, cb.st);
+          // [avg | max | min] only: the one-hot duration and bias counts are sums of R (k_lin_z5), and 3 W columns are one
+          // 384-column tile of the count kernel where 3 W + D + 1 were two
+          KT_RUN("k_expf_mfma(state)", cb.st, launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, spec_stats_x(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s, f32));
+          tk.stop(1);
+        }
+        uint32_t t_max = 0;
+        for (uint64_t u = u0; u < u1; u++) t_max = std::max(t_max, b->T[u]);
+        KT_RUN("k_lin_z5", cb.st, launch_lin_z5(cb.st, l, bv, u0, (uint32_t)nutt, t_max, nfr, cb.R, cb.Z, cb.slab_d));
+        if (pframe_supported(W0))
+          KT_RUN("k_ztf", cb.st, launch_ztf(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nfr, cb.rpc_l, cb.nch_l, cb.slab_l));
+        else
+          KT_RUN("k_expf_mfma(samples)", cb.st, launch_expf_mfma(cb.st, cb.Z, 5 * l.L, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, l,
+                           spec_samples(W0), cb.rpc_l, cb.nch_l, cb.slab_l));
+        nl += 2;
       } else {
         PhaseTimer tk(h, PH_K_EXPF, cb.st);
         if (fast) KT_RUN("k_expf_mfma(state)", cb.st, launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, scrf_spec_state(l), cb.rpc_s, cb.nch_s, cb.slab_s, f32));
@@ -1872,6 +1936,15 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
           launch_reduce_slabs(cb.st, cb.slab_d, cb.nch_s, l.L, l, ScrfGemmSpec{0, 0, l.D, (uint32_t)l.use_sb, l.sbv, 8 * W0, 0}, cb.grad);
         } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_dense(l, W0), cb.grad);
         if (!side) launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, (cb.la ? 6 : 5) * l.L, l, spec_samples(W0), cb.grad);
+      } else if (cb.hybrid) {
+        const uint32_t W0 = b->recipe[0].in_width;
+        uint32_t t_max = 0;
+        for (uint64_t u = u0; u < u1; u++) t_max = std::max(t_max, b->T[u]);
+        int seg_len = 0;
+        const uint32_t nblk_d = (uint32_t)nutt * lin_z5_segments((uint32_t)nutt, l.L, l.D, t_max, &seg_len);
+        launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, spec_stats_x(l, W0), cb.grad);
+        launch_reduce_slabs(cb.st, cb.slab_d, nblk_d, l.L, l, ScrfGemmSpec{0, 0, l.D, (uint32_t)l.use_sb, l.sbv, 8 * W0, 0}, cb.grad);
+        launch_reduce_slabs(cb.st, cb.slab_l, cb.nch_l, 5 * l.L, l, spec_samples(W0), cb.grad);
       } else launch_reduce_slabs(cb.st, cb.slab_s, cb.nch_s, l.L, l, scrf_spec_state(l), cb.grad);
       if (side) HIPCHK(h, hipStreamWaitEvent(cb.st, h->ev_join, 0));   // the side stream's weights are in
       else if (trans_done) {}
@@ -2406,6 +2479,9 @@ extern "C" int scrf_viterbi_batch(scrf_handle h, scrf_batch b, uint32_t* seg_lab
 extern "C" int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused) {
   if (!h || !b || !fused) return SCRF_ERR_INVALID;
   *fused = b->fused_ok && h->fuse_windows ? 1 : 0;
+  // 3: hybrid (materialised dense statistics, sampled blocks through the per-frame projections)
+  if (!*fused && b->hybrid_ok && h->hybrid && h->fuse_windows && h->cfg.train_precision >= SCRF_PREC_FAST && h->cfg.train_precision != SCRF_PREC_FAST32 &&
+      h->lin_dp && wave_path(h, true)) *fused = 3;
   // 2: training runs with the linear window average (SCRF_PREC_FASTLIN on a shape its kernels take)
   if (*fused && h->cfg.train_precision == SCRF_PREC_FASTLIN && h->lin_dp && wave_path(h, true) &&
       fused_la_supported(h->lay, b->recipe[0].in_width)) *fused = 2;

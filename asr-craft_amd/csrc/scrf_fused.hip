@@ -917,6 +917,12 @@ struct LzWin {
     ((v[std::integral_constant<int, fu_off_c(D0 + 1, K)>::value] += r[D0]), ...);
   }
   __device__ __forceinline__ void add(const double (&r)[DMAX]) { add_seq(r, std::make_integer_sequence<int, DMAX>{}); }
+  // the same from an LDS image of the frame's rows, rows[d0 * 64 + lane] (k_lin_z5)
+  template <int... D0>
+  __device__ __forceinline__ void add_lds_seq(const double* rows, std::integer_sequence<int, D0...>) {
+    ((v[std::integral_constant<int, fu_off_c(D0 + 1, K)>::value] += rows[D0 * 64]), ...);
+  }
+  __device__ __forceinline__ void add_lds(const double* rows) { add_lds_seq(rows, std::make_integer_sequence<int, DMAX>{}); }
   // after frame t: frame t - MO is final; slide by one frame
   __device__ __forceinline__ void retire(double* Zk, int t, size_t zstride) {
     if (t >= MO) __builtin_nontemporal_store(v[MO], &Zk[(size_t)(t - MO) * zstride]);
@@ -996,6 +1002,193 @@ __global__ __launch_bounds__(64, 2) void k_lin_z(ScrfLayout lay, ScrfBatchView b
   w2.flush(Zu + 2 * (size_t)L, T, zs);
   w3.flush(Zu + 3 * (size_t)L, T, zs);
   w4.flush(Zu + 4 * (size_t)L, T, zs);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lin_z5 (hybrid path, any D up to 40 and any L): the per-frame sums Z_k[f] of R for the five sample positions AND the
+// per-duration sums of R (the counts of the one-hot duration columns and of the bias) in one walk over R.  k_lin_z keeps
+// the five sliding windows of a wavefront in registers -- 2 x 5 x ~D/2 of them, which spills at D = 40 (46.8 ms at
+// BASELINE config 5).  Here a workgroup of six wavefronts owns (utterance, 64 outputs, frame segment): the frame's rows are
+// staged once in LDS (double buffered, loads a frame ahead), wavefront k < 5 slides sample position k's window, wavefront
+// 5 adds the rows into per-duration registers.  Frame segments as in k_post_z's split form (boundary frames added from
+// both sides into the zeroed Z).  dslab[(utterance, segment)][o][D + bias] is reduced like the fused count kernel's.
+// ------------------------------------------------------------------------------------------
+// One role's frame loop (K < 5: sample position K's window; K = 5: the per-duration sums).  Every role runs the same loop
+// with the same two barriers per frame and its share of the staging; the roles are separate functions so that a
+// wavefront's registers hold ITS window only (one loop with six branches keeps all of them live: 300 registers, spills).
+template <int K, int DMAX>
+__device__ __forceinline__ void lz5_role(double* rows, const double* __restrict__ Ru, double* __restrict__ Zk, double* __restrict__ dout,
+                                         const ScrfLayout& lay, int T, int fa, int fb, uint32_t ocols, uint32_t o, bool act, int lane) {
+  const uint32_t D = lay.D, L = lay.L;
+  const size_t zs = (size_t)5 * L;
+  const int own_lo = fa, own_hi = (fb == T) ? 0x7fffffff : fb - (int)D + 1;
+  // staging: thread -> elements e = tid + 384 j of the frame's [DMAX][64] image (row e / 64, output e % 64)
+  constexpr int NE = (DMAX * 64 + 383) / 384;
+  auto fetch = [&](int t, double (&x)[NE]) {
+    const uint32_t nd = t < T ? scrf_node_max_dur((uint32_t)t, D) : 0;
+    const double* Rt = Ru + scrf_seg_base((uint32_t)(t < T ? t : 0), D) * (uint64_t)L;
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+      const uint32_t e = threadIdx.x + 384 * j, d0 = e >> 6, c = e & 63;
+      x[j] = (d0 < nd && c < ocols) ? __builtin_nontemporal_load(&Rt[(uint64_t)d0 * L + c]) : 0.0;
+    }
+  };
+  auto stash = [&](int buf, const double (&x)[NE]) {
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+      const uint32_t e = threadIdx.x + 384 * j;
+      if (e < (uint32_t)DMAX * 64) rows[buf * DMAX * 64 + e] = x[j];
+    }
+  };
+  double x[NE];
+  fetch(fa, x);
+  stash(0, x);
+  LzWin<(K < 5 ? K : 0), DMAX> w;
+  double cd[K == 5 ? DMAX : 1];
+  if (K < 5) w.clear();
+  else {
+#pragma unroll
+    for (int d0 = 0; d0 < (K == 5 ? DMAX : 1); d0++) cd[d0] = 0.0;
+  }
+  for (int t = fa; t < fb; t++) {
+    const int cur = (t - fa) & 1;
+    if (t + 1 < fb) fetch(t + 1, x);                       // in flight under this frame's adds
+    __syncthreads();                                       // frame t's image is complete
+    const double* img = rows + cur * DMAX * 64 + lane;
+    if (K < 5) {
+      w.add_lds(img);
+      w.retire_seg(Zk, act ? t : -1000000, zs, own_lo, own_hi);
+    } else {
+#pragma unroll
+      for (int d0 = 0; d0 < (K == 5 ? DMAX : 1); d0++) cd[d0] += img[d0 * 64];
+    }
+    if (t + 1 < fb) stash(cur ^ 1, x);                     // the other image: last read before the previous frame's second barrier
+    __syncthreads();
+  }
+  if (!act) return;
+  if (K < 5) w.flush_seg(Zk, fb, zs, own_lo, own_hi);
+  else {
+    const uint32_t nd1 = D + (lay.use_sb ? 1 : 0);
+    double bsum = 0.0;
+#pragma unroll
+    for (int d0 = 0; d0 < (K == 5 ? DMAX : 1); d0++) {
+      if ((uint32_t)d0 < D) { dout[(uint64_t)o * nd1 + d0] = cd[d0]; bsum += cd[d0]; }
+    }
+    if (lay.use_sb) dout[(uint64_t)o * nd1 + D] = bsum * lay.sbv;
+  }
+}
+template <int DMAX>
+__global__ __launch_bounds__(384) void k_lin_z5(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, const double* __restrict__ R,
+                                                double* __restrict__ Z, double* __restrict__ dslab, int seg_len) {
+  __shared__ double rows[2 * DMAX * 64];
+  const uint32_t D = lay.D, L = lay.L;
+  const uint32_t u = u0 + blockIdx.x;
+  const int T = (int)bv.T[u];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t o = blockIdx.y * 64 + lane;
+  const bool act = o < L;
+  const int fa = (int)blockIdx.z * seg_len;
+  const int fb = fa + seg_len < T ? fa + seg_len : T;
+  const uint32_t nd1 = D + (lay.use_sb ? 1 : 0);
+  double* dout = dslab + ((uint64_t)blockIdx.x * gridDim.z + blockIdx.z) * L * nd1;
+  if (fa >= T) {   // an empty segment still owns its slab block
+    if (wave == 5 && act) for (uint32_t j = 0; j < nd1; j++) dout[(uint64_t)o * nd1 + j] = 0.0;
+    return;
+  }
+  const double* Ru = R + (bv.seg_off[u] - bv.seg_off[u0]) * (uint64_t)L + blockIdx.y * 64;
+  double* Zu = Z + (bv.frame_off[u] - bv.frame_off[u0]) * (uint64_t)(5 * L) + o;
+  const uint32_t ocols = L - blockIdx.y * 64 < 64 ? L - blockIdx.y * 64 : 64;
+  if (wave == 0) lz5_role<0, DMAX>(rows, Ru, Zu, dout, lay, T, fa, fb, ocols, o, act, lane);
+  else if (wave == 1) lz5_role<1, DMAX>(rows, Ru, Zu + L, dout, lay, T, fa, fb, ocols, o, act, lane);
+  else if (wave == 2) lz5_role<2, DMAX>(rows, Ru, Zu + 2 * (size_t)L, dout, lay, T, fa, fb, ocols, o, act, lane);
+  else if (wave == 3) lz5_role<3, DMAX>(rows, Ru, Zu + 3 * (size_t)L, dout, lay, T, fa, fb, ocols, o, act, lane);
+  else if (wave == 4) lz5_role<4, DMAX>(rows, Ru, Zu + 4 * (size_t)L, dout, lay, T, fa, fb, ocols, o, act, lane);
+  else lz5_role<5, DMAX>(rows, Ru, Zu, dout, lay, T, fa, fb, ocols, o, act, lane);
+}
+// frame segments per utterance so that the launch has about 1024 workgroups, none shorter than 2 D frames
+uint32_t lin_z5_segments(uint32_t n_utts, uint32_t L, uint32_t D, uint32_t t_max, int* seg_len) {
+  const uint64_t wgs = (uint64_t)n_utts * ((L + 63) / 64);
+  uint32_t want = wgs >= 1024 ? 1 : (uint32_t)((1024 + wgs - 1) / wgs);
+  int sl = (int)((t_max + want - 1) / (want ? want : 1));
+  if (sl < (int)(2 * D)) sl = (int)(2 * D);
+  if (sl < 1) sl = 1;
+  *seg_len = sl;
+  const uint32_t nz = (t_max + sl - 1) / sl;
+  return nz ? nz : 1;
+}
+void launch_lin_z5(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint32_t t_max, uint64_t n_frames,
+                   const double* R, double* Z, double* dslab) {
+  if (n_utts == 0) return;
+  int seg_len = 0;
+  const uint32_t nz = lin_z5_segments(n_utts, lay.L, lay.D, t_max, &seg_len);
+  if (nz > 1) hipMemsetAsync(Z, 0, sizeof(double) * n_frames * 5 * lay.L, st);
+  dim3 grid(n_utts, (lay.L + 63) / 64, nz);
+#define LZ5_GO(N) hipLaunchKernelGGL(k_lin_z5<N>, grid, dim3(384), 0, st, lay, bv, u0, R, Z, dslab, seg_len)
+  if (lay.D <= 8) LZ5_GO(8);
+  else if (lay.D <= 16) LZ5_GO(16);
+  else if (lay.D <= 25) LZ5_GO(25);
+  else if (lay.D <= 32) LZ5_GO(32);
+  else LZ5_GO(40);
+#undef LZ5_GO
+}
+
+// k_add_p_exp (hybrid path: materialised dense statistics, L <= 256): the sampled blocks' share of the scores,
+//   S[(t, d)][l] += sum_k P[t - d + 1 + s_k(d)][k][l],   s_k(d) = ceil(float(0.1 d) (2k + 1)) - 1
+// (io/CRF_InFtrStream_SeqMultiWindow.cpp:556-884), and in the same pass what k_true_scores and k_exp_rows do for the
+// linear-domain recursion: the labelled window's score, the row maximum, S -> exp(S - smax[row]).  One workgroup per
+// frame, one wavefront per window row (lanes over the labels, L / 64 values per lane); the P rows of neighbouring
+// frames overlap almost completely, so the gathers are L2 hits.
+__global__ __launch_bounds__(256) void k_add_p_exp(ScrfLayout lay, ScrfBatchView bv, const uint32_t* __restrict__ frame_u, uint32_t u0,
+                                                   const double* __restrict__ P, double* __restrict__ S, double* __restrict__ smax,
+                                                   double* __restrict__ s_true) {
+  const uint32_t L = lay.L, D = lay.D;
+  const uint64_t fi = blockIdx.x;
+  const uint64_t gf = bv.frame_off[u0] + fi;
+  const uint32_t u = frame_u[gf];
+  const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
+  const uint64_t fb = bv.frame_off[u] - bv.frame_off[u0];
+  const uint32_t nd = scrf_node_max_dur(t, D);
+  const uint64_t row0 = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lab = bv.labels ? bv.labels[gf] : SCRF_LAB_BAD;
+  uint32_t al = SCRF_LAB_BAD, ld = SCRF_LAB_BAD;
+  if (lab != SCRF_LAB_BAD && lab < L * D) { al = lab % L; ld = lab / L + 1; }
+  if (threadIdx.x == 0 && (ld == SCRF_LAB_BAD || ld > nd)) s_true[fi] = 0.0;
+  for (uint32_t d0 = wave; d0 < nd; d0 += 4) {
+    const float ot = (float)((double)(d0 + 1) * 0.1);
+    double* Sr = S + (row0 + d0) * L;
+    const double* Pb = P + (fb + t - d0) * (uint64_t)(5 * L);
+    uint32_t step[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) step[k] = (uint32_t)ceilf(ot * (float)(2 * k + 1)) - 1u;
+    double v[4];
+    double m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t l = lane + 64 * j;
+      v[j] = -INFINITY;
+      if (l < L) {
+        double acc = Sr[l];
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc += Pb[(uint64_t)step[k] * (5 * L) + (uint64_t)k * L + l];
+        v[j] = acc;
+        m = fmax(m, acc);
+        if (d0 + 1 == ld && l == al) s_true[fi] = acc;
+      }
+    }
+    m = wave_max_f64_dpp(m);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t l = lane + 64 * j;
+      if (l < L) Sr[l] = exp_nonpos(v[j] - m);
+    }
+    if (lane == 0) smax[row0 + d0] = m;
+  }
+}
+void launch_add_p_exp(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                      const double* P, double* S, double* smax, double* s_true) {
+  if (n_frames == 0) return;
+  hipLaunchKernelGGL(k_add_p_exp, dim3((uint32_t)n_frames), dim3(256), 0, st, lay, bv, frame_u, u0, P, S, smax, s_true);
 }
 
 void launch_lin_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
@@ -2077,6 +2270,10 @@ int fused_supported(const ScrfLayout& lay, uint32_t W, int f32) {
   // groups (measured 253.6 ms fused against 206.4 ms materialised per 128 utterances).  The z-blocked count kernel is for
   // one label group.
   if (!fused_expf_plain_fits(lay, W) && lay.L > 64) return 0;
+  // several label groups with the D = 40 forms (k_post_z<40> and the count kernel spill): the hybrid path is faster
+  // (L = 200, D = 40, W = 40, 128 x 1000 frames: 66.8 ms fused, 49.6 ms hybrid; at D <= 25 the fused kernels win: 38.5 vs
+  // 46.5 ms at L = 200, W = 39)
+  if (lay.L > 64 && lay.D > 32) return 0;
   return fused_scores_tb(W, lay.D) >= 1;
 }
 // SCRF_PREC_FASTLIN needs the wave-specialised count kernel (the only one without the avg group); other shapes run the

@@ -156,6 +156,11 @@ void launch_pframe(hipStream_t st, const float* F, uint32_t W, uint64_t n_frames
                    const ScrfLayout& lay, uint32_t n_out, double* P);
 void launch_ztf(hipStream_t st, const double* Zm, uint32_t n_out, const float* F, uint32_t W, uint64_t n_frames,
                 uint64_t rows_per_chunk, uint32_t n_chunks, double* slab, int narrow = 0);
+uint32_t lin_z5_segments(uint32_t n_utts, uint32_t L, uint32_t D, uint32_t t_max, int* seg_len);
+void launch_lin_z5(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, uint32_t t_max, uint64_t n_frames,
+                   const double* R, double* Z, double* dslab);
+void launch_add_p_exp(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0, uint64_t n_frames,
+                      const double* P, double* S, double* smax, double* s_true);
 void launch_post_z(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                    const uint32_t* next_lab, const double* s_true, const double* M, int m_per_frame, double* ES,
                    const double* smax, const ScrfDpLin& o, const double* zx, double* numer_f, int* status, double* Z,

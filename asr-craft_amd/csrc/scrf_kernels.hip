@@ -44,8 +44,10 @@ __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __re
   const uint64_t gf = bv.frame_off[u0] + blockIdx.x;
   const uint32_t u = find_utt(bv.frame_off, u0, u1, gf);
   const uint32_t t = (uint32_t)(gf - bv.frame_off[u]);
-  // first_only: the caller reads this stream's columns from the node's FIRST window row alone (per-frame transition features)
-  const uint32_t avail = first_only ? 1u : scrf_node_max_dur(t, D);
+  // first_only bit 0: the caller reads this stream's columns from the node's FIRST window row alone (per-frame transition
+  // features); bit 1: the five sampled blocks are not written (hybrid path: they go through the per-frame projections)
+  const bool samples = !(first_only & 2);
+  const uint32_t avail = (first_only & 1) ? 1u : scrf_node_max_dur(t, D);
   const uint64_t rowbase = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
   const float* last = frames + (sframe_off[u] + lctx + t) * (uint64_t)W;
   const bool segftr = (D != 1) && extract;
@@ -63,11 +65,13 @@ __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __re
         o[j] = first[j];
       } else {
         float ot = (float)((double)w * 0.1);
+        if (samples) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-          float prod = ot * (float)(2 * k + 1);
-          uint32_t step = (uint32_t)ceilf(prod) - 1u;
-          o[k * W + j] = first[(uint64_t)step * W + j];
+          for (int k = 0; k < 5; k++) {
+            float prod = ot * (float)(2 * k + 1);
+            uint32_t step = (uint32_t)ceilf(prod) - 1u;
+            o[k * W + j] = first[(uint64_t)step * W + j];
+          }
         }
         float v = first[j];
         acc_sum = __fadd_rn(acc_sum, v);

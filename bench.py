@@ -203,6 +203,12 @@ def other_config(eng_mod, name, device_id, scratch_gib, with_cpu=True):
     # flops the dense contraction kernels of the general path issue on the matrix pipe (2 per MAC)
     issued = {"k_scores_mfma(state)": 2.0 * nseg * Lc * (Fs + 1), "k_expf_mfma(state)": 2.0 * nseg * Lc * (Fs + 1),
               "k_scores_mfma(trans)": 2.0 * T * Lc * Lc * (Ft + 1), "k_expf_mfma(trans)": 2.0 * (T - 1) * Lc * Lc * (Ft + 1)}
+    path = eng.batch_fused_mode(b)
+    if path == 3:
+        # hybrid path: the five sampled blocks (5 W of the 8 W + D columns) leave the dense contractions (per-frame
+        # projections / per-frame sums); the count contraction also drops the one-hot duration and bias columns
+        issued["k_scores_mfma(state)"] = 2.0 * nseg * Lc * (3 * W + Dc + 1)
+        issued["k_expf_mfma(state)"] = 2.0 * nseg * Lc * (3 * W)
     dom_name, dom_ms, _ = kt[0]
     dom_flops = issued.get(dom_name)
     ent = {"name": name, "workload": "%d labels, D=%d, %d-dim x %d frames, %s, lambda_len %d, %d utterances per step"
@@ -212,6 +218,8 @@ def other_config(eng_mod, name, device_id, scratch_gib, with_cpu=True):
            "frac_algorithmic": round(f_alg * U / (ms * 1e-3) / (PEAK["mfma_f64_tflops"] * 1e12), 4),
            "dominant_kernel": {"name": dom_name, "ms": round(dom_ms, 3),
                                "frac_executed": round(dom_flops * U / (dom_ms * 1e-3) / (PEAK["mfma_f64_tflops"] * 1e12), 4) if dom_flops else None},
+           "path": {0: "general (materialised windows)", 1: "fused window synthesis", 2: "fused, linear window average",
+                    3: "hybrid (materialised dense statistics; sampled blocks through per-frame projections and sums)"}.get(path, str(path)),
            "kernels_ms": {nm: round(m_, 3) for nm, m_, _ in kt[:8]}}
     # HBM bytes per step of this shape from the separate rocprofv3 --pmc passes (tools/collect_profiles.sh)
     tr, why = measured_traffic(name)

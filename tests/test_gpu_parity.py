@@ -245,6 +245,40 @@ def test_fused_state_part_with_materialised_transition_streams(si, monkeypatch):
     assert np.abs(a - bb).max() <= 1e-10 * np.abs(bb).max()
 
 
+HYBRID_SHAPES = [   # (streams too wide for the fused kernels at these label counts: 3 W + D + 1 > 208 columns)
+    dict(L=65, D=5, in_w=70, Ts=[1, 2, 9, 30], lam_scale=0.05),      # two 64-output groups, utterances shorter than 2 D
+    dict(L=130, D=12, in_w=66, Ts=[27, 1, 260], lam_scale=0.05),     # a long utterance in a small launch: frame segments in k_lin_z5
+    dict(L=200, D=40, in_w=60, Ts=[45, 130], lam_scale=0.05),        # config 5's label space and maximum duration
+    dict(L=96, D=25, in_w=62, Ts=[60, 24], lam_scale=0.05),
+    dict(L=70, D=6, in_w=90, Ts=[20, 7], lam_scale=0.05),            # sampled blocks through the generic contractions (W > 80)
+    dict(L=66, D=4, in_w=69, Ts=[9, 14, 3, 1, 11, 8], scratch_bytes=1 << 18, lam_scale=0.05),   # several chunks
+]
+
+
+@pytest.mark.parametrize("si", range(len(HYBRID_SHAPES)))
+def test_hybrid_path_sampled_blocks_leave_the_dense_contractions(si, monkeypatch):
+    """BASELINE config 5's structure (round 4): one segment-recipe stream with more labels than the fused kernels' LDS
+    images take.  The window vectors stay materialised, but the five sampled blocks go through per-frame projections
+    (scores: k_add_p) and per-frame sums (counts: k_lin_z5 + Z^T F), the one-hot duration and bias counts are sums of R, and
+    the dense contractions keep [avg | max | min] only.  Against the oracle and against the general path (SCRF_HYBRID=0):
+    exact re-associations, FAST bounds."""
+    res = {}
+    for hy in ("1", "0"):
+        monkeypatch.setenv("SCRF_HYBRID", hy)
+        c = Case(seed=870 + si, precision=scrf_amd.PREC_FAST, **HYBRID_SHAPES[si])
+        eng = c.engine(); b = c.batch(eng)
+        assert eng.batch_fused_mode(b) == (3 if hy == "1" else 0)
+        numer, zx = eng.fb_batch(b)
+        g = eng.get_grad()
+        og, on, oz = c.oracle_gradient()
+        assert np.abs(numer - on).max() <= 1e-9 * max(1, np.abs(on).max())
+        assert np.abs(zx - oz).max() <= 1e-11 * np.abs(oz).max()
+        assert np.abs(g - og).max() / np.abs(og).max() <= 1e-9
+        res[hy] = g.copy()
+        b.close(); eng.close()
+    assert np.abs(res["1"] - res["0"]).max() <= 1e-10 * np.abs(res["0"]).max()
+
+
 FUSED_SHAPES = [
     dict(L=3, D=3, in_w=2, Ts=[1, 2, 3, 4, 7]),
     dict(L=50, D=5, in_w=45, Ts=[1, 13, 40, 77]),       # two output groups, two column chunks per group

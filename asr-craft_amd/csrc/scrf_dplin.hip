@@ -639,7 +639,11 @@ __global__ __launch_bounds__(64 * DPV_NW, MPF ? 2 : 4) void k_dp_lin_mv(
 // needs for the duration step is its own column of the ring, so that part needs no barrier.  The
 // transition matrix stays in memory (L2-resident): rows are read coalesced.
 // ------------------------------------------------------------------------------------------
-template <int DMAX, int MPF>
+// Round 4, LR > 0 (time-invariant transitions, L <= LR): the lane's column of the transition matrix lives in REGISTERS for
+// the whole sweep.  One workgroup per CU is one wavefront per SIMD, i.e. all 512 vector + accumulation registers: 208 rows
+// are 416 of them.  The transition step was 200 loads per lane and frame from L2, a few in flight at a time: 13 us per
+// frame at L = 200, of which the loads' round trips were ~10.
+template <int DMAX, int MPF, int LR>
 __global__ __launch_bounds__(256) void k_dp_lin_mw(
     ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
     const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
@@ -670,10 +674,28 @@ __global__ __launch_bounds__(256) void k_dp_lin_mw(
   const double sh0 = MPF ? 0.0 : mshift[0];
   double* cw = cbuf + wave * 64;
   int err = 0;
+  double er[LR > 0 ? LR : 1];
+  if (LR > 0) {
+    const double* Em = dir ? ET : E;
+#pragma unroll
+    for (int c = 0; c < LR; c++) er[c] = (c < L) ? Em[(size_t)(c < L ? c : 0) * L + lc] : 0.0;
+  }
 
   // sum_c v[c] * Em[c*L + lc], v exchanged through abuf (caller places the barriers)
   auto matvec = [&](const double* Em) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (LR > 0) {
+      // abuf holds zeros from L up to the workgroup's 64 * NW entries >= LR
+#pragma unroll
+      for (int c = 0; c < LR; c += 4) {
+        const double2 a01 = *(const double2*)(abuf + c), a23 = *(const double2*)(abuf + c + 2);
+        s0 = fma(a01.x, er[c], s0);
+        s1 = fma(a01.y, er[c + 1], s1);
+        s2 = fma(a23.x, er[c + 2], s2);
+        s3 = fma(a23.y, er[c + 3], s3);
+      }
+      return (s0 + s1) + (s2 + s3);
+    }
     int c = 0;
     for (; c + 4 <= L; c += 4) {
       const double2 a01 = *(const double2*)(abuf + c), a23 = *(const double2*)(abuf + c + 2);
@@ -822,15 +844,24 @@ static void launch_dp_lin_mw_t(hipStream_t st, const ScrfLayout& lay, ScrfBatchV
                                const double* mshift, int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
   const uint32_t nw = (lay.L + 63) / 64;
   const size_t sm = sizeof(double) * ((((size_t)lay.D * lay.L + 1) & ~(size_t)1) + 64 * nw + 64 + 64 * nw + 16);
-  if (m_per_frame) {
-    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, 1>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E,
-                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);
-  } else {
-    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, 0>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E,
-                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);
-  }
+#define MW_GO(MPF, LR)                                                                                                          \
+  do {                                                                                                                          \
+    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, MPF, LR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);          \
+    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, MPF, LR>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E, \
+                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);                                   \
+  } while (0)
+  // the matrix column in registers (SCRF_DPLIN_EREG=0: from L2 every frame, as before round 4)
+  static const bool ereg = !(getenv("SCRF_DPLIN_EREG") && atoi(getenv("SCRF_DPLIN_EREG")) == 0);
+  // Measured (ms per launch, from L2 -> in registers): L = 200, D = 25, 512 x 300 frames 17.6 -> 9.4 (LR = 208: 49 spilled
+  // registers, still a gain); L = 96, D = 25, 1024 utterances 10.2 -> 6.5; L = 128, D = 10: 5.4 -> 4.3.  At DMAX = 40 the
+  // duration step's 80 registers leave room for 128 rows only: L = 200 spills 141 registers and LOSES (13.7 -> 17.8), so
+  // that shape (BASELINE config 5) keeps the matrix in L2.
+  if (m_per_frame || !ereg) { if (m_per_frame) MW_GO(1, 0); else MW_GO(0, 0); }
+  else if (lay.L <= 128) MW_GO(0, 128);
+  else if (DMAX <= 25 && lay.L <= 192) MW_GO(0, 192);
+  else if (DMAX <= 25 && lay.L <= 208) MW_GO(0, 208);
+  else MW_GO(0, 0);
+#undef MW_GO
 }
 
 void launch_true_scores(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, const uint32_t* frame_u, uint32_t u0,

@@ -952,12 +952,15 @@ static ScrfGemmSpec spec_samples(uint32_t W) { return ScrfGemmSpec{2, 0, W, 0, 0
 static ScrfGemmSpec spec_dense(const ScrfLayout& l, uint32_t W) {
   return ScrfGemmSpec{0, 0, 3 * W + l.D, (uint32_t)l.use_sb, l.sbv, 5 * W, 0};
 }
-static ScrfGemmSpec spec_stats_x(const ScrfLayout& l, uint32_t W) {   // [avg | max | min] of a materialised window vector
-  return ScrfGemmSpec{0, l.sfs + 5 * W, 3 * W, 0, 0.0, 5 * W, 0};
+// hybrid path: the materialised row holds [avg | max | min | onehot(d)] only (k_windows without the sampled blocks), padded
+// to whole 16-byte groups
+static uint32_t hybrid_row_floats(const ScrfLayout& l, uint32_t W) { return (3 * W + l.D + 3) & ~3u; }
+static ScrfGemmSpec spec_stats_x(const ScrfLayout& l, uint32_t W) {   // [avg | max | min] of that row
+  (void)l;
+  return ScrfGemmSpec{0, 0, 3 * W, 0, 0.0, 5 * W, 0};
 }
-// the same column groups read from a materialised window vector (hybrid path): X columns 5 W .. 8 W + D - 1
-static ScrfGemmSpec spec_dense_x(const ScrfLayout& l, uint32_t W) {
-  return ScrfGemmSpec{0, l.sfs + 5 * W, 3 * W + l.D, (uint32_t)l.use_sb, l.sbv, 5 * W, 0};
+static ScrfGemmSpec spec_dense_x(const ScrfLayout& l, uint32_t W) {   // the whole row + bias
+  return ScrfGemmSpec{0, 0, 3 * W + l.D, (uint32_t)l.use_sb, l.sbv, 5 * W, 0};
 }
 
 static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t nfr, uint64_t nseg, const Need& nd) {
@@ -970,7 +973,7 @@ static size_t chunk_bytes(scrf_handle h, scrf_batch b, uint64_t nutt, uint64_t n
     tot += pad256(nfr * ng * l.L * sizeof(double));                // P (scores) / Z (counts)
     if (nd.post) tot += pad256((size_t)512 * ng * l.L * W0 * sizeof(double));
     if (b->mixed) tot += pad256(nseg * l.F * sizeof(float));     // the transition streams' windows
-  } else if (b->mode == 1) tot += pad256(nseg * l.F * sizeof(float));
+  } else if (b->mode == 1) tot += pad256(nseg * (nd.hybrid ? hybrid_row_floats(l, W0) : l.F) * sizeof(float));
   if (nd.hybrid) tot += pad256(nfr * 5 * l.L * sizeof(double)) + pad256((size_t)512 * 5 * l.L * W0 * sizeof(double)) +   // P / Z, slab_l
                         pad256((size_t)(nutt + 1024) * l.L * (l.D + 1) * sizeof(double));                                 // per-duration sums
   if (nd.vitfast) tot += pad256(nseg * l.L * sizeof(float)) + pad256((size_t)decode_fix_cap(nseg, l.L) * 8) + 256;  // Wn, list, count
@@ -1054,7 +1057,7 @@ static int carve(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, const Ne
       cb->nch_l = (uint32_t)((nfr + cb->rpc_l - 1) / cb->rpc_l);
       cb->slab_l = a.take<double>((size_t)512 * ng * l.L * W0);
     }
-  } else if (b->mode == 1) cb->X = a.take<float>(nseg * l.F);
+  } else if (b->mode == 1) cb->X = a.take<float>(nseg * (nd.hybrid ? hybrid_row_floats(l, b->recipe[0].in_width) : l.F));
   else cb->X = b->d_windows + b->seg_off[u0] * l.F;
   if (nd.hybrid) {
     cb->hybrid = true;
@@ -1292,7 +1295,8 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
       // precision materialise every row.
       const bool first_only = fast && l.use_tf && !segtrans(h) && l.D > 1 && (col > l.sfe || col + b->width[s] <= l.sfs);
       KT_RUN("k_windows", cb.st, launch_windows(cb.st, b->d_frames[s], b->d_sframe_off[s], bv, u0, u1, nfr, r.in_width, l.D, r.left_ctx,
-                     r.right_ctx, r.extract_seg_ftr, cb.X, l.F, col, (first_only ? 1 : 0) | (cb.hybrid ? 2 : 0)));
+                     r.right_ctx, r.extract_seg_ftr, cb.X, cb.hybrid ? hybrid_row_floats(l, r.in_width) : l.F, col,
+                     (first_only ? 1 : 0) | (cb.hybrid ? 2 : 0)));
       col += b->width[s];
     }
     tm.stop(b->n_streams);
@@ -1307,7 +1311,7 @@ static int run_scores(scrf_handle h, scrf_batch b, uint32_t u0, uint32_t u1, Chu
     else KT_RUN("k_scores_mfma(samples)", cb.st, launch_scores_mfma(cb.st, b->d_frames[0] + b->frame_off[u0] * W0, W0, nullptr, nfr, h->d_lambda, l,
                                                                      spec_samples(W0), 5 * l.L, cb.P, f32));
     PhaseTimer tk(h, PH_K_SCORE, cb.st);
-    KT_RUN("k_scores_mfma(state)", cb.st, launch_scores_mfma(cb.st, cb.X, l.F, nullptr, nseg, h->d_lambda, l, spec_dense_x(l, W0), l.L, cb.S, f32));
+    KT_RUN("k_scores_mfma(state)", cb.st, launch_scores_mfma(cb.st, cb.X, hybrid_row_floats(l, W0), nullptr, nseg, h->d_lambda, l, spec_dense_x(l, W0), l.L, cb.S, f32));
     // + the labelled windows' scores, the row maxima and exp(S - smax) for the linear-domain recursion (cb.lin)
     KT_RUN("k_add_p_exp", cb.st, launch_add_p_exp(cb.st, l, bv, b->d_frame_u, u0, nfr, cb.P, cb.S, cb.smax, cb.s_true));
     cb.es_ready = true;
@@ -1893,7 +1897,7 @@ static int fb_run(scrf_handle h, scrf_batch b, int latch[2], bool* used_lin) {
           PhaseTimer tk(h, PH_K_EXPF, cb.st);
           // [avg | max | min] only: the one-hot duration and bias counts are sums of R (k_lin_z5), and 3 W columns are one
           // 384-column tile of the count kernel where 3 W + D + 1 were two
-          KT_RUN("k_expf_mfma(state)", cb.st, launch_expf_mfma(cb.st, cb.R, l.L, cb.X, l.F, nullptr, nseg, l, spec_stats_x(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s, f32));
+          KT_RUN("k_expf_mfma(state)", cb.st, launch_expf_mfma(cb.st, cb.R, l.L, cb.X, hybrid_row_floats(l, W0), nullptr, nseg, l, spec_stats_x(l, W0), cb.rpc_s, cb.nch_s, cb.slab_s, f32));
           tk.stop(1);
         }
         uint32_t t_max = 0;

@@ -47,6 +47,7 @@ __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __re
   // first_only bit 0: the caller reads this stream's columns from the node's FIRST window row alone (per-frame transition
   // features); bit 1: the five sampled blocks are not written (hybrid path: they go through the per-frame projections)
   const bool samples = !(first_only & 2);
+  const uint32_t sh = samples ? 0u : 5u * W;   // without the sampled blocks the row is compact: [avg | max | min | onehot], stride F
   const uint32_t avail = (first_only & 1) ? 1u : scrf_node_max_dur(t, D);
   const uint64_t rowbase = (bv.seg_off[u] - bv.seg_off[u0]) + scrf_seg_base(t, D);
   const float* last = frames + (sframe_off[u] + lctx + t) * (uint64_t)W;
@@ -75,11 +76,11 @@ __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __re
         }
         float v = first[j];
         acc_sum = __fadd_rn(acc_sum, v);
-        o[5 * W + j] = __fdiv_rn(acc_sum, (float)w);
+        o[5 * W + j - sh] = __fdiv_rn(acc_sum, (float)w);
         if (v > acc_max) acc_max = v;
-        o[6 * W + j] = acc_max;
+        o[6 * W + j - sh] = acc_max;
         if (v < acc_min) acc_min = v;
-        o[7 * W + j] = acc_min;
+        o[7 * W + j - sh] = acc_min;
       }
       o += body;
       const float* rb = extract ? last : first;
@@ -87,9 +88,11 @@ __global__ void k_windows(const float* __restrict__ frames, const uint64_t* __re
     }
   }
   if (segftr) {
-    for (uint32_t idx = threadIdx.x; idx < avail * D; idx += blockDim.x) {
-      uint32_t w = idx / D + 1, k = idx % D;
-      X[(rowbase + w - 1) * (uint64_t)F + out_col + lctx * W + 8 * W + k] = (k + 1 == w) ? 1.0f : 0.0f;
+    // compact rows (no sampled blocks): the one-hot block runs to the end of the row, so that the pad floats are zeros
+    const uint32_t Dp = samples ? D : F - 3 * W;
+    for (uint32_t idx = threadIdx.x; idx < avail * Dp; idx += blockDim.x) {
+      uint32_t w = idx / Dp + 1, k = idx % Dp;
+      X[(rowbase + w - 1) * (uint64_t)F + out_col + lctx * W + 8 * W - sh + k] = (k + 1 == w) ? 1.0f : 0.0f;
     }
   }
 }

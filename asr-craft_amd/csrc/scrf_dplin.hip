@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * DPV_NW, MPF ? 2 : 4) void k_dp_lin_mv(
 // the whole sweep.  One workgroup per CU is one wavefront per SIMD, i.e. all 512 vector + accumulation registers: 208 rows
 // are 416 of them.  The transition step was 200 loads per lane and frame from L2, a few in flight at a time: 13 us per
 // frame at L = 200, of which the loads' round trips were ~10.
-template <int DMAX, int MPF, int LR>
+template <int DMAX, int MPF, int LR, int TAIL>
 __global__ __launch_bounds__(256) void k_dp_lin_mw(
     ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts, const double* __restrict__ ES,
     const double* __restrict__ smax, const double* __restrict__ E, const double* __restrict__ ET,
@@ -693,6 +693,25 @@ __global__ __launch_bounds__(256) void k_dp_lin_mw(
         s1 = fma(a01.y, er[c + 1], s1);
         s2 = fma(a23.x, er[c + 2], s2);
         s3 = fma(a23.y, er[c + 3], s3);
+      }
+      // rows past the register part (D = 40: the duration step's registers leave room for 128 rows) from memory, eight
+      // loads in flight at a time
+      if (TAIL) {
+        // (the row addresses do not depend on the frame: left alone, the compiler computes all of them ahead of the frame
+        // loop and keeps them in registers -- 350 spilled ones; the empty asm makes the base pointer a per-frame value)
+        const double* Et = Em + lc;
+        asm volatile("" : "+v"(Et));
+#pragma unroll 1
+        for (int c = LR; c < L; c += 8) {
+          double e[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) e[i] = (c + i < L) ? Et[(size_t)(c + i < L ? c + i : 0) * L] : 0.0;
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) {
+            s0 = fma(abuf[c + i], e[i], s0);
+            s1 = fma(abuf[c + i + 1], e[i + 1], s1);
+          }
+        }
       }
       return (s0 + s1) + (s2 + s3);
     }
@@ -844,23 +863,25 @@ static void launch_dp_lin_mw_t(hipStream_t st, const ScrfLayout& lay, ScrfBatchV
                                const double* mshift, int m_per_frame, const ScrfDpLin& o, double* zx, int* status) {
   const uint32_t nw = (lay.L + 63) / 64;
   const size_t sm = sizeof(double) * ((((size_t)lay.D * lay.L + 1) & ~(size_t)1) + 64 * nw + 64 + 64 * nw + 16);
-#define MW_GO(MPF, LR)                                                                                                          \
-  do {                                                                                                                          \
-    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, MPF, LR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);          \
-    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, MPF, LR>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E, \
-                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);                                   \
+#define MW_GO(MPF, LR, TAIL)                                                                                                          \
+  do {                                                                                                                                \
+    hipFuncSetAttribute((const void*)k_dp_lin_mw<DMAX, MPF, LR, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);          \
+    hipLaunchKernelGGL((k_dp_lin_mw<DMAX, MPF, LR, TAIL>), dim3(2 * n_utts), dim3(64 * nw), sm, st, lay, bv, u0, n_utts, ES, smax, E, \
+                       ET, mshift, o.a, o.ga, o.p, o.gp, o.b, o.gb, o.sd, o.gsd, zx, status);                                         \
   } while (0)
   // the matrix column in registers (SCRF_DPLIN_EREG=0: from L2 every frame, as before round 4)
   static const bool ereg = !(getenv("SCRF_DPLIN_EREG") && atoi(getenv("SCRF_DPLIN_EREG")) == 0);
   // Measured (ms per launch, from L2 -> in registers): L = 200, D = 25, 512 x 300 frames 17.6 -> 9.4 (LR = 208: 49 spilled
   // registers, still a gain); L = 96, D = 25, 1024 utterances 10.2 -> 6.5; L = 128, D = 10: 5.4 -> 4.3.  At DMAX = 40 the
-  // duration step's 80 registers leave room for 128 rows only: L = 200 spills 141 registers and LOSES (13.7 -> 17.8), so
-  // that shape (BASELINE config 5) keeps the matrix in L2.
-  if (m_per_frame || !ereg) { if (m_per_frame) MW_GO(1, 0); else MW_GO(0, 0); }
-  else if (lay.L <= 128) MW_GO(0, 128);
-  else if (DMAX <= 25 && lay.L <= 192) MW_GO(0, 192);
-  else if (DMAX <= 25 && lay.L <= 208) MW_GO(0, 208);
-  else MW_GO(0, 0);
+  // duration step's 80 registers leave room for 128 rows only (L = 200 in full spills 141 registers and LOSES: 13.7 ->
+  // 17.8): there 128 rows live in registers and the rest comes from L2 (TAIL).
+  static const bool tail_on = !(getenv("SCRF_DPLIN_TAIL") && atoi(getenv("SCRF_DPLIN_TAIL")) == 0);
+  if (m_per_frame || !ereg) { if (m_per_frame) MW_GO(1, 0, 0); else MW_GO(0, 0, 0); }
+  else if (lay.L <= 128) MW_GO(0, 128, 0);
+  else if (DMAX <= 25 && lay.L <= 192) MW_GO(0, 192, 0);
+  else if (DMAX <= 25 && lay.L <= 208) MW_GO(0, 208, 0);
+  else if (DMAX > 25 && tail_on) MW_GO(0, 128, 1);
+  else MW_GO(0, 0, 0);
 #undef MW_GO
 }
 

@@ -10,7 +10,9 @@ bad = 0
 for name, kw, scratch in [
         ("many-short", dict(L=48, D=10, in_w=13, Ts=[int(t) for t in rng.randint(1, 60, 3000)], seed=1, lam_scale=0.05), 8 << 20),
         ("long", dict(L=48, D=25, in_w=39, Ts=[5000, 1, 7000, 300], seed=2, lam_scale=0.02), 0),
-        ("long-L100", dict(L=100, D=10, in_w=8, Ts=[4000, 33], seed=3, lam_scale=0.02), 0)]:
+        ("long-L100", dict(L=100, D=10, in_w=8, Ts=[4000, 33], seed=3, lam_scale=0.02), 0),
+        ("long-hybrid", dict(L=200, D=40, in_w=60, Ts=[2500, 50, 700], seed=4, lam_scale=0.01), 0),       # round 4: hybrid path, k_lin_z5 segments
+        ("few-long-48", dict(L=48, D=25, in_w=39, Ts=[3000, 2999], seed=5, lam_scale=0.02), 0)]:          # round 4: k_post_z in segments
     res = {}
     for prec in (0, 1):
         c = Case(precision=prec, scratch_bytes=scratch, **kw)

@@ -181,8 +181,14 @@ int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n, uint32_t 
 int scrf_batch_destroy(scrf_handle h, scrf_batch b);
 int scrf_batch_info(scrf_handle h, scrf_batch b, uint32_t* n_utts, uint64_t* n_frames,
                     uint64_t* n_segs, uint64_t* n_arcs);
-/* 1 if the FAST / decode kernels synthesise this batch's windows on the fly (one segment-recipe
- * stream, no context, no transition features, shape within the kernels' LDS budget), else 0 */
+/* Which training path the batch takes under the handle's precision:
+ *   0  general (window vectors materialised, dense contractions over all of their columns);
+ *   1  the FAST / decode kernels synthesise stream 0's windows on the fly (a segment-recipe stream without context whose
+ *      shape fits the kernels' LDS budget; transition features, if any, on further streams);
+ *   2  the same with the linear window average (SCRF_PREC_FASTLIN on a shape its kernels take);
+ *   3  hybrid: one such stream with more labels than the fused kernels take -- windows materialised without their sampled
+ *      blocks, which go through per-frame projections and per-frame sums.
+ * Nonzero = no full window image in HBM. */
 int scrf_batch_is_fused(scrf_handle h, scrf_batch b, int* fused);
 
 /* ---- hot path: forward-backward + gradient ------------------------------------------------ */

@@ -10,10 +10,13 @@
 #include <algorithm>
 #include <iterator>
 #include <limits>
+#include <memory>
 #include <random>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 #include "ftr_files.h"
 #include "lbfgs.h"
@@ -148,13 +151,36 @@ void CRF_Model::resetLambda() { std::fill(lambda.begin(), lambda.end(), 0.0); }
 
 // one value per line in the stream default format (6 significant digits, "%g"), as the reference's
 // `ofile << lambda[i] << endl` (CRF_Model.cpp); buffered -- a stdtrans TIMIT model has 4.4 M lines
+// (round 4: the text of large vectors is formatted by a few threads, slice by slice, and written in order -- the same
+// bytes as one fprintf per value; the TIMIT demo wrote its three 4.4 M-line files per epoch in 1.06 s of a 2.8 s epoch)
 static bool write_vec(const char* fname, const double* v, size_t n) {
   FILE* o = fopen(fname, "w");
   if (!o) throw runtime_error(string("CRF_Model::writeToFile() caught exception: cannot open the file:\n") + fname);
   std::vector<char> buf(1 << 20);
   setvbuf(o, buf.data(), _IOFBF, buf.size());
   bool ok = true;
-  for (size_t i = 0; i < n && ok; i++) ok = fprintf(o, "%g\n", v[i]) > 0;
+  if (n >= (1u << 16)) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
+    const size_t per = (n + nt - 1) / nt;
+    std::vector<std::string> part(nt);
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++)
+      th.emplace_back([&, k]() {
+        const size_t a = k * per, b = std::min(n, a + per);
+        std::string& out = part[k];
+        out.reserve((b > a ? b - a : 0) * 14);
+        char line[64];
+        for (size_t i = a; i < b; i++) {
+          const int m = snprintf(line, sizeof line, "%g\n", v[i]);
+          out.append(line, (size_t)m);
+        }
+      });
+    for (auto& t : th) t.join();
+    for (unsigned k = 0; k < nt && ok; k++) ok = part[k].empty() || fwrite(part[k].data(), 1, part[k].size(), o) == part[k].size();
+  } else {
+    for (size_t i = 0; i < n && ok; i++) ok = fprintf(o, "%g\n", v[i]) > 0;
+  }
   ok = fclose(o) == 0 && ok;
   if (!ok) throw runtime_error(string("CRF_Model::writeToFile() caught exception: errors when writing the weights to the file:\n") + fname);
   return true;
@@ -644,6 +670,25 @@ void grab(CRF_FeatureStream* strm, CRF_Model* crf, HeldUtt* h) {
   h->u.frames.clear();
 }
 
+// SCRF_HOST_TIMING=1: where the trainer's wall time goes (cumulative seconds per step of the loop, printed once per epoch)
+struct HostClock {
+  bool on = getenv("SCRF_HOST_TIMING") && atoi(getenv("SCRF_HOST_TIMING")) != 0;
+  double t[6] = {0, 0, 0, 0, 0, 0};   // grab, batch, forward-backward, sums, update, epoch end (pull + files)
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void report(int iter) {
+    if (!on) return;
+    std::cout << "host timing, iteration " << iter << " (s): utterances " << t[0] << " batch " << t[1] << " forward-backward " << t[2]
+              << " sums " << t[3] << " update " << t[4] << " epoch end " << t[5] << std::endl;
+  }
+};
+HostClock g_clock;
+const double g_process_t0 = HostClock::now();   // library load
+struct ClockScope {
+  int k; double t0;
+  explicit ClockScope(int k_) : k(k_), t0(g_clock.on ? HostClock::now() : 0.0) {}
+  ~ClockScope() { if (g_clock.on) g_clock.t[k] += HostClock::now() - t0; }
+};
+
 struct BatchGuard {
   crf_amd::Engine* e;
   scrf_batch b = nullptr;
@@ -800,13 +845,16 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
     if (segids[s] == QN_SEGID_BAD) continue;
     const QNUInt32 share = crf_amd_minibatch_share(minibatch, N, s);
     std::vector<HeldUtt> utts;
-    do {  // thread run loop: at least one utterance, then until the share is reached or the view ends
-      utts.emplace_back();
-      grab(ftrStrms[s], crf, &utts.back());
-      segids[s] = ftrStrms[s]->nextseg();
-    } while (utts.size() < share && segids[s] != QN_SEGID_BAD);
+    {
+      ClockScope cs(0);
+      do {  // thread run loop: at least one utterance, then until the share is reached or the view ends
+        utts.emplace_back();
+        grab(ftrStrms[s], crf, &utts.back());
+        segids[s] = ftrStrms[s]->nextseg();
+      } while (utts.size() < share && segids[s] != QN_SEGID_BAD);
+    }
     BatchGuard g{e};
-    make_batch(e, ftrStrms[s], utts, &g);
+    { ClockScope cs(1); make_batch(e, ftrStrms[s], utts, &g); }
     if (grad && !dist) e->check(scrf_zero_grad(e->h), "accumulateGradient");
     if (dist) {
       // this rank's one batch of the step and the collective in one call: the engine reduces the transition block
@@ -819,7 +867,7 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
       if (fb_rc != SCRF_OK) local_failure = string("CRF_Minibatch_GradAccumulator::accumulateGradient() caught exception: ") + scrf_last_error(e->h);
       continue;
     }
-    e->check(scrf_fb_batch(e->h, g.b, nullptr, nullptr), "CRF_Minibatch_GradAccumulator::accumulateGradient()");
+    { ClockScope cs(2); e->check(scrf_fb_batch(e->h, g.b, nullptr, nullptr), "CRF_Minibatch_GradAccumulator::accumulateGradient()"); }
     if (grad && !dist) {   // per-stream gradient and sums to the host (they restart with every scrf_zero_grad)
       double sums[3] = {0, 0, 0};
       e->check(scrf_get_batch_sums(e->h, sums), "accumulateGradient");
@@ -869,6 +917,7 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
   if (grad) {
     for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;
   } else {
+    ClockScope cs(3);
     double sums[3] = {0, 0, 0};
     e->check(scrf_get_batch_sums(e->h, sums), "accumulateGradient");
     totNumer = sums[0];
@@ -908,8 +957,33 @@ CRF_SGTrainer::CRF_SGTrainer(CRF_Model* crf, std::vector<CRF_FeatureStream*> s, 
 
 void CRF_SGTrainer::train() { sgtrainMinibatch(); }   // both branches of the reference's train() (:58-65)
 
+namespace {
+// The three weight-sized text files of an iteration (and its done marker, last) are written by a thread of their own
+// while the next iteration's minibatches run: at the TIMIT demo's size an iteration is 0.45 s of minibatches and 0.4 s
+// of files.  The thread works on copies; the next iteration end, the final writes and every exit path wait for it, and
+// an error in it surfaces there.  SCRF_ASYNC_WRITE=0: written in line, as before.
+struct EpochWriter {
+  std::thread th;
+  std::string err;
+  bool async = !(getenv("SCRF_ASYNC_WRITE") && atoi(getenv("SCRF_ASYNC_WRITE")) == 0);
+  void wait() {
+    if (th.joinable()) th.join();
+    if (!err.empty()) { const std::string m = err; err.clear(); throw runtime_error(m); }
+  }
+  template <class F> void run(F&& job) {
+    wait();
+    if (!async) { job(); return; }
+    th = std::thread([this, job]() {
+      try { job(); } catch (const std::exception& ex) { err = ex.what(); }
+    });
+  }
+  ~EpochWriter() { if (th.joinable()) th.join(); }
+};
+}  // namespace
+
 void CRF_SGTrainer::sgtrainMinibatch() {
   crf_amd::Engine* e = crf_ptr->engine();
+  EpochWriter writer;
   crf_ptr->pushLambda();
   const QNUInt32 n = crf_ptr->getLambdaLen();
   const bool chief = !crf_ptr->distributed() || crf_ptr->distRank() == 0;   // one writer of files and progress lines
@@ -935,6 +1009,7 @@ void CRF_SGTrainer::sgtrainMinibatch() {
   // the reference's prior step scales the gradient by (1 - 1/gvar) (:300-303); kept as written
   const float invSquareVar = useGvar ? 1 / gvar : 0.0f;
   gaccum->rewindAllAndNextSegs();
+  if (chief && g_clock.on) std::cout << "host timing: " << HostClock::now() - g_process_t0 << " s from program start to the first minibatch (inputs, model, device)" << std::endl;
   bool start = true;
   while (iCounter < maxIters) {
     if (start && chief) {
@@ -954,28 +1029,30 @@ void CRF_SGTrainer::sgtrainMinibatch() {
                 << " Batch-Avg LogLi: " << logLi / inc << " Iter-Avg LogLi: " << totLogLi / uCounter << std::endl;
     if (useGvar) e->check(scrf_gauss_prior(e->h, invSquareVar), "sgtrainMinibatch");
     // update on the device: lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0
-    e->check(scrf_sgd_step(e->h, useAdagrad ? eta : (double)lr, useAdagrad, eps), "sgtrainMinibatch");
+    { ClockScope cs(4); e->check(scrf_sgd_step(e->h, useAdagrad ? eta : (double)lr, useAdagrad, eps), "sgtrainMinibatch"); }
     accCnt += (int)inc;
     if (endOfIter) {
+      ClockScope cs_end(5);
       crf_ptr->pullLambda();
       const double* acc = crf_ptr->getLambdaAcc();
       for (QNUInt32 i = 0; i < n; i++) lambdaAvg[i] = acc[i] / (float)accCnt;
       if (chief) {
-        std::stringstream ss;
-        ss << weight_fname << ".i" << iCounter << ".out";
-        std::cout << "Writing Iteration " << iCounter << " weights to file " << ss.str() << std::endl;
-        crf_ptr->writeToFile(ss.str().c_str());
-        std::stringstream sa;
-        sa << weight_fname << ".i" << iCounter << ".avg.out";
-        crf_ptr->writeToFile(sa.str().c_str(), lambdaAvg.data(), n);
-        if (useAdagrad) {
-          std::stringstream sg;
-          sg << weight_fname << ".i" << iCounter << ".gradSqrAcc.out";
-          crf_ptr->writeToFile(sg.str().c_str(), crf_ptr->getGradSqrAcc(), n);
-        }
+        const string base = weight_fname + ".i" + std::to_string(iCounter);
+        std::cout << "Writing Iteration " << iCounter << " weights to file " << base << ".out" << std::endl;
+        auto lam = std::make_shared<std::vector<double>>(crf_ptr->getLambda(), crf_ptr->getLambda() + n);
+        auto avg = std::make_shared<std::vector<double>>(lambdaAvg);
+        std::shared_ptr<std::vector<double>> gsa;
+        if (useAdagrad) gsa = std::make_shared<std::vector<double>>(crf_ptr->getGradSqrAcc(), crf_ptr->getGradSqrAcc() + n);
+        const string done = weight_dir + "/.done.train.i" + std::to_string(iCounter);
+        writer.run([base, lam, avg, gsa, done]() {
+          write_vec((base + ".out").c_str(), lam->data(), lam->size());
+          write_vec((base + ".avg.out").c_str(), avg->data(), avg->size());
+          if (gsa) write_vec((base + ".gradSqrAcc.out").c_str(), gsa->data(), gsa->size());
+          touch(done);   // the marker last: a resumed run trusts the files it names
+        });
       }
       gaccum->rewindAllAndNextSegs();
-      if (chief) touchDoneFileIter(iCounter);
+      if (chief) g_clock.report(iCounter);
       iCounter++;
       uCounter = 0;
       totLogLi = 0.0;
@@ -986,6 +1063,7 @@ void CRF_SGTrainer::sgtrainMinibatch() {
       }
     }
   }
+  writer.wait();
   crf_ptr->pullLambda();
   if (chief) {
     std::cout << "Writing Final Iteration weights to file " << weight_fname << std::endl;

@@ -101,3 +101,20 @@ def test_mlf_manager_gives_the_references_transcripts_back(tmp_path):
     for ol in ("timit_sisx_test.core.neworder.olist", "timit_sisx_test.dt_set.neworder.olist", "timit_sisx_test.core+rest.neworder.olist"):
         names = [ln.strip()[:-4] for ln in open(os.path.join(G, ol)) if ln.strip()]
         assert len(names) > 100 and all(n in keys for n in names), ol
+
+
+def test_large_weight_file_text_is_the_stream_rendering(tmp_path):
+    """The trainer writes three weight-sized text files per epoch, one value per line in the reference's stream format
+    (`ofile << lambda[i] << endl`).  Vectors of 65536 values and more are formatted by several threads, slice by slice:
+    the file must be the same bytes as the one-value-at-a-time stream rendering (both sizes of the switch)."""
+    lib = os.path.join(ROOT, "asr-craft_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libcrf_amd_host.so")):
+        import __graft_entry__ as g
+        g.build()
+    exe = str(tmp_path / "weight_file_text")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "asr-craft_amd", "host"),
+                    os.path.join(ROOT, "tests", "host", "weight_file_text.cpp"), "-o", exe, "-L" + lib, "-Wl,-rpath," + lib,
+                    "-lcrf_amd_host", "-lscrf_amd"], check=True, timeout=300)
+    for n in (1000, 300001):
+        r = subprocess.run([exe, str(tmp_path / ("w%d.txt" % n)), str(n)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr

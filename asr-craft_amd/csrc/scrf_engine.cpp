@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "scrf_kernels.h"
@@ -104,6 +105,20 @@ struct scrf_engine_s {
   // second lane: alternate chunks of a batch run on a second stream so that the VALU-bound DP
   // kernels of one chunk overlap the MFMA-bound contractions of the other
   hipStream_t stream2 = nullptr;
+  // Batch arrays (scrf_batch_create / scrf_batch_destroy) come from a pool and are uploaded on a stream of their own:
+  // a trainer that makes one batch per minibatch used to synchronise the device at every destroy (hipFree) and to wait
+  // for the previous minibatch's kernels at every upload.  A freed block carries the epoch of its destroy call; the
+  // engine stream's event of that epoch says when the last kernel that could read it has finished, and only then is the
+  // block handed out again (otherwise a fresh one is allocated).  SCRF_BATCH_POOL=0: hipMalloc / hipFree as before.
+  struct PoolBlock { void* p; size_t cap; uint64_t epoch; };
+  std::vector<PoolBlock> pool_free;
+  std::unordered_map<void*, size_t> pool_cap;     // live blocks
+  hipStream_t up_stream = nullptr;
+  hipEvent_t pool_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint64_t pool_epoch = 0, pool_done = 0;         // destroy calls so far / epochs known to be finished
+  size_t pool_bytes = 0;                          // bytes sitting in pool_free
+  bool pool_on = true;
+  bool pool_up = true;     // uploads on their own stream (SCRF_BATCH_POOL=2: on the engine stream)
   char* scratch2 = nullptr;
   size_t scratch2_cap = 0;
   double* d_grad2 = nullptr;
@@ -320,6 +335,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   if (const char* e = getenv("SCRF_COMM_OVERLAP")) h->comm_overlap_on = atoi(e) != 0;
   if (const char* e = getenv("SCRF_LINDP")) h->lin_dp = atoi(e) != 0;
   if (const char* e = getenv("SCRF_FAST_DECODE")) h->fast_decode = atoi(e) != 0;
+  if (const char* e = getenv("SCRF_BATCH_POOL")) { h->pool_on = atoi(e) != 0; h->pool_up = atoi(e) != 2; }
   if (const char* e = getenv("SCRF_HYBRID")) { h->hybrid = atoi(e) != 0; h->hybrid_first = atoi(e) == 2; }
   if (const char* e = getenv("SCRF_DECODE_BOUND_SCALE")) h->decode_bound_factor = std::max(1.0, atof(e));   // widening only: < 1 would void the bound
   memset(h->ms, 0, sizeof(h->ms));
@@ -360,6 +376,7 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_grad2, nb));
   CRCHK(hipMalloc((void**)&h->d_sums2, sizeof(double) * 4));
   CRCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  CRCHK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
   CRCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CRCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   CRCHK(hipMemsetAsync(h->d_lambda, 0, nb, h->stream));
@@ -396,6 +413,10 @@ extern "C" int scrf_destroy(scrf_handle h) {
   if (h->kev[0]) hipEventDestroy(h->kev[0]);
   if (h->kev[1]) hipEventDestroy(h->kev[1]);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->up_stream) { hipStreamSynchronize(h->up_stream); hipStreamDestroy(h->up_stream); }
+  for (auto& bl : h->pool_free) hipFree(bl.p);   // (the engine stream was synchronised above)
+  for (auto& kv : h->pool_cap) hipFree(kv.first);
+  for (int i = 0; i < 8; i++) if (h->pool_ev[i]) hipEventDestroy(h->pool_ev[i]);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   hipFree(h->dec_lab); hipFree(h->dec_n); hipFree(h->dec_cost);
@@ -568,12 +589,77 @@ static int ensure_scratch(scrf_handle h, size_t bytes, int lane = 0) {
 // ---------------------------------------------------------------------------------------------
 // batches
 // ---------------------------------------------------------------------------------------------
+// ---- the batch-array pool (see the handle) ----
+static size_t pool_class(size_t bytes) {   // size classes: powers of two from 64 KB (a minibatch's arrays vary in size from step to step)
+  size_t c = 64u << 10;
+  while (c < bytes) c *= 2;
+  return c;
+}
+static void pool_poll(scrf_handle h) {   // which destroy epochs have finished on the device
+  while (h->pool_done < h->pool_epoch) {
+    hipEvent_t ev = h->pool_ev[(h->pool_done + 1) % 8];
+    if (!ev || hipEventQuery(ev) != hipSuccess) break;
+    h->pool_done++;
+  }
+}
+static int pool_alloc(scrf_handle h, size_t bytes, void** out) {
+  *out = nullptr;
+  if (!h->pool_on) { HIPCHK(h, hipMalloc(out, bytes)); return SCRF_OK; }
+  const size_t cap = pool_class(bytes);
+  pool_poll(h);
+  for (size_t i = 0; i < h->pool_free.size(); i++) {
+    const auto& bl = h->pool_free[i];
+    if (bl.cap == cap && bl.epoch <= h->pool_done) {
+      *out = bl.p;
+      h->pool_bytes -= bl.cap;
+      h->pool_free[i] = h->pool_free.back();
+      h->pool_free.pop_back();
+      h->pool_cap[*out] = cap;
+      return SCRF_OK;
+    }
+  }
+  HIPCHK(h, hipMalloc(out, cap));
+  h->pool_cap[*out] = cap;
+  return SCRF_OK;
+}
+static void pool_release(scrf_handle h, void* p) {   // inside a destroy call: the block carries the epoch being closed
+  if (!p) return;
+  auto it = h ? h->pool_cap.find(p) : decltype(h->pool_cap.find(p))();
+  if (!h || !h->pool_on || it == h->pool_cap.end()) { hipFree(p); return; }
+  h->pool_free.push_back({p, it->second, h->pool_epoch + 1});
+  h->pool_bytes += it->second;
+  h->pool_cap.erase(it);
+}
+static void pool_close_epoch(scrf_handle h) {   // after the releases of one destroy call
+  const uint64_t e = h->pool_epoch + 1;
+  hipEvent_t& ev = h->pool_ev[e % 8];
+  if (ev) { hipEventSynchronize(ev); if (h->pool_done < e - 8 && e >= 8) h->pool_done = e - 8; }   // the slot's old epoch (e - 8) is long past
+  else hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  hipEventRecord(ev, h->stream);
+  h->pool_epoch = e;
+  // keep the pool bounded: beyond 8 GiB of idle blocks, give the finished ones back
+  if (h->pool_bytes > ((size_t)8 << 30)) {
+    pool_poll(h);
+    for (size_t i = 0; i < h->pool_free.size();) {
+      if (h->pool_free[i].epoch <= h->pool_done) {
+        h->pool_bytes -= h->pool_free[i].cap;
+        hipFree(h->pool_free[i].p);
+        h->pool_free[i] = h->pool_free.back();
+        h->pool_free.pop_back();
+      } else i++;
+    }
+  }
+}
+
 template <class Tp>
 static int upload(scrf_handle h, Tp** d, const Tp* src, size_t n) {
   *d = nullptr;
   if (n == 0) n = 1;
-  HIPCHK(h, hipMalloc((void**)d, sizeof(Tp) * n));
-  if (src) HIPCHK(h, hipMemcpyAsync(*d, src, sizeof(Tp) * n, hipMemcpyHostToDevice, h->stream));
+  void* p = nullptr;
+  int rc = pool_alloc(h, sizeof(Tp) * n, &p);
+  if (rc != SCRF_OK) return rc;
+  *d = (Tp*)p;
+  if (src) HIPCHK(h, hipMemcpyAsync(*d, src, sizeof(Tp) * n, hipMemcpyHostToDevice, (h->pool_on && h->pool_up) ? h->up_stream : h->stream));
   return SCRF_OK;
 }
 
@@ -586,12 +672,17 @@ static uint64_t shadow_num_arcs(scrf_handle h, uint32_t T) {
 
 extern "C" int scrf_batch_destroy(scrf_handle h, scrf_batch b) {
   if (!b) return SCRF_OK;
-  if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }
-  hipFree(b->d_T); hipFree(b->d_frame_off); hipFree(b->d_seg_off); hipFree(b->d_arc_off);
-  hipFree(b->d_labels); hipFree(b->d_next_lab); hipFree(b->d_prev_lab); hipFree(b->d_trans_counts); hipFree(b->d_windows); hipFree(b->d_frame_u); hipFree(b->d_xm_f);
-  for (int s = 0; s < SCRF_MAX_STREAMS; s++) { hipFree(b->d_frames[s]); hipFree(b->d_sframe_off[s]); }
-  hipFree(b->d_numer); hipFree(b->d_zx); hipFree(b->d_status);
-  hipFree(b->d_tiles[0]); hipFree(b->d_tiles[1]); hipFree(b->d_tiles[2]);
+  if (h) hipSetDevice(h->device);
+  if (h && !h->pool_on) hipStreamSynchronize(h->stream);
+  // (pool: no synchronisation here -- the blocks wait in the pool until the engine stream has passed this point)
+#define BFREE(p) pool_release(h, (void*)(p))
+  BFREE(b->d_T); BFREE(b->d_frame_off); BFREE(b->d_seg_off); BFREE(b->d_arc_off);
+  BFREE(b->d_labels); BFREE(b->d_next_lab); BFREE(b->d_prev_lab); BFREE(b->d_trans_counts); BFREE(b->d_windows); BFREE(b->d_frame_u); BFREE(b->d_xm_f);
+  for (int s = 0; s < SCRF_MAX_STREAMS; s++) { BFREE(b->d_frames[s]); BFREE(b->d_sframe_off[s]); }
+  BFREE(b->d_numer); BFREE(b->d_zx); BFREE(b->d_status);
+  BFREE(b->d_tiles[0]); BFREE(b->d_tiles[1]); BFREE(b->d_tiles[2]);
+#undef BFREE
+  if (h && h->pool_on) pool_close_epoch(h);
   delete b;
   return SCRF_OK;
 }
@@ -642,7 +733,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
   const uint64_t NF = b->frame_off[n], NS = b->seg_off[n];
   int rc;
 #define BCHK(x) do { rc = (x); if (rc != SCRF_OK) { scrf_batch_destroy(h, b); return rc; } } while (0)
-#define BSYNC() do { hipError_t e_ = hipStreamSynchronize(h->stream); if (e_ != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "scrf_batch_create: %s", hipGetErrorString(e_)); } } while (0)
+#define BSYNC() do { hipError_t e_ = hipStreamSynchronize((h->pool_on && h->pool_up) ? h->up_stream : h->stream); if (e_ != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "scrf_batch_create: %s", hipGetErrorString(e_)); } } while (0)
   BCHK(upload(h, &b->d_T, b->T.data(), n));
   BCHK(upload(h, &b->d_frame_off, b->frame_off.data(), n + 1));
   BCHK(upload(h, &b->d_seg_off, b->seg_off.data(), n + 1));
@@ -696,7 +787,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
     BCHK(upload<float>(h, &b->d_windows, nullptr, NS * lay.F + 64));  // tail pad: wide loads may over-read 12 B
     for (uint32_t u = 0; u < n; u++) {
       hipError_t e = hipMemcpyAsync(b->d_windows + b->seg_off[u] * lay.F, utts[u].windows,
-                                    sizeof(float) * (b->seg_off[u + 1] - b->seg_off[u]) * lay.F, hipMemcpyHostToDevice, h->stream);
+                                    sizeof(float) * (b->seg_off[u + 1] - b->seg_off[u]) * lay.F, hipMemcpyHostToDevice, (h->pool_on && h->pool_up) ? h->up_stream : h->stream);
       if (e != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "window upload failed: %s", hipGetErrorString(e)); }
     }
   } else {
@@ -714,7 +805,7 @@ extern "C" int scrf_batch_create(scrf_handle h, const scrf_utt* utts, uint32_t n
       BSYNC();
       for (uint32_t u = 0; u < n; u++) {
         hipError_t e = hipMemcpyAsync(b->d_frames[s] + so[u] * recipes[s].in_width, utts[u].frames[s],
-                                      sizeof(float) * (so[u + 1] - so[u]) * recipes[s].in_width, hipMemcpyHostToDevice, h->stream);
+                                      sizeof(float) * (so[u + 1] - so[u]) * recipes[s].in_width, hipMemcpyHostToDevice, (h->pool_on && h->pool_up) ? h->up_stream : h->stream);
         if (e != hipSuccess) { scrf_batch_destroy(h, b); return fail(h, SCRF_ERR_HIP, "frame upload failed: %s", hipGetErrorString(e)); }
       }
     }

@@ -709,8 +709,12 @@ void launch_viterbi(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv, uin
 // before the boundary step so that their latency hides under it.  Same additions in the same order
 // and the same strict-improvement scans as k_viterbi (bit-identical labels and costs).
 // ------------------------------------------------------------------------------------------
+// LV > 0 (round 4; L <= LV, L a multiple of 4): the lane's column of float(-M) sits in registers and the previous node's
+// costs are read four at a time (one 16-byte broadcast read instead of eight 4-byte ones per four predecessors); two
+// comparison chains (even / odd predecessors) merged at the end -- the minimum, and among equal costs the smallest
+// predecessor, exactly what the one strict-improvement scan selects.
 #define VF_WAVES 4
-template <int DMAX>
+template <int DMAX, int LV>
 __global__ __launch_bounds__(64 * VF_WAVES) void k_viterbi_fast(ScrfLayout lay, ScrfBatchView bv, uint32_t u0, uint32_t n_utts,
                                                                 const float* __restrict__ Wn, const double* __restrict__ M,
                                                                 uint16_t* __restrict__ bp_b, uint16_t* __restrict__ bp_e,
@@ -740,18 +744,51 @@ __global__ __launch_bounds__(64 * VF_WAVES) void k_viterbi_fast(ScrfLayout lay, 
   }
   const int l = lane < L ? lane : L - 1;   // idle lanes shadow the last label, their stores are masked
   const bool act = lane < L;
+  float mcol[LV > 0 ? LV : 1];
+  if (LV > 0) {
+#pragma unroll
+    for (int p = 0; p < LV; p++) mcol[p] = p < L ? Mf[p * L + l] : INFINITY;   // past L: never an improvement
+  }
+  // the frame's D weights are requested a whole frame ahead (round 4: they were requested at the top of their own frame,
+  // with only the boundary step to cover an HBM round trip)
+  float wv_n[DMAX];
+  auto fetch_w = [&](int t, float (&w)[DMAX]) {
+    const int tt = t < T ? t : T - 1;
+    const uint64_t base = scrf_seg_base(tt, D);
+    const int nd = tt + 1 < D ? tt + 1 : D;
+#pragma unroll
+    for (int i = 0; i < DMAX; i++) w[i] = i < nd ? Wu[(base + i) * L + l] : 0.0f;
+  };
+  fetch_w(0, wv_n);
   for (int t = 0; t < T; t++) {
-    const uint64_t base = scrf_seg_base(t, D);
     const int nd = t + 1 < D ? t + 1 : D;
     float wv[DMAX];
 #pragma unroll
-    for (int i = 0; i < DMAX; i++) wv[i] = i < nd ? Wu[(base + i) * L + l] : 0.0f;
+    for (int i = 0; i < DMAX; i++) wv[i] = wv_n[i];
+    fetch_w(t + 1, wv_n);
     if (t >= 1) {
       float best = INFINITY;
       int arg = 0;
-      for (int p = 0; p < L; p++) {
-        const float cst = de_prev[p] + Mf[p * L + l];
-        if (cst < best) { best = cst; arg = p; }
+      if (LV > 0) {
+        float b1 = INFINITY;
+        int a1 = 0;
+#pragma unroll
+        for (int p = 0; p < LV; p += 4) {
+          if (p < L) {   // wave-uniform; L is a multiple of 4, so the four entries exist
+            const float4 dp = *(const float4*)(de_prev + p);
+            const float c0 = dp.x + mcol[p], c1 = dp.y + mcol[p + 1], c2 = dp.z + mcol[p + 2], c3 = dp.w + mcol[p + 3];
+            if (c0 < best) { best = c0; arg = p; }
+            if (c1 < b1) { b1 = c1; a1 = p + 1; }
+            if (c2 < best) { best = c2; arg = p + 2; }
+            if (c3 < b1) { b1 = c3; a1 = p + 3; }
+          }
+        }
+        if (b1 < best || (b1 == best && a1 < arg)) { best = b1; arg = a1; }
+      } else {
+        for (int p = 0; p < L; p++) {
+          const float cst = de_prev[p] + Mf[p * L + l];
+          if (cst < best) { best = cst; arg = p; }
+        }
       }
       if (act) { db[(t % D) * L + l] = best; bpb[(size_t)t * L + l] = (uint16_t)arg; }
     }
@@ -815,16 +852,25 @@ void launch_viterbi_fast(hipStream_t st, const ScrfLayout& lay, ScrfBatchView bv
   if (n_utts == 0) return;
   const size_t sm = sizeof(float) * ((size_t)lay.L * lay.L + VF_WAVES * ((size_t)lay.L + (size_t)lay.D * lay.L));
   const dim3 grid((n_utts + VF_WAVES - 1) / VF_WAVES), block(64 * VF_WAVES);
-#define VF_GO(N)                                                                                                         \
-  do {                                                                                                                   \
-    hipFuncSetAttribute((const void*)k_viterbi_fast<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);            \
-    hipLaunchKernelGGL(k_viterbi_fast<N>, grid, block, sm, st, lay, bv, u0, n_utts, Wn, M, bp_b, bp_e, out_labels, out_n, \
-                       out_cost);                                                                                        \
+#define VF_GO2(N, LV)                                                                                                          \
+  do {                                                                                                                         \
+    hipFuncSetAttribute((const void*)k_viterbi_fast<N, LV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);              \
+    hipLaunchKernelGGL((k_viterbi_fast<N, LV>), grid, block, sm, st, lay, bv, u0, n_utts, Wn, M, bp_b, bp_e, out_labels, out_n, \
+                       out_cost);                                                                                              \
+  } while (0)
+  // register column + 16-byte reads of the previous node's costs: L a multiple of 4 (the LDS vectors stay 16-byte aligned)
+  static const bool vec_ok = !(getenv("SCRF_VITERBI_VEC") && atoi(getenv("SCRF_VITERBI_VEC")) == 0);
+#define VF_GO(N)                                                     \
+  do {                                                               \
+    if (vec_ok && lay.L % 4 == 0 && lay.L <= 48) VF_GO2(N, 48);      \
+    else if (vec_ok && lay.L % 4 == 0) VF_GO2(N, 64);                \
+    else VF_GO2(N, 0);                                               \
   } while (0)
   if (lay.D <= 12) VF_GO(12);
   else if (lay.D <= 25) VF_GO(25);
   else VF_GO(40);
 #undef VF_GO
+#undef VF_GO2
 }
 
 // ------------------------------------------------------------------------------------------

@@ -689,3 +689,30 @@ def test_random_shape_sweep_through_every_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "general_shape_sweep.py"), "60", "7"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_batches_destroyed_with_kernels_in_flight_reuse_pooled_arrays_safely(monkeypatch):
+    """A trainer makes one batch per minibatch and destroys it as soon as scrf_fb_batch has returned -- while the count
+    kernels that read the batch's arrays are still running.  Batch arrays come from a pool whose blocks are handed out
+    again only once the engine stream has passed their destroy call (round 4; before, every destroy synchronised the
+    device).  Forty batches of alternating shapes back to back, gradients accumulated on the device: the sum must equal
+    the sum of the same batches run one by one with the pool off."""
+    shapes = [dict(L=48, D=10, in_w=13, Ts=[57, 33, 90, 12]), dict(L=48, D=10, in_w=13, Ts=[20, 64, 5]),
+              dict(L=48, D=10, in_w=13, Ts=[130, 7, 41, 77, 19])]
+    res = {}
+    for pool in ("1", "0"):
+        monkeypatch.setenv("SCRF_BATCH_POOL", pool)
+        c0 = Case(seed=901, precision=scrf_amd.PREC_FAST, **shapes[0])
+        eng = c0.engine()
+        eng.zero_grad()
+        for i in range(40):
+            c = Case(seed=901 + i % 3, precision=scrf_amd.PREC_FAST, **shapes[i % 3])
+            b = c.batch(eng)
+            eng.fb_batch(b, want_scalars=False)   # returns once the recursion's status is known; contractions in flight
+            b.close()
+            if pool == "0" or i % 7 == 0:
+                eng.synchronize()
+        res[pool] = eng.get_grad().copy()
+        eng.close()
+    assert np.isfinite(res["1"]).all()
+    assert np.abs(res["1"] - res["0"]).max() <= 1e-12 * np.abs(res["0"]).max()

@@ -98,6 +98,9 @@ struct scrf_engine_s {
   double* d_sums_stage = nullptr;
   int* d_latch = nullptr;     // {status code, utterance} of the first failed utterance of the batch in flight
   int* h_latch = nullptr;     // pinned copy, valid once ev_status has completed
+  double* h_sums = nullptr;   // pinned image of the batch sums (scrf_queue_batch_sums / scrf_take_batch_sums)
+  hipEvent_t ev_sums = nullptr;
+  bool sums_queued = false;
   hipEvent_t ev_status = nullptr;
   uint64_t n_lin_fallback = 0;   // batches redone through the log-domain recursion
   char* scratch = nullptr;
@@ -370,6 +373,8 @@ extern "C" int scrf_create(const scrf_config* cfg, scrf_handle* out) {
   CRCHK(hipMalloc((void**)&h->d_latch, sizeof(int) * 2));
   CRCHK(hipHostMalloc((void**)&h->h_latch, sizeof(int) * 2, hipHostMallocDefault));
   h->h_latch[0] = h->h_latch[1] = 0;
+  CRCHK(hipHostMalloc((void**)&h->h_sums, sizeof(double) * 4, hipHostMallocDefault));
+  CRCHK(hipEventCreateWithFlags(&h->ev_sums, hipEventDisableTiming));
   CRCHK(hipEventCreateWithFlags(&h->ev_status, hipEventDisableTiming));
   CRCHK(hipEventCreate(&h->kev[0]));
   CRCHK(hipEventCreate(&h->kev[1]));
@@ -409,6 +414,8 @@ extern "C" int scrf_destroy(scrf_handle h) {
   hipFree(h->d_grad2); hipFree(h->d_sums2); hipFree(h->scratch2);
   hipFree(h->d_stage); hipFree(h->d_sums_stage); hipFree(h->d_latch);
   if (h->h_latch) hipHostFree(h->h_latch);
+  if (h->h_sums) hipHostFree(h->h_sums);
+  if (h->ev_sums) hipEventDestroy(h->ev_sums);
   if (h->ev_status) hipEventDestroy(h->ev_status);
   if (h->kev[0]) hipEventDestroy(h->kev[0]);
   if (h->kev[1]) hipEventDestroy(h->kev[1]);
@@ -553,6 +560,27 @@ extern "C" int scrf_get_batch_sums(scrf_handle h, double* sums3) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(sums3, h->d_sums, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SCRF_OK;
+}
+
+// The same without stopping the host: the copy is queued behind the work issued so far and read later (a trainer reads
+// minibatch k's sums after it has issued minibatch k + 1, whose batch it can then prepare while k's count kernels run).
+extern "C" int scrf_queue_batch_sums(scrf_handle h) {
+  if (!h) return SCRF_ERR_INVALID;
+  if (h->sums_queued) return fail(h, SCRF_ERR_INVALID, "scrf_queue_batch_sums: the sums queued before have not been taken");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->h_sums, h->d_sums, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_sums, h->stream));
+  h->sums_queued = true;
+  return SCRF_OK;
+}
+extern "C" int scrf_take_batch_sums(scrf_handle h, double* sums3) {
+  if (!h || !sums3) return SCRF_ERR_INVALID;
+  if (!h->sums_queued) return fail(h, SCRF_ERR_INVALID, "scrf_take_batch_sums: nothing queued");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventSynchronize(h->ev_sums));
+  for (int i = 0; i < 3; i++) sums3[i] = h->h_sums[i];
+  h->sums_queued = false;
   return SCRF_OK;
 }
 

@@ -916,6 +916,16 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
   // averaged over ACTIVE STREAMS (reference quirk, :306-308)
   if (grad) {
     for (QNUInt32 i = 0; i < n; i++) grad[i] /= nActive;
+  } else if (deferSums) {
+    ClockScope cs(3);
+    if (sumsQueued) {   // the minibatch before: its copy finished long ago (this minibatch's recursion ran behind it)
+      double sums[3] = {0, 0, 0};
+      e->check(scrf_take_batch_sums(e->h, sums), "accumulateGradient");
+      prevNumer = sums[0]; prevZx = sums[1]; prevReady = true;
+    }
+    e->check(scrf_queue_batch_sums(e->h), "accumulateGradient");
+    sumsQueued = true;
+    if (nActive > 1) e->check(scrf_div_grad(e->h, (double)nActive), "accumulateGradient");
   } else {
     ClockScope cs(3);
     double sums[3] = {0, 0, 0};
@@ -926,6 +936,20 @@ double CRF_Minibatch_GradAccumulator::accumulate(double* grad, double* Zx_out, Q
   }
   *isEndOfIter = nEnd == (int)N;
   return totNumer;
+}
+
+bool CRF_Minibatch_GradAccumulator::takePreviousSums(double* numer, double* Zx) {
+  if (!prevReady) return false;
+  *numer = prevNumer; *Zx = prevZx;
+  prevReady = false;
+  return true;
+}
+void CRF_Minibatch_GradAccumulator::takeCurrentSums(double* numer, double* Zx) {
+  if (!sumsQueued) throw runtime_error("CRF_Minibatch_GradAccumulator::takeCurrentSums: no minibatch is outstanding");
+  double sums[3] = {0, 0, 0};
+  crf->engine()->check(scrf_take_batch_sums(crf->engine()->h, sums), "accumulateGradient");
+  *numer = sums[0]; *Zx = sums[1];
+  sumsQueued = false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,6 +1016,10 @@ void CRF_SGTrainer::sgtrainMinibatch() {
                    : new CRF_Minibatch_GradAccumulator(crf_ptr, own_streams));
   gaccum->setMinibatch((QNUInt32)minibatch);
   gaccum->setUttReport((int)uttRpt);
+  // one process: the sums of a minibatch are read one minibatch later (SCRF_ASYNC_SUMS=0: at once, as before round 4)
+  const bool defer = !crf_ptr->distributed() && !(getenv("SCRF_ASYNC_SUMS") && atoi(getenv("SCRF_ASYNC_SUMS")) == 0);
+  gaccum->setDeferSums(defer);
+  QNUInt32 waitInc = 0, waitAfter = 0;
   std::vector<double> lambdaAvg(n, 0.0);
   int iCounter = (int)crf_ptr->getInitIter();
   QNUInt32 uCounter = 0;
@@ -1021,12 +1049,25 @@ void CRF_SGTrainer::sgtrainMinibatch() {
     bool endOfIter = false;
     double Zx = 0.0;
     const double numer = gaccum->accumulateGradientOnDevice(&Zx, &inc, &endOfIter);
-    const double logLi = numer - Zx;
-    totLogLi += logLi;
     uCounter += inc;
-    if (chief && uttRpt > 0 && uCounter % uttRpt == 0)
-      std::cout << " Finished Utt: " << uCounter - 1 << " Batch-Avg Numerator: " << numer / inc << " Batch-Avg Zx: " << Zx / inc
-                << " Batch-Avg LogLi: " << logLi / inc << " Iter-Avg LogLi: " << totLogLi / uCounter << std::endl;
+    // the minibatch's share of the log-likelihood and its progress line -- at once, or (deferred sums) one minibatch later,
+    // in the same order and with the same text
+    auto account = [&](double nm, double zx, QNUInt32 n_utts, QNUInt32 u_after) {
+      const double logLi = nm - zx;
+      totLogLi += logLi;
+      if (chief && uttRpt > 0 && u_after % uttRpt == 0)
+        std::cout << " Finished Utt: " << u_after - 1 << " Batch-Avg Numerator: " << nm / n_utts << " Batch-Avg Zx: " << zx / n_utts
+                  << " Batch-Avg LogLi: " << logLi / n_utts << " Iter-Avg LogLi: " << totLogLi / u_after << std::endl;
+    };
+    if (defer) {
+      double pn = 0.0, pz = 0.0;
+      if (gaccum->takePreviousSums(&pn, &pz)) account(pn, pz, waitInc, waitAfter);
+      waitInc = inc; waitAfter = uCounter;
+      if (endOfIter) {   // the iteration's last minibatch: its numbers are needed now
+        gaccum->takeCurrentSums(&pn, &pz);
+        account(pn, pz, waitInc, waitAfter);
+      }
+    } else account(numer, Zx, inc, uCounter);
     if (useGvar) e->check(scrf_gauss_prior(e->h, invSquareVar), "sgtrainMinibatch");
     // update on the device: lambda += lr*g | AdaGrad; lambdaAcc += lambda; g = 0
     { ClockScope cs(4); e->check(scrf_sgd_step(e->h, useAdagrad ? eta : (double)lr, useAdagrad, eps), "sgtrainMinibatch"); }

@@ -397,9 +397,18 @@ class CRF_Minibatch_GradAccumulator {
   // the same minibatch, but the summed and averaged gradient STAYS in the engine's device buffer
   // (what CRF_SGTrainer uses: no 2 x lambda_len doubles over PCIe per minibatch)
   double accumulateGradientOnDevice(double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
+  // Deferred sums (one process, gradient on the device): accumulateGradientOnDevice then returns 0 / *Zx_out = 0 and only
+  // QUEUES the copy of {numerator, Zx} behind the minibatch's kernels; the values of the minibatch BEFORE, read in
+  // passing, wait in takePreviousSums, and takeCurrentSums waits for the one just issued (end of an iteration).  The
+  // trainer prepares minibatch k + 1's batch while k's count kernels run instead of stopping for k's sums first.
+  void setDeferSums(bool on) { deferSums = on; }
+  bool takePreviousSums(double* numer, double* Zx);
+  void takeCurrentSums(double* numer, double* Zx);
 
  protected:
   double accumulate(double* grad, double* Zx_out, QNUInt32* uttCount, bool* isEndOfIter);
+  bool deferSums = false, sumsQueued = false, prevReady = false;
+  double prevNumer = 0.0, prevZx = 0.0;
   CRF_Model* crf;
   std::vector<CRF_FeatureStream*> ftrStrms;
   std::vector<QN_SegID> segids;

@@ -220,6 +220,11 @@ int scrf_grad_device_ptr(scrf_handle h, void** dptr);            /* for an exter
 int scrf_set_grad_buffer(scrf_handle h, void* dptr);
 /* sums over the batch kept on device: {sum numer, sum zx, n_utts} */
 int scrf_get_batch_sums(scrf_handle h, double* sums3);
+/* The same in two halves, for a trainer that does not want to stop at every minibatch: `queue` copies the sums to a
+ * pinned image behind the work issued so far (before the next scrf_zero_grad resets them), `take` waits for that copy
+ * only.  One outstanding copy at a time. */
+int scrf_queue_batch_sums(scrf_handle h);
+int scrf_take_batch_sums(scrf_handle h, double* sums3);
 
 /* ---- parity hooks: the node accessors of nodes/CRF_StateNode.h:67-115 ---------------------- */
 /* getStateValue(lab,dur) / getTransValue(p,c): S[N_seg][L], M[T][L*L] of utterance u (EXACT).  For

@@ -69,6 +69,9 @@ VEC_IO(grad_sqr_acc, gsa)
 int scrf_zero_grad(scrf_handle h) { h->grad.assign(h->n, 0.0); h->sums[0] = h->sums[1] = h->sums[2] = 0.0; return SCRF_OK; }
 int scrf_get_grad(scrf_handle h, double* g, uint32_t n) { if (n != h->n) return SCRF_ERR_INVALID; memcpy(g, h->grad.data(), sizeof(double) * n); return SCRF_OK; }
 int scrf_get_batch_sums(scrf_handle h, double* s3) { memcpy(s3, h->sums, sizeof(h->sums)); return SCRF_OK; }
+static double g_queued_sums[3];
+int scrf_queue_batch_sums(scrf_handle h) { memcpy(g_queued_sums, h->sums, sizeof(g_queued_sums)); return SCRF_OK; }
+int scrf_take_batch_sums(scrf_handle, double* s3) { memcpy(s3, g_queued_sums, sizeof(g_queued_sums)); return SCRF_OK; }
 int scrf_scale_grad(scrf_handle h, double s) { for (double& g : h->grad) g *= s; return SCRF_OK; }
 int scrf_div_grad(scrf_handle h, double d) { for (double& g : h->grad) g /= d; return SCRF_OK; }
 int scrf_gauss_prior(scrf_handle h, float inv) { for (double& g : h->grad) g -= g * inv; return SCRF_OK; }

@@ -567,8 +567,9 @@ extern "C" int scrf_get_batch_sums(scrf_handle h, double* sums3) {
 // minibatch k's sums after it has issued minibatch k + 1, whose batch it can then prepare while k's count kernels run).
 extern "C" int scrf_queue_batch_sums(scrf_handle h) {
   if (!h) return SCRF_ERR_INVALID;
-  if (h->sums_queued) return fail(h, SCRF_ERR_INVALID, "scrf_queue_batch_sums: the sums queued before have not been taken");
   HIPCHK(h, hipSetDevice(h->device));
+  // (a copy queued before and never taken -- a caller that gave up on its minibatch -- is superseded: the image is
+  // written in stream order)
   HIPCHK(h, hipMemcpyAsync(h->h_sums, h->d_sums, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipEventRecord(h->ev_sums, h->stream));
   h->sums_queued = true;

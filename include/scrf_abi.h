@@ -222,7 +222,7 @@ int scrf_set_grad_buffer(scrf_handle h, void* dptr);
 int scrf_get_batch_sums(scrf_handle h, double* sums3);
 /* The same in two halves, for a trainer that does not want to stop at every minibatch: `queue` copies the sums to a
  * pinned image behind the work issued so far (before the next scrf_zero_grad resets them), `take` waits for that copy
- * only.  One outstanding copy at a time. */
+ * only.  One image: a second `queue` before `take` supersedes the first. */
 int scrf_queue_batch_sums(scrf_handle h);
 int scrf_take_batch_sums(scrf_handle h, double* sums3);
 
